@@ -1,0 +1,159 @@
+/*
+ * mgard_hip.h -- C ABI of the MI355X-native MGARD-X hot path
+ * (multilevel decomposition chain + level-wise linear quantizer).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ * Every entry point names the reference (CODARcode/MGARD v1.6.0) interface it
+ * replaces; paths are relative to the reference checkout.
+ *
+ * Conventions
+ *  - All data pointers are DEVICE pointers on the hierarchy's device unless the
+ *    parameter name starts with h_ (host).
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream). Calls
+ *    are asynchronous with respect to the host unless stated otherwise.
+ *  - Arrays are dense row-major with the LAST dimension fastest, shape given at
+ *    hierarchy creation (mgard_x convention, shape[D-1] = fastest).
+ *  - Return value: MGH_SUCCESS (0) or a negative mgh_status. No exceptions
+ *    cross this boundary. mgh_last_error() gives a human-readable message.
+ */
+#ifndef MGARD_HIP_H
+#define MGARD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum mgh_status {
+  MGH_SUCCESS = 0,
+  MGH_ERR_INVALID_ARGUMENT = -1,
+  MGH_ERR_UNSUPPORTED_DIMENSION = -2, /* cf. NotSupportHigherNumberOfDimensionsFailure */
+  MGH_ERR_UNSUPPORTED_DTYPE = -3,     /* cf. NotSupportDataTypeFailure */
+  MGH_ERR_DEVICE = -4,                /* HIP runtime error (message in mgh_last_error) */
+  MGH_ERR_OUT_OF_MEMORY = -5,
+  MGH_ERR_NO_DEVICE = -6 /* cf. BackendNotAvailableFailure */
+} mgh_status;
+
+/* mgard_x::data_type (include/mgard-x/Utilities/Types.h:41) */
+typedef enum mgh_dtype { MGH_FLOAT = 0, MGH_DOUBLE = 1 } mgh_dtype;
+/* mgard_x::error_bound_type (include/mgard-x/Utilities/Types.h:32) */
+typedef enum mgh_error_bound { MGH_REL = 0, MGH_ABS = 1 } mgh_error_bound;
+
+#define MGH_MAX_DIM 5
+
+/* Opaque handle: level shapes + per-level spacing tables on host and device,
+ * plus the device workspace the kernels need. Replaces
+ * mgard_x::Hierarchy<D,T,HIP> (include/mgard-x/Hierarchy/Hierarchy.hpp:193-418,
+ * ctor :712-757) together with the workspace half of
+ * mgard_x::DataRefactor<D,T,HIP> (include/mgard-x/DataRefactoring/DataRefactor.hpp:19-71). */
+typedef struct mgh_hierarchy mgh_hierarchy;
+
+const char *mgh_last_error(void);
+/* Number of visible HIP devices (0 if none / no driver). */
+int mgh_device_count(void);
+
+/* h_coords: NULL for a uniform grid (Hierarchy(shape, config), Hierarchy.hpp:712),
+ * else D host arrays of `dtype` with shape[d] strictly increasing coordinates
+ * (Hierarchy(shape, coords, config), Hierarchy.hpp:741). normalize_coordinates
+ * mirrors Config::normalize_coordinates (Config/Config.h:22), max_level mirrors
+ * Config::max_larget_level (pass UINT64_MAX for "no limit"). */
+int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int dtype,
+                         const void *const *h_coords, int normalize_coordinates,
+                         uint64_t max_level, int device);
+void mgh_hierarchy_destroy(mgh_hierarchy *h);
+
+int mgh_l_target(const mgh_hierarchy *h);                       /* Hierarchy::l_target() */
+int mgh_level_shape(const mgh_hierarchy *h, int level, uint64_t *out_shape); /* ::level_shape(l) */
+uint64_t mgh_total_num_elems(const mgh_hierarchy *h);           /* ::total_num_elems() */
+/* Device bytes held by the handle (tables + workspace). */
+size_t mgh_device_bytes(const mgh_hierarchy *h);
+
+/* Host copies of the per-level tables, for inspection/tests. kind: 0=dist
+ * (Hierarchy::dist), 1=ratio (::ratio), 2=am, 3=bm (n+1 entries, ::am/::bm),
+ * 4=level_marks (int32, only level == l_target). Returns the number of entries
+ * written to h_out (capacity `cap` entries), or a negative status. */
+int64_t mgh_hierarchy_table(const mgh_hierarchy *h, int kind, int level, int dim, void *h_out,
+                            uint64_t cap);
+
+/* Norm used for REL error bounds. Replaces Compressor::CalculateNorm ->
+ * norm_calculator (include/mgard-x/CompressionLowLevel/NormCalculator.hpp:12-80).
+ * s = +inf: max|x|; otherwise sqrt(sum x^2 / N) (normalize_coordinates) or
+ * sqrt(sum x^2); 0 -> epsilon. SYNCHRONOUS (returns the value to the host). */
+int mgh_norm(mgh_hierarchy *h, const void *d_data, double s, double *h_norm_out, void *stream);
+
+/* Multilevel decomposition. Replaces Compressor::Decompose ->
+ * DataRefactor::Decompose -> multi_dimension::decompose
+ * (include/mgard-x/DataRefactoring/MultiDimension/DataRefactoring.hpp:25-177).
+ * d_coeff receives the coefficients in MGARD-X's in-place reordered layout
+ * (coarse corner first, level by level). d_coeff may equal d_data (the
+ * reference's in-place behaviour; costs one extra copy here). */
+int mgh_decompose(mgh_hierarchy *h, const void *d_data, void *d_coeff, void *stream);
+
+/* Inverse. Replaces Compressor::Recompose -> multi_dimension::recompose
+ * (DataRefactoring.hpp:179-317). d_data may equal d_coeff. */
+int mgh_recompose(mgh_hierarchy *h, const void *d_coeff, void *d_data, void *stream);
+
+/* Level-wise linear quantizer. Replaces Compressor::Quantize ->
+ * LinearQuantizer::Quantize (include/mgard-x/Quantization/LinearQuantization.hpp
+ * :564-683; quantizers :495-545; kernel :21-301). Output keeps the reordered N-D
+ * layout (config.reorder == 0). With prep_huffman != 0 values are shifted by
+ * dict_size/2 and values outside [0, dict_size) go to the outlier list
+ * (linear index, shifted value) while 0 is stored in d_quantized (:208-241).
+ * d_outlier_count is a single uint64 on the device, zeroed by this call; if it
+ * ends up larger than outlier_capacity only the first outlier_capacity entries
+ * were stored and the caller must retry with bigger buffers (:621-676).
+ * Outlier order is unspecified (atomic order), as in the reference. */
+int mgh_quantize(mgh_hierarchy *h, const void *d_coeff, int error_bound_type, double tol,
+                 double s, double norm, uint64_t dict_size, int prep_huffman,
+                 int64_t *d_quantized, uint64_t *d_outlier_count, uint64_t *d_outlier_idx,
+                 int64_t *d_outlier_val, uint64_t outlier_capacity, void *stream);
+
+/* Replaces Compressor::Dequantize -> LinearQuantizer::Dequantize
+ * (LinearQuantization.hpp:685-780, OutlierRestore :304-350). d_quantized is
+ * modified (outliers scattered back), like the reference. */
+int mgh_dequantize(mgh_hierarchy *h, int64_t *d_quantized, int error_bound_type, double tol,
+                   double s, double norm, uint64_t dict_size, int prep_huffman,
+                   const uint64_t *d_outlier_idx, const int64_t *d_outlier_val,
+                   uint64_t outlier_count, void *d_coeff, void *stream);
+
+/* The fused hot path: [norm] + decompose + quantize in one call, what
+ * Compressor::Compress runs before the lossless stage
+ * (include/mgard-x/CompressionLowLevel/Compressor.hpp:193-237, lines 216-218).
+ * Coefficients are quantized as they are produced; the float coefficient array
+ * is not materialised unless d_coeff_opt != NULL. For REL bounds pass
+ * norm <= 0 to have the norm computed here (returned through h_norm_out if not
+ * NULL; this makes the call synchronise once), or a positive norm to use it.
+ * Results are identical to mgh_decompose followed by mgh_quantize. */
+int mgh_decompose_quantize(mgh_hierarchy *h, const void *d_data, int error_bound_type,
+                           double tol, double s, double norm, double *h_norm_out,
+                           uint64_t dict_size, int prep_huffman, int64_t *d_quantized,
+                           uint64_t *d_outlier_count, uint64_t *d_outlier_idx,
+                           int64_t *d_outlier_val, uint64_t outlier_capacity,
+                           void *d_coeff_opt, void *stream);
+
+/* Inverse of the above: dequantize + recompose
+ * (Compressor::Decompress, Compressor.hpp:239-272, lines 256-257). */
+int mgh_dequantize_recompose(mgh_hierarchy *h, int64_t *d_quantized, int error_bound_type,
+                             double tol, double s, double norm, uint64_t dict_size,
+                             int prep_huffman, const uint64_t *d_outlier_idx,
+                             const int64_t *d_outlier_val, uint64_t outlier_count, void *d_data,
+                             void *stream);
+
+/* Per-kernel timing hook used by bench.py for the roofline line: when enabled,
+ * every kernel launched through this handle is bracketed by HIP events on the
+ * launch stream; mgh_profile_read() synchronises and returns accumulated
+ * milliseconds and launch counts per kernel name since the last reset.
+ * (Reference counterpart: DeviceRuntime::TimingAllKernels,
+ * src/mgard-x/RuntimeX/DeviceAdapters/DeviceAdapterSerial.cpp:18-19.) */
+int mgh_profile_enable(mgh_hierarchy *h, int enable);
+/* Writes up to cap entries; returns number of distinct kernels. names[i] points
+ * to a static string. */
+int mgh_profile_read(mgh_hierarchy *h, const char **names, double *total_ms, uint64_t *launches,
+                     int cap, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGARD_HIP_H */

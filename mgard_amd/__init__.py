@@ -1,0 +1,257 @@
+"""mgard_amd -- MI355X-native MGARD-X hot path (multilevel decomposition + level-wise linear
+quantizer) behind the C ABI of include/mgard_hip.h.
+
+This module is the thin Python host side used by the tests and bench.py: torch supplies device
+memory and streams, every computation goes through libmgard_hip.so (hand-written HIP kernels).
+There is no CPU fallback: without the built library or without a GPU the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+REL, ABS = 0, 1          # mgard_x::error_bound_type
+FLOAT, DOUBLE = 0, 1     # mgard_x::data_type
+INF = float("inf")
+
+_lib = None
+
+SYMBOLS = [
+    "mgh_last_error", "mgh_device_count", "mgh_hierarchy_create", "mgh_hierarchy_destroy",
+    "mgh_l_target", "mgh_level_shape", "mgh_total_num_elems", "mgh_device_bytes",
+    "mgh_hierarchy_table", "mgh_norm", "mgh_decompose", "mgh_recompose", "mgh_quantize",
+    "mgh_dequantize", "mgh_decompose_quantize", "mgh_dequantize_recompose",
+    "mgh_profile_enable", "mgh_profile_read",
+]
+
+
+class MgardHipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load_library():
+    """Loads libmgard_hip.so (importing torch first so that both share one HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_build.LIB):
+        raise MgardHipError(
+            "libmgard_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    import torch  # noqa: F401  (loads libamdhip64.so.7 that our library binds to)
+    L = C.CDLL(_build.LIB)
+    vp, u64, i64p, u64p = C.c_void_p, C.c_uint64, C.POINTER(C.c_int64), C.POINTER(C.c_uint64)
+    L.mgh_last_error.restype = C.c_char_p
+    L.mgh_device_count.restype = C.c_int
+    L.mgh_hierarchy_create.argtypes = [C.POINTER(vp), C.c_int, u64p, C.c_int, C.POINTER(vp),
+                                       C.c_int, u64, C.c_int]
+    L.mgh_hierarchy_destroy.argtypes = [vp]
+    L.mgh_hierarchy_destroy.restype = None
+    L.mgh_l_target.argtypes = [vp]
+    L.mgh_level_shape.argtypes = [vp, C.c_int, u64p]
+    L.mgh_total_num_elems.argtypes = [vp]
+    L.mgh_total_num_elems.restype = u64
+    L.mgh_device_bytes.argtypes = [vp]
+    L.mgh_device_bytes.restype = C.c_size_t
+    L.mgh_hierarchy_table.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, u64]
+    L.mgh_hierarchy_table.restype = C.c_int64
+    L.mgh_norm.argtypes = [vp, vp, C.c_double, C.POINTER(C.c_double), vp]
+    L.mgh_decompose.argtypes = [vp, vp, vp, vp]
+    L.mgh_recompose.argtypes = [vp, vp, vp, vp]
+    L.mgh_quantize.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, C.c_double, u64, C.c_int,
+                               vp, vp, vp, vp, u64, vp]
+    L.mgh_dequantize.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, C.c_double, u64,
+                                 C.c_int, vp, vp, u64, vp, vp]
+    L.mgh_decompose_quantize.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, C.c_double,
+                                         C.POINTER(C.c_double), u64, C.c_int, vp, vp, vp, vp, u64,
+                                         vp, vp]
+    L.mgh_dequantize_recompose.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, C.c_double,
+                                           u64, C.c_int, vp, vp, u64, vp, vp]
+    L.mgh_profile_enable.argtypes = [vp, C.c_int]
+    L.mgh_profile_read.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), u64p,
+                                   C.c_int, C.c_int]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc < 0:
+        raise MgardHipError("mgard_hip error %d: %s" % (rc, load_library().mgh_last_error().decode()))
+    return rc
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_NP = {FLOAT: np.float32, DOUBLE: np.float64}
+
+
+class Hierarchy:
+    """Host mirror of mgard_x::Hierarchy<D,T,HIP> + the stages of mgard_x::Compressor<D,T,HIP>
+    (reference include/mgard-x/CompressionLowLevel/Compressor.h:39-78): norm, decompose,
+    quantize, dequantize, recompose on torch device tensors."""
+
+    def __init__(self, shape, dtype="float32", coords=None, normalize_coordinates=True,
+                 max_level=None, device=0):
+        import torch
+        L = load_library()
+        if not torch.cuda.is_available():
+            raise MgardHipError("no HIP device visible: mgard_amd has no CPU fallback")
+        self.shape = tuple(int(s) for s in shape)
+        self.D = len(self.shape)
+        self.np_dtype = np.dtype(dtype)
+        self.dtype = {np.dtype(np.float32): FLOAT, np.dtype(np.float64): DOUBLE}[self.np_dtype]
+        self.torch_dtype = torch.float32 if self.dtype == FLOAT else torch.float64
+        self.device = int(device)
+        shp = (C.c_uint64 * self.D)(*self.shape)
+        cptr = None
+        if coords is not None:
+            self._coords = [np.ascontiguousarray(c, dtype=self.np_dtype) for c in coords]
+            cptr = (C.c_void_p * self.D)(*[c.ctypes.data for c in self._coords])
+        h = C.c_void_p()
+        _check(L.mgh_hierarchy_create(C.byref(h), self.D, shp, self.dtype, cptr,
+                                      int(normalize_coordinates),
+                                      2**64 - 1 if max_level is None else int(max_level),
+                                      self.device))
+        self._h = h
+        self.l_target = L.mgh_l_target(h)
+        self.total = int(L.mgh_total_num_elems(h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().mgh_hierarchy_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- introspection ----
+    def level_shape(self, l):
+        out = (C.c_uint64 * self.D)()
+        _check(load_library().mgh_level_shape(self._h, l, out))
+        return tuple(int(x) for x in out)
+
+    def device_bytes(self):
+        return int(load_library().mgh_device_bytes(self._h))
+
+    def table(self, kind, level, dim):
+        kinds = {"dist": 0, "ratio": 1, "am": 2, "bm": 3, "marks": 4}
+        n = max(self.shape) + 1
+        buf = np.zeros(n, dtype=np.int32 if kind == "marks" else self.np_dtype)
+        k = _check(load_library().mgh_hierarchy_table(self._h, kinds[kind], level, dim,
+                                                      buf.ctypes.data, n))
+        return buf[:k].copy()
+
+    # ---- stages ----
+    def _chk(self, t, dtype=None):
+        import torch
+        assert t.is_cuda and t.is_contiguous() and t.numel() == self.total, "bad tensor"
+        assert t.dtype == (dtype or self.torch_dtype), "bad dtype"
+        assert t.device.index == self.device
+        return C.c_void_p(t.data_ptr())
+
+    def norm(self, data, s=INF):
+        out = C.c_double()
+        _check(load_library().mgh_norm(self._h, self._chk(data), s, C.byref(out), _stream()))
+        return out.value
+
+    def decompose(self, data, out=None):
+        import torch
+        out = torch.empty_like(data) if out is None else out
+        _check(load_library().mgh_decompose(self._h, self._chk(data), self._chk(out), _stream()))
+        return out
+
+    def recompose(self, coeff, out=None):
+        import torch
+        out = torch.empty_like(coeff) if out is None else out
+        _check(load_library().mgh_recompose(self._h, self._chk(coeff), self._chk(out), _stream()))
+        return out
+
+    def _outlier_bufs(self, cap):
+        import torch
+        dev = torch.device("cuda", self.device)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        idx = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+        val = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+        return cnt, idx, val
+
+    def quantize(self, coeff, ebtype, tol, s, norm, dict_size=8192, prep_huffman=True,
+                 outlier_cap=None, out=None):
+        """Returns (q int64 tensor, outlier_idx, outlier_val, outlier_count)."""
+        import torch
+        cap = self.total if outlier_cap is None else int(outlier_cap)
+        q = torch.empty(self.shape, dtype=torch.int64, device=coeff.device) if out is None else out
+        cnt, idx, val = self._outlier_bufs(cap)
+        _check(load_library().mgh_quantize(
+            self._h, self._chk(coeff), ebtype, tol, s, norm, dict_size, int(prep_huffman),
+            self._chk(q, torch.int64), C.c_void_p(cnt.data_ptr()), C.c_void_p(idx.data_ptr()),
+            C.c_void_p(val.data_ptr()), cap, _stream()))
+        n = int(cnt.item())
+        k = min(n, cap)
+        return q, idx[:k], val[:k], n
+
+    def dequantize(self, q, ebtype, tol, s, norm, dict_size=8192, prep_huffman=True,
+                   outlier_idx=None, outlier_val=None, out=None):
+        import torch
+        out = torch.empty(self.shape, dtype=self.torch_dtype, device=q.device) if out is None else out
+        n = 0 if outlier_idx is None else int(outlier_idx.numel())
+        _check(load_library().mgh_dequantize(
+            self._h, self._chk(q, torch.int64), ebtype, tol, s, norm, dict_size, int(prep_huffman),
+            C.c_void_p(outlier_idx.data_ptr() if n else 0),
+            C.c_void_p(outlier_val.data_ptr() if n else 0), n, self._chk(out), _stream()))
+        return out
+
+    def decompose_quantize(self, data, ebtype, tol, s, norm=0.0, dict_size=8192,
+                           prep_huffman=True, outlier_cap=None, bufs=None, coeff_out=None):
+        """The fused hot path (Compressor::Compress up to the lossless stage). Returns
+        (q, outlier_idx, outlier_val, outlier_count, norm). `bufs` = (q, cnt, idx, val) lets a
+        caller reuse output buffers; then no host sync happens and outlier_count is the device
+        tensor."""
+        import torch
+        cap = self.total if outlier_cap is None else int(outlier_cap)
+        if bufs is None:
+            q = torch.empty(self.shape, dtype=torch.int64, device=data.device)
+            cnt, idx, val = self._outlier_bufs(cap)
+        else:
+            q, cnt, idx, val = bufs
+            cap = int(idx.numel())
+        nout = C.c_double()
+        _check(load_library().mgh_decompose_quantize(
+            self._h, self._chk(data), ebtype, tol, s, norm, C.byref(nout), dict_size,
+            int(prep_huffman), self._chk(q, torch.int64), C.c_void_p(cnt.data_ptr()),
+            C.c_void_p(idx.data_ptr()), C.c_void_p(val.data_ptr()), cap,
+            C.c_void_p(coeff_out.data_ptr()) if coeff_out is not None else None, _stream()))
+        if bufs is not None:
+            return q, idx, val, cnt, nout.value
+        n = int(cnt.item())
+        k = min(n, cap)
+        return q, idx[:k], val[:k], n, nout.value
+
+    def dequantize_recompose(self, q, ebtype, tol, s, norm, dict_size=8192, prep_huffman=True,
+                             outlier_idx=None, outlier_val=None, out=None):
+        import torch
+        out = torch.empty(self.shape, dtype=self.torch_dtype, device=q.device) if out is None else out
+        n = 0 if outlier_idx is None else int(outlier_idx.numel())
+        _check(load_library().mgh_dequantize_recompose(
+            self._h, self._chk(q, torch.int64), ebtype, tol, s, norm, dict_size, int(prep_huffman),
+            C.c_void_p(outlier_idx.data_ptr() if n else 0),
+            C.c_void_p(outlier_val.data_ptr() if n else 0), n, self._chk(out), _stream()))
+        return out
+
+    # ---- per-kernel timing (HIP events on the launch stream) ----
+    def profile(self, enable=True):
+        _check(load_library().mgh_profile_enable(self._h, int(enable)))
+
+    def profile_read(self, reset=True):
+        cap = 64
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        cnt = (C.c_uint64 * cap)()
+        n = _check(load_library().mgh_profile_read(self._h, names, ms, cnt, cap, int(reset)))
+        return {names[i].decode(): (ms[i], int(cnt[i])) for i in range(min(n, cap))}

@@ -1,0 +1,712 @@
+// C ABI implementation (include/mgard_hip.h) of the MI355X-native MGARD-X hot
+// path. Host orchestration only: the level loop of
+// multi_dimension::decompose/recompose
+// (reference include/mgard-x/DataRefactoring/MultiDimension/DataRefactoring.hpp:25-317)
+// over the HIP kernels in kernels_*.hpp.
+#include "../../include/mgard_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "hierarchy.hpp"
+#include "kernels_v1.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      return fail(_e == hipErrorOutOfMemory ? MGH_ERR_OUT_OF_MEMORY : MGH_ERR_DEVICE,          \
+                  std::string(#expr) + ": " + hipGetErrorString(_e));                          \
+  } while (0)
+
+struct ProfileEntry {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  double total_ms = 0;
+  uint64_t launches = 0;
+};
+
+} // namespace
+
+struct mgh_hierarchy {
+  int dtype = MGH_FLOAT;
+  int device = 0;
+  int D = 0, L = 0;
+  uint64_t total = 0;
+  void *host = nullptr;  // HostHierarchy<T>*
+  void *impl = nullptr;  // DeviceState<T>*
+  bool profiling = false;
+  std::map<std::string, ProfileEntry> prof;
+  size_t device_bytes = 0;
+};
+
+namespace {
+
+using namespace mgh;
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+};
+
+template <typename T> struct LevelTables {
+  // index k = 0,1,2 <-> (r, c, f) of the 3-D view; nullptr for inactive dims
+  const T *ratio[3] = {nullptr, nullptr, nullptr};   // fine level l
+  const T *mass[3] = {nullptr, nullptr, nullptr};    // l -> l-1
+  const T *thomas[3] = {nullptr, nullptr, nullptr};  // coarse level l-1
+  Box3 box;
+  bool active[3] = {false, false, false};
+};
+
+template <typename T> struct DeviceState {
+  HostHierarchy<T> *hh = nullptr;
+  T *tables = nullptr;
+  int *marks = nullptr;
+  std::vector<LevelTables<T>> lt;  // [l], l >= 1
+  std::vector<T *> nodal;          // [l] compact nodal buffers, l = 0..L-1
+  T *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;
+  T *scratch_full = nullptr;       // lazily allocated full-size copy
+  T *qz = nullptr;                 // 2*(L+1): quantizers, volumes
+  unsigned long long *scalar = nullptr;  // 8-byte device scalar (norm / counters)
+  QuantMeta qmeta;
+  size_t full_I = 0, full_J = 0;   // strides of the full array in the 3-D view
+};
+
+template <typename T> HostHierarchy<T> *HH(const mgh_hierarchy *h) {
+  return static_cast<HostHierarchy<T> *>(h->host);
+}
+template <typename T> DeviceState<T> *DS(const mgh_hierarchy *h) {
+  return static_cast<DeviceState<T> *>(h->impl);
+}
+
+// ---- profiled launch -------------------------------------------------------
+template <typename F> int launch(mgh_hierarchy *h, const char *name, hipStream_t s, F &&f) {
+  if (!h->profiling) {
+    f();
+    HIP_TRY(hipGetLastError());
+    return MGH_SUCCESS;
+  }
+  hipEvent_t a, b;
+  HIP_TRY(hipEventCreate(&a));
+  HIP_TRY(hipEventCreate(&b));
+  HIP_TRY(hipEventRecord(a, s));
+  f();
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(b, s));
+  h->prof[name].pending.emplace_back(a, b);
+  return MGH_SUCCESS;
+}
+
+#define TRY(expr)                 \
+  do {                            \
+    int _rc = (expr);             \
+    if (_rc != MGH_SUCCESS) return _rc; \
+  } while (0)
+
+inline dim3 grid3(uint32_t n0, uint32_t n1, uint32_t n2, dim3 blk) {
+  return dim3((n2 + blk.x - 1) / blk.x, (n1 + blk.y - 1) / blk.y, n0);
+}
+
+template <typename T> int dev_alloc(mgh_hierarchy *h, T **p, size_t count) {
+  *p = nullptr;
+  if (count == 0) return MGH_SUCCESS;
+  HIP_TRY(hipMalloc((void **)p, count * sizeof(T)));
+  h->device_bytes += count * sizeof(T);
+  return MGH_SUCCESS;
+}
+
+template <typename T> int build_device_state(mgh_hierarchy *h) {
+  HostHierarchy<T> *hh = HH<T>(h);
+  auto *ds = new DeviceState<T>();
+  h->impl = ds;
+  ds->hh = hh;
+  const int D = hh->D, L = hh->L;
+  if (D > 3) return MGH_SUCCESS;  // tables for D > 3 are built by the ND path (not yet)
+
+  // ---- spacing tables: one arena, one upload --------------------------------
+  std::vector<T> arena;
+  auto push = [&](const std::vector<T> &v) {
+    size_t off = arena.size();
+    arena.insert(arena.end(), v.begin(), v.end());
+    while (arena.size() % 4) arena.push_back(0);  // keep 16-byte alignment for f32
+    return off;
+  };
+  struct Off {
+    size_t ratio[3], mass[3], thomas[3];
+  };
+  std::vector<Off> offs(L + 1);
+  ds->lt.resize(L + 1);
+  for (int l = 1; l <= L; l++) {
+    LevelTables<T> &t = ds->lt[l];
+    for (int k = 0; k < 3; k++) {
+      const int d = D - 3 + k;
+      if (d < 0) {
+        t.box.n[k] = t.box.m[k] = 1;
+        t.active[k] = false;
+        continue;
+      }
+      t.active[k] = true;
+      t.box.n[k] = (uint32_t)hh->level_shape[l][d];
+      t.box.m[k] = (uint32_t)hh->level_shape[l - 1][d];
+      offs[l].ratio[k] = push(hh->lv[l][d].ratio);
+      offs[l].mass[k] = push(hh->mass_table(l, d));
+      offs[l].thomas[k] = push(hh->thomas_table(l - 1, d));
+    }
+  }
+  TRY(dev_alloc(h, &ds->tables, arena.size()));
+  HIP_TRY(hipMemcpy(ds->tables, arena.data(), arena.size() * sizeof(T), hipMemcpyHostToDevice));
+  for (int l = 1; l <= L; l++)
+    for (int k = 0; k < 3; k++)
+      if (ds->lt[l].active[k]) {
+        ds->lt[l].ratio[k] = ds->tables + offs[l].ratio[k];
+        ds->lt[l].mass[k] = ds->tables + offs[l].mass[k];
+        ds->lt[l].thomas[k] = ds->tables + offs[l].thomas[k];
+      }
+
+  // ---- level marks ------------------------------------------------------------
+  std::vector<int> marks;
+  ds->qmeta.D = D;
+  ds->qmeta.calc_vol = 0;
+  for (int d = 0; d < D; d++) {
+    ds->qmeta.shape[d] = (uint32_t)hh->shape[d];
+    ds->qmeta.markoff[d] = (uint32_t)marks.size();
+    marks.insert(marks.end(), hh->marks[d].begin(), hh->marks[d].end());
+  }
+  TRY(dev_alloc(h, &ds->marks, marks.size()));
+  HIP_TRY(hipMemcpy(ds->marks, marks.data(), marks.size() * sizeof(int), hipMemcpyHostToDevice));
+
+  // ---- workspace ----------------------------------------------------------------
+  ds->nodal.assign(L + 1, nullptr);
+  for (int l = 0; l < L; l++) {
+    size_t cnt = 1;
+    for (int d = 0; d < D; d++) cnt *= hh->level_shape[l][d];
+    TRY(dev_alloc(h, &ds->nodal[l], cnt));
+  }
+  if (L >= 1) {
+    const Box3 &b = ds->lt[L].box;
+    TRY(dev_alloc(h, &ds->t1, (size_t)b.n[0] * b.n[1] * b.m[2]));
+    TRY(dev_alloc(h, &ds->t2, (size_t)b.n[0] * b.m[1] * b.m[2]));
+    TRY(dev_alloc(h, &ds->t3, (size_t)b.m[0] * b.m[1] * b.m[2]));
+  }
+  TRY(dev_alloc(h, &ds->qz, (size_t)2 * (L + 1)));
+  TRY(dev_alloc(h, &ds->scalar, (size_t)2));
+  ds->full_J = hh->shape[D - 1];
+  ds->full_I = (D >= 2 ? hh->shape[D - 2] : 1) * ds->full_J;
+  return MGH_SUCCESS;
+}
+
+template <typename T> void destroy_state(mgh_hierarchy *h) {
+  auto *ds = DS<T>(h);
+  if (ds) {
+    (void)hipFree(ds->tables);
+    (void)hipFree(ds->marks);
+    for (T *p : ds->nodal) (void)hipFree(p);
+    (void)hipFree(ds->t1);
+    (void)hipFree(ds->t2);
+    (void)hipFree(ds->t3);
+    (void)hipFree(ds->scratch_full);
+    (void)hipFree(ds->qz);
+    (void)hipFree(ds->scalar);
+    delete ds;
+  }
+  delete HH<T>(h);
+}
+
+template <typename T> int ensure_scratch(mgh_hierarchy *h) {
+  auto *ds = DS<T>(h);
+  if (!ds->scratch_full) TRY(dev_alloc(h, &ds->scratch_full, (size_t)h->total));
+  return MGH_SUCCESS;
+}
+
+// ---- correction = IPK(LPK(coefficients)) then +/- into nodal[l-1] --------------
+// CalcCorrection3D (Correction/CalcCorrection3D.hpp:26-185) + AddND/SubtractND.
+template <typename T>
+int correction(mgh_hierarchy *h, int l, const T *coef, size_t cI, size_t cJ, T *target, int sign,
+               hipStream_t s) {
+  auto *ds = DS<T>(h);
+  const LevelTables<T> &t = ds->lt[l];
+  const Box3 &b = t.box;
+  const dim3 blk(64, 4, 1);
+  // LPK1 along f: (nr, nc, nf) -> (nr, nc, ff)
+  TRY(launch(h, "lpk_f", s, [&] {
+    k_lpk<T, 2><<<grid3(b.n[0], b.n[1], b.m[2], blk), blk, 0, s>>>(
+        b.n[0], b.n[1], b.n[2], b.n[2], b.m[2], coef, cI, cJ, ds->t1, (size_t)b.n[1] * b.m[2],
+        (size_t)b.m[2], t.mass[2], b.m[0], b.m[1]);
+  }));
+  T *cur = ds->t1;
+  if (t.active[1]) {
+    TRY(launch(h, "lpk_c", s, [&] {
+      k_lpk<T, 1><<<grid3(b.n[0], b.m[1], b.m[2], blk), blk, 0, s>>>(
+          b.n[0], b.n[1], b.m[2], b.n[1], b.m[1], cur, (size_t)b.n[1] * b.m[2], (size_t)b.m[2],
+          ds->t2, (size_t)b.m[1] * b.m[2], (size_t)b.m[2], t.mass[1], 0, 0);
+    }));
+    cur = ds->t2;
+  }
+  if (t.active[0]) {
+    TRY(launch(h, "lpk_r", s, [&] {
+      k_lpk<T, 0><<<grid3(b.m[0], b.m[1], b.m[2], blk), blk, 0, s>>>(
+          b.n[0], b.m[1], b.m[2], b.n[0], b.m[0], cur, (size_t)b.m[1] * b.m[2], (size_t)b.m[2],
+          ds->t3, (size_t)b.m[1] * b.m[2], (size_t)b.m[2], t.mass[0], 0, 0);
+    }));
+    cur = ds->t3;
+  }
+  // IPK along f, c, r; the last one applies the correction to `target`
+  const int last = t.active[0] ? 0 : (t.active[1] ? 1 : 2);
+  {
+    const dim3 pb(64, 1, 1);  // pencils over (i, j)
+    const dim3 g((b.m[1] + 63) / 64, b.m[0], 1);
+    TRY(launch(h, "ipk_f", s, [&] {
+      k_ipk<T, 2><<<g, pb, 0, s>>>(b.m[0], b.m[1], b.m[2], cur, t.thomas[2],
+                                   last == 2 ? target : nullptr, sign);
+    }));
+  }
+  if (t.active[1]) {
+    const dim3 pb(64, 1, 1);  // pencils over (i, k)
+    const dim3 g((b.m[2] + 63) / 64, b.m[0], 1);
+    TRY(launch(h, "ipk_c", s, [&] {
+      k_ipk<T, 1><<<g, pb, 0, s>>>(b.m[0], b.m[1], b.m[2], cur, t.thomas[1],
+                                   last == 1 ? target : nullptr, sign);
+    }));
+  }
+  if (t.active[0]) {
+    const dim3 pb(64, 1, 1);  // pencils over (j, k)
+    const dim3 g((b.m[2] + 63) / 64, b.m[1], 1);
+    TRY(launch(h, "ipk_r", s, [&] {
+      k_ipk<T, 0><<<g, pb, 0, s>>>(b.m[0], b.m[1], b.m[2], cur, t.thomas[0], target, sign);
+    }));
+  }
+  return MGH_SUCCESS;
+}
+
+template <typename T>
+int decompose_impl(mgh_hierarchy *h, const T *data, T *coeff, hipStream_t s) {
+  auto *ds = DS<T>(h);
+  if (h->D > 3) return fail(MGH_ERR_UNSUPPORTED_DIMENSION, "decompose: D > 3 not implemented");
+  const int L = h->L;
+  const size_t fI = ds->full_I, fJ = ds->full_J;
+  const T *src = data;
+  size_t sI = fI, sJ = fJ;
+  if ((const void *)data == (const void *)coeff) {
+    TRY(ensure_scratch<T>(h));
+    HIP_TRY(hipMemcpyAsync(ds->scratch_full, data, h->total * sizeof(T), hipMemcpyDeviceToDevice, s));
+    src = ds->scratch_full;
+  }
+  const dim3 blk(64, 4, 1);
+  for (int l = L; l >= 1; l--) {
+    const LevelTables<T> &t = ds->lt[l];
+    const Box3 &b = t.box;
+    T *coarse = ds->nodal[l - 1];
+    TRY(launch(h, "gpk_reo", s, [&] {
+      k_gpk_reo<T><<<grid3(b.n[0], b.n[1], b.n[2], blk), blk, 0, s>>>(
+          b, src, sI, sJ, coarse, coeff, fI, fJ, t.ratio[0], t.ratio[1], t.ratio[2]);
+    }));
+    TRY(correction<T>(h, l, coeff, fI, fJ, coarse, +1, s));
+    src = coarse;
+    sJ = b.m[2];
+    sI = (size_t)b.m[1] * b.m[2];
+  }
+  // level-0 nodal values are the head of the coefficient array
+  if (L >= 1) {
+    const Box3 &b = ds->lt[1].box;
+    TRY(launch(h, "copy_box", s, [&] {
+      k_copy_box<T><<<grid3(b.m[0], b.m[1], b.m[2], blk), blk, 0, s>>>(
+          b.m[0], b.m[1], b.m[2], ds->nodal[0], (size_t)b.m[1] * b.m[2], (size_t)b.m[2], coeff, fI,
+          fJ);
+    }));
+  } else if ((const void *)data != (const void *)coeff) {
+    HIP_TRY(hipMemcpyAsync(coeff, data, h->total * sizeof(T), hipMemcpyDeviceToDevice, s));
+  }
+  return MGH_SUCCESS;
+}
+
+template <typename T>
+int recompose_impl(mgh_hierarchy *h, const T *coeff, T *data, hipStream_t s) {
+  auto *ds = DS<T>(h);
+  if (h->D > 3) return fail(MGH_ERR_UNSUPPORTED_DIMENSION, "recompose: D > 3 not implemented");
+  const int L = h->L;
+  const size_t fI = ds->full_I, fJ = ds->full_J;
+  const T *C = coeff;
+  if ((const void *)data == (const void *)coeff) {
+    if (L == 0) return MGH_SUCCESS;
+    TRY(ensure_scratch<T>(h));
+    HIP_TRY(hipMemcpyAsync(ds->scratch_full, coeff, h->total * sizeof(T), hipMemcpyDeviceToDevice, s));
+    C = ds->scratch_full;
+  }
+  if (L == 0) {
+    HIP_TRY(hipMemcpyAsync(data, coeff, h->total * sizeof(T), hipMemcpyDeviceToDevice, s));
+    return MGH_SUCCESS;
+  }
+  const dim3 blk(64, 4, 1);
+  {
+    const Box3 &b = ds->lt[1].box;
+    TRY(launch(h, "copy_box", s, [&] {
+      k_copy_box<T><<<grid3(b.m[0], b.m[1], b.m[2], blk), blk, 0, s>>>(
+          b.m[0], b.m[1], b.m[2], C, fI, fJ, ds->nodal[0], (size_t)b.m[1] * b.m[2], (size_t)b.m[2]);
+    }));
+  }
+  for (int l = 1; l <= L; l++) {
+    const LevelTables<T> &t = ds->lt[l];
+    const Box3 &b = t.box;
+    T *coarse = ds->nodal[l - 1];
+    TRY(correction<T>(h, l, C, fI, fJ, coarse, -1, s));
+    T *out = (l == L) ? data : ds->nodal[l];
+    const size_t oJ = (l == L) ? fJ : b.n[2];
+    const size_t oI = (l == L) ? fI : (size_t)b.n[1] * b.n[2];
+    TRY(launch(h, "gpk_rev", s, [&] {
+      k_gpk_rev<T><<<grid3(b.n[0], b.n[1], b.n[2], blk), blk, 0, s>>>(
+          b, coarse, C, fI, fJ, out, oI, oJ, t.ratio[0], t.ratio[1], t.ratio[2]);
+    }));
+  }
+  return MGH_SUCCESS;
+}
+
+template <typename T>
+int upload_quantizers(mgh_hierarchy *h, int ebtype, double tol, double s, double norm,
+                      bool reciprocal, hipStream_t st) {
+  auto *ds = DS<T>(h);
+  auto *hh = HH<T>(h);
+  const int L = h->L;
+  std::vector<T> q(2 * (L + 1));
+  hh->quantizers(ebtype, (T)tol, (T)s, (T)norm, reciprocal, q.data());
+  const bool calc_vol = !((T)s == std::numeric_limits<T>::infinity());
+  for (int l = 0; l <= L; l++) q[L + 1 + l] = calc_vol ? hh->level_volume(l, !reciprocal) : (T)1;
+  ds->qmeta.calc_vol = calc_vol ? 1 : 0;
+  // pageable-memory async copies are staged by the runtime before returning
+  HIP_TRY(hipMemcpyAsync(ds->qz, q.data(), q.size() * sizeof(T), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return MGH_SUCCESS;
+}
+
+template <typename T>
+int quantize_impl(mgh_hierarchy *h, const T *coeff, int ebtype, double tol, double s, double norm,
+                  uint64_t dict_size, int prep_huffman, int64_t *q, uint64_t *ocount,
+                  uint64_t *oidx, int64_t *oval, uint64_t ocap, hipStream_t st) {
+  auto *ds = DS<T>(h);
+  TRY(upload_quantizers<T>(h, ebtype, tol, s, norm, true, st));
+  if (ocount) HIP_TRY(hipMemsetAsync(ocount, 0, sizeof(uint64_t), st));
+  const size_t total = h->total;
+  const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
+  TRY(launch(h, "quantize", st, [&] {
+    k_quantize<T><<<grid, 256, 0, st>>>(ds->qmeta, total, coeff, ds->marks, ds->qz,
+                                        ds->qz + (h->L + 1), (int64_t)dict_size, prep_huffman, q,
+                                        (unsigned long long *)ocount, oidx, oval,
+                                        (unsigned long long)ocap);
+  }));
+  return MGH_SUCCESS;
+}
+
+template <typename T>
+int dequantize_impl(mgh_hierarchy *h, int64_t *q, int ebtype, double tol, double s, double norm,
+                    uint64_t dict_size, int prep_huffman, const uint64_t *oidx,
+                    const int64_t *oval, uint64_t ocount, T *coeff, hipStream_t st) {
+  auto *ds = DS<T>(h);
+  TRY(upload_quantizers<T>(h, ebtype, tol, s, norm, false, st));
+  const size_t total = h->total;
+  if (prep_huffman && ocount) {
+    TRY(launch(h, "outlier_restore", st, [&] {
+      k_outlier_restore<<<(unsigned)((ocount + 255) / 256), 256, 0, st>>>(q, oidx, oval, ocount);
+    }));
+  }
+  const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
+  TRY(launch(h, "dequantize", st, [&] {
+    k_dequantize<T><<<grid, 256, 0, st>>>(ds->qmeta, total, q, ds->marks, ds->qz,
+                                          ds->qz + (h->L + 1), (int64_t)dict_size, prep_huffman,
+                                          coeff);
+  }));
+  return MGH_SUCCESS;
+}
+
+template <typename T>
+int norm_impl(mgh_hierarchy *h, const T *data, double s, double *out, hipStream_t st) {
+  auto *ds = DS<T>(h);
+  auto *hh = HH<T>(h);
+  const size_t total = h->total;
+  const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 16);
+  HIP_TRY(hipMemsetAsync(ds->scalar, 0, 8, st));
+  T norm;
+  if ((T)s == std::numeric_limits<T>::infinity()) {
+    TRY(launch(h, "absmax", st, [&] { k_absmax<T><<<grid, 256, 0, st>>>(data, total, ds->scalar); }));
+    unsigned long long bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, ds->scalar, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (sizeof(T) == 4) {
+      uint32_t b32 = (uint32_t)bits;
+      float f;
+      std::memcpy(&f, &b32, 4);
+      norm = (T)f;
+    } else {
+      double d;
+      std::memcpy(&d, &bits, 8);
+      norm = (T)d;
+    }
+  } else {
+    TRY(launch(h, "sqsum", st, [&] { k_sqsum<T><<<grid, 256, 0, st>>>(data, total, (double *)ds->scalar); }));
+    double sum = 0;
+    HIP_TRY(hipMemcpyAsync(&sum, ds->scalar, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    norm = (T)sum;
+    // NormCalculator.hpp:62-66
+    norm = hh->normalize_coordinates ? std::sqrt(norm / (T)total) : std::sqrt(norm);
+  }
+  if (norm == 0) norm = std::numeric_limits<T>::epsilon();
+  *out = (double)norm;
+  return MGH_SUCCESS;
+}
+
+template <typename T>
+int64_t table_impl(const mgh_hierarchy *h, int kind, int level, int dim, void *out, uint64_t cap) {
+  auto *hh = HH<T>(h);
+  if (dim < 0 || dim >= hh->D) return fail(MGH_ERR_INVALID_ARGUMENT, "dim");
+  if (kind == 4) {
+    const auto &m = hh->marks[dim];
+    if (cap < m.size()) return fail(MGH_ERR_INVALID_ARGUMENT, "capacity");
+    std::memcpy(out, m.data(), m.size() * sizeof(int));
+    return (int64_t)m.size();
+  }
+  if (level < 0 || level > hh->L) return fail(MGH_ERR_INVALID_ARGUMENT, "level");
+  const auto &q = hh->lv[level][dim];
+  const std::vector<T> *v = kind == 0 ? &q.dist : kind == 1 ? &q.ratio : kind == 2 ? &q.am
+                            : kind == 3 ? &q.bm : nullptr;
+  if (!v) return fail(MGH_ERR_INVALID_ARGUMENT, "kind");
+  if (cap < v->size()) return fail(MGH_ERR_INVALID_ARGUMENT, "capacity");
+  std::memcpy(out, v->data(), v->size() * sizeof(T));
+  return (int64_t)v->size();
+}
+
+#define DISPATCH(h, call_f, call_d)                                              \
+  ((h)->dtype == MGH_FLOAT ? (call_f) : (call_d))
+
+} // namespace
+
+extern "C" {
+
+const char *mgh_last_error(void) { return g_last_error.c_str(); }
+
+int mgh_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int dtype,
+                         const void *const *h_coords, int normalize_coordinates,
+                         uint64_t max_level, int device) {
+  if (!out || !shape) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (D < 1 || D > MGH_MAX_DIM) return fail(MGH_ERR_UNSUPPORTED_DIMENSION, "D must be 1..5");
+  if (dtype != MGH_FLOAT && dtype != MGH_DOUBLE) return fail(MGH_ERR_UNSUPPORTED_DTYPE, "dtype");
+  if (mgh_device_count() <= device || device < 0)
+    return fail(MGH_ERR_NO_DEVICE, "HIP device " + std::to_string(device) + " not available");
+  HIP_TRY(hipSetDevice(device));
+  auto *h = new mgh_hierarchy();
+  h->dtype = dtype;
+  h->device = device;
+  h->D = D;
+  bool ok;
+  if (dtype == MGH_FLOAT) {
+    auto *hh = new HostHierarchy<float>();
+    h->host = hh;
+    ok = hh->init(D, shape, (const float *const *)h_coords, normalize_coordinates != 0, max_level);
+    hh->normalize_coordinates = normalize_coordinates != 0;
+    h->L = hh->L;
+    h->total = ok ? hh->total() : 0;
+  } else {
+    auto *hh = new HostHierarchy<double>();
+    h->host = hh;
+    ok = hh->init(D, shape, (const double *const *)h_coords, normalize_coordinates != 0, max_level);
+    hh->normalize_coordinates = normalize_coordinates != 0;
+    h->L = hh->L;
+    h->total = ok ? hh->total() : 0;
+  }
+  if (!ok) {
+    if (dtype == MGH_FLOAT) delete HH<float>(h); else delete HH<double>(h);
+    delete h;
+    return fail(MGH_ERR_INVALID_ARGUMENT,
+                "invalid shape: every dimension must have at least 3 nodes");
+  }
+  int rc = DISPATCH(h, build_device_state<float>(h), build_device_state<double>(h));
+  if (rc != MGH_SUCCESS) {
+    mgh_hierarchy_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return MGH_SUCCESS;
+}
+
+void mgh_hierarchy_destroy(mgh_hierarchy *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  for (auto &kv : h->prof)
+    for (auto &ev : kv.second.pending) {
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+  if (h->dtype == MGH_FLOAT) destroy_state<float>(h); else destroy_state<double>(h);
+  delete h;
+}
+
+int mgh_l_target(const mgh_hierarchy *h) { return h ? h->L : MGH_ERR_INVALID_ARGUMENT; }
+
+int mgh_level_shape(const mgh_hierarchy *h, int level, uint64_t *out_shape) {
+  if (!h || !out_shape || level < 0 || level > h->L) return fail(MGH_ERR_INVALID_ARGUMENT, "level");
+  for (int d = 0; d < h->D; d++)
+    out_shape[d] = h->dtype == MGH_FLOAT ? HH<float>(h)->level_shape[level][d]
+                                         : HH<double>(h)->level_shape[level][d];
+  return MGH_SUCCESS;
+}
+
+uint64_t mgh_total_num_elems(const mgh_hierarchy *h) { return h ? h->total : 0; }
+size_t mgh_device_bytes(const mgh_hierarchy *h) { return h ? h->device_bytes : 0; }
+
+
+int64_t mgh_hierarchy_table(const mgh_hierarchy *h, int kind, int level, int dim, void *h_out,
+                            uint64_t cap) {
+  if (!h || !h_out) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
+  return DISPATCH(h, table_impl<float>(h, kind, level, dim, h_out, cap),
+                  table_impl<double>(h, kind, level, dim, h_out, cap));
+}
+
+int mgh_norm(mgh_hierarchy *h, const void *d_data, double s, double *h_norm_out, void *stream) {
+  if (!h || !d_data || !h_norm_out) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  return DISPATCH(h, norm_impl<float>(h, (const float *)d_data, s, h_norm_out, (hipStream_t)stream),
+                  norm_impl<double>(h, (const double *)d_data, s, h_norm_out, (hipStream_t)stream));
+}
+
+int mgh_decompose(mgh_hierarchy *h, const void *d_data, void *d_coeff, void *stream) {
+  if (!h || !d_data || !d_coeff) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  return DISPATCH(h, decompose_impl<float>(h, (const float *)d_data, (float *)d_coeff, (hipStream_t)stream),
+                  decompose_impl<double>(h, (const double *)d_data, (double *)d_coeff, (hipStream_t)stream));
+}
+
+int mgh_recompose(mgh_hierarchy *h, const void *d_coeff, void *d_data, void *stream) {
+  if (!h || !d_data || !d_coeff) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  return DISPATCH(h, recompose_impl<float>(h, (const float *)d_coeff, (float *)d_data, (hipStream_t)stream),
+                  recompose_impl<double>(h, (const double *)d_coeff, (double *)d_data, (hipStream_t)stream));
+}
+
+int mgh_quantize(mgh_hierarchy *h, const void *d_coeff, int ebtype, double tol, double s,
+                 double norm, uint64_t dict_size, int prep_huffman, int64_t *d_quantized,
+                 uint64_t *d_outlier_count, uint64_t *d_outlier_idx, int64_t *d_outlier_val,
+                 uint64_t outlier_capacity, void *stream) {
+  if (!h || !d_coeff || !d_quantized) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
+  if (prep_huffman && (!d_outlier_count || (outlier_capacity && (!d_outlier_idx || !d_outlier_val))))
+    return fail(MGH_ERR_INVALID_ARGUMENT, "outlier buffers required with prep_huffman");
+  HIP_TRY(hipSetDevice(h->device));
+  return DISPATCH(h,
+                  quantize_impl<float>(h, (const float *)d_coeff, ebtype, tol, s, norm, dict_size,
+                                       prep_huffman, d_quantized, d_outlier_count, d_outlier_idx,
+                                       d_outlier_val, outlier_capacity, (hipStream_t)stream),
+                  quantize_impl<double>(h, (const double *)d_coeff, ebtype, tol, s, norm, dict_size,
+                                        prep_huffman, d_quantized, d_outlier_count, d_outlier_idx,
+                                        d_outlier_val, outlier_capacity, (hipStream_t)stream));
+}
+
+int mgh_dequantize(mgh_hierarchy *h, int64_t *d_quantized, int ebtype, double tol, double s,
+                   double norm, uint64_t dict_size, int prep_huffman,
+                   const uint64_t *d_outlier_idx, const int64_t *d_outlier_val,
+                   uint64_t outlier_count, void *d_coeff, void *stream) {
+  if (!h || !d_coeff || !d_quantized) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  return DISPATCH(h,
+                  dequantize_impl<float>(h, d_quantized, ebtype, tol, s, norm, dict_size,
+                                         prep_huffman, d_outlier_idx, d_outlier_val, outlier_count,
+                                         (float *)d_coeff, (hipStream_t)stream),
+                  dequantize_impl<double>(h, d_quantized, ebtype, tol, s, norm, dict_size,
+                                          prep_huffman, d_outlier_idx, d_outlier_val, outlier_count,
+                                          (double *)d_coeff, (hipStream_t)stream));
+}
+
+int mgh_decompose_quantize(mgh_hierarchy *h, const void *d_data, int ebtype, double tol, double s,
+                           double norm, double *h_norm_out, uint64_t dict_size, int prep_huffman,
+                           int64_t *d_quantized, uint64_t *d_outlier_count,
+                           uint64_t *d_outlier_idx, int64_t *d_outlier_val,
+                           uint64_t outlier_capacity, void *d_coeff_opt, void *stream) {
+  if (!h || !d_data || !d_quantized) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  if (ebtype == MGH_REL && !(norm > 0)) {
+    int rc = mgh_norm(h, d_data, s, &norm, stream);
+    if (rc != MGH_SUCCESS) return rc;
+  }
+  if (h_norm_out) *h_norm_out = norm;
+  void *coeff = d_coeff_opt;
+  if (!coeff) {
+    int rc = DISPATCH(h, ensure_scratch<float>(h), ensure_scratch<double>(h));
+    if (rc != MGH_SUCCESS) return rc;
+    coeff = h->dtype == MGH_FLOAT ? (void *)DS<float>(h)->scratch_full
+                                  : (void *)DS<double>(h)->scratch_full;
+    if (coeff == d_data) return fail(MGH_ERR_INVALID_ARGUMENT, "aliasing");
+  }
+  int rc = mgh_decompose(h, d_data, coeff, stream);
+  if (rc != MGH_SUCCESS) return rc;
+  return mgh_quantize(h, coeff, ebtype, tol, s, norm, dict_size, prep_huffman, d_quantized,
+                      d_outlier_count, d_outlier_idx, d_outlier_val, outlier_capacity, stream);
+}
+
+int mgh_dequantize_recompose(mgh_hierarchy *h, int64_t *d_quantized, int ebtype, double tol,
+                             double s, double norm, uint64_t dict_size, int prep_huffman,
+                             const uint64_t *d_outlier_idx, const int64_t *d_outlier_val,
+                             uint64_t outlier_count, void *d_data, void *stream) {
+  if (!h || !d_data || !d_quantized) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
+  int rc = mgh_dequantize(h, d_quantized, ebtype, tol, s, norm, dict_size, prep_huffman,
+                          d_outlier_idx, d_outlier_val, outlier_count, d_data, stream);
+  if (rc != MGH_SUCCESS) return rc;
+  return mgh_recompose(h, d_data, d_data, stream);
+}
+
+int mgh_profile_enable(mgh_hierarchy *h, int enable) {
+  if (!h) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
+  h->profiling = enable != 0;
+  return MGH_SUCCESS;
+}
+
+int mgh_profile_read(mgh_hierarchy *h, const char **names, double *total_ms, uint64_t *launches,
+                     int cap, int reset) {
+  if (!h) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  int n = 0;
+  for (auto &kv : h->prof) {
+    ProfileEntry &e = kv.second;
+    for (auto &ev : e.pending) {
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+      e.total_ms += ms;
+      e.launches++;
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+    e.pending.clear();
+    if (n < cap) {
+      if (names) names[n] = kv.first.c_str();
+      if (total_ms) total_ms[n] = e.total_ms;
+      if (launches) launches[n] = e.launches;
+    }
+    n++;
+    if (reset) {
+      e.total_ms = 0;
+      e.launches = 0;
+    }
+  }
+  return n;
+}
+
+} // extern "C"

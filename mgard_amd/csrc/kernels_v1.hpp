@@ -1,0 +1,388 @@
+// Straightforward (one thread per output element) HIP kernels for the MGARD-X
+// decomposition chain. They are the correctness baseline of this library: every
+// arithmetic expression keeps the reference's operation order, and the file is
+// compiled with -ffp-contract=off so no FMA is formed (the reference never
+// defines MGARD_X_FMA). Tuned kernels (kernels_fast.hpp) must match these
+// bit-for-bit.
+//
+// Layout vocabulary: a level-l "nodal" array is the natural-order box
+// (nr, nc, nf); the "reordered" layout puts the coarse nodes first along every
+// dim ([0,rr) x [0,cc) x [0,ff)) and the coefficients behind them, exactly like
+// the sub-array views of
+// include/mgard-x/DataRefactoring/MultiDimension/Coefficient/CalcCoefficients3D.hpp:51-73.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mgh {
+
+// Coefficient/GPKFunctor.h:21-23 (non-FMA branch)
+template <typename T> __device__ __forceinline__ T lerp_ref(T v0, T v1, T t) {
+  T r = v0 + v0 * t * (T)-1;
+  r = r + t * v1;
+  return r;
+}
+
+struct Box3 {
+  uint32_t n[3];  // fine sizes (r, c, f)
+  uint32_t m[3];  // coarse sizes (rr, cc, ff)
+};
+
+// fine index of reordered index i along a dim: coarse node -> min(2i, n-1),
+// coefficient -> odd node 2(i-m)+1
+__device__ __forceinline__ uint32_t fine_pos(uint32_t i, uint32_t n, uint32_t m, bool &odd) {
+  odd = i >= m;
+  if (odd) return 2 * (i - m) + 1;
+  uint32_t p = 2 * i;
+  return p < n - 1 ? p : n - 1;
+}
+
+// ---------------------------------------------------------------------------
+// GPK: coefficient computation + reordering. Restates GpkReo3D
+// (Coefficient/GridProcessingKernel3D.hpp:21-1179). src: natural fine box with
+// element strides (sI, sJ, 1). Coarse nodes go to `coarse` (compact m[0..2]),
+// coefficients to `dst` (strides dI, dJ, 1) at their reordered position.
+// When dst_coarse_too != 0 the coarse nodes are ALSO written to dst (used on
+// the last level so that dst holds the complete result).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_gpk_reo(Box3 b, const T *__restrict__ src, size_t sI, size_t sJ, T *__restrict__ coarse,
+          T *__restrict__ dst, size_t dI, size_t dJ, const T *__restrict__ ratio_r,
+          const T *__restrict__ ratio_c, const T *__restrict__ ratio_f) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t j = blockIdx.y * blockDim.y + threadIdx.y;
+  const uint32_t i = blockIdx.z;
+  if (k >= b.n[2] || j >= b.n[1] || i >= b.n[0]) return;
+  bool ro, co, fo;
+  const uint32_t rp = fine_pos(i, b.n[0], b.m[0], ro);
+  const uint32_t cp = fine_pos(j, b.n[1], b.m[1], co);
+  const uint32_t fp = fine_pos(k, b.n[2], b.m[2], fo);
+  const T center = src[rp * sI + cp * sJ + fp];
+  if (!ro && !co && !fo) {
+    coarse[((size_t)i * b.m[1] + j) * b.m[2] + k] = center;
+    return;
+  }
+  const uint32_t r0 = ro ? rp - 1 : rp, r1 = rp + 1;
+  const uint32_t c0 = co ? cp - 1 : cp, c1 = cp + 1;
+  const uint32_t f0 = fo ? fp - 1 : fp, f1 = fp + 1;
+  T hr[2];
+#pragma unroll
+  for (int a = 0; a < 2; a++) {
+    if (a == 1 && !ro) break;
+    const uint32_t ri = a ? r1 : r0;
+    T gc[2];
+#pragma unroll
+    for (int bb = 0; bb < 2; bb++) {
+      if (bb == 1 && !co) break;
+      const uint32_t ci = bb ? c1 : c0;
+      const T *row = src + ri * sI + ci * sJ;
+      gc[bb] = fo ? lerp_ref(row[f0], row[f1], ratio_f[f0]) : row[f0];
+    }
+    hr[a] = co ? lerp_ref(gc[0], gc[1], ratio_c[c0]) : gc[0];
+  }
+  const T res = ro ? lerp_ref(hr[0], hr[1], ratio_r[r0]) : hr[0];
+  dst[i * dI + j * dJ + k] = center - res;
+}
+
+// GpkRev3D (GridProcessingKernel3D.hpp:1231-2352): natural fine box out of
+// (coarse compact, coefficients in `coef` reordered layout). One thread per
+// fine node; odd nodes add the interpolant of their coarse neighbours.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_gpk_rev(Box3 b, const T *__restrict__ coarse, const T *__restrict__ coef, size_t cI, size_t cJ,
+          T *__restrict__ out, size_t oI, size_t oJ, const T *__restrict__ ratio_r,
+          const T *__restrict__ ratio_c, const T *__restrict__ ratio_f) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t j = blockIdx.y * blockDim.y + threadIdx.y;
+  const uint32_t i = blockIdx.z;
+  if (k >= b.n[2] || j >= b.n[1] || i >= b.n[0]) return;
+  bool ro, co, fo;
+  const uint32_t rp = fine_pos(i, b.n[0], b.m[0], ro);
+  const uint32_t cp = fine_pos(j, b.n[1], b.m[1], co);
+  const uint32_t fp = fine_pos(k, b.n[2], b.m[2], fo);
+  const size_t mJ = b.m[2], mI = (size_t)b.m[1] * b.m[2];
+  // coarse index of the even fine position p (or of the padded last node)
+  auto cidx = [](uint32_t p, uint32_t n, uint32_t m) -> uint32_t {
+    return (p == n - 1) ? m - 1 : p / 2;
+  };
+  if (!ro && !co && !fo) {
+    out[rp * oI + cp * oJ + fp] = coarse[i * mI + j * mJ + k];
+    return;
+  }
+  const uint32_t r0 = cidx(ro ? rp - 1 : rp, b.n[0], b.m[0]), r1 = cidx(rp + 1, b.n[0], b.m[0]);
+  const uint32_t c0 = cidx(co ? cp - 1 : cp, b.n[1], b.m[1]), c1 = cidx(cp + 1, b.n[1], b.m[1]);
+  const uint32_t f0 = cidx(fo ? fp - 1 : fp, b.n[2], b.m[2]), f1 = cidx(fp + 1, b.n[2], b.m[2]);
+  T hr[2];
+#pragma unroll
+  for (int a = 0; a < 2; a++) {
+    if (a == 1 && !ro) break;
+    const uint32_t ri = a ? r1 : r0;
+    T gc[2];
+#pragma unroll
+    for (int bb = 0; bb < 2; bb++) {
+      if (bb == 1 && !co) break;
+      const uint32_t ci = bb ? c1 : c0;
+      const T *row = coarse + ri * mI + ci * mJ;
+      gc[bb] = fo ? lerp_ref(row[f0], row[f1], ratio_f[fp - 1]) : row[f0];
+    }
+    hr[a] = co ? lerp_ref(gc[0], gc[1], ratio_c[cp - 1]) : gc[0];
+  }
+  T res = coef[i * cI + j * cJ + k];
+  res += ro ? lerp_ref(hr[0], hr[1], ratio_r[rp - 1]) : hr[0];
+  out[rp * oI + cp * oJ + fp] = res;
+}
+
+// ---------------------------------------------------------------------------
+// LPK: fused mass matrix * restriction along one axis. Restates
+// Lpk1/2/3Reo3D (Correction/LinearProcessingKernel3D.hpp:27-400, 449-717,
+// 762-1048) with mass_trans (Correction/LPKFunctor.h:77-93) on host-prepared
+// per-node constants (hierarchy.hpp: mass_table).
+// in: (n0,n1,n2) box in reordered layout along AXIS (even part [0,m), odd part
+// [m, n)), strides (iI, iJ, 1). out: same box with AXIS shrunk to m, strides
+// (oI, oJ, 1). zero_i/zero_j (LPK1 only): rows with i < zero_i && j < zero_j
+// read their even part as 0 (zero_r/zero_c/zero_f, :98-101).
+// ---------------------------------------------------------------------------
+template <typename T, int AXIS>
+__global__ void __launch_bounds__(256)
+k_lpk(uint32_t n0, uint32_t n1, uint32_t n2, uint32_t n, uint32_t m, const T *__restrict__ in,
+      size_t iI, size_t iJ, T *__restrict__ out, size_t oI, size_t oJ,
+      const T *__restrict__ mt, uint32_t zero_i, uint32_t zero_j) {
+  // output extents
+  const uint32_t e0 = AXIS == 0 ? m : n0, e1 = AXIS == 1 ? m : n1, e2 = AXIS == 2 ? m : n2;
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t j = blockIdx.y * blockDim.y + threadIdx.y;
+  const uint32_t i = blockIdx.z;
+  if (k >= e2 || j >= e1 || i >= e0) return;
+  const uint32_t q = AXIS == 0 ? i : (AXIS == 1 ? j : k); // coarse index along AXIS
+  const size_t st = AXIS == 0 ? iI : (AXIS == 1 ? iJ : 1);
+  const size_t base = (AXIS == 0 ? 0 : i * iI) + (AXIS == 1 ? 0 : j * iJ) + (AXIS == 2 ? 0 : k);
+  const uint32_t nodd = n - m;
+  const bool ez = (AXIS == 2) && (i < zero_i) && (j < zero_j);
+  const T *pe = in + base;            // even part
+  const T *po = in + base + m * st;   // odd part
+  const T a = (q >= 1 && !ez) ? pe[(q - 1) * st] : (T)0;
+  const T bq = (q >= 1 && q - 1 < nodd) ? po[(q - 1) * st] : (T)0;
+  const T c = ez ? (T)0 : pe[q * st];
+  const T d = (q < nodd) ? po[q * st] : (T)0;
+  const T e = (q + 1 < m && !ez) ? pe[(q + 1) * st] : (T)0;
+  const T w0 = mt[0 * m + q], w1 = mt[1 * m + q], w2 = mt[2 * m + q], w3 = mt[3 * m + q],
+          w4 = mt[4 * m + q], w5 = mt[5 * m + q], w6 = mt[6 * m + q], r1 = mt[7 * m + q],
+          r4 = mt[8 * m + q];
+  const T tb = a * w0 + bq * w1 + c * w2;
+  T tc = bq * w2 + c * w3 + d * w4;
+  const T td = c * w4 + d * w5 + e * w6;
+  tc += tb * r1 + td * r4;
+  out[i * oI + j * oJ + k] = tc;
+}
+
+// ---------------------------------------------------------------------------
+// IPK: Thomas solve along one axis, in place on a compact (n0,n1,n2) box.
+// Restates Ipk1/2/3Reo3D (Correction/IterativeProcessingKernel3D.hpp:28-371,
+// 418-745, 792-1169) with tridiag_forward2/backward2 (IPKFunctor.h:127,147).
+// tt: thomas_table (hierarchy.hpp) of the solved dim: [0,n) forward
+// multiplier, [n,2n) backward am, [2n,3n) backward bm.
+// One thread per pencil. If add_to != nullptr the solution is ADDED (sign=+1)
+// or SUBTRACTED (sign=-1) into add_to (compact, same shape) during the backward
+// sweep instead of being stored (AddND / SubtractND,
+// CopyND/LevelwiseProcessingKernel.hpp:69-74).
+// ---------------------------------------------------------------------------
+template <typename T, int AXIS>
+__global__ void __launch_bounds__(256)
+k_ipk(uint32_t n0, uint32_t n1, uint32_t n2, T *__restrict__ x, const T *__restrict__ tt,
+      T *__restrict__ add_to, int sign) {
+  const uint32_t n = AXIS == 0 ? n0 : (AXIS == 1 ? n1 : n2);
+  // pencil coordinates: the two non-AXIS dims; fastest-varying thread index maps
+  // to the fastest non-AXIS dim
+  const uint32_t pa = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t pb = blockIdx.y * blockDim.y + threadIdx.y;
+  uint32_t ea, eb;
+  size_t base, st;
+  const size_t sI = (size_t)n1 * n2, sJ = n2;
+  if (AXIS == 2) { // pencils over (i=pb, j=pa)
+    ea = n1; eb = n0;
+    if (pa >= ea || pb >= eb) return;
+    base = pb * sI + pa * sJ; st = 1;
+  } else if (AXIS == 1) { // pencils over (i=pb, k=pa)
+    ea = n2; eb = n0;
+    if (pa >= ea || pb >= eb) return;
+    base = pb * sI + pa; st = sJ;
+  } else { // pencils over (j=pb, k=pa)
+    ea = n2; eb = n1;
+    if (pa >= ea || pb >= eb) return;
+    base = pb * sJ + pa; st = sI;
+  }
+  T *p = x + base;
+  T prev = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    T cur = p[i * st];
+    cur = cur - prev * tt[i];
+    p[i * st] = cur;
+    prev = cur;
+  }
+  prev = 0;
+  for (uint32_t kk = 0; kk < n; kk++) {
+    const uint32_t i = n - 1 - kk;
+    T cur = p[i * st];
+    cur = (cur - tt[n + i] * prev) / tt[2 * n + i];
+    if (add_to) {
+      T *q = add_to + base + i * st;
+      if (sign > 0) *q += cur; else *q -= cur;
+    } else {
+      p[i * st] = cur;
+    }
+    prev = cur;
+  }
+}
+
+// dst (strides dI,dJ) <- src (strides sI,sJ) over an (n0,n1,n2) box
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_copy_box(uint32_t n0, uint32_t n1, uint32_t n2, const T *__restrict__ src, size_t sI, size_t sJ,
+           T *__restrict__ dst, size_t dI, size_t dJ) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t j = blockIdx.y * blockDim.y + threadIdx.y;
+  const uint32_t i = blockIdx.z;
+  if (k >= n2 || j >= n1 || i >= n0) return;
+  dst[i * dI + j * dJ + k] = src[i * sI + j * sJ + k];
+}
+
+// ---------------------------------------------------------------------------
+// Level-wise linear quantizer (Quantization/LinearQuantization.hpp:146-264).
+// marks: D arrays concatenated (offset markoff[d]) giving the level of an index
+// along dim d; qz[level] = quantizer (reciprocal for quantize), vol[level] =
+// sqrt(prod volumes) or 1. shape/strides describe the dense array, last dim
+// fastest; idx decomposition from the linear index.
+// ---------------------------------------------------------------------------
+struct QuantMeta {
+  int D;
+  int calc_vol;
+  uint32_t shape[5];
+  uint32_t markoff[5];
+};
+
+template <typename T> __device__ __forceinline__ T abs_t(T x);
+template <> __device__ __forceinline__ float abs_t<float>(float x) { return fabsf(x); }
+template <> __device__ __forceinline__ double abs_t<double>(double x) { return fabs(x); }
+template <typename T> __device__ __forceinline__ T copysign_t(T x, T y);
+template <> __device__ __forceinline__ float copysign_t<float>(float x, float y) { return copysignf(x, y); }
+template <> __device__ __forceinline__ double copysign_t<double>(double x, double y) { return copysign(x, y); }
+
+template <typename T>
+__device__ __forceinline__ int64_t quantize_one(T t, T quantizer, T volume) {
+  return (int64_t)copysign_t((T)0.5 + abs_t(t * quantizer * volume), t);
+}
+
+__device__ __forceinline__ int level_of(const QuantMeta &m, const int *__restrict__ marks,
+                                        size_t lin) {
+  int level = 0;
+  for (int d = m.D - 1; d >= 0; d--) {
+    const uint32_t id = (uint32_t)(lin % m.shape[d]);
+    lin /= m.shape[d];
+    const int lv = marks[m.markoff[d] + id];
+    level = lv > level ? lv : level;
+  }
+  return level;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_quantize(QuantMeta m, size_t total, const T *__restrict__ v, const int *__restrict__ marks,
+           const T *__restrict__ qz, const T *__restrict__ vol, int64_t dict_size,
+           int prep_huffman, int64_t *__restrict__ q, unsigned long long *outlier_count,
+           uint64_t *__restrict__ outlier_idx, int64_t *__restrict__ outlier_val,
+           unsigned long long outlier_cap) {
+  for (size_t lin = (size_t)blockIdx.x * blockDim.x + threadIdx.x; lin < total;
+       lin += (size_t)gridDim.x * blockDim.x) {
+    const int level = m.calc_vol ? level_of(m, marks, lin) : 0;
+    const T t = v[lin];
+    int64_t qd = quantize_one(t, qz[level], m.calc_vol ? vol[level] : (T)1);
+    if (prep_huffman) {
+      qd += dict_size / 2;
+      if (!(qd >= 0 && qd < dict_size)) {
+        const unsigned long long o = atomicAdd(outlier_count, 1ULL);
+        if (o < outlier_cap) {
+          outlier_idx[o] = lin;
+          outlier_val[o] = qd;
+        }
+        qd = 0;
+      }
+    }
+    q[lin] = qd;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_dequantize(QuantMeta m, size_t total, const int64_t *__restrict__ q,
+             const int *__restrict__ marks, const T *__restrict__ qz, const T *__restrict__ vol,
+             int64_t dict_size, int prep_huffman, T *__restrict__ v) {
+  for (size_t lin = (size_t)blockIdx.x * blockDim.x + threadIdx.x; lin < total;
+       lin += (size_t)gridDim.x * blockDim.x) {
+    const int level = m.calc_vol ? level_of(m, marks, lin) : 0;
+    int64_t qd = q[lin];
+    if (prep_huffman) qd -= dict_size / 2;
+    const T volume = m.calc_vol ? vol[level] : (T)1;
+    v[lin] = (qz[level] * volume) * (T)qd;
+  }
+}
+
+// OutlierRestore (LinearQuantization.hpp:304-350)
+__global__ void __launch_bounds__(256)
+k_outlier_restore(int64_t *__restrict__ q, const uint64_t *__restrict__ idx,
+                  const int64_t *__restrict__ val, uint64_t count) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < count) q[idx[t]] = val[t];
+}
+
+// ---------------------------------------------------------------------------
+// Norm reductions (CompressionLowLevel/NormCalculator.hpp:44-71). absmax is
+// order independent; the square sum is accumulated per thread / wave / block in
+// T and combined with one atomic per block on a double, so it is deterministic
+// only up to the atomic order (the reference's GPU path is a tree reduction and
+// is not bit-reproducible either).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_absmax(const T *__restrict__ v, size_t n, unsigned long long *out_bits) {
+  T m = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const T a = abs_t(v[i]);
+    m = a > m ? a : m;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const T o = __shfl_down(m, off, 64);
+    m = o > m ? o : m;
+  }
+  __shared__ T sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); w++) m = sm[w] > m ? sm[w] : m;
+    // non-negative IEEE values order like their bit patterns
+    unsigned long long bits;
+    if (sizeof(T) == 4) bits = __float_as_uint((float)m); else bits = __double_as_longlong((double)m);
+    atomicMax(out_bits, bits);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_sqsum(const T *__restrict__ v, size_t n, double *out) {
+  T acc = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    acc += v[i] * v[i];
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ T sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); w++) acc += sm[w];
+    atomicAdd(out, (double)acc);
+  }
+}
+
+} // namespace mgh
