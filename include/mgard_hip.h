@@ -148,6 +148,9 @@ int mgh_dequantize_recompose(mgh_hierarchy *h, int64_t *d_quantized, int error_b
  * (Reference counterpart: DeviceRuntime::TimingAllKernels,
  * src/mgard-x/RuntimeX/DeviceAdapters/DeviceAdapterSerial.cpp:18-19.) */
 int mgh_profile_enable(mgh_hierarchy *h, int enable);
+/* Restrict the event bracketing to launches of one kernel name (NULL = all), so
+ * that a timed region can carry events on its dominant kernel only. */
+int mgh_profile_filter(mgh_hierarchy *h, const char *kernel_name_or_null);
 /* Writes up to cap entries; returns number of distinct kernels. names[i] points
  * to a static string. */
 int mgh_profile_read(mgh_hierarchy *h, const char **names, double *total_ms, uint64_t *launches,

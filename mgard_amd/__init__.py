@@ -23,7 +23,7 @@ SYMBOLS = [
     "mgh_l_target", "mgh_level_shape", "mgh_total_num_elems", "mgh_device_bytes",
     "mgh_hierarchy_table", "mgh_norm", "mgh_decompose", "mgh_recompose", "mgh_quantize",
     "mgh_dequantize", "mgh_decompose_quantize", "mgh_dequantize_recompose",
-    "mgh_profile_enable", "mgh_profile_read",
+    "mgh_profile_enable", "mgh_profile_filter", "mgh_profile_read",
 ]
 
 
@@ -73,6 +73,7 @@ def load_library():
     L.mgh_dequantize_recompose.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, C.c_double,
                                            u64, C.c_int, vp, vp, u64, vp, vp]
     L.mgh_profile_enable.argtypes = [vp, C.c_int]
+    L.mgh_profile_filter.argtypes = [vp, C.c_char_p]
     L.mgh_profile_read.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), u64p,
                                    C.c_int, C.c_int]
     _lib = L
@@ -245,7 +246,8 @@ class Hierarchy:
         return out
 
     # ---- per-kernel timing (HIP events on the launch stream) ----
-    def profile(self, enable=True):
+    def profile(self, enable=True, only=None):
+        _check(load_library().mgh_profile_filter(self._h, only.encode() if only else None))
         _check(load_library().mgh_profile_enable(self._h, int(enable)))
 
     def profile_read(self, reset=True):

@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -18,6 +19,8 @@
 
 #include "hierarchy.hpp"
 #include "kernels_v1.hpp"
+#include "kernels_ipk.hpp"
+#include "kernels_fused.hpp"
 
 namespace {
 
@@ -52,6 +55,8 @@ struct mgh_hierarchy {
   void *host = nullptr;  // HostHierarchy<T>*
   void *impl = nullptr;  // DeviceState<T>*
   bool profiling = false;
+  bool force_v1 = false;  // MGH_FORCE_V1=1: run the one-thread-per-element kernels only
+  std::string prof_filter;  // empty = every kernel
   std::map<std::string, ProfileEntry> prof;
   size_t device_bytes = 0;
 };
@@ -97,7 +102,7 @@ template <typename T> DeviceState<T> *DS(const mgh_hierarchy *h) {
 
 // ---- profiled launch -------------------------------------------------------
 template <typename F> int launch(mgh_hierarchy *h, const char *name, hipStream_t s, F &&f) {
-  if (!h->profiling) {
+  if (!h->profiling || (!h->prof_filter.empty() && h->prof_filter != name)) {
     f();
     HIP_TRY(hipGetLastError());
     return MGH_SUCCESS;
@@ -234,6 +239,87 @@ template <typename T> int ensure_scratch(mgh_hierarchy *h) {
   return MGH_SUCCESS;
 }
 
+// LDS budget for the IPK tiles: whole pencils of 64 (or 32) lanes must fit.
+constexpr size_t kLdsPerCU = 160 * 1024;
+constexpr size_t kIpkLdsTwoPerCU = 80 * 1024;
+
+template <typename K> int allow_big_lds(K kernel) {
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCU));
+  return MGH_SUCCESS;
+}
+
+// Thomas solve along `axis` of the compact (m[0], m[1], m[2]) box.
+template <typename T>
+int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt, T *add_to,
+               int sign, hipStream_t s) {
+  const uint32_t n = m[axis];
+  static const char *names[3] = {"ipk_r", "ipk_c", "ipk_f"};
+  const char *name = names[axis];
+  if (axis == 2) {
+    const uint32_t npencil = m[0] * m[1];
+    const uint32_t pad = (n % 2 == 0) ? 1u : 0u;
+    const uint32_t magic = (uint32_t)((((uint64_t)1 << 32) + n - 1) / n);  // e/n for e < 2^17
+    const size_t row = (size_t)(n + pad) * sizeof(T);
+    if (64 * row <= kIpkLdsTwoPerCU || (64 * row <= kLdsPerCU && 32 * row > kIpkLdsTwoPerCU)) {
+      static bool once = false;
+      if (!once) { TRY(allow_big_lds(k_ipk_lds_contig<T, 64>)); once = true; }
+      return launch(h, name, s, [&] {
+        k_ipk_lds_contig<T, 64><<<(npencil + 63) / 64, 256, 64 * row, s>>>(
+            npencil, n, pad, magic, x, tt, add_to, sign);
+      });
+    }
+    if (32 * row <= kLdsPerCU) {
+      static bool once = false;
+      if (!once) { TRY(allow_big_lds(k_ipk_lds_contig<T, 32>)); once = true; }
+      return launch(h, name, s, [&] {
+        k_ipk_lds_contig<T, 32><<<(npencil + 31) / 32, 256, 32 * row, s>>>(
+            npencil, n, pad, magic, x, tt, add_to, sign);
+      });
+    }
+  } else {
+    const uint32_t n_outer = axis == 1 ? m[0] : 1;
+    const uint32_t n_inner = axis == 1 ? m[2] : m[1] * m[2];
+    const size_t outer_stride = (size_t)m[1] * m[2];
+    const size_t stride = axis == 1 ? (size_t)m[2] : (size_t)m[1] * m[2];
+    const uint32_t np = n_outer * n_inner;
+    const size_t col = (size_t)n * sizeof(T);
+    if (64 * col <= kIpkLdsTwoPerCU || (64 * col <= kLdsPerCU && 32 * col > kIpkLdsTwoPerCU)) {
+      static bool once = false;
+      if (!once) { TRY(allow_big_lds(k_ipk_lds_strided<T, 64>)); once = true; }
+      return launch(h, name, s, [&] {
+        k_ipk_lds_strided<T, 64><<<(np + 63) / 64, 256, 64 * col, s>>>(
+            n_outer, n_inner, outer_stride, stride, n, x, tt, add_to, sign);
+      });
+    }
+    if (32 * col <= kLdsPerCU) {
+      static bool once = false;
+      if (!once) { TRY(allow_big_lds(k_ipk_lds_strided<T, 32>)); once = true; }
+      return launch(h, name, s, [&] {
+        k_ipk_lds_strided<T, 32><<<(np + 31) / 32, 256, 32 * col, s>>>(
+            n_outer, n_inner, outer_stride, stride, n, x, tt, add_to, sign);
+      });
+    }
+  }
+  // pencils too long for LDS: one thread per pencil straight from global memory
+  const dim3 pb(64, 1, 1);
+  if (axis == 2) {
+    const dim3 g((m[1] + 63) / 64, m[0], 1);
+    return launch(h, name, s, [&] {
+      k_ipk<T, 2><<<g, pb, 0, s>>>(m[0], m[1], m[2], x, tt, add_to, sign);
+    });
+  } else if (axis == 1) {
+    const dim3 g((m[2] + 63) / 64, m[0], 1);
+    return launch(h, name, s, [&] {
+      k_ipk<T, 1><<<g, pb, 0, s>>>(m[0], m[1], m[2], x, tt, add_to, sign);
+    });
+  }
+  const dim3 g((m[2] + 63) / 64, m[1], 1);
+  return launch(h, name, s, [&] {
+    k_ipk<T, 0><<<g, pb, 0, s>>>(m[0], m[1], m[2], x, tt, add_to, sign);
+  });
+}
+
 // ---- correction = IPK(LPK(coefficients)) then +/- into nodal[l-1] --------------
 // CalcCorrection3D (Correction/CalcCorrection3D.hpp:26-185) + AddND/SubtractND.
 template <typename T>
@@ -268,31 +354,106 @@ int correction(mgh_hierarchy *h, int l, const T *coef, size_t cI, size_t cJ, T *
   }
   // IPK along f, c, r; the last one applies the correction to `target`
   const int last = t.active[0] ? 0 : (t.active[1] ? 1 : 2);
+  TRY(ipk_launch<T>(h, 2, b.m, cur, t.thomas[2], last == 2 ? target : nullptr, sign, s));
+  if (t.active[1])
+    TRY(ipk_launch<T>(h, 1, b.m, cur, t.thomas[1], last == 1 ? target : nullptr, sign, s));
+  if (t.active[0]) TRY(ipk_launch<T>(h, 0, b.m, cur, t.thomas[0], target, sign, s));
+  return MGH_SUCCESS;
+}
+
+// Quantizer constants on the host (LinearQuantization.hpp:495-545 + volumes :186-195)
+template <typename T> struct QuantParams {
+  std::vector<T> qz, vol;  // per level
+  int64_t dict_size = 0;
+  int prep_huffman = 0;
+  int64_t *q = nullptr;
+  unsigned long long *ocount = nullptr;
+  uint64_t *oidx = nullptr;
+  int64_t *oval = nullptr;
+  unsigned long long ocap = 0;
+};
+
+template <typename T>
+QuantParams<T> make_quant_params(mgh_hierarchy *h, int ebtype, double tol, double s, double norm,
+                                 bool reciprocal) {
+  auto *hh = HH<T>(h);
+  QuantParams<T> qp;
+  qp.qz.resize(h->L + 1);
+  qp.vol.resize(h->L + 1);
+  hh->quantizers(ebtype, (T)tol, (T)s, (T)norm, reciprocal, qp.qz.data());
+  const bool calc_vol = !((T)s == std::numeric_limits<T>::infinity());
+  for (int l = 0; l <= h->L; l++) qp.vol[l] = calc_vol ? hh->level_volume(l, !reciprocal) : (T)1;
+  return qp;
+}
+
+// Level loop on the fused kernels (3 active dims): per level one fused
+// coefficient/quantize/load-vector pass, three Thomas solves (the last one adds
+// the correction into the coarse nodal array), then the head.
+template <typename T, int OUT>
+int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams<T> *qp,
+                    hipStream_t s) {
+  auto *ds = DS<T>(h);
+  const int L = h->L;
+  const size_t fI = ds->full_I, fJ = ds->full_J;
+  const T *src = data;
+  size_t sI = fI, sJ = fJ;
+  constexpr int TC = 8, TF = 32, RCH = 16;
+  FusedArgs<T> A{};
+  A.coef = coeff;
+  A.dI = fI;
+  A.dJ = fJ;
+  if (OUT == OUT_Q) {
+    A.q = qp->q;
+    A.dict_size = qp->dict_size;
+    A.prep_huffman = qp->prep_huffman;
+    A.outlier_count = qp->ocount;
+    A.outlier_idx = qp->oidx;
+    A.outlier_val = qp->oval;
+    A.outlier_cap = qp->ocap;
+  }
+  for (int l = L; l >= 1; l--) {
+    const LevelTables<T> &t = ds->lt[l];
+    const Box3 &b = t.box;
+    for (int k = 0; k < 3; k++) {
+      A.n[k] = (int)b.n[k];
+      A.m[k] = (int)b.m[k];
+      A.ratio[k] = t.ratio[k];
+      A.mass[k] = t.mass[k];
+    }
+    A.u = src;
+    A.uI = sI;
+    A.uJ = sJ;
+    A.coarse = ds->nodal[l - 1];
+    A.load = ds->t3;
+    if (OUT == OUT_Q) {
+      A.quantizer = qp->qz[l];
+      A.volume = qp->vol[l];
+    }
+    const dim3 grid((b.m[2] + TF - 1) / TF, (b.m[1] + TC - 1) / TC, (b.m[0] + RCH - 1) / RCH);
+    TRY(launch(h, OUT == OUT_Q ? "level_fused_q" : "level_fused", s, [&] {
+      k_level_fused<T, OUT, TC, TF, RCH><<<grid, 256, 0, s>>>(A);
+    }));
+    TRY(ipk_launch<T>(h, 2, b.m, ds->t3, t.thomas[2], nullptr, +1, s));
+    TRY(ipk_launch<T>(h, 1, b.m, ds->t3, t.thomas[1], nullptr, +1, s));
+    TRY(ipk_launch<T>(h, 0, b.m, ds->t3, t.thomas[0], ds->nodal[l - 1], +1, s));
+    src = ds->nodal[l - 1];
+    sJ = b.m[2];
+    sI = (size_t)b.m[1] * b.m[2];
+  }
   {
-    const dim3 pb(64, 1, 1);  // pencils over (i, j)
-    const dim3 g((b.m[1] + 63) / 64, b.m[0], 1);
-    TRY(launch(h, "ipk_f", s, [&] {
-      k_ipk<T, 2><<<g, pb, 0, s>>>(b.m[0], b.m[1], b.m[2], cur, t.thomas[2],
-                                   last == 2 ? target : nullptr, sign);
-    }));
-  }
-  if (t.active[1]) {
-    const dim3 pb(64, 1, 1);  // pencils over (i, k)
-    const dim3 g((b.m[2] + 63) / 64, b.m[0], 1);
-    TRY(launch(h, "ipk_c", s, [&] {
-      k_ipk<T, 1><<<g, pb, 0, s>>>(b.m[0], b.m[1], b.m[2], cur, t.thomas[1],
-                                   last == 1 ? target : nullptr, sign);
-    }));
-  }
-  if (t.active[0]) {
-    const dim3 pb(64, 1, 1);  // pencils over (j, k)
-    const dim3 g((b.m[2] + 63) / 64, b.m[1], 1);
-    TRY(launch(h, "ipk_r", s, [&] {
-      k_ipk<T, 0><<<g, pb, 0, s>>>(b.m[0], b.m[1], b.m[2], cur, t.thomas[0], target, sign);
+    const Box3 &b = ds->lt[1].box;
+    if (OUT == OUT_Q) {
+      A.quantizer = qp->qz[0];
+      A.volume = qp->vol[0];
+    }
+    TRY(launch(h, "head_out", s, [&] {
+      k_head_out<T, OUT><<<1, 256, 0, s>>>((int)b.m[0], (int)b.m[1], (int)b.m[2], ds->nodal[0], A);
     }));
   }
   return MGH_SUCCESS;
 }
+
+inline bool fused_ok(const mgh_hierarchy *h) { return h->D == 3 && h->L >= 1; }
 
 template <typename T>
 int decompose_impl(mgh_hierarchy *h, const T *data, T *coeff, hipStream_t s) {
@@ -307,6 +468,7 @@ int decompose_impl(mgh_hierarchy *h, const T *data, T *coeff, hipStream_t s) {
     HIP_TRY(hipMemcpyAsync(ds->scratch_full, data, h->total * sizeof(T), hipMemcpyDeviceToDevice, s));
     src = ds->scratch_full;
   }
+  if (fused_ok(h) && !h->force_v1) return decompose_fused<T, OUT_T>(h, src, coeff, nullptr, s);
   const dim3 blk(64, 4, 1);
   for (int l = L; l >= 1; l--) {
     const LevelTables<T> &t = ds->lt[l];
@@ -334,6 +496,7 @@ int decompose_impl(mgh_hierarchy *h, const T *data, T *coeff, hipStream_t s) {
   }
   return MGH_SUCCESS;
 }
+
 
 template <typename T>
 int recompose_impl(mgh_hierarchy *h, const T *coeff, T *data, hipStream_t s) {
@@ -437,7 +600,7 @@ int norm_impl(mgh_hierarchy *h, const T *data, double s, double *out, hipStream_
   auto *ds = DS<T>(h);
   auto *hh = HH<T>(h);
   const size_t total = h->total;
-  const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 16);
+  const unsigned grid = (unsigned)std::min<size_t>((total + 1023) / 1024, 256 * 8);
   HIP_TRY(hipMemsetAsync(ds->scalar, 0, 8, st));
   T norm;
   if ((T)s == std::numeric_limits<T>::infinity()) {
@@ -489,6 +652,21 @@ int64_t table_impl(const mgh_hierarchy *h, int kind, int level, int dim, void *o
   return (int64_t)v->size();
 }
 
+template <typename T>
+int fused_q_entry(mgh_hierarchy *h, const T *data, int ebtype, double tol, double s, double norm,
+                  uint64_t dict_size, int prep_huffman, int64_t *q, uint64_t *ocount,
+                  uint64_t *oidx, int64_t *oval, uint64_t ocap, hipStream_t st) {
+  QuantParams<T> qp = make_quant_params<T>(h, ebtype, tol, s, norm, true);
+  qp.dict_size = (int64_t)dict_size;
+  qp.prep_huffman = prep_huffman;
+  qp.q = q;
+  qp.ocount = (unsigned long long *)ocount;
+  qp.oidx = oidx;
+  qp.oval = oval;
+  qp.ocap = ocap;
+  return decompose_fused<T, OUT_Q>(h, data, nullptr, &qp, st);
+}
+
 #define DISPATCH(h, call_f, call_d)                                              \
   ((h)->dtype == MGH_FLOAT ? (call_f) : (call_d))
 
@@ -515,6 +693,10 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     return fail(MGH_ERR_NO_DEVICE, "HIP device " + std::to_string(device) + " not available");
   HIP_TRY(hipSetDevice(device));
   auto *h = new mgh_hierarchy();
+  {
+    const char *e = std::getenv("MGH_FORCE_V1");
+    h->force_v1 = e && e[0] == '1';
+  }
   h->dtype = dtype;
   h->device = device;
   h->D = D;
@@ -635,18 +817,32 @@ int mgh_dequantize(mgh_hierarchy *h, int64_t *d_quantized, int ebtype, double to
                                           (double *)d_coeff, (hipStream_t)stream));
 }
 
-int mgh_decompose_quantize(mgh_hierarchy *h, const void *d_data, int ebtype, double tol, double s,
+int mgh_decompose_quantize(mgh_hierarchy *h, const void *d_data, int error_bound_type, double tol, double s,
                            double norm, double *h_norm_out, uint64_t dict_size, int prep_huffman,
                            int64_t *d_quantized, uint64_t *d_outlier_count,
                            uint64_t *d_outlier_idx, int64_t *d_outlier_val,
                            uint64_t outlier_capacity, void *d_coeff_opt, void *stream) {
   if (!h || !d_data || !d_quantized) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
   HIP_TRY(hipSetDevice(h->device));
-  if (ebtype == MGH_REL && !(norm > 0)) {
+  if (error_bound_type == MGH_REL && !(norm > 0)) {
     int rc = mgh_norm(h, d_data, s, &norm, stream);
     if (rc != MGH_SUCCESS) return rc;
   }
   if (h_norm_out) *h_norm_out = norm;
+  if (!d_coeff_opt && fused_ok(h) && !h->force_v1) {
+    if (prep_huffman && (!d_outlier_count || (outlier_capacity && (!d_outlier_idx || !d_outlier_val))))
+      return fail(MGH_ERR_INVALID_ARGUMENT, "outlier buffers required with prep_huffman");
+    if (d_outlier_count) HIP_TRY(hipMemsetAsync(d_outlier_count, 0, sizeof(uint64_t), (hipStream_t)stream));
+    return DISPATCH(h,
+                    fused_q_entry<float>(h, (const float *)d_data, error_bound_type, tol, s, norm,
+                                         dict_size, prep_huffman, d_quantized, d_outlier_count,
+                                         d_outlier_idx, d_outlier_val, outlier_capacity,
+                                         (hipStream_t)stream),
+                    fused_q_entry<double>(h, (const double *)d_data, error_bound_type, tol, s, norm,
+                                          dict_size, prep_huffman, d_quantized, d_outlier_count,
+                                          d_outlier_idx, d_outlier_val, outlier_capacity,
+                                          (hipStream_t)stream));
+  }
   void *coeff = d_coeff_opt;
   if (!coeff) {
     int rc = DISPATCH(h, ensure_scratch<float>(h), ensure_scratch<double>(h));
@@ -657,8 +853,9 @@ int mgh_decompose_quantize(mgh_hierarchy *h, const void *d_data, int ebtype, dou
   }
   int rc = mgh_decompose(h, d_data, coeff, stream);
   if (rc != MGH_SUCCESS) return rc;
-  return mgh_quantize(h, coeff, ebtype, tol, s, norm, dict_size, prep_huffman, d_quantized,
-                      d_outlier_count, d_outlier_idx, d_outlier_val, outlier_capacity, stream);
+  return mgh_quantize(h, coeff, error_bound_type, tol, s, norm, dict_size, prep_huffman,
+                      d_quantized, d_outlier_count, d_outlier_idx, d_outlier_val,
+                      outlier_capacity, stream);
 }
 
 int mgh_dequantize_recompose(mgh_hierarchy *h, int64_t *d_quantized, int ebtype, double tol,
@@ -675,6 +872,12 @@ int mgh_dequantize_recompose(mgh_hierarchy *h, int64_t *d_quantized, int ebtype,
 int mgh_profile_enable(mgh_hierarchy *h, int enable) {
   if (!h) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
   h->profiling = enable != 0;
+  return MGH_SUCCESS;
+}
+
+int mgh_profile_filter(mgh_hierarchy *h, const char *name) {
+  if (!h) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
+  h->prof_filter = name ? name : "";
   return MGH_SUCCESS;
 }
 

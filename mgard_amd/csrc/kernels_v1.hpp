@@ -342,12 +342,32 @@ k_outlier_restore(int64_t *__restrict__ q, const uint64_t *__restrict__ idx,
 // only up to the atomic order (the reference's GPU path is a tree reduction and
 // is not bit-reproducible either).
 // ---------------------------------------------------------------------------
+template <typename T> struct Vec16 { using type = float4; static constexpr int N = 4; };
+template <> struct Vec16<double> { using type = double2; static constexpr int N = 2; };
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_absmax(const T *__restrict__ v, size_t n, unsigned long long *out_bits) {
+  using V = typename Vec16<T>::type;
+  constexpr int VN = Vec16<T>::N;
   T m = 0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (size_t)gridDim.x * blockDim.x) {
+  // 16-byte loads over the aligned body (v comes 16-byte aligned from the allocator;
+  // a misaligned pointer falls back to the scalar loop entirely)
+  const bool aligned = (reinterpret_cast<uintptr_t>(v) & 15) == 0;
+  const size_t nvec = aligned ? n / VN : 0;
+  const V *vv = reinterpret_cast<const V *>(v);
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nth = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = tid; i < nvec; i += nth) {
+    const V x = vv[i];
+    const T *xs = reinterpret_cast<const T *>(&x);
+#pragma unroll
+    for (int u = 0; u < VN; u++) {
+      const T a = abs_t(xs[u]);
+      m = a > m ? a : m;
+    }
+  }
+  for (size_t i = nvec * VN + tid; i < n; i += nth) {
     const T a = abs_t(v[i]);
     m = a > m ? a : m;
   }

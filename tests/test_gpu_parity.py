@@ -221,3 +221,23 @@ def test_invalid_arguments():
         mg.Hierarchy((2, 5))          # dims < 3 are rejected (Hierarchy.hpp:742-756)
     with pytest.raises(mg.MgardHipError):
         mg.Hierarchy((5,) * 6)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(17, 20, 33), (34, 33, 32), (65, 70, 129)])
+def test_simple_kernels_match_fused_kernels(shape, dt, monkeypatch):
+    """MGH_FORCE_V1=1 selects the one-thread-per-element kernels; both kernel sets must give
+    the oracle's bits."""
+    torch, mg = _gpu()
+    u = smooth_field(shape, dt, noise=1e-2)
+    ref = oracle.Hierarchy(shape, dt).decompose(u)
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MGH_FORCE_V1", flag)
+        h = mg.Hierarchy(shape, dt)
+        c = h.decompose(torch.from_numpy(u).cuda())
+        assert_bit_equal(c.cpu().numpy(), ref, "MGH_FORCE_V1=%s" % flag)
+        q, oi, ov, n, nrm = h.decompose_quantize(torch.from_numpy(u).cuda(), mg.ABS, 1e-3, np.inf, 1.0)
+        rq, roi, rov, rn = oracle.Hierarchy(shape, dt).quantize(ref, oracle.ABS, dt(1e-3), dt(np.inf), dt(1))
+        assert n == rn
+        np.testing.assert_array_equal(q.cpu().numpy(), rq)
+        h.close()
