@@ -21,6 +21,7 @@
 #include "kernels_v1.hpp"
 #include "kernels_ipk.hpp"
 #include "kernels_fused.hpp"
+#include "kernels_tail.hpp"
 
 namespace {
 
@@ -241,7 +242,6 @@ template <typename T> int ensure_scratch(mgh_hierarchy *h) {
 
 // LDS budget for the IPK tiles: whole pencils of 64 (or 32) lanes must fit.
 constexpr size_t kLdsPerCU = 160 * 1024;
-constexpr size_t kIpkLdsTwoPerCU = 80 * 1024;
 
 template <typename K> int allow_big_lds(K kernel) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
@@ -256,50 +256,55 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
   const uint32_t n = m[axis];
   static const char *names[3] = {"ipk_r", "ipk_c", "ipk_f"};
   const char *name = names[axis];
-  if (axis == 2) {
-    const uint32_t npencil = m[0] * m[1];
+  // tile width (pencils per workgroup): whole pencils must fit in LDS; among the fitting
+  // widths take the one that needs the fewest "rounds" of resident workgroups
+  const size_t pencil_bytes = (size_t)(n + (axis == 2 && n % 2 == 0 ? 1 : 0)) * sizeof(T);
+  const uint32_t npencil = axis == 2 ? m[0] * m[1] : (axis == 1 ? m[0] * m[2] : m[1] * m[2]);
+  int best_w = 0;
+  size_t best_rounds = ~(size_t)0;
+  for (int w : {64, 48, 32, 16}) {
+    const size_t lds = w * pencil_bytes;
+    if (lds > kLdsPerCU) continue;
+    const size_t per_cu = std::min<size_t>(kLdsPerCU / lds, 8);
+    const size_t blocks = (npencil + w - 1) / w;
+    const size_t rounds = (blocks + per_cu * 256 - 1) / (per_cu * 256);
+    if (rounds < best_rounds) {
+      best_rounds = rounds;
+      best_w = w;
+    }
+  }
+  if (axis == 2 && best_w) {
     const uint32_t pad = (n % 2 == 0) ? 1u : 0u;
     const uint32_t magic = (uint32_t)((((uint64_t)1 << 32) + n - 1) / n);  // e/n for e < 2^17
-    const size_t row = (size_t)(n + pad) * sizeof(T);
-    if (64 * row <= kIpkLdsTwoPerCU || (64 * row <= kLdsPerCU && 32 * row > kIpkLdsTwoPerCU)) {
-      static bool once = false;
-      if (!once) { TRY(allow_big_lds(k_ipk_lds_contig<T, 64>)); once = true; }
-      return launch(h, name, s, [&] {
-        k_ipk_lds_contig<T, 64><<<(npencil + 63) / 64, 256, 64 * row, s>>>(
-            npencil, n, pad, magic, x, tt, add_to, sign);
-      });
-    }
-    if (32 * row <= kLdsPerCU) {
-      static bool once = false;
-      if (!once) { TRY(allow_big_lds(k_ipk_lds_contig<T, 32>)); once = true; }
-      return launch(h, name, s, [&] {
-        k_ipk_lds_contig<T, 32><<<(npencil + 31) / 32, 256, 32 * row, s>>>(
-            npencil, n, pad, magic, x, tt, add_to, sign);
-      });
-    }
-  } else {
+    static bool once = false;
+    if (!once) { TRY(allow_big_lds(k_ipk_lds_contig<T>)); once = true; }
+    const uint32_t P = (uint32_t)best_w;
+    return launch(h, name, s, [&] {
+      k_ipk_lds_contig<T><<<(npencil + P - 1) / P, 256, P * pencil_bytes, s>>>(
+          npencil, n, pad, magic, P, x, tt, add_to, sign);
+    });
+  }
+  if (axis != 2 && best_w) {
     const uint32_t n_outer = axis == 1 ? m[0] : 1;
     const uint32_t n_inner = axis == 1 ? m[2] : m[1] * m[2];
     const size_t outer_stride = (size_t)m[1] * m[2];
     const size_t stride = axis == 1 ? (size_t)m[2] : (size_t)m[1] * m[2];
-    const uint32_t np = n_outer * n_inner;
-    const size_t col = (size_t)n * sizeof(T);
-    if (64 * col <= kIpkLdsTwoPerCU || (64 * col <= kLdsPerCU && 32 * col > kIpkLdsTwoPerCU)) {
-      static bool once = false;
-      if (!once) { TRY(allow_big_lds(k_ipk_lds_strided<T, 64>)); once = true; }
-      return launch(h, name, s, [&] {
-        k_ipk_lds_strided<T, 64><<<(np + 63) / 64, 256, 64 * col, s>>>(
-            n_outer, n_inner, outer_stride, stride, n, x, tt, add_to, sign);
-      });
-    }
-    if (32 * col <= kLdsPerCU) {
-      static bool once = false;
-      if (!once) { TRY(allow_big_lds(k_ipk_lds_strided<T, 32>)); once = true; }
-      return launch(h, name, s, [&] {
-        k_ipk_lds_strided<T, 32><<<(np + 31) / 32, 256, 32 * col, s>>>(
-            n_outer, n_inner, outer_stride, stride, n, x, tt, add_to, sign);
-      });
-    }
+    const size_t lds = best_w * pencil_bytes;
+    const unsigned blocks = (npencil + best_w - 1) / best_w;
+#define MGH_STRIDED(W)                                                                        \
+  {                                                                                           \
+    static bool once = false;                                                                 \
+    if (!once) { TRY(allow_big_lds(k_ipk_lds_strided<T, W>)); once = true; }                  \
+    return launch(h, name, s, [&] {                                                           \
+      k_ipk_lds_strided<T, W><<<blocks, 256, lds, s>>>(n_outer, n_inner, outer_stride,        \
+                                                       stride, n, x, tt, add_to, sign);       \
+    });                                                                                       \
+  }
+    if (best_w == 64) MGH_STRIDED(64)
+    if (best_w == 48) MGH_STRIDED(48)
+    if (best_w == 32) MGH_STRIDED(32)
+    MGH_STRIDED(16)
+#undef MGH_STRIDED
   }
   // pencils too long for LDS: one thread per pencil straight from global memory
   const dim3 pb(64, 1, 1);
@@ -397,7 +402,7 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
   const size_t fI = ds->full_I, fJ = ds->full_J;
   const T *src = data;
   size_t sI = fI, sJ = fJ;
-  constexpr int TC = 8, TF = 32, RCH = 16;
+  constexpr int TC = 8, TF = 32;
   FusedArgs<T> A{};
   A.coef = coeff;
   A.dI = fI;
@@ -411,7 +416,16 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
     A.outlier_val = qp->oval;
     A.outlier_cap = qp->ocap;
   }
-  for (int l = L; l >= 1; l--) {
+  // levels whose working set fits in one workgroup's LDS run inside the tail kernel
+  constexpr size_t kTailLdsMax = 150 * 1024;
+  int l_tail = 0;  // levels l_tail .. 1 go to the tail (0 = none)
+  for (int l = std::min(L, kTailMaxLevels); l >= 1; l--) {
+    if (tail_lds_elems(ds->lt[l].box) * sizeof(T) <= kTailLdsMax) {
+      l_tail = l;
+      break;
+    }
+  }
+  for (int l = L; l > l_tail; l--) {
     const LevelTables<T> &t = ds->lt[l];
     const Box3 &b = t.box;
     for (int k = 0; k < 3; k++) {
@@ -429,10 +443,20 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
       A.quantizer = qp->qz[l];
       A.volume = qp->vol[l];
     }
-    const dim3 grid((b.m[2] + TF - 1) / TF, (b.m[1] + TC - 1) / TC, (b.m[0] + RCH - 1) / RCH);
-    TRY(launch(h, OUT == OUT_Q ? "level_fused_q" : "level_fused", s, [&] {
-      k_level_fused<T, OUT, TC, TF, RCH><<<grid, 256, 0, s>>>(A);
-    }));
+    // long marches (RCH = 16: 9% r-halo) when there are plenty of tiles, short ones
+    // (RCH = 4) on the small levels where the march length is pure latency
+    const unsigned gx = (b.m[2] + TF - 1) / TF, gy = (b.m[1] + TC - 1) / TC;
+    if ((size_t)gx * gy * ((b.m[0] + 15) / 16) >= 2048) {
+      const dim3 grid(gx, gy, (b.m[0] + 15) / 16);
+      TRY(launch(h, OUT == OUT_Q ? "level_fused_q" : "level_fused", s, [&] {
+        k_level_fused<T, OUT, TC, TF, 16><<<grid, 256, 0, s>>>(A);
+      }));
+    } else {
+      const dim3 grid(gx, gy, (b.m[0] + 3) / 4);
+      TRY(launch(h, OUT == OUT_Q ? "level_fused_q" : "level_fused", s, [&] {
+        k_level_fused<T, OUT, TC, TF, 4><<<grid, 256, 0, s>>>(A);
+      }));
+    }
     TRY(ipk_launch<T>(h, 2, b.m, ds->t3, t.thomas[2], nullptr, +1, s));
     TRY(ipk_launch<T>(h, 1, b.m, ds->t3, t.thomas[1], nullptr, +1, s));
     TRY(ipk_launch<T>(h, 0, b.m, ds->t3, t.thomas[0], ds->nodal[l - 1], +1, s));
@@ -440,7 +464,36 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
     sJ = b.m[2];
     sI = (size_t)b.m[1] * b.m[2];
   }
-  {
+  if (l_tail >= 1) {
+    TailArgs<T> TA{};
+    TA.nlevels = l_tail;
+    TA.fine = src;
+    TA.fI = sI;
+    TA.fJ = sJ;
+    for (int l = l_tail; l >= 1; l--) {
+      TailLevel<T> &tl = TA.lv[l_tail - l];
+      const LevelTables<T> &t = ds->lt[l];
+      tl.b = t.box;
+      for (int k = 0; k < 3; k++) {
+        tl.ratio[k] = t.ratio[k];
+        tl.mass[k] = t.mass[k];
+        tl.thomas[k] = t.thomas[k];
+      }
+      if (OUT == OUT_Q) {
+        tl.quantizer = qp->qz[l];
+        tl.volume = qp->vol[l];
+      }
+    }
+    if (OUT == OUT_Q) {
+      TA.head_quantizer = qp->qz[0];
+      TA.head_volume = qp->vol[0];
+    }
+    TA.out = A;
+    const size_t lds = tail_lds_elems(ds->lt[l_tail].box) * sizeof(T);
+    static bool once = false;
+    if (!once) { TRY(allow_big_lds(k_tail<T, OUT>)); once = true; }
+    TRY(launch(h, "tail", s, [&] { k_tail<T, OUT><<<1, 1024, lds, s>>>(TA); }));
+  } else {
     const Box3 &b = ds->lt[1].box;
     if (OUT == OUT_Q) {
       A.quantizer = qp->qz[0];

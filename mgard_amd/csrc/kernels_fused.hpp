@@ -149,6 +149,8 @@ k_level_fused(FusedArgs<T> A) {
   __shared__ T t1s[WC][TF + 1];
   __shared__ T rfs[WF];
   __shared__ T rcs[WC];
+  __shared__ T rrs[2 * RCH + 3];  // ratio_r[p - 1] of plane p = r_lo + index
+  __shared__ T wrs[RCH][9];       // r-sweep constants of the chunk's coarse planes
 #define LI(lc, lf) ((lc) * ROW + ((lf) & 1) * HF + ((lf) >> 1))
 
   const int tid = threadIdx.x;
@@ -172,6 +174,14 @@ k_level_fused(FusedArgs<T> A) {
   for (int e = tid; e < WC; e += NT) {
     const int P = c_lo + e;
     rcs[e] = (P >= 0 && P < nc) ? A.ratio[1][P] : (T)0;
+  }
+  for (int e = tid; e < 2 * RCH + 3; e += NT) {
+    const int P = r_lo + e - 1;  // left neighbour of plane r_lo + e
+    rrs[e] = (P >= 0 && P < nr) ? A.ratio[0][P] : (T)0;
+  }
+  for (int e = tid; e < RCH * 9; e += NT) {
+    const int R = R0 + e / 9, k = e % 9;
+    wrs[e / 9][k] = R < mr ? A.mass[0][k * mr + R] : (T)0;
   }
   // per-thread sweep constants: f-sweep for jf = tid % TF, c-sweep for jc = tid / TF
   const int jf = tid % TF, jc = tid / TF;
@@ -323,7 +333,7 @@ k_level_fused(FusedArgs<T> A) {
     const bool pv = p >= 0 && p <= Pmax_r && p != ghost_r;
     // ---------------- Phase A: coefficient field on the window -----------------
     {
-      const T rr = (p_odd && p >= 1 && p - 1 < nr) ? A.ratio[0][p - 1] : (T)0;
+      const T rr = rrs[p - r_lo];
       T cv[4], centre;
       cell_coeff(own, p, pv, rr, cv, centre);
       const bool own_r = pv && p >= 2 * R0 && p < 2 * R0 + 2 * RCH;
@@ -374,7 +384,7 @@ k_level_fused(FusedArgs<T> A) {
       if (R < mr && Jc < mc && Jf < mf) {
         T wr[9];
 #pragma unroll
-        for (int k = 0; k < 9; k++) wr[k] = A.mass[0][k * mr + R];
+        for (int k = 0; k < 9; k++) wr[k] = wrs[R - R0][k];
         A.load[((size_t)R * mc + Jc) * mf + Jf] =
             mass_apply(win[0], win[1], win[2], win[3], win[4], wr);
       }

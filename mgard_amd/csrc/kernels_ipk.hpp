@@ -72,15 +72,15 @@ __device__ __forceinline__ void thomas_lds(T *s, uint32_t stride, uint32_t n,
 // wave 0 runs the P sweeps, all waves stream the result out. LDS rows are padded
 // by `pad` (0 for odd n, 1 for even n) so that lane t walking row t is
 // bank-conflict free; row = e / n is computed as umulhi(e, magic).
-template <typename T, int P>
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_ipk_lds_contig(uint32_t npencil, uint32_t n, uint32_t pad, uint32_t magic,
+k_ipk_lds_contig(uint32_t npencil, uint32_t n, uint32_t pad, uint32_t magic, uint32_t P,
                  T *__restrict__ x, const T *__restrict__ tt, T *__restrict__ add_to, int sign) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T *sm = reinterpret_cast<T *>(smem_raw);
   const uint32_t tid = threadIdx.x;
   const uint32_t p0 = blockIdx.x * P;
-  const uint32_t cnt = min((uint32_t)P, npencil - p0);
+  const uint32_t cnt = min(P, npencil - p0);
   const size_t base = (size_t)p0 * n;
   const uint32_t total = cnt * n;
   const T *g = x + base;
@@ -137,11 +137,11 @@ k_ipk_lds_strided(uint32_t n_outer, uint32_t n_inner, size_t outer_stride, size_
                   T *__restrict__ add_to, int sign) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T *sm = reinterpret_cast<T *>(smem_raw);
-  constexpr int RW = 256 / W;  // rows covered per pass by the block
+  constexpr int RW = 256 / W;  // rows covered per pass by the block (W = 48: 240 threads busy)
   const uint32_t col = threadIdx.x % W;
   const uint32_t r0 = threadIdx.x / W;
   const uint32_t p = blockIdx.x * W + col;
-  const bool live = p < n_outer * n_inner;
+  const bool live = r0 < (uint32_t)RW && p < n_outer * n_inner;
   const size_t base = live ? (size_t)(p / n_inner) * outer_stride + (p % n_inner) : 0;
   constexpr int U = 8;
   if (live) {

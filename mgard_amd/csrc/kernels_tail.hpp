@@ -1,0 +1,177 @@
+// Tail kernel: all the small levels of the hierarchy in ONE launch.
+//
+// Below ~33^3 a level is pure launch latency (4-5 us per kernel, 4+ kernels per
+// level, 5+ levels). Here a single 1024-thread workgroup walks those levels:
+// per level the phases of kernels_v1.hpp (coefficients [+quantize], the three
+// mass/restriction sweeps, the three Thomas solves, the correction) run back to
+// back, separated by workgroup barriers only. Intermediate arrays are tiny and
+// stay in L2; the load vector lives in LDS for the Thomas solves. Arithmetic is
+// the shared element code of kernels_v1.hpp / kernels_ipk.hpp: bit-identical.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels_fused.hpp"
+#include "kernels_ipk.hpp"
+#include "kernels_v1.hpp"
+
+namespace mgh {
+
+constexpr int kTailMaxLevels = 10;
+
+template <typename T> struct TailLevel {
+  Box3 b;
+  const T *ratio[3];
+  const T *mass[3];
+  const T *thomas[3];
+  T quantizer, volume;
+};
+
+template <typename T> struct TailArgs {
+  int nlevels;  // lv[0] is the finest level handled here
+  TailLevel<T> lv[kTailMaxLevels];
+  const T *fine;  // nodal array of lv[0], strides (fI, fJ, 1)
+  size_t fI, fJ;
+  T head_quantizer, head_volume;
+  FusedArgs<T> out;    // coefficient / quantized output + outlier list
+};
+
+// LDS elements needed for a first tail level with fine box n and coarse box m
+inline size_t tail_lds_elems(const Box3 &b) {
+  const size_t nf = (size_t)b.n[0] * b.n[1] * b.n[2];
+  const size_t mc = (size_t)b.m[0] * b.m[1] * b.m[2];
+  return 2 * nf + (size_t)b.n[0] * b.n[1] * b.m[2] + (size_t)b.n[0] * b.m[1] * b.m[2] + 2 * mc;
+}
+
+template <typename T, int OUT>
+__global__ void __launch_bounds__(1024)
+k_tail(TailArgs<T> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const uint32_t tid = threadIdx.x, NT = blockDim.x;
+  FusedArgs<T> O = A.out;
+  // carve LDS for the first (largest) level; deeper levels reuse the same regions
+  T *X, *Y, *C, *T1, *T2, *T3;
+  {
+    const Box3 &b = A.lv[0].b;
+    const size_t nf = (size_t)b.n[0] * b.n[1] * b.n[2];
+    const size_t mc = (size_t)b.m[0] * b.m[1] * b.m[2];
+    T *base = reinterpret_cast<T *>(smem_raw);
+    X = base;
+    C = X + nf;
+    T1 = C + nf;
+    T2 = T1 + (size_t)b.n[0] * b.n[1] * b.m[2];
+    T3 = T2 + (size_t)b.n[0] * b.m[1] * b.m[2];
+    Y = T3 + mc;
+    // bring the nodal values of the first tail level into LDS
+    const uint32_t n1 = b.n[1], n2 = b.n[2];
+    for (uint32_t e = tid; e < nf; e += NT) {
+      const uint32_t k = e % n2, j = (e / n2) % n1, i = e / (n2 * n1);
+      X[e] = A.fine[i * A.fI + j * A.fJ + k];
+    }
+  }
+  __syncthreads();
+  for (int li = 0; li < A.nlevels; li++) {
+    const TailLevel<T> &L = A.lv[li];
+    const Box3 b = L.b;
+    const uint32_t n0 = b.n[0], n1 = b.n[1], n2 = b.n[2];
+    const uint32_t m0 = b.m[0], m1 = b.m[1], m2 = b.m[2];
+    O.quantizer = L.quantizer;
+    O.volume = L.volume;
+    // ---- coefficients (+ output) and coarse nodes ----
+    {
+      const uint32_t total = n0 * n1 * n2;
+      for (uint32_t e0 = 0; e0 < total; e0 += NT) {
+        const uint32_t e = e0 + tid;
+        const bool live = e < total;
+        const uint32_t ee = live ? e : 0;
+        const uint32_t k = ee % n2, j = (ee / n2) % n1, i = ee / (n2 * n1);
+        bool is_coarse;
+        const T v = gpk_reo_elem(b, (const T *)X, (size_t)n1 * n2, (size_t)n2, L.ratio[0],
+                                 L.ratio[1], L.ratio[2], i, j, k, is_coarse);
+        const size_t lin = (size_t)i * O.dI + (size_t)j * O.dJ + k;
+        if (live) {
+          if (is_coarse)
+            Y[((size_t)i * m1 + j) * m2 + k] = v;
+          else
+            C[ee] = v;
+        }
+        const bool emit = live && !is_coarse;
+        if (OUT == OUT_T) {
+          if (emit) O.coef[lin] = v;
+        } else {
+          const T vv[1] = {v};
+          const size_t ll[1] = {lin};
+          const bool on[1] = {emit};
+          emit_quantized<T, 1>(O, vv, ll, on);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- mass/restriction sweeps: f, c, r ----
+    {
+      const uint32_t total = n0 * n1 * m2;
+      for (uint32_t e = tid; e < total; e += NT) {
+        const uint32_t k = e % m2, j = (e / m2) % n1, i = e / (m2 * n1);
+        T1[e] = lpk_elem<T, 2>(n2, m2, (const T *)C, (size_t)n1 * n2, (size_t)n2, L.mass[2], m0,
+                               m1, i, j, k);
+      }
+    }
+    __syncthreads();
+    {
+      const uint32_t total = n0 * m1 * m2;
+      for (uint32_t e = tid; e < total; e += NT) {
+        const uint32_t k = e % m2, j = (e / m2) % m1, i = e / (m2 * m1);
+        T2[e] = lpk_elem<T, 1>(n1, m1, (const T *)T1, (size_t)n1 * m2, (size_t)m2, L.mass[1], 0, 0,
+                               i, j, k);
+      }
+    }
+    __syncthreads();
+    const uint32_t mtot = m0 * m1 * m2;
+    for (uint32_t e = tid; e < mtot; e += NT) {
+      const uint32_t k = e % m2, j = (e / m2) % m1, i = e / (m2 * m1);
+      T3[e] = lpk_elem<T, 0>(n0, m0, (const T *)T2, (size_t)m1 * m2, (size_t)m2, L.mass[0], 0, 0,
+                             i, j, k);
+    }
+    __syncthreads();
+    // ---- Thomas solves in LDS: f, c, r ----
+    for (uint32_t p = tid; p < m0 * m1; p += NT) thomas_lds<T>(T3 + (size_t)p * m2, 1, m2, L.thomas[2]);
+    __syncthreads();
+    for (uint32_t p = tid; p < m0 * m2; p += NT)
+      thomas_lds<T>(T3 + (size_t)(p / m2) * m1 * m2 + (p % m2), m2, m1, L.thomas[1]);
+    __syncthreads();
+    for (uint32_t p = tid; p < m1 * m2; p += NT) thomas_lds<T>(T3 + p, m1 * m2, m0, L.thomas[0]);
+    __syncthreads();
+    // ---- apply the correction (AddND); the corrected coarse nodes are the next level ----
+    for (uint32_t e = tid; e < mtot; e += NT) Y[e] += T3[e];
+    __syncthreads();
+    T *tmp = X;
+    X = Y;
+    Y = tmp;
+  }
+  // ---- head: level-0 nodal values (now in X) ----
+  {
+    const TailLevel<T> &L = A.lv[A.nlevels - 1];
+    const uint32_t m0 = L.b.m[0], m1 = L.b.m[1], m2 = L.b.m[2];
+    const uint32_t total = m0 * m1 * m2;
+    O.quantizer = A.head_quantizer;
+    O.volume = A.head_volume;
+    for (uint32_t e0 = 0; e0 < total; e0 += NT) {
+      const uint32_t e = e0 + tid;
+      const bool live = e < total;
+      const uint32_t ee = live ? e : 0;
+      const uint32_t k = ee % m2, j = (ee / m2) % m1, i = ee / (m2 * m1);
+      const size_t lin = (size_t)i * O.dI + (size_t)j * O.dJ + k;
+      const T v = X[ee];
+      if (OUT == OUT_T) {
+        if (live) O.coef[lin] = v;
+      } else {
+        const T vv[1] = {v};
+        const size_t ll[1] = {lin};
+        const bool on[1] = {live};
+        emit_quantized<T, 1>(O, vv, ll, on);
+      }
+    }
+  }
+}
+
+} // namespace mgh

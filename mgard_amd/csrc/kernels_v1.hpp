@@ -45,24 +45,21 @@ __device__ __forceinline__ uint32_t fine_pos(uint32_t i, uint32_t n, uint32_t m,
 // When dst_coarse_too != 0 the coarse nodes are ALSO written to dst (used on
 // the last level so that dst holds the complete result).
 // ---------------------------------------------------------------------------
+// value of reordered node (i, j, k): the raw node for an all-coarse position
+// (is_coarse = true), else node minus the interpolant of its coarse neighbours
 template <typename T>
-__global__ void __launch_bounds__(256)
-k_gpk_reo(Box3 b, const T *__restrict__ src, size_t sI, size_t sJ, T *__restrict__ coarse,
-          T *__restrict__ dst, size_t dI, size_t dJ, const T *__restrict__ ratio_r,
-          const T *__restrict__ ratio_c, const T *__restrict__ ratio_f) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t j = blockIdx.y * blockDim.y + threadIdx.y;
-  const uint32_t i = blockIdx.z;
-  if (k >= b.n[2] || j >= b.n[1] || i >= b.n[0]) return;
+__device__ __forceinline__ T gpk_reo_elem(const Box3 &b, const T *__restrict__ src, size_t sI,
+                                          size_t sJ, const T *__restrict__ ratio_r,
+                                          const T *__restrict__ ratio_c,
+                                          const T *__restrict__ ratio_f, uint32_t i, uint32_t j,
+                                          uint32_t k, bool &is_coarse) {
   bool ro, co, fo;
   const uint32_t rp = fine_pos(i, b.n[0], b.m[0], ro);
   const uint32_t cp = fine_pos(j, b.n[1], b.m[1], co);
   const uint32_t fp = fine_pos(k, b.n[2], b.m[2], fo);
   const T center = src[rp * sI + cp * sJ + fp];
-  if (!ro && !co && !fo) {
-    coarse[((size_t)i * b.m[1] + j) * b.m[2] + k] = center;
-    return;
-  }
+  is_coarse = !ro && !co && !fo;
+  if (is_coarse) return center;
   const uint32_t r0 = ro ? rp - 1 : rp, r1 = rp + 1;
   const uint32_t c0 = co ? cp - 1 : cp, c1 = cp + 1;
   const uint32_t f0 = fo ? fp - 1 : fp, f1 = fp + 1;
@@ -82,7 +79,24 @@ k_gpk_reo(Box3 b, const T *__restrict__ src, size_t sI, size_t sJ, T *__restrict
     hr[a] = co ? lerp_ref(gc[0], gc[1], ratio_c[c0]) : gc[0];
   }
   const T res = ro ? lerp_ref(hr[0], hr[1], ratio_r[r0]) : hr[0];
-  dst[i * dI + j * dJ + k] = center - res;
+  return center - res;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_gpk_reo(Box3 b, const T *__restrict__ src, size_t sI, size_t sJ, T *__restrict__ coarse,
+          T *__restrict__ dst, size_t dI, size_t dJ, const T *__restrict__ ratio_r,
+          const T *__restrict__ ratio_c, const T *__restrict__ ratio_f) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t j = blockIdx.y * blockDim.y + threadIdx.y;
+  const uint32_t i = blockIdx.z;
+  if (k >= b.n[2] || j >= b.n[1] || i >= b.n[0]) return;
+  bool is_coarse;
+  const T v = gpk_reo_elem(b, src, sI, sJ, ratio_r, ratio_c, ratio_f, i, j, k, is_coarse);
+  if (is_coarse)
+    coarse[((size_t)i * b.m[1] + j) * b.m[2] + k] = v;
+  else
+    dst[i * dI + j * dJ + k] = v;
 }
 
 // GpkRev3D (GridProcessingKernel3D.hpp:1231-2352): natural fine box out of
@@ -144,16 +158,9 @@ k_gpk_rev(Box3 b, const T *__restrict__ coarse, const T *__restrict__ coef, size
 // read their even part as 0 (zero_r/zero_c/zero_f, :98-101).
 // ---------------------------------------------------------------------------
 template <typename T, int AXIS>
-__global__ void __launch_bounds__(256)
-k_lpk(uint32_t n0, uint32_t n1, uint32_t n2, uint32_t n, uint32_t m, const T *__restrict__ in,
-      size_t iI, size_t iJ, T *__restrict__ out, size_t oI, size_t oJ,
-      const T *__restrict__ mt, uint32_t zero_i, uint32_t zero_j) {
-  // output extents
-  const uint32_t e0 = AXIS == 0 ? m : n0, e1 = AXIS == 1 ? m : n1, e2 = AXIS == 2 ? m : n2;
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t j = blockIdx.y * blockDim.y + threadIdx.y;
-  const uint32_t i = blockIdx.z;
-  if (k >= e2 || j >= e1 || i >= e0) return;
+__device__ __forceinline__ T lpk_elem(uint32_t n, uint32_t m, const T *__restrict__ in, size_t iI,
+                                      size_t iJ, const T *__restrict__ mt, uint32_t zero_i,
+                                      uint32_t zero_j, uint32_t i, uint32_t j, uint32_t k) {
   const uint32_t q = AXIS == 0 ? i : (AXIS == 1 ? j : k); // coarse index along AXIS
   const size_t st = AXIS == 0 ? iI : (AXIS == 1 ? iJ : 1);
   const size_t base = (AXIS == 0 ? 0 : i * iI) + (AXIS == 1 ? 0 : j * iJ) + (AXIS == 2 ? 0 : k);
@@ -173,7 +180,21 @@ k_lpk(uint32_t n0, uint32_t n1, uint32_t n2, uint32_t n, uint32_t m, const T *__
   T tc = bq * w2 + c * w3 + d * w4;
   const T td = c * w4 + d * w5 + e * w6;
   tc += tb * r1 + td * r4;
-  out[i * oI + j * oJ + k] = tc;
+  return tc;
+}
+
+template <typename T, int AXIS>
+__global__ void __launch_bounds__(256)
+k_lpk(uint32_t n0, uint32_t n1, uint32_t n2, uint32_t n, uint32_t m, const T *__restrict__ in,
+      size_t iI, size_t iJ, T *__restrict__ out, size_t oI, size_t oJ,
+      const T *__restrict__ mt, uint32_t zero_i, uint32_t zero_j) {
+  // output extents
+  const uint32_t e0 = AXIS == 0 ? m : n0, e1 = AXIS == 1 ? m : n1, e2 = AXIS == 2 ? m : n2;
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t j = blockIdx.y * blockDim.y + threadIdx.y;
+  const uint32_t i = blockIdx.z;
+  if (k >= e2 || j >= e1 || i >= e0) return;
+  out[i * oI + j * oJ + k] = lpk_elem<T, AXIS>(n, m, in, iI, iJ, mt, zero_i, zero_j, i, j, k);
 }
 
 // ---------------------------------------------------------------------------
