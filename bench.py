@@ -63,8 +63,11 @@ def algorithmic_bytes_per_step(h, esz):
         # fused kernels (kernels_fast.hpp) -- see DESIGN.md
         # fused level kernel: read the fine nodes once, write the quantized coefficients
         # (int64), the coarse nodes and the load vector
-        add("level_fused_q", vol(n) * esz + (vol(n) - vol(m)) * 8 + 2 * vol(m) * esz)
-        add("level_fused", vol(n) * esz + (vol(n) - vol(m)) * esz + 2 * vol(m) * esz)
+        # (capi.hip: levels with >= 2048 tiles of 8x32x16 coarse nodes use the long-march
+        # variant "level_fused_q", smaller ones "level_fused_q_small")
+        big = -(-m[2] // 32) * -(-m[1] // 8) * -(-m[0] // 16) >= 2048
+        add("level_fused_q" if big else "level_fused_q_small",
+            vol(n) * esz + (vol(n) - vol(m)) * 8 + 2 * vol(m) * esz)
     add("copy_box", 2 * vol((1,) * (3 - len(h.shape)) + tuple(h.level_shape(0))) * esz)
     return out
 
@@ -99,6 +102,7 @@ def main():
     import numpy as np
     import torch
     import mgard_amd
+    from mgard_amd import distributed as mdist
     from tests.util import smooth_field
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,18 +132,17 @@ def main():
     oidx = torch.empty(cap, dtype=torch.int64, device=dev)
     oval = torch.empty(cap, dtype=torch.int64, device=dev)
     bufs = (q, cnt, oidx, oval)
-    nrm_t = torch.zeros(1, dtype=torch.float64, device=dev)
 
     def step():
         if world == 1:
             # REL bound: norm computed inside the call
             return h.decompose_quantize(d_u, mgard_amd.REL, TOL, float("inf"), 0.0, bufs=bufs)[4]
-        # decomposed domain: global norm = MAX of subdomain norms (one scalar all-reduce),
-        # then an ABS bound of tol * norm per subdomain (s = inf)
-        nrm_t[0] = h.norm(d_u, float("inf"))
-        dist.all_reduce(nrm_t, op=dist.ReduceOp.MAX)
-        g = float(nrm_t.item())
-        h.decompose_quantize(d_u, mgard_amd.ABS, TOL * g, float("inf"), 1.0, bufs=bufs)
+        # decomposed domain: global norm = MAX of subdomain norms (one scalar all-reduce over
+        # RCCL), then an ABS bound per subdomain (mgard_amd/distributed.py)
+        g = mdist.global_norm(h.norm(d_u, float("inf")), float("inf"), N * world, True,
+                              device=dev)
+        atol = mdist.local_abs_tol(mdist.REL, g, TOL, float("inf"), world)
+        h.decompose_quantize(d_u, mgard_amd.ABS, atol, float("inf"), 1.0, bufs=bufs)
         return g
 
     def barrier():

@@ -453,7 +453,7 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
       }));
     } else {
       const dim3 grid(gx, gy, (b.m[0] + 3) / 4);
-      TRY(launch(h, OUT == OUT_Q ? "level_fused_q" : "level_fused", s, [&] {
+      TRY(launch(h, OUT == OUT_Q ? "level_fused_q_small" : "level_fused_small", s, [&] {
         k_level_fused<T, OUT, TC, TF, 4><<<grid, 256, 0, s>>>(A);
       }));
     }

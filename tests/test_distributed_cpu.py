@@ -1,0 +1,83 @@
+"""N > 1 control flow on CPU: two gloo ranks, one subdomain each; the scalar norm all-reduce and
+the per-subdomain ABS tolerance reproduce the single-domain REL behaviour (the compute itself
+is done by the CPU oracle here -- the distributed logic is what is under test)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from tests.util import smooth_field
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, s, out):
+    import torch.distributed as dist
+    import oracle
+    from mgard_amd import distributed as mdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    oracle.set_num_threads(1)
+    shape = (24, 17, 20)
+    u = smooth_field(shape, np.float64)
+    lo, hi = mdist.split_slowest(shape, world, rank)
+    sub = np.ascontiguousarray(u[lo:hi])
+    sval = np.float64(s)
+    local = oracle.norm(sub, sval, normalize_coordinates=False)
+    g = mdist.global_norm(local, s, u.size, True)
+    tol = 1e-3
+    atol = mdist.local_abs_tol(mdist.REL, g, tol, s, world)
+    h = oracle.Hierarchy(sub.shape, np.float64)
+    c = h.decompose(sub)
+    q, oi, ov, n = h.quantize(c, oracle.ABS, np.float64(atol), sval, np.float64(1))
+    back = h.recompose(h.dequantize(q, oracle.ABS, np.float64(atol), sval, np.float64(1),
+                                    outlier_idx=oi, outlier_val=ov))
+    err_inf = float(np.max(np.abs(back - sub)))
+    err_sq = float(np.sum((back - sub) ** 2))
+    out.put((rank, g, atol, err_inf, err_sq, sub.size))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("s", [float("inf"), 0.0])
+def test_two_rank_norm_exchange_and_error_bound(s):
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, s, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    u = smooth_field((24, 17, 20), np.float64)
+    tol = 1e-3
+    if np.isinf(s):
+        ref = float(np.max(np.abs(u)))
+    else:
+        ref = float(np.sqrt(np.mean(u ** 2)))
+    for rank, g, atol, e_inf, e_sq, n in res:
+        assert abs(g - ref) <= 1e-12 * ref          # both ranks hold the GLOBAL norm
+    if np.isinf(s):
+        assert all(r[3] <= tol * ref for r in res)  # L-inf bound holds on every subdomain
+    else:
+        tot = sum(r[4] for r in res)
+        assert np.sqrt(tot / u.size) <= tol * ref   # global L2 bound from the local budgets
+
+
+def test_split_slowest():
+    from mgard_amd import distributed as mdist
+    assert [mdist.split_slowest((10, 3), 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert mdist.local_abs_tol(mdist.REL, 2.0, 1e-3, float("inf"), 8) == 2e-3
+    assert mdist.local_abs_tol(mdist.ABS, 2.0, 1e-3, float("inf"), 8) == 1e-3
