@@ -132,18 +132,19 @@ def main():
     oidx = torch.empty(cap, dtype=torch.int64, device=dev)
     oval = torch.empty(cap, dtype=torch.int64, device=dev)
     bufs = (q, cnt, oidx, oval)
+    nrm_t = torch.zeros(1, dtype=torch.float32, device=dev)
 
     def step():
         if world == 1:
-            # REL bound: norm computed inside the call
-            return h.decompose_quantize(d_u, mgard_amd.REL, TOL, float("inf"), 0.0, bufs=bufs)[4]
+            # REL bound: norm computed inside the call, on the device (no host round trip)
+            return h.decompose_quantize(d_u, mgard_amd.REL, TOL, float("inf"), 0.0, bufs=bufs,
+                                        want_norm=False)[4]
         # decomposed domain: global norm = MAX of subdomain norms (one scalar all-reduce over
         # RCCL), then an ABS bound per subdomain (mgard_amd/distributed.py)
-        g = mdist.global_norm(h.norm(d_u, float("inf")), float("inf"), N * world, True,
-                              device=dev)
-        atol = mdist.local_abs_tol(mdist.REL, g, TOL, float("inf"), world)
-        h.decompose_quantize(d_u, mgard_amd.ABS, atol, float("inf"), 1.0, bufs=bufs)
-        return g
+        h.norm_device(d_u, float("inf"), out=nrm_t)
+        dist.all_reduce(nrm_t, op=dist.ReduceOp.MAX)
+        h.decompose_quantize_dn(d_u, mgard_amd.REL, TOL, float("inf"), nrm_t, world, bufs)
+        return None
 
     def barrier():
         torch.cuda.synchronize()

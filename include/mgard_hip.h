@@ -133,6 +133,26 @@ int mgh_decompose_quantize(mgh_hierarchy *h, const void *d_data, int error_bound
                            int64_t *d_outlier_val, uint64_t outlier_capacity,
                            void *d_coeff_opt, void *stream);
 
+/* Norm that stays on the device: writes one value of the hierarchy's dtype to
+ * d_norm_out (max|x| for s = +inf, else the L2 norm of this array as
+ * norm_calculator defines it). ASYNCHRONOUS. For a decomposed domain the caller
+ * reduces the per-subdomain values itself (MAX for s = +inf; RCCL all-reduce). */
+int mgh_norm_device(mgh_hierarchy *h, const void *d_data, double s, void *d_norm_out,
+                    void *stream);
+
+/* Fused hot path for one subdomain of a decomposed domain, fully asynchronous:
+ * d_norm = GLOBAL norm (dtype of the hierarchy, on the device). The bound applied
+ * is the reference's per-subdomain bound, calc_local_abs_tol
+ * (include/mgard-x/CompressionHighLevel/ErrorToleranceCalculator.hpp:134-155,
+ * applied at CompressionHighLevel.hpp:122-144): REL, s=inf: (T)(tol*norm) as an
+ * ABS bound; REL, finite s: sqrt((tol*norm)^2 / num_subdomains); ABS: tol resp.
+ * sqrt(tol^2 / num_subdomains). 3-D only. */
+int mgh_decompose_quantize_dn(mgh_hierarchy *h, const void *d_data, int error_bound_type,
+                              double tol, double s, const void *d_norm, uint64_t num_subdomains,
+                              uint64_t dict_size, int prep_huffman, int64_t *d_quantized,
+                              uint64_t *d_outlier_count, uint64_t *d_outlier_idx,
+                              int64_t *d_outlier_val, uint64_t outlier_capacity, void *stream);
+
 /* Inverse of the above: dequantize + recompose
  * (Compressor::Decompress, Compressor.hpp:239-272, lines 256-257). */
 int mgh_dequantize_recompose(mgh_hierarchy *h, int64_t *d_quantized, int error_bound_type,

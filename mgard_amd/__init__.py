@@ -23,6 +23,7 @@ SYMBOLS = [
     "mgh_l_target", "mgh_level_shape", "mgh_total_num_elems", "mgh_device_bytes",
     "mgh_hierarchy_table", "mgh_norm", "mgh_decompose", "mgh_recompose", "mgh_quantize",
     "mgh_dequantize", "mgh_decompose_quantize", "mgh_dequantize_recompose",
+    "mgh_norm_device", "mgh_decompose_quantize_dn",
     "mgh_profile_enable", "mgh_profile_filter", "mgh_profile_read",
 ]
 
@@ -70,6 +71,9 @@ def load_library():
     L.mgh_decompose_quantize.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, C.c_double,
                                          C.POINTER(C.c_double), u64, C.c_int, vp, vp, vp, vp, u64,
                                          vp, vp]
+    L.mgh_norm_device.argtypes = [vp, vp, C.c_double, vp, vp]
+    L.mgh_decompose_quantize_dn.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, vp, u64, u64,
+                                            C.c_int, vp, vp, vp, vp, u64, vp]
     L.mgh_dequantize_recompose.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, C.c_double,
                                            u64, C.c_int, vp, vp, u64, vp, vp]
     L.mgh_profile_enable.argtypes = [vp, C.c_int]
@@ -208,8 +212,29 @@ class Hierarchy:
             C.c_void_p(outlier_val.data_ptr() if n else 0), n, self._chk(out), _stream()))
         return out
 
+    def norm_device(self, data, s=INF, out=None):
+        """Asynchronous norm: returns a 1-element device tensor of the hierarchy's dtype."""
+        import torch
+        out = torch.empty(1, dtype=self.torch_dtype, device=data.device) if out is None else out
+        _check(load_library().mgh_norm_device(self._h, self._chk(data), s,
+                                              C.c_void_p(out.data_ptr()), _stream()))
+        return out
+
+    def decompose_quantize_dn(self, data, ebtype, tol, s, d_norm, num_subdomains, bufs,
+                              dict_size=8192, prep_huffman=True):
+        """Fused hot path with a device-resident GLOBAL norm (decomposed domain); fully async."""
+        import torch
+        q, cnt, idx, val = bufs
+        _check(load_library().mgh_decompose_quantize_dn(
+            self._h, self._chk(data), ebtype, tol, s, C.c_void_p(d_norm.data_ptr()),
+            int(num_subdomains), dict_size, int(prep_huffman), self._chk(q, torch.int64),
+            C.c_void_p(cnt.data_ptr()), C.c_void_p(idx.data_ptr()), C.c_void_p(val.data_ptr()),
+            int(idx.numel()), _stream()))
+        return q, idx, val, cnt
+
     def decompose_quantize(self, data, ebtype, tol, s, norm=0.0, dict_size=8192,
-                           prep_huffman=True, outlier_cap=None, bufs=None, coeff_out=None):
+                           prep_huffman=True, outlier_cap=None, bufs=None, coeff_out=None,
+                           want_norm=True):
         """The fused hot path (Compressor::Compress up to the lossless stage). Returns
         (q, outlier_idx, outlier_val, outlier_count, norm). `bufs` = (q, cnt, idx, val) lets a
         caller reuse output buffers; then no host sync happens and outlier_count is the device
@@ -224,7 +249,8 @@ class Hierarchy:
             cap = int(idx.numel())
         nout = C.c_double()
         _check(load_library().mgh_decompose_quantize(
-            self._h, self._chk(data), ebtype, tol, s, norm, C.byref(nout), dict_size,
+            self._h, self._chk(data), ebtype, tol, s, norm,
+            C.byref(nout) if want_norm else None, dict_size,
             int(prep_huffman), self._chk(q, torch.int64), C.c_void_p(cnt.data_ptr()),
             C.c_void_p(idx.data_ptr()), C.c_void_p(val.data_ptr()), cap,
             C.c_void_p(coeff_out.data_ptr()) if coeff_out is not None else None, _stream()))

@@ -90,6 +90,7 @@ template <typename T> struct DeviceState {
   T *scratch_full = nullptr;       // lazily allocated full-size copy
   T *qz = nullptr;                 // 2*(L+1): quantizers, volumes
   unsigned long long *scalar = nullptr;  // 8-byte device scalar (norm / counters)
+  T *normval = nullptr;                  // norm as T, written by k_make_qparams
   QuantMeta qmeta;
   size_t full_I = 0, full_J = 0;   // strides of the full array in the 3-D view
 };
@@ -212,6 +213,7 @@ template <typename T> int build_device_state(mgh_hierarchy *h) {
   }
   TRY(dev_alloc(h, &ds->qz, (size_t)2 * (L + 1)));
   TRY(dev_alloc(h, &ds->scalar, (size_t)2));
+  TRY(dev_alloc(h, &ds->normval, (size_t)2));
   ds->full_J = hh->shape[D - 1];
   ds->full_I = (D >= 2 ? hh->shape[D - 2] : 1) * ds->full_J;
   return MGH_SUCCESS;
@@ -229,6 +231,7 @@ template <typename T> void destroy_state(mgh_hierarchy *h) {
     (void)hipFree(ds->scratch_full);
     (void)hipFree(ds->qz);
     (void)hipFree(ds->scalar);
+    (void)hipFree(ds->normval);
     delete ds;
   }
   delete HH<T>(h);
@@ -376,6 +379,7 @@ template <typename T> struct QuantParams {
   uint64_t *oidx = nullptr;
   int64_t *oval = nullptr;
   unsigned long long ocap = 0;
+  const T *d_qp = nullptr;  // device table [2 * (L + 1)] (k_make_qparams) instead of qz / vol
 };
 
 template <typename T>
@@ -415,6 +419,8 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
     A.outlier_idx = qp->oidx;
     A.outlier_val = qp->oval;
     A.outlier_cap = qp->ocap;
+    A.qp = qp->d_qp;
+    A.nlev = L + 1;
   }
   // levels whose working set fits in one workgroup's LDS run inside the tail kernel
   constexpr size_t kTailLdsMax = 150 * 1024;
@@ -439,7 +445,8 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
     A.uJ = sJ;
     A.coarse = ds->nodal[l - 1];
     A.load = ds->t3;
-    if (OUT == OUT_Q) {
+    A.level = l;
+    if (OUT == OUT_Q && !qp->d_qp) {
       A.quantizer = qp->qz[l];
       A.volume = qp->vol[l];
     }
@@ -479,12 +486,13 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
         tl.mass[k] = t.mass[k];
         tl.thomas[k] = t.thomas[k];
       }
-      if (OUT == OUT_Q) {
+      tl.level = l;
+      if (OUT == OUT_Q && !qp->d_qp) {
         tl.quantizer = qp->qz[l];
         tl.volume = qp->vol[l];
       }
     }
-    if (OUT == OUT_Q) {
+    if (OUT == OUT_Q && !qp->d_qp) {
       TA.head_quantizer = qp->qz[0];
       TA.head_volume = qp->vol[0];
     }
@@ -495,7 +503,7 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
     TRY(launch(h, "tail", s, [&] { k_tail<T, OUT><<<1, 1024, lds, s>>>(TA); }));
   } else {
     const Box3 &b = ds->lt[1].box;
-    if (OUT == OUT_Q) {
+    if (OUT == OUT_Q && !qp->d_qp) {
       A.quantizer = qp->qz[0];
       A.volume = qp->vol[0];
     }
@@ -648,6 +656,42 @@ int dequantize_impl(mgh_hierarchy *h, int64_t *q, int ebtype, double tol, double
   return MGH_SUCCESS;
 }
 
+// Launch the norm reduction; the result stays in ds->scalar (absmax bits or double sum).
+template <typename T> int norm_launch(mgh_hierarchy *h, const T *data, double s, hipStream_t st) {
+  auto *ds = DS<T>(h);
+  const size_t total = h->total;
+  const unsigned grid = (unsigned)std::min<size_t>((total + 1023) / 1024, 256 * 8);
+  HIP_TRY(hipMemsetAsync(ds->scalar, 0, 8, st));
+  if ((T)s == std::numeric_limits<T>::infinity())
+    return launch(h, "absmax", st, [&] { k_absmax<T><<<grid, 256, 0, st>>>(data, total, ds->scalar); });
+  return launch(h, "sqsum", st, [&] { k_sqsum<T><<<grid, 256, 0, st>>>(data, total, (double *)ds->scalar); });
+}
+
+// Quantizer table on the device from a device-resident norm (no host round trip).
+template <typename T>
+int make_qparams_launch(mgh_hierarchy *h, const T *d_norm, int ebtype, double tol, double s,
+                        int decomposed, uint64_t nsub, hipStream_t st) {
+  auto *ds = DS<T>(h);
+  auto *hh = HH<T>(h);
+  if (h->L + 1 > kMaxLevels) return fail(MGH_ERR_INVALID_ARGUMENT, "too many levels");
+  QParamArgs<T> P{};
+  P.d_norm = d_norm;
+  P.scalar = ds->scalar;
+  P.s_is_inf = ((T)s == std::numeric_limits<T>::infinity()) ? 1 : 0;
+  P.rel = ebtype == MGH_REL ? 1 : 0;
+  P.decomposed = decomposed;
+  P.normalize = hh->normalize_coordinates ? 1 : 0;
+  P.total = h->total;
+  P.nsub = nsub;
+  P.tol = (T)tol;
+  P.nlev = h->L + 1;
+  hh->quantizer_denominators((T)s, P.den);
+  for (int l = 0; l <= h->L; l++) P.vol[l] = P.s_is_inf ? (T)1 : hh->level_volume(l, false);
+  P.qp = ds->qz;
+  P.norm_out = ds->normval;
+  return launch(h, "make_qparams", st, [&] { k_make_qparams<T><<<1, 64, 0, st>>>(P); });
+}
+
 template <typename T>
 int norm_impl(mgh_hierarchy *h, const T *data, double s, double *out, hipStream_t st) {
   auto *ds = DS<T>(h);
@@ -718,6 +762,35 @@ int fused_q_entry(mgh_hierarchy *h, const T *data, int ebtype, double tol, doubl
   qp.oval = oval;
   qp.ocap = ocap;
   return decompose_fused<T, OUT_Q>(h, data, nullptr, &qp, st);
+}
+
+// Same with the norm (and hence the quantizers) never leaving the device: d_norm given, or
+// computed here (REL). h_norm_out != NULL costs one synchronisation at the END of the call.
+template <typename T>
+int fused_q_entry_device(mgh_hierarchy *h, const T *data, int ebtype, double tol, double s,
+                         const T *d_norm, int decomposed, uint64_t nsub, double *h_norm_out,
+                         uint64_t dict_size, int prep_huffman, int64_t *q, uint64_t *ocount,
+                         uint64_t *oidx, int64_t *oval, uint64_t ocap, hipStream_t st) {
+  auto *ds = DS<T>(h);
+  if (!d_norm && ebtype == MGH_REL) TRY(norm_launch<T>(h, data, s, st));
+  TRY(make_qparams_launch<T>(h, d_norm, ebtype, tol, s, decomposed, nsub, st));
+  QuantParams<T> qp;
+  qp.d_qp = ds->qz;
+  qp.dict_size = (int64_t)dict_size;
+  qp.prep_huffman = prep_huffman;
+  qp.q = q;
+  qp.ocount = (unsigned long long *)ocount;
+  qp.oidx = oidx;
+  qp.oval = oval;
+  qp.ocap = ocap;
+  TRY((decompose_fused<T, OUT_Q>(h, data, nullptr, &qp, st)));
+  if (h_norm_out) {
+    T nv = 0;
+    HIP_TRY(hipMemcpyAsync(&nv, ds->normval, sizeof(T), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *h_norm_out = (double)nv;
+  }
+  return MGH_SUCCESS;
 }
 
 #define DISPATCH(h, call_f, call_d)                                              \
@@ -877,6 +950,22 @@ int mgh_decompose_quantize(mgh_hierarchy *h, const void *d_data, int error_bound
                            uint64_t outlier_capacity, void *d_coeff_opt, void *stream) {
   if (!h || !d_data || !d_quantized) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
   HIP_TRY(hipSetDevice(h->device));
+  const bool fused = !d_coeff_opt && fused_ok(h) && !h->force_v1;
+  if (fused && error_bound_type == MGH_REL && !(norm > 0)) {
+    // the norm and the quantizers stay on the device: no host round trip inside the call
+    if (prep_huffman && (!d_outlier_count || (outlier_capacity && (!d_outlier_idx || !d_outlier_val))))
+      return fail(MGH_ERR_INVALID_ARGUMENT, "outlier buffers required with prep_huffman");
+    if (d_outlier_count) HIP_TRY(hipMemsetAsync(d_outlier_count, 0, sizeof(uint64_t), (hipStream_t)stream));
+    return DISPATCH(h,
+                    fused_q_entry_device<float>(h, (const float *)d_data, error_bound_type, tol, s,
+                                                nullptr, 0, 1, h_norm_out, dict_size, prep_huffman,
+                                                d_quantized, d_outlier_count, d_outlier_idx,
+                                                d_outlier_val, outlier_capacity, (hipStream_t)stream),
+                    fused_q_entry_device<double>(h, (const double *)d_data, error_bound_type, tol, s,
+                                                 nullptr, 0, 1, h_norm_out, dict_size, prep_huffman,
+                                                 d_quantized, d_outlier_count, d_outlier_idx,
+                                                 d_outlier_val, outlier_capacity, (hipStream_t)stream));
+  }
   if (error_bound_type == MGH_REL && !(norm > 0)) {
     int rc = mgh_norm(h, d_data, s, &norm, stream);
     if (rc != MGH_SUCCESS) return rc;
@@ -909,6 +998,49 @@ int mgh_decompose_quantize(mgh_hierarchy *h, const void *d_data, int error_bound
   return mgh_quantize(h, coeff, error_bound_type, tol, s, norm, dict_size, prep_huffman,
                       d_quantized, d_outlier_count, d_outlier_idx, d_outlier_val,
                       outlier_capacity, stream);
+}
+
+int mgh_norm_device(mgh_hierarchy *h, const void *d_data, double s, void *d_norm_out,
+                    void *stream) {
+  if (!h || !d_data || !d_norm_out) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  if (h->dtype == MGH_FLOAT) {
+    TRY(norm_launch<float>(h, (const float *)d_data, s, st));
+    // ABS/undecomposed parameters are irrelevant here: only the norm conversion is wanted
+    TRY(make_qparams_launch<float>(h, nullptr, MGH_ABS, 1.0, s, 0, 1, st));
+    HIP_TRY(hipMemcpyAsync(d_norm_out, DS<float>(h)->normval, sizeof(float), hipMemcpyDeviceToDevice, st));
+  } else {
+    TRY(norm_launch<double>(h, (const double *)d_data, s, st));
+    TRY(make_qparams_launch<double>(h, nullptr, MGH_ABS, 1.0, s, 0, 1, st));
+    HIP_TRY(hipMemcpyAsync(d_norm_out, DS<double>(h)->normval, sizeof(double), hipMemcpyDeviceToDevice, st));
+  }
+  return MGH_SUCCESS;
+}
+
+int mgh_decompose_quantize_dn(mgh_hierarchy *h, const void *d_data, int error_bound_type,
+                              double tol, double s, const void *d_norm, uint64_t num_subdomains,
+                              uint64_t dict_size, int prep_huffman, int64_t *d_quantized,
+                              uint64_t *d_outlier_count, uint64_t *d_outlier_idx,
+                              int64_t *d_outlier_val, uint64_t outlier_capacity, void *stream) {
+  if (!h || !d_data || !d_quantized || !d_norm) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
+  if (!fused_ok(h) || h->force_v1)
+    return fail(MGH_ERR_UNSUPPORTED_DIMENSION, "device-norm entry point needs the fused 3-D path");
+  if (prep_huffman && (!d_outlier_count || (outlier_capacity && (!d_outlier_idx || !d_outlier_val))))
+    return fail(MGH_ERR_INVALID_ARGUMENT, "outlier buffers required with prep_huffman");
+  HIP_TRY(hipSetDevice(h->device));
+  if (d_outlier_count) HIP_TRY(hipMemsetAsync(d_outlier_count, 0, sizeof(uint64_t), (hipStream_t)stream));
+  return DISPATCH(h,
+                  fused_q_entry_device<float>(h, (const float *)d_data, error_bound_type, tol, s,
+                                              (const float *)d_norm, 1, num_subdomains, nullptr,
+                                              dict_size, prep_huffman, d_quantized, d_outlier_count,
+                                              d_outlier_idx, d_outlier_val, outlier_capacity,
+                                              (hipStream_t)stream),
+                  fused_q_entry_device<double>(h, (const double *)d_data, error_bound_type, tol, s,
+                                               (const double *)d_norm, 1, num_subdomains, nullptr,
+                                               dict_size, prep_huffman, d_quantized, d_outlier_count,
+                                               d_outlier_idx, d_outlier_val, outlier_capacity,
+                                               (hipStream_t)stream));
 }
 
 int mgh_dequantize_recompose(mgh_hierarchy *h, int64_t *d_quantized, int ebtype, double tol,

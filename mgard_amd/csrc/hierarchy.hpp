@@ -181,18 +181,27 @@ template <typename T> struct HostHierarchy {
     return t;
   }
 
-  // Quantization/LinearQuantization.hpp:495-545 (MultiDim decomposition)
-  void quantizers(int ebtype_rel0_abs1, T tol, T s, T norm, bool reciprocal, T *out) const {
-    double abs_tol = tol;
-    if (ebtype_rel0_abs1 == 0) abs_tol *= norm;
-    abs_tol *= 2;
+  // Denominators of the level quantizers: quantizer[l] = (T)(abs_tol / den[l])
+  // (Quantization/LinearQuantization.hpp:495-545, MultiDim decomposition)
+  void quantizer_denominators(T s, double *den) const {
     const uint64_t l_target = (uint64_t)L;
     const uint64_t dof = total();
     for (int l = 0; l <= L; l++) {
       if (s == std::numeric_limits<T>::infinity())
-        out[l] = (abs_tol) / ((l_target + 1) * (1 + std::pow(3, D)));
+        den[l] = ((l_target + 1) * (1 + std::pow(3, D)));
       else
-        out[l] = (abs_tol) / (std::exp2(s * l) * std::sqrt((double)dof));
+        den[l] = (std::exp2(s * l) * std::sqrt((double)dof));
+    }
+  }
+
+  void quantizers(int ebtype_rel0_abs1, T tol, T s, T norm, bool reciprocal, T *out) const {
+    double abs_tol = tol;
+    if (ebtype_rel0_abs1 == 0) abs_tol *= norm;
+    abs_tol *= 2;
+    std::vector<double> den(L + 1);
+    quantizer_denominators(s, den.data());
+    for (int l = 0; l <= L; l++) {
+      out[l] = (abs_tol) / den[l];
       if (reciprocal) out[l] = 1.0f / out[l];
     }
   }

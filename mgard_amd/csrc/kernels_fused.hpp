@@ -48,8 +48,11 @@ template <typename T> struct FusedArgs {
   size_t dI, dJ;
   const T *ratio[3];  // fine-level interpolation ratios
   const T *mass[3];   // mass_table SoA [9][m]
-  // quantizer of this level (LinearQuantization.hpp:196-245)
+  // quantizer of this level (LinearQuantization.hpp:196-245): by value, or -- when the norm
+  // never left the device -- read from qp[level] / qp[nlev + level] (k_make_qparams)
   T quantizer, volume;
+  const T *qp;
+  int level, nlev;
   int64_t dict_size;
   int prep_huffman;
   unsigned long long *outlier_count;
@@ -153,6 +156,10 @@ k_level_fused(FusedArgs<T> A) {
   __shared__ T wrs[RCH][9];       // r-sweep constants of the chunk's coarse planes
 #define LI(lc, lf) ((lc) * ROW + ((lf) & 1) * HF + ((lf) >> 1))
 
+  if (OUT == OUT_Q && A.qp) {
+    A.quantizer = A.qp[A.level];
+    A.volume = A.qp[A.nlev + A.level];
+  }
   const int tid = threadIdx.x;
   const int F0 = blockIdx.x * TF, C0 = blockIdx.y * TC, R0 = blockIdx.z * RCH;
   const int nr = A.n[0], nc = A.n[1], nf = A.n[2];
@@ -420,6 +427,10 @@ k_level_fused(FusedArgs<T> A) {
 template <typename T, int OUT>
 __global__ void __launch_bounds__(256)
 k_head_out(int m0, int m1, int m2, const T *__restrict__ nodal, FusedArgs<T> A) {
+  if (OUT == OUT_Q && A.qp) {
+    A.quantizer = A.qp[0];
+    A.volume = A.qp[A.nlev];
+  }
   const int total = m0 * m1 * m2;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const int k = e % m2, j = (e / m2) % m1, i = e / (m2 * m1);
@@ -442,6 +453,66 @@ k_head_out(int m0, int m1, int m2, const T *__restrict__ nodal, FusedArgs<T> A) 
       }
       A.q[lin] = qd;
     }
+  }
+}
+
+// Quantizer table on the device (LinearQuantization.hpp:495-545) from a norm that stays on the
+// device: qp[l] = 1 / (T)(abs_tol / den[l]), qp[nlev + l] = vol[l].
+// abs_tol = 2 * tol * norm (REL), 2 * tol (ABS), or 2 * (T)(tol * norm) resp.
+// 2 * sqrt((tol*norm)^2 / nsub) (decomposed domain, ErrorToleranceCalculator.hpp:134-155).
+// All operations are single IEEE operations in the reference's order, so the values equal the
+// host computation bit for bit. norm source: d_norm (T) if given, else the reduction scalar
+// (absmax bits, or the double sum of squares).
+constexpr int kMaxLevels = 40;
+template <typename T> struct QParamArgs {
+  const T *d_norm;                  // optional
+  const unsigned long long *scalar;  // reduction result
+  int s_is_inf, rel, decomposed, normalize;
+  unsigned long long total, nsub;
+  T tol;
+  int nlev;
+  double den[kMaxLevels];
+  T vol[kMaxLevels];
+  T *qp;
+  T *norm_out;
+};
+
+template <typename T> __global__ void k_make_qparams(QParamArgs<T> P) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  T norm;
+  if (P.d_norm) {
+    norm = *P.d_norm;
+  } else if (P.s_is_inf) {
+    const unsigned long long bits = *P.scalar;
+    if (sizeof(T) == 4) norm = (T)__uint_as_float((unsigned)bits); else norm = (T)__longlong_as_double((long long)bits);
+  } else {
+    const double sum = __longlong_as_double((long long)*P.scalar);
+    norm = (T)sum;
+    if (sizeof(T) == 4) norm = P.normalize ? (T)sqrtf((float)(norm / (T)P.total)) : (T)sqrtf((float)norm);
+    else norm = P.normalize ? (T)sqrt((double)(norm / (T)P.total)) : (T)sqrt((double)norm);
+  }
+  if (!P.d_norm && norm == 0) norm = sizeof(T) == 4 ? (T)1.1920928955078125e-7f : (T)2.220446049250313e-16;
+  *P.norm_out = norm;
+  double abs_tol;
+  if (P.decomposed) {
+    T lt;
+    if (P.s_is_inf) {
+      lt = P.rel ? P.tol * norm : P.tol;
+    } else {
+      const T a = P.rel ? (P.tol * norm) * (P.tol * norm) / (T)P.nsub : (P.tol * P.tol) / (T)P.nsub;
+      lt = sizeof(T) == 4 ? (T)sqrtf((float)a) : (T)sqrt((double)a);
+    }
+    abs_tol = lt;
+  } else {
+    abs_tol = P.tol;
+    if (P.rel) abs_tol *= norm;
+  }
+  abs_tol *= 2;
+  for (int l = 0; l < P.nlev; l++) {
+    T q = (T)(abs_tol / P.den[l]);
+    q = 1.0f / q;
+    P.qp[l] = q;
+    P.qp[P.nlev + l] = P.vol[l];
   }
 }
 

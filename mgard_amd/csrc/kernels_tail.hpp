@@ -25,6 +25,7 @@ template <typename T> struct TailLevel {
   const T *mass[3];
   const T *thomas[3];
   T quantizer, volume;
+  int level;
 };
 
 template <typename T> struct TailArgs {
@@ -75,8 +76,8 @@ k_tail(TailArgs<T> A) {
     const Box3 b = L.b;
     const uint32_t n0 = b.n[0], n1 = b.n[1], n2 = b.n[2];
     const uint32_t m0 = b.m[0], m1 = b.m[1], m2 = b.m[2];
-    O.quantizer = L.quantizer;
-    O.volume = L.volume;
+    O.quantizer = O.qp ? O.qp[L.level] : L.quantizer;
+    O.volume = O.qp ? O.qp[O.nlev + L.level] : L.volume;
     // ---- coefficients (+ output) and coarse nodes ----
     {
       const uint32_t total = n0 * n1 * n2;
@@ -153,8 +154,8 @@ k_tail(TailArgs<T> A) {
     const TailLevel<T> &L = A.lv[A.nlevels - 1];
     const uint32_t m0 = L.b.m[0], m1 = L.b.m[1], m2 = L.b.m[2];
     const uint32_t total = m0 * m1 * m2;
-    O.quantizer = A.head_quantizer;
-    O.volume = A.head_volume;
+    O.quantizer = O.qp ? O.qp[0] : A.head_quantizer;
+    O.volume = O.qp ? O.qp[O.nlev] : A.head_volume;
     for (uint32_t e0 = 0; e0 < total; e0 += NT) {
       const uint32_t e = e0 + tid;
       const bool live = e < total;

@@ -241,3 +241,42 @@ def test_simple_kernels_match_fused_kernels(shape, dt, monkeypatch):
         assert n == rn
         np.testing.assert_array_equal(q.cpu().numpy(), rq)
         h.close()
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("s,nsub", [(np.inf, 8), (0.0, 4)])
+def test_device_norm_path_decomposed_domain(dt, s, nsub):
+    """mgh_norm_device + mgh_decompose_quantize_dn (nothing returns to the host) apply the
+    reference's per-subdomain bound calc_local_abs_tol (ErrorToleranceCalculator.hpp:134-155)."""
+    torch, mg = _gpu()
+    shape = (34, 33, 65)
+    u = smooth_field(shape, dt)
+    h = mg.Hierarchy(shape, dt)
+    o = oracle.Hierarchy(shape, dt)
+    ud = torch.from_numpy(u).cuda()
+    dn = h.norm_device(ud, s)
+    g = dt(dn.item())
+    if np.isinf(s):
+        assert g == dt(oracle.norm(u, dt(s)))
+        g_used = g
+        atol = dt(1e-3) * g_used
+    else:
+        g_used = dt(oracle.norm(u, dt(s)))  # L2 is not bit-reproducible: inject the oracle's
+        dn.fill_(float(g_used))
+        a = (dt(1e-3) * g_used) * (dt(1e-3) * g_used) / dt(nsub)
+        atol = np.sqrt(a, dtype=dt)
+    cap = u.size
+    bufs = (torch.empty(shape, dtype=torch.int64, device="cuda"),
+            torch.zeros(1, dtype=torch.int64, device="cuda"),
+            torch.empty(cap, dtype=torch.int64, device="cuda"),
+            torch.empty(cap, dtype=torch.int64, device="cuda"))
+    q, oi, ov, cnt = h.decompose_quantize_dn(ud, mg.REL, 1e-3, s, dn, nsub, bufs)
+    rq, roi, rov, rn = o.quantize(o.decompose(u), oracle.ABS, dt(atol), dt(s), dt(1))
+    n = int(cnt.item())
+    assert n == rn
+    np.testing.assert_array_equal(q.cpu().numpy(), rq)
+    gi, gv = _outlier_set(oi[:n].cpu().numpy(), ov[:n].cpu().numpy())
+    ri, rv = _outlier_set(roi, rov)
+    np.testing.assert_array_equal(gi, ri)
+    np.testing.assert_array_equal(gv, rv)
+    h.close()
