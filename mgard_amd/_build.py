@@ -8,7 +8,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libmgard_hip.so")
+# MGARD_HIP_LIB: developer override to A/B two builds of the library in one session
+LIB = os.environ.get("MGARD_HIP_LIB", os.path.join(HERE, "libmgard_hip.so"))
 SOURCES = ["capi.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
                "-shared", "-Wall"]
