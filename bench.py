@@ -182,6 +182,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # HBM traffic of the dominant kernel from the committed PMC passes (same workload only)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_512cube_f32.json")
+    if shape == SHAPE and os.path.exists(tpath):
+        t = json.load(open(tpath)).get(dominant)
+        if t:
+            traffic = int((t["fetch_kib"] * t["read_correction"] + t["write_kib"]) * 1024)
     in_bytes = N * 4
     value = in_bytes * args.steps * world / elapsed / 1e9
     alg = algorithmic_bytes_per_step(h, 4)
@@ -204,7 +211,7 @@ def main():
         "hbm_frac_whole_step": round(12.0 * N / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
         "roofline": {"bound": "hbm", "kernel": dominant,
                      "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "avg_launch_ms": round(dom_ms / max(dom_launches, 1), 5),
                      "launches": dom_launches,
                      "algorithmic_bytes_per_step": alg.get(dominant, 0),

@@ -280,3 +280,46 @@ def test_device_norm_path_decomposed_domain(dt, s, nsub):
     np.testing.assert_array_equal(gi, ri)
     np.testing.assert_array_equal(gv, rv)
     h.close()
+
+
+def _host_mem_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+@pytest.mark.parametrize("n", [512, 1024])
+def test_full_size_roundtrip_and_parity(n):
+    """BASELINE.json configs[1] (512^3) and configs[4] (1024^3 compress + decompress round trip):
+    quantized integers bit-exact vs the CPU oracle at FULL size, and the round-trip L-inf error
+    within the requested tolerance."""
+    torch, mg = _gpu()
+    shape = (n, n, n)
+    if _host_mem_gb() < (24 if n == 512 else 120):
+        pytest.skip("not enough host memory for the full-size oracle run")
+    u = smooth_field(shape, np.float32)
+    h = mg.Hierarchy(shape, np.float32)
+    ud = torch.from_numpy(u).cuda()
+    tol = 1e-3
+    q, oi, ov, cnt, nrm = h.decompose_quantize(ud, mg.REL, tol, np.inf, outlier_cap=u.size // 8)
+    assert cnt <= u.size // 8
+    assert nrm == float(np.max(np.abs(u)))
+    back = h.dequantize_recompose(q.clone(), mg.REL, tol, np.inf, nrm, outlier_idx=oi, outlier_val=ov)
+    err = float((back - ud).abs().max().item())
+    assert err <= tol * nrm, (err, tol * nrm)
+    del back
+    o = oracle.Hierarchy(shape, np.float32)
+    c = o.decompose(u)
+    rq, roi, rov, rn = o.quantize(c, oracle.REL, np.float32(tol), np.float32(np.inf), np.float32(nrm),
+                                  outlier_cap=u.size // 8)
+    del c
+    assert cnt == rn
+    assert np.array_equal(q.cpu().numpy(), rq)
+    gi, gv = _outlier_set(oi.cpu().numpy(), ov.cpu().numpy())
+    ri, rv = _outlier_set(roi, rov)
+    assert np.array_equal(gi, ri) and np.array_equal(gv, rv)
+    h.close()
