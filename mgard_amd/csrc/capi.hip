@@ -456,12 +456,18 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
     if ((size_t)gx * gy * ((b.m[0] + 15) / 16) >= 2048) {
       const dim3 grid(gx, gy, (b.m[0] + 15) / 16);
       TRY(launch(h, OUT == OUT_Q ? "level_fused_q" : "level_fused", s, [&] {
-        k_level_fused<T, OUT, TC, TF, 16><<<grid, 256, 0, s>>>(A);
+        k_level_fused<T, OUT, TC, TF, 16, false><<<grid, 256, 0, s>>>(A);
       }));
-    } else {
+    } else if ((size_t)gx * gy * ((b.m[0] + 3) / 4) >= 256) {
       const dim3 grid(gx, gy, (b.m[0] + 3) / 4);
       TRY(launch(h, OUT == OUT_Q ? "level_fused_q_small" : "level_fused_small", s, [&] {
-        k_level_fused<T, OUT, TC, TF, 4><<<grid, 256, 0, s>>>(A);
+        k_level_fused<T, OUT, TC, TF, 4, false><<<grid, 256, 0, s>>>(A);
+      }));
+    } else {
+      // few tiles: the march length is the whole cost -> one coarse plane per block
+      const dim3 grid(gx, gy, b.m[0]);
+      TRY(launch(h, OUT == OUT_Q ? "level_fused_q_small" : "level_fused_small", s, [&] {
+        k_level_fused<T, OUT, TC, TF, 1, true><<<grid, 256, 0, s>>>(A);
       }));
     }
     TRY(ipk_launch<T>(h, 2, b.m, ds->t3, t.thomas[2], nullptr, +1, s));

@@ -136,7 +136,11 @@ __device__ __forceinline__ void emit_quantized(const FusedArgs<T> &A, const T (&
     if (on[k]) A.q[lin[k]] = qd[k];
 }
 
-template <typename T, int OUT, int TC, int TF, int RCH>
+// PAIR = true runs the (odd, even) plane pair through each phase together: 3 barriers per pair
+// instead of 5 and more independent work per phase, at the price of ~15 more VGPRs. It pays
+// on the small levels, where a block's march is pure latency; on the big levels occupancy
+// matters more (PAIR = false).
+template <typename T, int OUT, int TC, int TF, int RCH, bool PAIR>
 __global__ void __launch_bounds__(256)
 k_level_fused(FusedArgs<T> A) {
   constexpr int WC = 2 * TC + 3;
@@ -148,8 +152,8 @@ k_level_fused(FusedArgs<T> A) {
   constexpr int NH = (TC + 2) * (TF + 2) - TC * TF;  // halo cells
   static_assert(NH <= NT, "halo cells are handled in one extra pass");
   __shared__ T raw[3][WC * ROW];
-  __shared__ T Cs[WC * ROW];
-  __shared__ T t1s[WC][TF + 1];
+  __shared__ T Cs2[PAIR ? 2 : 1][WC * ROW];     // coefficient field (of the plane pair)
+  __shared__ T t1s2[PAIR ? 2 : 1][WC][TF + 1];  // f-swept rows
   __shared__ T rfs[WF];
   __shared__ T rcs[WC];
   __shared__ T rrs[2 * RCH + 3];  // ratio_r[p - 1] of plane p = r_lo + index
@@ -284,7 +288,7 @@ k_level_fused(FusedArgs<T> A) {
   // coefficient field of one cell on plane p; returns the four values (ee, eo, oe, oo) and the
   // raw centre of the (even, even) node. Interpolation: f innermost, then c, then r
   // (GridProcessingKernel3D.hpp:614-617, 737-744, 854-871).
-  auto cell_coeff = [&](const Cell &c, int p, bool pv, T rr, T(&cv)[4], T &centre) {
+  auto cell_coeff = [&](const Cell &c, int p, bool pv, T rr, T *Cs, T(&cv)[4], T &centre) {
     const bool p_odd = p & 1;
     const T *cur = raw[(p + 6) % 3];
     T r[4];
@@ -334,58 +338,58 @@ k_level_fused(FusedArgs<T> A) {
     if (c.c1 && c.f1) Cs[c.i11] = cv[3];
   };
 
-  // Phases A-D for one fine plane whose raw neighbours are in the LDS ring
-  auto process_plane = [&](int p) {
+  // Phase A for one fine plane whose raw neighbours are in the LDS ring: coefficient field of
+  // the window into Cs, owned coefficients / coarse nodes to HBM
+  auto phase_a = [&](int p, T *Cs) {
     const bool p_odd = p & 1;
     const bool pv = p >= 0 && p <= Pmax_r && p != ghost_r;
-    // ---------------- Phase A: coefficient field on the window -----------------
-    {
-      const T rr = rrs[p - r_lo];
-      T cv[4], centre;
-      cell_coeff(own, p, pv, rr, cv, centre);
-      const bool own_r = pv && p >= 2 * R0 && p < 2 * R0 + 2 * RCH;
-      if (own_r) {
-        const int oi = p_odd ? mr + (p - 1) / 2 : p / 2;
-        const size_t ob = (size_t)oi * A.dI;
-        const bool on[4] = {p_odd && own.vc0 && own.vf0, own.vc0 && own.vf1, own.vc1 && own.vf0,
-                            own.vc1 && own.vf1};
-        const size_t lin[4] = {ob + ob_c0 + ok0, ob + ob_c0 + ok1, ob + ob_c1 + ok0,
-                               ob + ob_c1 + ok1};
-        if (!p_odd && own.vc0 && own.vf0)
-          A.coarse[(size_t)(p / 2) * mc * mf + coarse_off] = centre;
-        if (OUT == OUT_T) {
+    const T rr = rrs[p - r_lo];
+    T cv[4], centre;
+    cell_coeff(own, p, pv, rr, Cs, cv, centre);
+    const bool own_r = pv && p >= 2 * R0 && p < 2 * R0 + 2 * RCH;
+    if (own_r) {
+      const int oi = p_odd ? mr + (p - 1) / 2 : p / 2;
+      const size_t ob = (size_t)oi * A.dI;
+      const bool on[4] = {p_odd && own.vc0 && own.vf0, own.vc0 && own.vf1, own.vc1 && own.vf0,
+                          own.vc1 && own.vf1};
+      const size_t lin[4] = {ob + ob_c0 + ok0, ob + ob_c0 + ok1, ob + ob_c1 + ok0,
+                             ob + ob_c1 + ok1};
+      if (!p_odd && own.vc0 && own.vf0)
+        A.coarse[(size_t)(p / 2) * mc * mf + coarse_off] = centre;
+      if (OUT == OUT_T) {
 #pragma unroll
-          for (int k = 0; k < 4; k++)
-            if (on[k]) A.coef[lin[k]] = cv[k];
-        } else {
-          emit_quantized<T, 4>(A, cv, lin, on);
-        }
-      }
-      if (tid < NH) {
-        T hv[4], hc;
-        cell_coeff(halo, p, pv, rr, hv, hc);
+        for (int k = 0; k < 4; k++)
+          if (on[k]) A.coef[lin[k]] = cv[k];
+      } else {
+        emit_quantized<T, 4>(A, cv, lin, on);
       }
     }
-    __syncthreads();
-    // ---------------- Phase B: f-sweep, rows lc, coarse column jf -----------------
+    if (tid < NH) {
+      T hv[4], hc;
+      cell_coeff(halo, p, pv, rr, Cs, hv, hc);
+    }
+  };
+  // Phase B: f-sweep of the window rows lc = jc, jc + TC, ... at coarse column jf
+  auto phase_b = [&](const T *Cs, T(*t1s)[TF + 1]) {
     for (int lc = jc; lc < WC; lc += TC) {
       const T *row = Cs + lc * ROW;
       t1s[lc][jf] = mass_apply(row[jf], row[HF + jf], row[jf + 1], row[HF + jf + 1], row[jf + 2], wf);
     }
-    __syncthreads();
-    // ---------------- Phase C: c-sweep, one value per thread ------------------------
-    {
-      const int lc = 2 * jc + 2;
-      const T v = mass_apply(t1s[lc - 2][jf], t1s[lc - 1][jf], t1s[lc][jf], t1s[lc + 1][jf],
-                             t1s[lc + 2][jf], wc);
-      win[0] = win[1];
-      win[1] = win[2];
-      win[2] = win[3];
-      win[3] = win[4];
-      win[4] = v;
-    }
-    // ---------------- Phase D: r-sweep on the register window -----------------------
-    if (!p_odd && p >= 2 * R0 + 2) {
+  };
+  // Phase C: c-sweep, one value per thread, pushed into the register window
+  auto phase_c = [&](const T(*t1s)[TF + 1]) {
+    const int lc = 2 * jc + 2;
+    const T v = mass_apply(t1s[lc - 2][jf], t1s[lc - 1][jf], t1s[lc][jf], t1s[lc + 1][jf],
+                           t1s[lc + 2][jf], wc);
+    win[0] = win[1];
+    win[1] = win[2];
+    win[2] = win[3];
+    win[3] = win[4];
+    win[4] = v;
+  };
+  // Phase D: r-sweep on the register window after even plane p = 2R + 2
+  auto phase_d = [&](int p) {
+    if (p >= 2 * R0 + 2) {
       const int R = (p - 2) / 2;
       const int Jc = C0 + jc, Jf = F0 + jf;
       if (R < mr && Jc < mc && Jf < mf) {
@@ -406,10 +410,14 @@ k_level_fused(FusedArgs<T> A) {
   fetch(r_lo + 1, pre_o);
   fetch(r_lo + 2, pre_e);
   __syncthreads();
-  process_plane(r_lo);
+  phase_a(r_lo, Cs2[0]);
+  __syncthreads();
+  phase_b(Cs2[0], t1s2[0]);
+  __syncthreads();
+  phase_c(t1s2[0]);
   for (int p = r_lo + 1; p < r_hi; p += 2) {
-    // ring slots of planes p-3 and p-2 are free: their last readers (phase A of plane p-2)
-    // are behind a barrier; phases C/D of plane p-1 do not touch the ring
+    // ring slots of planes p-3 and p-2 are free: their last readers (phase A of the previous
+    // pair) are behind a barrier; phases B-D do not touch the ring
     stash(p, pre_o);
     stash(p + 1, pre_e);
     __syncthreads();
@@ -417,8 +425,31 @@ k_level_fused(FusedArgs<T> A) {
       fetch(p + 2, pre_o);
       fetch(p + 3, pre_e);
     }
-    process_plane(p);
-    process_plane(p + 1);
+    if (PAIR) {
+      phase_a(p, Cs2[0]);
+      phase_a(p + 1, Cs2[PAIR ? 1 : 0]);
+      __syncthreads();
+      phase_b(Cs2[0], t1s2[0]);
+      phase_b(Cs2[PAIR ? 1 : 0], t1s2[PAIR ? 1 : 0]);
+      __syncthreads();
+      phase_c(t1s2[0]);
+      phase_c(t1s2[PAIR ? 1 : 0]);
+      phase_d(p + 1);
+    } else {
+      phase_a(p, Cs2[0]);
+      __syncthreads();
+      phase_b(Cs2[0], t1s2[0]);
+      __syncthreads();
+      phase_c(t1s2[0]);
+      // (Cs2[0] was last read before the previous barrier; t1s2[0] is rewritten only after
+      // the next one)
+      phase_a(p + 1, Cs2[0]);
+      __syncthreads();
+      phase_b(Cs2[0], t1s2[0]);
+      __syncthreads();
+      phase_c(t1s2[0]);
+      phase_d(p + 1);
+    }
   }
 #undef LI
 }
