@@ -130,8 +130,11 @@ class Hierarchy:
         self.total = int(L.mgh_total_num_elems(h))
 
     def close(self):
-        if getattr(self, "_h", None):
-            load_library().mgh_hierarchy_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:
+            try:
+                _lib.mgh_hierarchy_destroy(self._h)
+            except Exception:  # interpreter shutdown
+                pass
             self._h = None
 
     __del__ = close

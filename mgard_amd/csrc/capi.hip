@@ -22,6 +22,7 @@
 #include "kernels_ipk.hpp"
 #include "kernels_fused.hpp"
 #include "kernels_tail.hpp"
+#include "kernels_recompose.hpp"
 
 namespace {
 
@@ -606,6 +607,81 @@ int recompose_impl(mgh_hierarchy *h, const T *coeff, T *data, hipStream_t s) {
   return MGH_SUCCESS;
 }
 
+
+// Fused decompression: outlier restore, then per level (coarse to fine) the load vector
+// straight from the quantized coefficients, three Thomas solves subtracting the correction
+// from the coarse nodes, and the node restore with the dequantizer fused in
+// (Compressor::Decompress lines 256-257 = Dequantize + Recompose).
+template <typename T>
+int dequantize_recompose_fused(mgh_hierarchy *h, int64_t *q, int ebtype, double tol, double s,
+                               double norm, uint64_t dict_size, int prep_huffman,
+                               const uint64_t *oidx, const int64_t *oval, uint64_t ocount, T *data,
+                               hipStream_t st) {
+  auto *ds = DS<T>(h);
+  auto *hh = HH<T>(h);
+  const int L = h->L;
+  if (prep_huffman && ocount) {
+    TRY(launch(h, "outlier_restore", st, [&] {
+      k_outlier_restore<<<(unsigned)((ocount + 255) / 256), 256, 0, st>>>(q, oidx, oval, ocount);
+    }));
+  }
+  std::vector<T> qz(L + 1);
+  hh->quantizers(ebtype, (T)tol, (T)s, (T)norm, false, qz.data());
+  const bool calc_vol = !((T)s == std::numeric_limits<T>::infinity());
+  RecomposeArgs<T> A{};
+  A.q = q;
+  A.dI = ds->full_I;
+  A.dJ = ds->full_J;
+  A.half = prep_huffman ? (int64_t)(dict_size / 2) : 0;
+  auto qv = [&](int l) { return qz[l] * (calc_vol ? hh->level_volume(l, true) : (T)1); };
+  {
+    const Box3 &b = ds->lt[1].box;
+    A.qv = qv(0);
+    TRY(launch(h, "head_in", st, [&] {
+      k_head_in_q<T><<<1, 256, 0, st>>>((int)b.m[0], (int)b.m[1], (int)b.m[2], A, ds->nodal[0]);
+    }));
+  }
+  constexpr int TC = 8, TF = 32;
+  for (int l = 1; l <= L; l++) {
+    const LevelTables<T> &t = ds->lt[l];
+    const Box3 &b = t.box;
+    for (int k = 0; k < 3; k++) {
+      A.n[k] = (int)b.n[k];
+      A.m[k] = (int)b.m[k];
+      A.ratio[k] = t.ratio[k];
+      A.mass[k] = t.mass[k];
+    }
+    A.qv = qv(l);
+    A.load = ds->t3;
+    A.coarse = ds->nodal[l - 1];
+    const unsigned gx = (b.m[2] + TF - 1) / TF, gy = (b.m[1] + TC - 1) / TC;
+    if ((size_t)gx * gy * ((b.m[0] + 15) / 16) >= 2048) {
+      TRY(launch(h, "loadvec_q", st, [&] {
+        k_level_loadvec_q<T, TC, TF, 16><<<dim3(gx, gy, (b.m[0] + 15) / 16), 256, 0, st>>>(A);
+      }));
+    } else if ((size_t)gx * gy * ((b.m[0] + 3) / 4) >= 256) {
+      TRY(launch(h, "loadvec_q_small", st, [&] {
+        k_level_loadvec_q<T, TC, TF, 4><<<dim3(gx, gy, (b.m[0] + 3) / 4), 256, 0, st>>>(A);
+      }));
+    } else {
+      TRY(launch(h, "loadvec_q_small", st, [&] {
+        k_level_loadvec_q<T, TC, TF, 1><<<dim3(gx, gy, b.m[0]), 256, 0, st>>>(A);
+      }));
+    }
+    TRY(ipk_launch<T>(h, 2, b.m, ds->t3, t.thomas[2], nullptr, -1, st));
+    TRY(ipk_launch<T>(h, 1, b.m, ds->t3, t.thomas[1], nullptr, -1, st));
+    TRY(ipk_launch<T>(h, 0, b.m, ds->t3, t.thomas[0], ds->nodal[l - 1], -1, st));
+    A.fine = (l == L) ? data : ds->nodal[l];
+    A.fJ = (l == L) ? ds->full_J : b.n[2];
+    A.fI = (l == L) ? ds->full_I : (size_t)b.n[1] * b.n[2];
+    const dim3 blk(64, 4, 1);
+    TRY(launch(h, "restore_q", st, [&] {
+      k_level_restore_q<T><<<grid3(b.n[0], b.n[1], (b.n[2] + 1) / 2, blk), blk, 0, st>>>(A);
+    }));
+  }
+  return MGH_SUCCESS;
+}
+
 template <typename T>
 int upload_quantizers(mgh_hierarchy *h, int ebtype, double tol, double s, double norm,
                       bool reciprocal, hipStream_t st) {
@@ -1054,6 +1130,18 @@ int mgh_dequantize_recompose(mgh_hierarchy *h, int64_t *d_quantized, int ebtype,
                              const uint64_t *d_outlier_idx, const int64_t *d_outlier_val,
                              uint64_t outlier_count, void *d_data, void *stream) {
   if (!h || !d_data || !d_quantized) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
+  if (fused_ok(h) && !h->force_v1) {
+    HIP_TRY(hipSetDevice(h->device));
+    return DISPATCH(h,
+                    dequantize_recompose_fused<float>(h, d_quantized, ebtype, tol, s, norm, dict_size,
+                                                      prep_huffman, d_outlier_idx, d_outlier_val,
+                                                      outlier_count, (float *)d_data,
+                                                      (hipStream_t)stream),
+                    dequantize_recompose_fused<double>(h, d_quantized, ebtype, tol, s, norm,
+                                                       dict_size, prep_huffman, d_outlier_idx,
+                                                       d_outlier_val, outlier_count,
+                                                       (double *)d_data, (hipStream_t)stream));
+  }
   int rc = mgh_dequantize(h, d_quantized, ebtype, tol, s, norm, dict_size, prep_huffman,
                           d_outlier_idx, d_outlier_val, outlier_count, d_data, stream);
   if (rc != MGH_SUCCESS) return rc;

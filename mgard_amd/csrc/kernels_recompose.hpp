@@ -1,0 +1,224 @@
+// Decompression side of the fused path (dequantize + recompose), gfx950.
+//
+//   k_level_loadvec_q : load vector Lr(Lc(Lf(C))) of level l straight from the QUANTIZED
+//                       coefficients (dequantized on the fly, never materialised as floats);
+//                       same marching / sweep structure as k_level_fused (kernels_fused.hpp),
+//                       minus the coefficient computation.
+//   k_level_restore_q : fine nodal array from the corrected coarse nodes and the quantized
+//                       coefficients: even nodes are copies, odd nodes = coefficient +
+//                       interpolant (GpkRev3D, GridProcessingKernel3D.hpp:1231-2352), with the
+//                       dequantizer of LinearQuantization.hpp:246-264 fused in.
+//   k_head_in_q       : level-0 nodal values out of the head of the quantized array.
+// Between the two, the Thomas solves of kernels_ipk.hpp subtract the correction from the
+// coarse nodes. Bit-identical to dequantize + recompose with kernels_v1.hpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels_fused.hpp"
+
+namespace mgh {
+
+template <typename T> struct RecomposeArgs {
+  int n[3], m[3];
+  const int64_t *q;  // quantized coefficients, reordered layout, strides (dI, dJ, 1)
+  size_t dI, dJ;
+  const T *coarse;   // compact (m0, m1, m2), corrected coarse nodes (restore only)
+  T *load;           // compact (m0, m1, m2) (loadvec only)
+  T *fine;           // natural fine box, strides (fI, fJ, 1) (restore only)
+  size_t fI, fJ;
+  const T *ratio[3];
+  const T *mass[3];
+  T qv;              // quantizer * reciprocal volume of this level (dequantize factor)
+  int64_t half;      // dict_size / 2 if the Huffman shift was applied, else 0
+};
+
+template <typename T> __device__ __forceinline__ T dequant_one(int64_t qd, int64_t half, T qv) {
+  return qv * (T)(qd - half);
+}
+
+template <typename T, int TC, int TF, int RCH>
+__global__ void __launch_bounds__(256)
+k_level_loadvec_q(RecomposeArgs<T> A) {
+  constexpr int WC = 2 * TC + 3;
+  constexpr int WF = 2 * TF + 3;
+  constexpr int HF = TF + 2;
+  constexpr int ROW = 2 * HF;
+  constexpr int NT = 256;
+  static_assert(TC * TF == NT, "one c-sweep output per thread");
+  constexpr int NL = (WC * WF + NT - 1) / NT;
+  __shared__ T Cs[WC * ROW];
+  __shared__ T t1s[WC][TF + 1];
+  __shared__ T wrs[RCH][9];
+#define LI(lc, lf) ((lc) * ROW + ((lf) & 1) * HF + ((lf) >> 1))
+  const int tid = threadIdx.x;
+  const int F0 = blockIdx.x * TF, C0 = blockIdx.y * TC, R0 = blockIdx.z * RCH;
+  const int nr = A.n[0], nc = A.n[1], nf = A.n[2];
+  const int mr = A.m[0], mc = A.m[1], mf = A.m[2];
+  const int c_lo = 2 * C0 - 2, f_lo = 2 * F0 - 2, r_lo = 2 * R0 - 2;
+  const int r_hi = min(2 * R0 + 2 * RCH, 2 * mr);
+  const int Pmax_r = 2 * mr - 2, Pmax_c = 2 * mc - 2, Pmax_f = 2 * mf - 2;
+  const int ghost_r = (nr % 2 == 0) ? nr - 1 : -7;
+  const int ghost_c = (nc % 2 == 0) ? nc - 1 : -7;
+  const int ghost_f = (nf % 2 == 0) ? nf - 1 : -7;
+  for (int e = tid; e < RCH * 9; e += NT) {
+    const int R = R0 + e / 9, k = e % 9;
+    wrs[e / 9][k] = R < mr ? A.mass[0][k * mr + R] : (T)0;
+  }
+  const int jf = tid % TF, jc = tid / TF;
+  T wf[9], wc[9];
+  {
+    const int Jf = F0 + jf, Jc = C0 + jc;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      wf[k] = Jf < mf ? A.mass[2][k * mf + Jf] : (T)0;
+      wc[k] = Jc < mc ? A.mass[1][k * mc + Jc] : (T)0;
+    }
+  }
+  T win[5] = {0, 0, 0, 0, 0};
+  // window elements of this thread: offset of the coefficient inside an r-plane of q, parity
+  constexpr uint32_t kNone = 0xffffffffu;
+  uint32_t qoff[NL];
+  int lds[NL];
+  bool evn[NL];  // even in c and f: a coefficient only on odd r-planes
+#pragma unroll
+  for (int k = 0; k < NL; k++) {
+    const int e = tid + k * NT;
+    const int lc = e / WF, lf = e - lc * WF;
+    const int Pc = c_lo + lc, Pf = f_lo + lf;
+    const bool ok = e < WC * WF && Pc >= 0 && Pc <= Pmax_c && Pf >= 0 && Pf <= Pmax_f &&
+                    Pc != ghost_c && Pf != ghost_f;
+    const int oj = (Pc & 1) ? mc + (Pc - 1) / 2 : Pc / 2;
+    const int okk = (Pf & 1) ? mf + (Pf - 1) / 2 : Pf / 2;
+    qoff[k] = ok ? (uint32_t)(oj * (int)A.dJ + okk) : kNone;
+    lds[k] = e < WC * WF ? LI(lc, lf) : -1;
+    evn[k] = !(lc & 1) && !(lf & 1);
+  }
+  auto fetch = [&](int p, int64_t(&reg)[NL]) {
+    const bool pv = p >= 0 && p <= Pmax_r && p != ghost_r;
+    const bool p_odd = p & 1;
+    const int oi = p_odd ? mr + (p - 1) / 2 : p / 2;
+    const int64_t *base = A.q + (size_t)(pv ? oi : 0) * A.dI;
+#pragma unroll
+    for (int k = 0; k < NL; k++)
+      reg[k] = (pv && qoff[k] != kNone && (p_odd || !evn[k])) ? base[qoff[k]] : A.half;
+  };
+  int64_t cur[NL], nxt[NL];
+  fetch(r_lo, cur);
+  for (int p = r_lo; p <= r_hi; p++) {
+    if (p < r_hi) fetch(p + 1, nxt);
+    // Phase A': dequantized coefficient field of the window (0 at coarse / missing nodes:
+    // a missing value was fetched as `half`, which dequantizes to exactly 0)
+#pragma unroll
+    for (int k = 0; k < NL; k++)
+      if (lds[k] >= 0) Cs[lds[k]] = dequant_one<T>(cur[k], A.half, A.qv);
+    __syncthreads();
+    for (int lc = jc; lc < WC; lc += TC) {
+      const T *row = Cs + lc * ROW;
+      t1s[lc][jf] = mass_apply(row[jf], row[HF + jf], row[jf + 1], row[HF + jf + 1], row[jf + 2], wf);
+    }
+    __syncthreads();
+    {
+      const int lc = 2 * jc + 2;
+      const T v = mass_apply(t1s[lc - 2][jf], t1s[lc - 1][jf], t1s[lc][jf], t1s[lc + 1][jf],
+                             t1s[lc + 2][jf], wc);
+      win[0] = win[1];
+      win[1] = win[2];
+      win[2] = win[3];
+      win[3] = win[4];
+      win[4] = v;
+    }
+    if (!(p & 1) && p >= 2 * R0 + 2) {
+      const int R = (p - 2) / 2;
+      const int Jc = C0 + jc, Jf = F0 + jf;
+      if (R < mr && Jc < mc && Jf < mf) {
+        T wr[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) wr[k] = wrs[R - R0][k];
+        A.load[((size_t)R * mc + Jc) * mf + Jf] =
+            mass_apply(win[0], win[1], win[2], win[3], win[4], wr);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NL; k++) cur[k] = nxt[k];
+  }
+#undef LI
+}
+
+// One thread per PAIR of fine nodes (fp = 2t, 2t + 1) of a fine row (rp, cp): consecutive
+// threads read consecutive quantized values in both the coarse-f and the coefficient-f part
+// of the reordered row and consecutive coarse nodes, and write 8 contiguous bytes each.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_level_restore_q(RecomposeArgs<T> A) {
+  const int nr = A.n[0], nc = A.n[1], nf = A.n[2];
+  const int mr = A.m[0], mc = A.m[1], mf = A.m[2];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;  // pair index along f
+  const int cp = blockIdx.y * blockDim.y + threadIdx.y;
+  const int rp = blockIdx.z;
+  if (2 * t >= nf || cp >= nc || rp >= nr) return;
+  // coarse index of an even fine position (or of the real last node of an even-sized dim),
+  // else the node is a coefficient node at odd position p
+  auto split = [](int p, int n, int m, bool &odd) -> int {
+    odd = (p & 1) && !(n % 2 == 0 && p == n - 1);
+    return odd ? m + (p - 1) / 2 : (p == n - 1 ? m - 1 : p / 2);
+  };
+  bool ro, co;
+  const int i = split(rp, nr, mr, ro), j = split(cp, nc, mc, co);
+  const size_t mJ = mf, mI = (size_t)mc * mf;
+  const int r0 = ro ? (rp - 1) / 2 : i, c0 = co ? (cp - 1) / 2 : j;
+  const T rr = ro ? A.ratio[0][rp - 1] : (T)0, rc = co ? A.ratio[1][cp - 1] : (T)0;
+  const int64_t *qrow = A.q + (size_t)i * A.dI + (size_t)j * A.dJ;
+  T *out = A.fine + (size_t)rp * A.fI + (size_t)cp * A.fJ;
+  // node E = fine 2t (coarse-f index t); node O = fine 2t+1: a coefficient node in f, or
+  // -- last node of an even-sized dim -- the coarse-f node t+1 = mf-1
+  const int fpO = 2 * t + 1;
+  const bool hasO = fpO < nf;
+  const bool fo = hasO && !(nf % 2 == 0 && fpO == nf - 1);
+  const bool pure_coarse = !ro && !co;
+  const T rf = fo ? A.ratio[2][fpO - 1] : (T)0;
+  const int t1 = min(t + 1, mf - 1);
+  // interpolants of both nodes from the (up to) 4 coarse rows, f innermost, then c, then r
+  T hE[2], hO[2];
+#pragma unroll
+  for (int a = 0; a < 2; a++) {
+    if (a == 1 && !ro) break;
+    T gE[2], gO[2];
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      if (b == 1 && !co) break;
+      const T *row = A.coarse + (size_t)(r0 + a) * mI + (size_t)(c0 + b) * mJ;
+      const T v0 = row[t], v1 = row[t1];
+      gE[b] = v0;
+      gO[b] = fo ? lerp_ref(v0, v1, rf) : v1;
+    }
+    hE[a] = co ? lerp_ref(gE[0], gE[1], rc) : gE[0];
+    hO[a] = co ? lerp_ref(gO[0], gO[1], rc) : gO[0];
+  }
+  const T iE = ro ? lerp_ref(hE[0], hE[1], rr) : hE[0];
+  const T iO = ro ? lerp_ref(hO[0], hO[1], rr) : hO[0];
+  // E: coarse node (pure copy) unless r or c is odd
+  T vE = iE;
+  if (!pure_coarse) vE = dequant_one<T>(qrow[t], A.half, A.qv) + iE;
+  out[2 * t] = vE;
+  if (hasO) {
+    T vO = iO;  // (pure coarse last node of an even-sized dim: iO = row[mf-1])
+    if (fo)
+      vO = dequant_one<T>(qrow[mf + t], A.half, A.qv) + iO;
+    else if (!pure_coarse)
+      vO = dequant_one<T>(qrow[mf - 1], A.half, A.qv) + iO;
+    out[fpO] = vO;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_head_in_q(int m0, int m1, int m2, RecomposeArgs<T> A, T *__restrict__ nodal) {
+  const int total = m0 * m1 * m2;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int k = e % m2, j = (e / m2) % m1, i = e / (m2 * m1);
+    nodal[e] = dequant_one<T>(A.q[(size_t)i * A.dI + (size_t)j * A.dJ + k], A.half, A.qv);
+  }
+}
+
+} // namespace mgh

@@ -323,3 +323,24 @@ def test_full_size_roundtrip_and_parity(n):
     ri, rv = _outlier_set(roi, rov)
     assert np.array_equal(gi, ri) and np.array_equal(gv, rv)
     h.close()
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("s", [np.inf, 0.0])
+@pytest.mark.parametrize("shape", [(5, 5, 5), (17, 20, 33), (34, 33, 32), (65, 70, 129), (100, 36, 260)])
+def test_fused_dequantize_recompose_bit_exact(shape, s, dt):
+    """mgh_dequantize_recompose (fused kernels for D = 3) against the oracle's
+    dequantize + recompose, with outliers and a small dictionary."""
+    torch, mg = _gpu()
+    u = smooth_field(shape, dt, noise=1e-2)
+    o = oracle.Hierarchy(shape, dt)
+    nrm = oracle.norm(u, dt(s))
+    rq, roi, rov, rn = o.quantize(o.decompose(u), oracle.REL, dt(1e-3), dt(s), dt(nrm), dict_size=256)
+    ref = o.recompose(o.dequantize(rq, oracle.REL, dt(1e-3), dt(s), dt(nrm), dict_size=256,
+                                   outlier_idx=roi, outlier_val=rov))
+    h = mg.Hierarchy(shape, dt)
+    back = h.dequantize_recompose(torch.from_numpy(rq).cuda(), mg.REL, 1e-3, s, nrm, dict_size=256,
+                                  outlier_idx=torch.from_numpy(roi.astype(np.int64)).cuda(),
+                                  outlier_val=torch.from_numpy(rov).cuda())
+    assert_bit_equal(back.cpu().numpy(), ref, "fused dequantize+recompose %r" % (shape,))
+    h.close()
