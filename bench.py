@@ -218,6 +218,30 @@ def main():
                      "kernel_ms_per_step_all": {k: round(v[0] / NPROF, 4)
                                                 for k, v in sorted(prof.items())}},
     }
+    if world == 1:
+        # decompression side (BASELINE.json configs[4] asks for the round trip): dequantize +
+        # recompose of the same volume, error against the requested tolerance
+        n_keep = int(cnt.item())
+        nrm_host = float(h.norm(d_u, float("inf")))
+        back = torch.empty_like(d_u)
+        q_work = q.clone()
+        for _ in range(2):
+            h.dequantize_recompose(q_work, mgard_amd.REL, TOL, float("inf"), nrm_host,
+                                   outlier_idx=oidx[:n_keep], outlier_val=oval[:n_keep], out=back)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ND = 10
+        for _ in range(ND):
+            h.dequantize_recompose(q_work, mgard_amd.REL, TOL, float("inf"), nrm_host,
+                                   outlier_idx=oidx[:n_keep], outlier_val=oval[:n_keep], out=back)
+        torch.cuda.synchronize()
+        d_ms = (time.perf_counter() - t1) / ND * 1e3
+        err = float((back - d_u).abs().max().item())
+        result["decompress"] = {"ms_per_step": round(d_ms, 4),
+                                "value": round(in_bytes / d_ms / 1e6, 3), "unit": "GB/s (output)",
+                                "roundtrip_linf_error": err, "tolerance_abs": TOL * nrm_host,
+                                "within_tolerance": bool(err <= TOL * nrm_host)}
+        del back, q_work
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, rq = cpu_baseline(u, TOL)
         result["cpu_baseline"] = base

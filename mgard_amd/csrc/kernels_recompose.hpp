@@ -200,14 +200,21 @@ k_level_restore_q(RecomposeArgs<T> A) {
   // E: coarse node (pure copy) unless r or c is odd
   T vE = iE;
   if (!pure_coarse) vE = dequant_one<T>(qrow[t], A.half, A.qv) + iE;
-  out[2 * t] = vE;
+  T vO = iO;  // (pure coarse last node of an even-sized dim: iO = row[mf-1])
   if (hasO) {
-    T vO = iO;  // (pure coarse last node of an even-sized dim: iO = row[mf-1])
     if (fo)
       vO = dequant_one<T>(qrow[mf + t], A.half, A.qv) + iO;
     else if (!pure_coarse)
       vO = dequant_one<T>(qrow[mf - 1], A.half, A.qv) + iO;
-    out[fpO] = vO;
+  }
+  // the pair is contiguous: one 2-element store when the row start allows it
+  T *dst = out + 2 * t;
+  if (hasO && (reinterpret_cast<uintptr_t>(dst) & (2 * sizeof(T) - 1)) == 0) {
+    struct alignas(2 * sizeof(T)) Pair { T a, b; };
+    *reinterpret_cast<Pair *>(dst) = Pair{vE, vO};
+  } else {
+    dst[0] = vE;
+    if (hasO) dst[1] = vO;
   }
 }
 
