@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shape", type=str, default=None, help="override, e.g. 256,256,256")
+    ap.add_argument("--force-dist-path", action="store_true",
+                    help="exercise the N>1 code path (process group + norm all-reduce) with any "
+                         "world size, e.g. 1 (developer check)")
     args = ap.parse_args()
 
     import numpy as np
@@ -112,7 +115,10 @@ def main():
         raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run "
                          "--nproc-per-node N bench.py --gpus N ...")
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist_path:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -135,7 +141,7 @@ def main():
     nrm_t = torch.zeros(1, dtype=torch.float32, device=dev)
 
     def step():
-        if world == 1:
+        if dist is None:
             # REL bound: norm computed inside the call, on the device (no host round trip)
             return h.decompose_quantize(d_u, mgard_amd.REL, TOL, float("inf"), 0.0, bufs=bufs,
                                         want_norm=False)[4]
@@ -207,7 +213,7 @@ def main():
                    "per_gpu_shape": list(shape), "l_target": h.l_target, "dict_size": 8192,
                    "outliers_per_step": n_out,
                    "parallelism": "1 subdomain per GPU%s" % (
-                       "" if world == 1 else ", scalar norm all-reduce over RCCL")},
+                       "" if dist is None else ", scalar norm all-reduce over RCCL")},
         "hbm_frac_whole_step": round(12.0 * N / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
         "roofline": {"bound": "hbm", "kernel": dominant,
                      "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -218,7 +224,7 @@ def main():
                      "kernel_ms_per_step_all": {k: round(v[0] / NPROF, 4)
                                                 for k, v in sorted(prof.items())}},
     }
-    if world == 1:
+    if dist is None:
         # decompression side (BASELINE.json configs[4] asks for the round trip): dequantize +
         # recompose of the same volume, error against the requested tolerance
         n_keep = int(cnt.item())
@@ -242,7 +248,7 @@ def main():
                                 "roundtrip_linf_error": err, "tolerance_abs": TOL * nrm_host,
                                 "within_tolerance": bool(err <= TOL * nrm_host)}
         del back, q_work
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and dist is None and not args.no_cpu_baseline:
         base, rq = cpu_baseline(u, TOL)
         result["cpu_baseline"] = base
         # parity spot check on the bench workload itself: quantized integers are bit-exact

@@ -676,7 +676,8 @@ int dequantize_recompose_fused(mgh_hierarchy *h, int64_t *q, int ebtype, double 
     A.fI = (l == L) ? ds->full_I : (size_t)b.n[1] * b.n[2];
     const dim3 blk(64, 4, 1);
     TRY(launch(h, "restore_q", st, [&] {
-      k_level_restore_q<T><<<grid3(b.n[0], b.n[1], (b.n[2] + 1) / 2, blk), blk, 0, st>>>(A);
+      // one 64-lane wave per fine row, 4 rows per block
+      k_level_restore_q<T><<<dim3(1, (b.n[1] + 3) / 4, b.n[0]), blk, 0, st>>>(A);
     }));
   }
   return MGH_SUCCESS;

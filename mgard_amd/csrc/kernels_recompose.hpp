@@ -145,18 +145,18 @@ k_level_loadvec_q(RecomposeArgs<T> A) {
 #undef LI
 }
 
-// One thread per PAIR of fine nodes (fp = 2t, 2t + 1) of a fine row (rp, cp): consecutive
-// threads read consecutive quantized values in both the coarse-f and the coefficient-f part
-// of the reordered row and consecutive coarse nodes, and write 8 contiguous bytes each.
+// One wave per fine row (rp, cp); a lane handles the node PAIRS (fp = 2t, 2t + 1) for
+// t = lane, lane + 64, ...: consecutive lanes read consecutive quantized values in both the
+// coarse-f and the coefficient-f part of the reordered row and consecutive coarse nodes, and
+// write 8 contiguous bytes each. Row-level index math is done once per wave.
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_level_restore_q(RecomposeArgs<T> A) {
   const int nr = A.n[0], nc = A.n[1], nf = A.n[2];
   const int mr = A.m[0], mc = A.m[1], mf = A.m[2];
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;  // pair index along f
   const int cp = blockIdx.y * blockDim.y + threadIdx.y;
   const int rp = blockIdx.z;
-  if (2 * t >= nf || cp >= nc || rp >= nr) return;
+  if (cp >= nc || rp >= nr) return;
   // coarse index of an even fine position (or of the real last node of an even-sized dim),
   // else the node is a coefficient node at odd position p
   auto split = [](int p, int n, int m, bool &odd) -> int {
@@ -170,51 +170,60 @@ k_level_restore_q(RecomposeArgs<T> A) {
   const T rr = ro ? A.ratio[0][rp - 1] : (T)0, rc = co ? A.ratio[1][cp - 1] : (T)0;
   const int64_t *qrow = A.q + (size_t)i * A.dI + (size_t)j * A.dJ;
   T *out = A.fine + (size_t)rp * A.fI + (size_t)cp * A.fJ;
-  // node E = fine 2t (coarse-f index t); node O = fine 2t+1: a coefficient node in f, or
-  // -- last node of an even-sized dim -- the coarse-f node t+1 = mf-1
-  const int fpO = 2 * t + 1;
-  const bool hasO = fpO < nf;
-  const bool fo = hasO && !(nf % 2 == 0 && fpO == nf - 1);
   const bool pure_coarse = !ro && !co;
-  const T rf = fo ? A.ratio[2][fpO - 1] : (T)0;
-  const int t1 = min(t + 1, mf - 1);
-  // interpolants of both nodes from the (up to) 4 coarse rows, f innermost, then c, then r
-  T hE[2], hO[2];
+  const T *rows[2][2];
 #pragma unroll
-  for (int a = 0; a < 2; a++) {
-    if (a == 1 && !ro) break;
-    T gE[2], gO[2];
+  for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int b = 0; b < 2; b++) {
-      if (b == 1 && !co) break;
-      const T *row = A.coarse + (size_t)(r0 + a) * mI + (size_t)(c0 + b) * mJ;
-      const T v0 = row[t], v1 = row[t1];
-      gE[b] = v0;
-      gO[b] = fo ? lerp_ref(v0, v1, rf) : v1;
+    for (int b = 0; b < 2; b++)
+      rows[a][b] = A.coarse + (size_t)(r0 + (ro ? a : 0)) * mI + (size_t)(c0 + (co ? b : 0)) * mJ;
+  const bool pair_aligned = (reinterpret_cast<uintptr_t>(out) & (2 * sizeof(T) - 1)) == 0;
+  const int npair = (nf + 1) / 2;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < npair; t += gridDim.x * blockDim.x) {
+    // node E = fine 2t (coarse-f index t); node O = fine 2t+1: a coefficient node in f, or
+    // -- last node of an even-sized dim -- the coarse-f node t+1 = mf-1
+    const int fpO = 2 * t + 1;
+    const bool hasO = fpO < nf;
+    const bool fo = hasO && !(nf % 2 == 0 && fpO == nf - 1);
+    const T rf = fo ? A.ratio[2][fpO - 1] : (T)0;
+    const int t1 = min(t + 1, mf - 1);
+    // interpolants of both nodes from the (up to) 4 coarse rows, f innermost, then c, then r
+    T hE[2], hO[2];
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+      if (a == 1 && !ro) break;
+      T gE[2], gO[2];
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        if (b == 1 && !co) break;
+        const T v0 = rows[a][b][t], v1 = rows[a][b][t1];
+        gE[b] = v0;
+        gO[b] = fo ? lerp_ref(v0, v1, rf) : v1;
+      }
+      hE[a] = co ? lerp_ref(gE[0], gE[1], rc) : gE[0];
+      hO[a] = co ? lerp_ref(gO[0], gO[1], rc) : gO[0];
     }
-    hE[a] = co ? lerp_ref(gE[0], gE[1], rc) : gE[0];
-    hO[a] = co ? lerp_ref(gO[0], gO[1], rc) : gO[0];
-  }
-  const T iE = ro ? lerp_ref(hE[0], hE[1], rr) : hE[0];
-  const T iO = ro ? lerp_ref(hO[0], hO[1], rr) : hO[0];
-  // E: coarse node (pure copy) unless r or c is odd
-  T vE = iE;
-  if (!pure_coarse) vE = dequant_one<T>(qrow[t], A.half, A.qv) + iE;
-  T vO = iO;  // (pure coarse last node of an even-sized dim: iO = row[mf-1])
-  if (hasO) {
-    if (fo)
-      vO = dequant_one<T>(qrow[mf + t], A.half, A.qv) + iO;
-    else if (!pure_coarse)
-      vO = dequant_one<T>(qrow[mf - 1], A.half, A.qv) + iO;
-  }
-  // the pair is contiguous: one 2-element store when the row start allows it
-  T *dst = out + 2 * t;
-  if (hasO && (reinterpret_cast<uintptr_t>(dst) & (2 * sizeof(T) - 1)) == 0) {
-    struct alignas(2 * sizeof(T)) Pair { T a, b; };
-    *reinterpret_cast<Pair *>(dst) = Pair{vE, vO};
-  } else {
-    dst[0] = vE;
-    if (hasO) dst[1] = vO;
+    const T iE = ro ? lerp_ref(hE[0], hE[1], rr) : hE[0];
+    const T iO = ro ? lerp_ref(hO[0], hO[1], rr) : hO[0];
+    // E: coarse node (pure copy) unless r or c is odd
+    T vE = iE;
+    if (!pure_coarse) vE = dequant_one<T>(qrow[t], A.half, A.qv) + iE;
+    T vO = iO;  // (pure coarse last node of an even-sized dim: iO = row[mf-1])
+    if (hasO) {
+      if (fo)
+        vO = dequant_one<T>(qrow[mf + t], A.half, A.qv) + iO;
+      else if (!pure_coarse)
+        vO = dequant_one<T>(qrow[mf - 1], A.half, A.qv) + iO;
+    }
+    // the pair is contiguous: one 2-element store when the row start allows it
+    T *dst = out + 2 * t;
+    if (hasO && pair_aligned) {
+      struct alignas(2 * sizeof(T)) Pair { T a, b; };
+      *reinterpret_cast<Pair *>(dst) = Pair{vE, vO};
+    } else {
+      dst[0] = vE;
+      if (hasO) dst[1] = vO;
+    }
   }
 }
 
