@@ -255,10 +255,12 @@ def main():
         result["parity_vs_cpu"] = bool(np.array_equal(q.cpu().numpy(), rq))
     else:
         result["cpu_baseline"] = None
-    if rank == 0:
-        print(json.dumps(result))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -23,6 +23,7 @@
 #include "kernels_fused.hpp"
 #include "kernels_tail.hpp"
 #include "kernels_recompose.hpp"
+#include "kernels_nd.hpp"
 
 namespace {
 
@@ -58,6 +59,7 @@ struct mgh_hierarchy {
   void *impl = nullptr;  // DeviceState<T>*
   bool profiling = false;
   bool force_v1 = false;  // MGH_FORCE_V1=1: run the one-thread-per-element kernels only
+  bool force_nd = false;  // MGH_FORCE_ND=1: run the generic N-D kernels also for D <= 3 (cross-check)
   std::string prof_filter;  // empty = every kernel
   std::map<std::string, ProfileEntry> prof;
   size_t device_bytes = 0;
@@ -85,7 +87,12 @@ template <typename T> struct DeviceState {
   HostHierarchy<T> *hh = nullptr;
   T *tables = nullptr;
   int *marks = nullptr;
-  std::vector<LevelTables<T>> lt;  // [l], l >= 1
+  std::vector<LevelTables<T>> lt;  // [l], l >= 1 (3-D view, D <= 3)
+  struct NdLevel {
+    const T *ratio[kNd], *mass[kNd], *thomas[kNd];
+  };
+  std::vector<NdLevel> nd;         // [l], l >= 1 (all D dims; used by the D > 3 path)
+  T *nd_w = nullptr, *nd_a = nullptr, *nd_b = nullptr;  // N-D scratch (lazily allocated)
   std::vector<T *> nodal;          // [l] compact nodal buffers, l = 0..L-1
   T *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;
   T *scratch_full = nullptr;       // lazily allocated full-size copy
@@ -145,7 +152,47 @@ template <typename T> int build_device_state(mgh_hierarchy *h) {
   h->impl = ds;
   ds->hh = hh;
   const int D = hh->D, L = hh->L;
-  if (D > 3) return MGH_SUCCESS;  // tables for D > 3 are built by the ND path (not yet)
+  if (D > 3) {
+    // generic per-dim tables for the N-D kernels
+    std::vector<T> arena;
+    auto push = [&](const std::vector<T> &v) {
+      size_t off = arena.size();
+      arena.insert(arena.end(), v.begin(), v.end());
+      while (arena.size() % 4) arena.push_back(0);
+      return off;
+    };
+    struct Off { size_t r[kNd], m[kNd], t[kNd]; };
+    std::vector<Off> offs(L + 1);
+    for (int l = 1; l <= L; l++)
+      for (int d = 0; d < D; d++) {
+        offs[l].r[d] = push(hh->lv[l][d].ratio);
+        offs[l].m[d] = push(hh->mass_table(l, d));
+        offs[l].t[d] = push(hh->thomas_table(l - 1, d));
+      }
+    TRY(dev_alloc(h, &ds->tables, arena.size()));
+    HIP_TRY(hipMemcpy(ds->tables, arena.data(), arena.size() * sizeof(T), hipMemcpyHostToDevice));
+    ds->nd.resize(L + 1);
+    for (int l = 1; l <= L; l++)
+      for (int d = 0; d < D; d++) {
+        ds->nd[l].ratio[d] = ds->tables + offs[l].r[d];
+        ds->nd[l].mass[d] = ds->tables + offs[l].m[d];
+        ds->nd[l].thomas[d] = ds->tables + offs[l].t[d];
+      }
+    std::vector<int> marks;
+    ds->qmeta.D = D;
+    ds->qmeta.calc_vol = 0;
+    for (int d = 0; d < D; d++) {
+      ds->qmeta.shape[d] = (uint32_t)hh->shape[d];
+      ds->qmeta.markoff[d] = (uint32_t)marks.size();
+      marks.insert(marks.end(), hh->marks[d].begin(), hh->marks[d].end());
+    }
+    TRY(dev_alloc(h, &ds->marks, marks.size()));
+    HIP_TRY(hipMemcpy(ds->marks, marks.data(), marks.size() * sizeof(int), hipMemcpyHostToDevice));
+    TRY(dev_alloc(h, &ds->qz, (size_t)2 * (L + 1)));
+    TRY(dev_alloc(h, &ds->scalar, (size_t)2));
+    TRY(dev_alloc(h, &ds->normval, (size_t)2));
+    return MGH_SUCCESS;
+  }
 
   // ---- spacing tables: one arena, one upload --------------------------------
   std::vector<T> arena;
@@ -186,6 +233,16 @@ template <typename T> int build_device_state(mgh_hierarchy *h) {
         ds->lt[l].mass[k] = ds->tables + offs[l].mass[k];
         ds->lt[l].thomas[k] = ds->tables + offs[l].thomas[k];
       }
+
+  // per-dim view of the same tables for the generic N-D kernels (cross-check path)
+  ds->nd.resize(L + 1);
+  for (int l = 1; l <= L; l++)
+    for (int d = 0; d < D; d++) {
+      const int k = d + 3 - D;
+      ds->nd[l].ratio[d] = ds->lt[l].ratio[k];
+      ds->nd[l].mass[d] = ds->lt[l].mass[k];
+      ds->nd[l].thomas[d] = ds->lt[l].thomas[k];
+    }
 
   // ---- level marks ------------------------------------------------------------
   std::vector<int> marks;
@@ -230,6 +287,9 @@ template <typename T> void destroy_state(mgh_hierarchy *h) {
     (void)hipFree(ds->t2);
     (void)hipFree(ds->t3);
     (void)hipFree(ds->scratch_full);
+    (void)hipFree(ds->nd_w);
+    (void)hipFree(ds->nd_a);
+    (void)hipFree(ds->nd_b);
     (void)hipFree(ds->qz);
     (void)hipFree(ds->scalar);
     (void)hipFree(ds->normval);
@@ -523,10 +583,149 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
 
 inline bool fused_ok(const mgh_hierarchy *h) { return h->D == 3 && h->L >= 1; }
 
+
+// ---- N-D path (D = 4, 5): in place on `v` (full array, reordered as levels proceed) -------
+template <typename T> int nd_ensure(mgh_hierarchy *h) {
+  auto *ds = DS<T>(h);
+  if (!ds->nd_w) {
+    TRY(dev_alloc(h, &ds->nd_w, (size_t)h->total));
+    TRY(dev_alloc(h, &ds->nd_a, (size_t)h->total));
+    TRY(dev_alloc(h, &ds->nd_b, (size_t)h->total));
+  }
+  return MGH_SUCCESS;
+}
+
+template <typename T> NdBox nd_box(mgh_hierarchy *h, int l) {
+  auto *hh = HH<T>(h);
+  NdBox b{};
+  b.D = h->D;
+  uint64_t sacc = 1;
+  for (int d = h->D - 1; d >= 0; d--) {
+    b.n[d] = (uint32_t)hh->level_shape[l][d];
+    b.m[d] = (uint32_t)hh->level_shape[l - 1][d];
+    b.fs[d] = sacc;
+    sacc *= hh->shape[d];
+  }
+  return b;
+}
+
+inline unsigned nd_grid(uint64_t total) {
+  return (unsigned)std::min<uint64_t>((total + 255) / 256, 256 * 16);
+}
+
+// correction of level l from the reordered coefficients in v; returns the compact result
+template <typename T>
+int nd_correction(mgh_hierarchy *h, int l, const T *v, const NdBox &b, T **out, hipStream_t st) {
+  auto *ds = DS<T>(h);
+  const int D = h->D;
+  NdSweep s{};
+  s.D = D;
+  for (int d = 0; d < D; d++) {
+    s.e[d] = b.n[d];
+    s.is[d] = b.fs[d];
+    s.mc[d] = b.m[d];
+  }
+  const T *cur = v;
+  T *bufs[2] = {ds->nd_a, ds->nd_b};
+  int which = 0;
+  for (int a = D - 1; a >= 0; a--) {
+    s.a = a;
+    s.n = b.n[a];
+    s.m = b.m[a];
+    s.zero_all_coarse = (a == D - 1) ? 1 : 0;
+    uint64_t total = 1;
+    for (int d = 0; d < D; d++) total *= (d == a ? s.m : s.e[d]);
+    T *dst = bufs[which];
+    TRY(launch(h, "nd_lpk", st, [&] {
+      k_nd_lpk<T><<<nd_grid(total), 256, 0, st>>>(s, cur, dst, ds->nd[l].mass[a], total);
+    }));
+    cur = dst;
+    which ^= 1;
+    s.e[a] = s.m;
+    uint64_t sacc = 1;
+    for (int d = D - 1; d >= 0; d--) {
+      s.is[d] = sacc;
+      sacc *= s.e[d];
+    }
+  }
+  T *x = const_cast<T *>(cur);
+  for (int a = D - 1; a >= 0; a--) {
+    uint64_t np = 1;
+    for (int d = 0; d < D; d++)
+      if (d != a) np *= s.e[d];
+    TRY(launch(h, "nd_ipk", st, [&] {
+      k_nd_ipk<T><<<nd_grid(np), 256, 0, st>>>(D, a, s, x, ds->nd[l].thomas[a], np);
+    }));
+  }
+  *out = x;
+  return MGH_SUCCESS;
+}
+
+template <typename T> int decompose_nd(mgh_hierarchy *h, T *v, hipStream_t st) {
+  auto *ds = DS<T>(h);
+  TRY(nd_ensure<T>(h));
+  for (int l = h->L; l >= 1; l--) {
+    const NdBox b = nd_box<T>(h, l);
+    NdTables<T> tb{};
+    uint64_t nn = 1, mm = 1;
+    for (int d = 0; d < h->D; d++) {
+      tb.ratio[d] = ds->nd[l].ratio[d];
+      nn *= b.n[d];
+      mm *= b.m[d];
+    }
+    TRY(launch(h, "nd_gather", st, [&] {
+      k_nd_gather<T><<<nd_grid(nn), 256, 0, st>>>(b, v, ds->nd_w, nn, 0);
+    }));
+    TRY(launch(h, "nd_coeff", st, [&] {
+      k_nd_coeff<T><<<nd_grid(nn), 256, 0, st>>>(b, tb, ds->nd_w, v, nn, 0);
+    }));
+    T *corr = nullptr;
+    TRY(nd_correction<T>(h, l, v, b, &corr, st));
+    TRY(launch(h, "nd_apply", st, [&] {
+      k_nd_apply<T><<<nd_grid(mm), 256, 0, st>>>(b, corr, v, mm, +1);
+    }));
+  }
+  return MGH_SUCCESS;
+}
+
+template <typename T> int recompose_nd(mgh_hierarchy *h, T *v, hipStream_t st) {
+  auto *ds = DS<T>(h);
+  TRY(nd_ensure<T>(h));
+  for (int l = 1; l <= h->L; l++) {
+    const NdBox b = nd_box<T>(h, l);
+    NdTables<T> tb{};
+    uint64_t nn = 1, mm = 1;
+    for (int d = 0; d < h->D; d++) {
+      tb.ratio[d] = ds->nd[l].ratio[d];
+      nn *= b.n[d];
+      mm *= b.m[d];
+    }
+    T *corr = nullptr;
+    TRY(nd_correction<T>(h, l, v, b, &corr, st));
+    TRY(launch(h, "nd_apply", st, [&] {
+      k_nd_apply<T><<<nd_grid(mm), 256, 0, st>>>(b, corr, v, mm, -1);
+    }));
+    TRY(launch(h, "nd_coeff", st, [&] {
+      k_nd_coeff<T><<<nd_grid(nn), 256, 0, st>>>(b, tb, ds->nd_w, v, nn, 1);
+    }));
+    TRY(launch(h, "nd_coeff", st, [&] {
+      k_nd_coeff<T><<<nd_grid(nn), 256, 0, st>>>(b, tb, ds->nd_w, v, nn, 2);
+    }));
+    TRY(launch(h, "nd_gather", st, [&] {
+      k_nd_gather<T><<<nd_grid(nn), 256, 0, st>>>(b, v, ds->nd_w, nn, 1);
+    }));
+  }
+  return MGH_SUCCESS;
+}
+
 template <typename T>
 int decompose_impl(mgh_hierarchy *h, const T *data, T *coeff, hipStream_t s) {
   auto *ds = DS<T>(h);
-  if (h->D > 3) return fail(MGH_ERR_UNSUPPORTED_DIMENSION, "decompose: D > 3 not implemented");
+  if (h->D > 3 || h->force_nd) {
+    if ((const void *)data != (const void *)coeff)
+      HIP_TRY(hipMemcpyAsync(coeff, data, h->total * sizeof(T), hipMemcpyDeviceToDevice, s));
+    return decompose_nd<T>(h, coeff, s);
+  }
   const int L = h->L;
   const size_t fI = ds->full_I, fJ = ds->full_J;
   const T *src = data;
@@ -569,7 +768,11 @@ int decompose_impl(mgh_hierarchy *h, const T *data, T *coeff, hipStream_t s) {
 template <typename T>
 int recompose_impl(mgh_hierarchy *h, const T *coeff, T *data, hipStream_t s) {
   auto *ds = DS<T>(h);
-  if (h->D > 3) return fail(MGH_ERR_UNSUPPORTED_DIMENSION, "recompose: D > 3 not implemented");
+  if (h->D > 3 || h->force_nd) {
+    if ((const void *)data != (const void *)coeff)
+      HIP_TRY(hipMemcpyAsync(data, coeff, h->total * sizeof(T), hipMemcpyDeviceToDevice, s));
+    return recompose_nd<T>(h, data, s);
+  }
   const int L = h->L;
   const size_t fI = ds->full_I, fJ = ds->full_J;
   const T *C = coeff;
@@ -905,6 +1108,9 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
   {
     const char *e = std::getenv("MGH_FORCE_V1");
     h->force_v1 = e && e[0] == '1';
+    const char *e2 = std::getenv("MGH_FORCE_ND");
+    h->force_nd = e2 && e2[0] == '1';
+    if (h->force_nd) h->force_v1 = true;  // keeps the fused entry points off
   }
   h->dtype = dtype;
   h->device = device;

@@ -1,0 +1,207 @@
+// Generic N-D (D <= 5) kernels: first correct HIP path for D = 4, 5 (one thread per element /
+// pencil, no tiling yet). Semantics = the reference's ND drivers
+//   CalcCoefficientsND.hpp:25-236  (interpolants built fastest dim first, coefficient =
+//                                   original - interpolant),
+//   CalcCorrectionND.hpp:25-267    (mass/restriction sweeps along D-1..0, the first one
+//                                   reading the all-coarse corner as zero; Thomas solves in
+//                                   the same order),
+//   CoefficientsRestoreND.hpp      (inverse),
+// with the same element arithmetic as kernels_v1.hpp (bit-identical for D <= 3, which the
+// tests use as a cross-check).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels_v1.hpp"
+
+namespace mgh {
+
+constexpr int kNd = 5;
+
+struct NdBox {
+  int D;
+  uint32_t n[kNd];  // fine extents of the level
+  uint32_t m[kNd];  // coarse extents
+  uint64_t fs[kNd];  // element strides of the full (reordered) array
+};
+
+template <typename T> struct NdTables {
+  const T *ratio[kNd];
+};
+
+__device__ __forceinline__ void nd_unravel(int D, const uint32_t *e, uint64_t lin, uint32_t *idx) {
+  for (int d = D - 1; d >= 0; d--) {
+    idx[d] = (uint32_t)(lin % e[d]);
+    lin /= e[d];
+  }
+}
+__device__ __forceinline__ uint64_t nd_ravel(int D, const uint32_t *e, const uint32_t *idx) {
+  uint64_t lin = 0;
+  for (int d = 0; d < D; d++) lin = lin * e[d] + idx[d];
+  return lin;
+}
+
+// compact natural-order copy of the fine box out of the full array (CopyND)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_nd_gather(NdBox b, const T *__restrict__ v, T *__restrict__ w, uint64_t total, int scatter) {
+  for (uint64_t lin = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; lin < total;
+       lin += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t idx[kNd];
+    nd_unravel(b.D, b.n, lin, idx);
+    uint64_t off = 0;
+    for (int d = 0; d < b.D; d++) off += idx[d] * b.fs[d];
+    if (scatter) const_cast<T *>(v)[off] = w[lin]; else w[lin] = v[off];
+  }
+}
+
+// interpolant of the node at natural position pos (odd dims marked) from the natural-order
+// compact box w: nested lerps, fastest dim innermost
+template <typename T>
+__device__ __forceinline__ T nd_interp(const NdBox &b, const NdTables<T> &tb, const T *w,
+                                       const uint32_t *pos, const bool *odd) {
+  int od[kNd], nod = 0;
+  for (int d = b.D - 1; d >= 0; d--)
+    if (odd[d]) od[nod++] = d;
+  T vals[1 << kNd];
+  for (int c = 0; c < (1 << nod); c++) {
+    uint32_t q[kNd];
+    for (int d = 0; d < b.D; d++) q[d] = pos[d];
+    for (int k = 0; k < nod; k++) q[od[k]] = pos[od[k]] + (((c >> k) & 1) ? 1 : -1);
+    vals[c] = w[nd_ravel(b.D, b.n, q)];
+  }
+  for (int k = 0; k < nod; k++) {
+    const T t = tb.ratio[od[k]][pos[od[k]] - 1];
+    const int cnt = 1 << (nod - k - 1);
+    for (int c = 0; c < cnt; c++) vals[c] = lerp_ref(vals[2 * c], vals[2 * c + 1], t);
+  }
+  return vals[0];
+}
+
+// mode 0: decompose: v[reordered] = node - interpolant (coarse nodes copied)
+// mode 1: recompose pass A: w[natural] = v[reordered] for all-coarse nodes
+// mode 2: recompose pass B: w[natural] = v[reordered] + interpolant(w) for the other nodes
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_nd_coeff(NdBox b, NdTables<T> tb, T *__restrict__ w, T *__restrict__ v, uint64_t total,
+           int mode) {
+  for (uint64_t lin = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; lin < total;
+       lin += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t idx[kNd], pos[kNd];
+    bool odd[kNd], any = false;
+    nd_unravel(b.D, b.n, lin, idx);
+    uint64_t off = 0;
+    for (int d = 0; d < b.D; d++) {
+      pos[d] = fine_pos(idx[d], b.n[d], b.m[d], odd[d]);
+      any |= odd[d];
+      off += idx[d] * b.fs[d];
+    }
+    const uint64_t wl = nd_ravel(b.D, b.n, pos);
+    if (mode == 0) {
+      const T centre = w[wl];
+      v[off] = any ? centre - nd_interp<T>(b, tb, w, pos, odd) : centre;
+    } else if (mode == 1) {
+      if (!any) w[wl] = v[off];
+    } else if (any) {
+      T res = v[off];
+      res += nd_interp<T>(b, tb, w, pos, odd);
+      w[wl] = res;
+    }
+  }
+}
+
+// mass/restriction sweep along dim a. in: extents e, strides is; out: compact, extents e with
+// e[a] -> m. One thread per output element.
+struct NdSweep {
+  int D, a;
+  uint32_t e[kNd];   // input extents
+  uint64_t is[kNd];  // input strides
+  uint32_t mc[kNd];  // coarse extents (zero rule)
+  uint32_t n, m;     // fine / coarse size of dim a
+  int zero_all_coarse;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_nd_lpk(NdSweep s, const T *__restrict__ in, T *__restrict__ out, const T *__restrict__ mt,
+         uint64_t total) {
+  for (uint64_t lin = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; lin < total;
+       lin += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t eo[kNd], idx[kNd];
+    for (int d = 0; d < s.D; d++) eo[d] = s.e[d];
+    eo[s.a] = s.m;
+    nd_unravel(s.D, eo, lin, idx);
+    uint64_t base = 0;
+    bool ez = s.zero_all_coarse;
+    for (int d = 0; d < s.D; d++) {
+      if (d == s.a) continue;
+      base += idx[d] * s.is[d];
+      if (idx[d] >= s.mc[d]) ez = false;
+    }
+    const uint32_t q = idx[s.a], m = s.m, nodd = s.n - s.m;
+    const uint64_t st = s.is[s.a];
+    const T *pe = in + base, *po = in + base + m * st;
+    const T a = (q >= 1 && !ez) ? pe[(q - 1) * st] : (T)0;
+    const T bq = (q >= 1 && q - 1 < nodd) ? po[(q - 1) * st] : (T)0;
+    const T c = ez ? (T)0 : pe[q * st];
+    const T d = (q < nodd) ? po[q * st] : (T)0;
+    const T e = (q + 1 < m && !ez) ? pe[(q + 1) * st] : (T)0;
+    const T w0 = mt[0 * m + q], w1 = mt[1 * m + q], w2 = mt[2 * m + q], w3 = mt[3 * m + q],
+            w4 = mt[4 * m + q], w5 = mt[5 * m + q], w6 = mt[6 * m + q], r1 = mt[7 * m + q],
+            r4 = mt[8 * m + q];
+    const T tb = a * w0 + bq * w1 + c * w2;
+    T tc = bq * w2 + c * w3 + d * w4;
+    const T td = c * w4 + d * w5 + e * w6;
+    tc += tb * r1 + td * r4;
+    out[lin] = tc;
+  }
+}
+
+// Thomas solve along dim a of a compact array with extents e; one thread per pencil
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_nd_ipk(int D, int a, NdSweep s, T *__restrict__ x, const T *__restrict__ tt, uint64_t npencil) {
+  for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npencil;
+       p += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t el[kNd], idx[kNd];
+    for (int d = 0; d < D; d++) el[d] = s.e[d];
+    el[a] = 1;
+    nd_unravel(D, el, p, idx);
+    uint64_t base = 0;
+    for (int d = 0; d < D; d++) base += idx[d] * s.is[d];
+    const uint64_t st = s.is[a];
+    const uint32_t n = s.e[a];
+    T *q = x + base;
+    T prev = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      T cur = q[i * st];
+      cur = cur - prev * tt[i];
+      q[i * st] = cur;
+      prev = cur;
+    }
+    prev = 0;
+    for (uint32_t kk = 0; kk < n; kk++) {
+      const uint32_t i = n - 1 - kk;
+      T cur = q[i * st];
+      cur = (cur - tt[n + i] * prev) / tt[2 * n + i];
+      q[i * st] = cur;
+      prev = cur;
+    }
+  }
+}
+
+// v[coarse box, full strides] +/-= corr[compact]
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_nd_apply(NdBox b, const T *__restrict__ corr, T *__restrict__ v, uint64_t total, int sign) {
+  for (uint64_t lin = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; lin < total;
+       lin += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t idx[kNd];
+    nd_unravel(b.D, b.m, lin, idx);
+    uint64_t off = 0;
+    for (int d = 0; d < b.D; d++) off += idx[d] * b.fs[d];
+    if (sign > 0) v[off] += corr[lin]; else v[off] -= corr[lin];
+  }
+}
+
+} // namespace mgh

@@ -63,7 +63,7 @@ def _declare(L):
         g = getattr(L, "mgxo_marks" + sfx)
         g.argtypes = [C.c_void_p, C.c_int]
         g.restype = C.POINTER(C.c_int)
-        for name in ("mgxo_decompose", "mgxo_recompose"):
+        for name in ("mgxo_decompose", "mgxo_recompose", "mgxo_decompose_nd", "mgxo_recompose_nd"):
             g = getattr(L, name + sfx)
             g.argtypes = [C.c_void_p, rp]
             g.restype = C.c_int
@@ -153,17 +153,20 @@ class Hierarchy:
     def _rp(self, a):
         return a.ctypes.data_as(C.POINTER(self.ct))
 
-    def decompose(self, data):
-        """Returns multilevel coefficients in MGARD-X's in-place reordered layout."""
+    def decompose(self, data, force_nd=False):
+        """Returns multilevel coefficients in MGARD-X's in-place reordered layout. force_nd
+        runs the generic N-D restatement (the D > 3 path) also for D <= 3."""
         v = np.array(data, dtype=self.dtype, order="C", copy=True).reshape(self.shape)
-        rc = getattr(lib(), "mgxo_decompose" + self.sfx)(self._h, self._rp(v))
+        fn = "mgxo_decompose_nd" if force_nd else "mgxo_decompose"
+        rc = getattr(lib(), fn + self.sfx)(self._h, self._rp(v))
         if rc:
             raise NotImplementedError("oracle decompose: D=%d unsupported" % self.D)
         return v
 
-    def recompose(self, coeffs):
+    def recompose(self, coeffs, force_nd=False):
         v = np.array(coeffs, dtype=self.dtype, order="C", copy=True).reshape(self.shape)
-        rc = getattr(lib(), "mgxo_recompose" + self.sfx)(self._h, self._rp(v))
+        fn = "mgxo_recompose_nd" if force_nd else "mgxo_recompose"
+        rc = getattr(lib(), fn + self.sfx)(self._h, self._rp(v))
         if rc:
             raise NotImplementedError("oracle recompose: D=%d unsupported" % self.D)
         return v

@@ -475,8 +475,10 @@ static void FN(full_strides)(const FN(mgxo_hier) * h, uint64_t *ld1, uint64_t *l
 
 /* MultiDimension/DataRefactoring.hpp:25-109 (decompose, D<=3): in place on the
  * dense row-major array v of the finest shape. stop_level = 0. */
+int FN(mgxo_decompose_nd)(const FN(mgxo_hier) * h, REAL *v);
+int FN(mgxo_recompose_nd)(const FN(mgxo_hier) * h, REAL *v);
 int FN(mgxo_decompose)(const FN(mgxo_hier) * h, REAL *v) {
-  if (h->D > 3) return -1;
+  if (h->D > 3) return FN(mgxo_decompose_nd)(h, v);
   uint64_t ld1, ld2, n0;
   FN(full_strides)(h, &ld1, &ld2, &n0);
   for (int l = h->L; l > 0; l--) {
@@ -506,7 +508,7 @@ int FN(mgxo_decompose)(const FN(mgxo_hier) * h, REAL *v) {
 
 /* MultiDimension/DataRefactoring.hpp:179-252 (recompose, D<=3). */
 int FN(mgxo_recompose)(const FN(mgxo_hier) * h, REAL *v) {
-  if (h->D > 3) return -1;
+  if (h->D > 3) return FN(mgxo_recompose_nd)(h, v);
   uint64_t ld1, ld2, n0;
   FN(full_strides)(h, &ld1, &ld2, &n0);
   for (int l = 1; l <= h->L; l++) {
@@ -528,6 +530,263 @@ int FN(mgxo_recompose)(const FN(mgxo_hier) * h, REAL *v) {
     for (uint64_t i = 0; i < nr; i++)
       for (uint64_t j = 0; j < nc; j++)
         memcpy(v + IDX3(i, j, 0, ld1, ld2), w + IDX3(i, j, 0, nc, nf), sizeof(REAL) * nf);
+    free(w);
+  }
+  return 0;
+}
+
+/* ======================================================================== */
+/* N-D path (D = 4, 5; also valid for D <= 3, where it is cross-checked      */
+/* against the 3-D code above).                                              */
+/* Reference: MultiDimension/DataRefactoring.hpp:111-177 (decompose, D > 3), */
+/* :254-317 (recompose); CalcCoefficientsND.hpp:25-236 -- interpolants are   */
+/* built 3 dims at a time, fastest dims first (GpkReo<..,INTERPOLATION,..>   */
+/* passes), i.e. nested lerps from the fastest to the slowest dim, then      */
+/* coefficient = original - interpolant (the CALC_COEFF pass);               */
+/* CalcCorrectionND.hpp:25-267 -- mass/restriction sweeps along dims         */
+/* D-1, D-2, ..., 0 (the first one reads the all-coarse corner as zero:      */
+/* zero_other && r<zero_r && c<zero_c && f<zero_f,                           */
+/* LinearProcessingKernel.hpp:104-124) then Thomas solves in the same order. */
+/* ======================================================================== */
+
+static uint64_t FN(nd_prod)(int D, const uint64_t *e) {
+  uint64_t p = 1;
+  for (int d = 0; d < D; d++) p *= e[d];
+  return p;
+}
+static void FN(nd_unravel)(int D, const uint64_t *e, uint64_t lin, uint64_t *idx) {
+  for (int d = D - 1; d >= 0; d--) {
+    idx[d] = lin % e[d];
+    lin /= e[d];
+  }
+}
+static uint64_t FN(nd_ravel)(int D, const uint64_t *e, const uint64_t *idx) {
+  uint64_t lin = 0;
+  for (int d = 0; d < D; d++) lin = lin * e[d] + idx[d];
+  return lin;
+}
+/* fine position of reordered index i (coarse node -> min(2i, n-1); coefficient -> odd) */
+static inline uint64_t FN(nd_fine_pos)(uint64_t i, uint64_t n, uint64_t m, int *odd) {
+  *odd = i >= m;
+  if (*odd) return 2 * (i - m) + 1;
+  return 2 * i < n - 1 ? 2 * i : n - 1;
+}
+
+/* interpolant of the node at natural position pos[] (odd[] marks its odd dims) from its
+ * even-index neighbours in the natural-order compact box w: nested lerps, fastest dim
+ * innermost. Returns the node value itself if no dim is odd. */
+static REAL FN(nd_interp)(const FN(mgxo_hier) * h, int l, const uint64_t *n, const REAL *w,
+                          const uint64_t *pos, const int *odd) {
+  const int D = h->D;
+  int od[MGXO_MAXD], nod = 0;
+  for (int d = D - 1; d >= 0; d--)
+    if (odd[d]) od[nod++] = d; /* od[0] = fastest odd dim */
+  REAL vals[1 << MGXO_MAXD];
+  for (int c = 0; c < (1 << nod); c++) {
+    uint64_t q[MGXO_MAXD];
+    for (int d = 0; d < D; d++) q[d] = pos[d];
+    for (int b = 0; b < nod; b++) q[od[b]] = pos[od[b]] + (((c >> b) & 1) ? 1 : -1);
+    vals[c] = w[FN(nd_ravel)(D, n, q)];
+  }
+  for (int b = 0; b < nod; b++) {
+    const REAL t = h->ratio[l][od[b]][pos[od[b]] - 1];
+    const int cnt = 1 << (nod - b - 1);
+    for (int c = 0; c < cnt; c++) vals[c] = FN(lerp)(vals[2 * c], vals[2 * c + 1], t);
+  }
+  return vals[0];
+}
+
+/* mass/restriction sweep along dim a: in has extents e (dim a: reordered [even | odd]), out has
+ * the same extents with e[a] -> m. zero_all_coarse: the first sweep reads the even part of
+ * lines whose other coordinates are all < mc[] as zero. */
+static REAL *FN(nd_lpk)(int D, const uint64_t *e, int a, uint64_t n, uint64_t m, const REAL *dist,
+                        const REAL *in, const uint64_t *in_strides, int zero_all_coarse,
+                        const uint64_t *mc, uint64_t *eo) {
+  for (int d = 0; d < D; d++) eo[d] = e[d];
+  eo[a] = m;
+  uint64_t el[MGXO_MAXD]; /* extents of the line index space (dim a collapsed) */
+  for (int d = 0; d < D; d++) el[d] = e[d];
+  el[a] = 1;
+  const uint64_t nlines = FN(nd_prod)(D, el);
+  REAL *out = (REAL *)malloc(sizeof(REAL) * FN(nd_prod)(D, eo));
+  uint64_t os[MGXO_MAXD];
+  {
+    uint64_t sacc = 1;
+    for (int d = D - 1; d >= 0; d--) {
+      os[d] = sacc;
+      sacc *= eo[d];
+    }
+  }
+#pragma omp parallel for schedule(static)
+  for (uint64_t ln = 0; ln < nlines; ln++) {
+    uint64_t idx[MGXO_MAXD];
+    FN(nd_unravel)(D, el, ln, idx);
+    uint64_t ib = 0, ob = 0;
+    int ez = zero_all_coarse;
+    for (int d = 0; d < D; d++) {
+      if (d == a) continue;
+      ib += idx[d] * in_strides[d];
+      ob += idx[d] * os[d];
+      if (idx[d] >= mc[d]) ez = 0;
+    }
+    FN(mass_trans_line)(n, m, dist, in + ib, ez, in + ib + m * in_strides[a], in_strides[a],
+                        out + ob, os[a]);
+  }
+  return out;
+}
+
+static void FN(nd_full_strides)(const FN(mgxo_hier) * h, uint64_t *fs) {
+  uint64_t sacc = 1;
+  for (int d = h->D - 1; d >= 0; d--) {
+    fs[d] = sacc;
+    sacc *= h->shape[d];
+  }
+}
+
+/* correction of level l from the reordered coefficients in v (full strides fs) */
+static REAL *FN(nd_correction)(const FN(mgxo_hier) * h, int l, const REAL *v, const uint64_t *fs) {
+  const int D = h->D;
+  uint64_t e[MGXO_MAXD], eo[MGXO_MAXD], mc[MGXO_MAXD];
+  for (int d = 0; d < D; d++) {
+    e[d] = h->lshape[l][d];
+    mc[d] = h->lshape[l - 1][d];
+  }
+  const REAL *cur = v;
+  uint64_t cs[MGXO_MAXD];
+  for (int d = 0; d < D; d++) cs[d] = fs[d];
+  REAL *owned = NULL;
+  for (int a = D - 1; a >= 0; a--) {
+    REAL *nx = FN(nd_lpk)(D, e, a, h->lshape[l][a], mc[a], h->dist[l][a], cur, cs,
+                          a == D - 1, mc, eo);
+    free(owned);
+    owned = nx;
+    cur = nx;
+    for (int d = 0; d < D; d++) e[d] = eo[d];
+    uint64_t sacc = 1;
+    for (int d = D - 1; d >= 0; d--) {
+      cs[d] = sacc;
+      sacc *= e[d];
+    }
+  }
+  /* Thomas solves along D-1 .. 0 on the compact coarse box */
+  for (int a = D - 1; a >= 0; a--) {
+    uint64_t el[MGXO_MAXD];
+    for (int d = 0; d < D; d++) el[d] = e[d];
+    el[a] = 1;
+    const uint64_t nlines = FN(nd_prod)(D, el);
+#pragma omp parallel for schedule(static)
+    for (uint64_t ln = 0; ln < nlines; ln++) {
+      uint64_t idx[MGXO_MAXD];
+      FN(nd_unravel)(D, el, ln, idx);
+      uint64_t b = 0;
+      for (int d = 0; d < D; d++) b += idx[d] * cs[d];
+      FN(thomas_line)(e[a], h->am[l - 1][a], h->bm[l - 1][a], owned + b, cs[a]);
+    }
+  }
+  return owned;
+}
+
+int FN(mgxo_decompose_nd)(const FN(mgxo_hier) * h, REAL *v) {
+  const int D = h->D;
+  uint64_t fs[MGXO_MAXD];
+  FN(nd_full_strides)(h, fs);
+  for (int l = h->L; l > 0; l--) {
+    uint64_t n[MGXO_MAXD], m[MGXO_MAXD];
+    for (int d = 0; d < D; d++) {
+      n[d] = h->lshape[l][d];
+      m[d] = h->lshape[l - 1][d];
+    }
+    const uint64_t nn = FN(nd_prod)(D, n);
+    REAL *w = (REAL *)malloc(sizeof(REAL) * nn);
+#pragma omp parallel for schedule(static)
+    for (uint64_t lin = 0; lin < nn; lin++) {
+      uint64_t idx[MGXO_MAXD];
+      FN(nd_unravel)(D, n, lin, idx);
+      uint64_t off = 0;
+      for (int d = 0; d < D; d++) off += idx[d] * fs[d];
+      w[lin] = v[off];
+    }
+#pragma omp parallel for schedule(static)
+    for (uint64_t lin = 0; lin < nn; lin++) {
+      uint64_t idx[MGXO_MAXD], pos[MGXO_MAXD];
+      int odd[MGXO_MAXD], any = 0;
+      FN(nd_unravel)(D, n, lin, idx);
+      uint64_t off = 0;
+      for (int d = 0; d < D; d++) {
+        pos[d] = FN(nd_fine_pos)(idx[d], n[d], m[d], &odd[d]);
+        any |= odd[d];
+        off += idx[d] * fs[d];
+      }
+      const REAL centre = w[FN(nd_ravel)(D, n, pos)];
+      v[off] = any ? centre - FN(nd_interp)(h, l, n, w, pos, odd) : centre;
+    }
+    free(w);
+    REAL *corr = FN(nd_correction)(h, l, v, fs);
+    const uint64_t mm = FN(nd_prod)(D, m);
+#pragma omp parallel for schedule(static)
+    for (uint64_t lin = 0; lin < mm; lin++) {
+      uint64_t idx[MGXO_MAXD];
+      FN(nd_unravel)(D, m, lin, idx);
+      uint64_t off = 0;
+      for (int d = 0; d < D; d++) off += idx[d] * fs[d];
+      v[off] += corr[lin];
+    }
+    free(corr);
+  }
+  return 0;
+}
+
+int FN(mgxo_recompose_nd)(const FN(mgxo_hier) * h, REAL *v) {
+  const int D = h->D;
+  uint64_t fs[MGXO_MAXD];
+  FN(nd_full_strides)(h, fs);
+  for (int l = 1; l <= h->L; l++) {
+    uint64_t n[MGXO_MAXD], m[MGXO_MAXD];
+    for (int d = 0; d < D; d++) {
+      n[d] = h->lshape[l][d];
+      m[d] = h->lshape[l - 1][d];
+    }
+    REAL *corr = FN(nd_correction)(h, l, v, fs);
+    const uint64_t mm = FN(nd_prod)(D, m), nn = FN(nd_prod)(D, n);
+#pragma omp parallel for schedule(static)
+    for (uint64_t lin = 0; lin < mm; lin++) {
+      uint64_t idx[MGXO_MAXD];
+      FN(nd_unravel)(D, m, lin, idx);
+      uint64_t off = 0;
+      for (int d = 0; d < D; d++) off += idx[d] * fs[d];
+      v[off] -= corr[lin];
+    }
+    free(corr);
+    /* natural-order box: first the coarse nodes, then coefficient nodes */
+    REAL *w = (REAL *)malloc(sizeof(REAL) * nn);
+    for (int pass = 0; pass < 2; pass++) {
+#pragma omp parallel for schedule(static)
+      for (uint64_t lin = 0; lin < nn; lin++) {
+        uint64_t idx[MGXO_MAXD], pos[MGXO_MAXD];
+        int odd[MGXO_MAXD], any = 0;
+        FN(nd_unravel)(D, n, lin, idx);
+        uint64_t off = 0;
+        for (int d = 0; d < D; d++) {
+          pos[d] = FN(nd_fine_pos)(idx[d], n[d], m[d], &odd[d]);
+          any |= odd[d];
+          off += idx[d] * fs[d];
+        }
+        if (pass == 0 && !any) w[FN(nd_ravel)(D, n, pos)] = v[off];
+        if (pass == 1 && any) {
+          REAL res = v[off];
+          res += FN(nd_interp)(h, l, n, w, pos, odd);
+          w[FN(nd_ravel)(D, n, pos)] = res;
+        }
+      }
+    }
+#pragma omp parallel for schedule(static)
+    for (uint64_t lin = 0; lin < nn; lin++) {
+      uint64_t idx[MGXO_MAXD];
+      FN(nd_unravel)(D, n, lin, idx);
+      uint64_t off = 0;
+      for (int d = 0; d < D; d++) off += idx[d] * fs[d];
+      v[off] = w[lin];
+    }
     free(w);
   }
   return 0;

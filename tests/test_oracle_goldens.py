@@ -88,3 +88,37 @@ def test_decompose_recompose_roundtrip(shape, dt):
     back = h.recompose(h.decompose(u))
     tol = 2e-5 if dt == np.float32 else 1e-13
     assert np.max(np.abs(back - u)) <= tol * max(1.0, np.max(np.abs(u))) * 10
+
+
+@pytest.mark.parametrize("kind", ["decomposition", "recomposition"])
+def test_4d_goldens(kind):
+    """The reference's 4-D goldens (3^4, test_decompose.cpp:339-431, :652-746) through the N-D
+    restatement (the D > 3 path of MGARD-X: CalcCoefficientsND / CalcCorrectionND)."""
+    c = CASES[(kind, "4D, dyadic, uniform")]
+    u = np.array(c["u"][:81], dtype=np.float32).reshape((3,) * 4)
+    h = oracle.Hierarchy((3,) * 4, np.float32, normalize_coordinates=False)
+    assert h.l_target == 1
+    if kind == "decomposition":
+        got = reordered_to_natural(h.decompose(u))
+    else:
+        got = h.recompose(natural_to_reordered(u))
+    assert approx(got.ravel(), c["expecteds"][1])
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(9,), (6, 9), (9, 6, 8), (17, 20, 33), (6, 6, 6)])
+def test_nd_restatement_equals_3d_restatement(shape, dt):
+    rng = np.random.default_rng(3)
+    u = rng.standard_normal(shape).astype(dt)
+    h = oracle.Hierarchy(shape, dt)
+    a, b = h.decompose(u), h.decompose(u, force_nd=True)
+    assert np.array_equal(a, b) and np.array_equal(np.signbit(a), np.signbit(b))
+    assert np.array_equal(h.recompose(a), h.recompose(a, force_nd=True))
+
+
+@pytest.mark.parametrize("shape", [(5, 5, 5, 5), (6, 9, 8, 12), (3, 4, 5, 6, 7)])
+def test_nd_roundtrip(shape):
+    rng = np.random.default_rng(5)
+    u = rng.standard_normal(shape)
+    h = oracle.Hierarchy(shape, np.float64)
+    assert np.max(np.abs(h.recompose(h.decompose(u)) - u)) < 1e-12
