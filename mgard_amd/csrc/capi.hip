@@ -265,8 +265,8 @@ template <typename T> int build_device_state(mgh_hierarchy *h) {
   }
   if (L >= 1) {
     const Box3 &b = ds->lt[L].box;
-    TRY(dev_alloc(h, &ds->t1, (size_t)b.n[0] * b.n[1] * b.m[2]));
-    TRY(dev_alloc(h, &ds->t2, (size_t)b.n[0] * b.m[1] * b.m[2]));
+    // t1 / t2 (intermediate sweeps of the one-thread-per-element path) are allocated on first
+    // use: the fused 3-D path never needs them
     TRY(dev_alloc(h, &ds->t3, (size_t)b.m[0] * b.m[1] * b.m[2]));
   }
   TRY(dev_alloc(h, &ds->qz, (size_t)2 * (L + 1)));
@@ -398,6 +398,11 @@ int correction(mgh_hierarchy *h, int l, const T *coef, size_t cI, size_t cJ, T *
   const LevelTables<T> &t = ds->lt[l];
   const Box3 &b = t.box;
   const dim3 blk(64, 4, 1);
+  if (!ds->t1) {
+    const Box3 &tb = ds->lt[h->L].box;
+    TRY(dev_alloc(h, &ds->t1, (size_t)tb.n[0] * tb.n[1] * tb.m[2]));
+    TRY(dev_alloc(h, &ds->t2, (size_t)tb.n[0] * tb.m[1] * tb.m[2]));
+  }
   // LPK1 along f: (nr, nc, nf) -> (nr, nc, ff)
   TRY(launch(h, "lpk_f", s, [&] {
     k_lpk<T, 2><<<grid3(b.n[0], b.n[1], b.m[2], blk), blk, 0, s>>>(
