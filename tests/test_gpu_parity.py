@@ -410,3 +410,52 @@ def test_reference_4d_goldens_through_gpu():
         h.close()
         n_checked += 1
     assert n_checked == 2
+
+
+def _random_cases(n_cases, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    budget = {1: 5000, 2: 40000, 3: 150000, 4: 150000, 5: 120000}
+    while len(cases) < n_cases:
+        D = int(rng.integers(1, 6))
+        lo, hi = 3, {1: 3000, 2: 220, 3: 70, 4: 22, 5: 12}[D]
+        shape = tuple(int(x) for x in rng.integers(lo, hi + 1, size=D))
+        if np.prod(shape) > budget[D]:
+            continue
+        cases.append((shape, bool(rng.integers(0, 2)), bool(rng.integers(0, 2)),
+                      [np.inf, 0.0, 1.0][int(rng.integers(0, 3))], bool(rng.integers(0, 2))))
+    return cases
+
+
+@pytest.mark.parametrize("case", _random_cases(48, 20261001), ids=lambda c: "x".join(map(str, c[0])))
+def test_random_shapes_bit_exact(case):
+    """Seeded sweep over ragged shapes in 1-5 D (even/odd/mixed sizes, levels limited by the
+    smallest dim), f32/f64, uniform/non-uniform grids, s in {inf, 0, 1}, REL/ABS: decompose,
+    quantize (+outliers) and the way back, all bit-exact against the oracle."""
+    torch, mg = _gpu()
+    shape, f64, nonuni, s, rel = case
+    dt = np.float64 if f64 else np.float32
+    coords = nonuniform_coords(shape, dt, seed=sum(shape)) if nonuni else None
+    u = smooth_field(shape, dt, seed=int(np.prod(shape)), noise=1e-2)
+    h = mg.Hierarchy(shape, dt, coords=coords)
+    o = oracle.Hierarchy(shape, dt, coords=coords)
+    ud = torch.from_numpy(u).cuda()
+    ref = o.decompose(u)
+    c = h.decompose(ud)
+    assert_bit_equal(c.cpu().numpy(), ref, "decompose")
+    eb = oracle.REL if rel else oracle.ABS
+    nrm = oracle.norm(u, dt(s)) if rel else 1.0
+    tol = 1e-3 if rel else 1e-3 * float(np.max(np.abs(u)))
+    q, oi, ov, n, _ = h.decompose_quantize(ud, eb, tol, s, nrm, dict_size=512)
+    rq, roi, rov, rn = o.quantize(ref, eb, dt(tol), dt(s), dt(nrm), dict_size=512)
+    assert n == rn
+    np.testing.assert_array_equal(q.cpu().numpy(), rq)
+    gi, gv = _outlier_set(oi.cpu().numpy(), ov.cpu().numpy())
+    ri, rv = _outlier_set(roi, rov)
+    np.testing.assert_array_equal(gi, ri)
+    np.testing.assert_array_equal(gv, rv)
+    back = h.dequantize_recompose(q, eb, tol, s, nrm, dict_size=512, outlier_idx=oi, outlier_val=ov)
+    rback = o.recompose(o.dequantize(rq, eb, dt(tol), dt(s), dt(nrm), dict_size=512,
+                                     outlier_idx=roi, outlier_val=rov))
+    assert_bit_equal(back.cpu().numpy(), rback, "dequantize+recompose")
+    h.close()
