@@ -30,6 +30,15 @@ template <typename T> struct NdTables {
 };
 
 __device__ __forceinline__ void nd_unravel(int D, const uint32_t *e, uint64_t lin, uint32_t *idx) {
+  if (lin < (1ull << 32)) {  // 32-bit divisions are several times cheaper
+    uint32_t l32 = (uint32_t)lin;
+    for (int d = D - 1; d >= 0; d--) {
+      const uint32_t q = l32 / e[d];
+      idx[d] = l32 - q * e[d];
+      l32 = q;
+    }
+    return;
+  }
   for (int d = D - 1; d >= 0; d--) {
     idx[d] = (uint32_t)(lin % e[d]);
     lin /= e[d];
@@ -55,27 +64,44 @@ k_nd_gather(NdBox b, const T *__restrict__ v, T *__restrict__ w, uint64_t total,
   }
 }
 
-// interpolant of the node at natural position pos (odd dims marked) from the natural-order
-// compact box w: nested lerps, fastest dim innermost
+// Nested lerps over K odd dims, slowest dim outermost (od[0] = fastest odd dim is the innermost
+// lerp); fully inlined recursion: no local arrays.
+template <typename T, int K> struct NdLerp {
+  static __device__ __forceinline__ T run(const T *w, uint64_t off, const uint64_t *st,
+                                          const T *t) {
+    return lerp_ref(NdLerp<T, K - 1>::run(w, off - st[K - 1], st, t),
+                    NdLerp<T, K - 1>::run(w, off + st[K - 1], st, t), t[K - 1]);
+  }
+};
+template <typename T> struct NdLerp<T, 0> {
+  static __device__ __forceinline__ T run(const T *w, uint64_t off, const uint64_t *, const T *) {
+    return w[off];
+  }
+};
+
+// interpolant of the node at natural position pos (linear offset wl in the natural-order
+// compact box w with strides ns; odd dims marked): nested lerps, fastest dim innermost
 template <typename T>
 __device__ __forceinline__ T nd_interp(const NdBox &b, const NdTables<T> &tb, const T *w,
-                                       const uint32_t *pos, const bool *odd) {
-  int od[kNd], nod = 0;
+                                       const uint32_t *pos, const bool *odd, uint64_t wl,
+                                       const uint64_t *ns) {
+  uint64_t st[kNd];
+  T t[kNd];
+  int nod = 0;
   for (int d = b.D - 1; d >= 0; d--)
-    if (odd[d]) od[nod++] = d;
-  T vals[1 << kNd];
-  for (int c = 0; c < (1 << nod); c++) {
-    uint32_t q[kNd];
-    for (int d = 0; d < b.D; d++) q[d] = pos[d];
-    for (int k = 0; k < nod; k++) q[od[k]] = pos[od[k]] + (((c >> k) & 1) ? 1 : -1);
-    vals[c] = w[nd_ravel(b.D, b.n, q)];
+    if (odd[d]) {
+      st[nod] = ns[d];
+      t[nod] = tb.ratio[d][pos[d] - 1];
+      nod++;
+    }
+  switch (nod) {
+  case 1: return NdLerp<T, 1>::run(w, wl, st, t);
+  case 2: return NdLerp<T, 2>::run(w, wl, st, t);
+  case 3: return NdLerp<T, 3>::run(w, wl, st, t);
+  case 4: return NdLerp<T, 4>::run(w, wl, st, t);
+  case 5: return NdLerp<T, 5>::run(w, wl, st, t);
+  default: return w[wl];
   }
-  for (int k = 0; k < nod; k++) {
-    const T t = tb.ratio[od[k]][pos[od[k]] - 1];
-    const int cnt = 1 << (nod - k - 1);
-    for (int c = 0; c < cnt; c++) vals[c] = lerp_ref(vals[2 * c], vals[2 * c + 1], t);
-  }
-  return vals[0];
 }
 
 // mode 0: decompose: v[reordered] = node - interpolant (coarse nodes copied)
@@ -90,21 +116,29 @@ k_nd_coeff(NdBox b, NdTables<T> tb, T *__restrict__ w, T *__restrict__ v, uint64
     uint32_t idx[kNd], pos[kNd];
     bool odd[kNd], any = false;
     nd_unravel(b.D, b.n, lin, idx);
-    uint64_t off = 0;
+    uint64_t ns[kNd];  // strides of the natural-order compact box
+    {
+      uint64_t sacc = 1;
+      for (int d = b.D - 1; d >= 0; d--) {
+        ns[d] = sacc;
+        sacc *= b.n[d];
+      }
+    }
+    uint64_t off = 0, wl = 0;
     for (int d = 0; d < b.D; d++) {
       pos[d] = fine_pos(idx[d], b.n[d], b.m[d], odd[d]);
       any |= odd[d];
       off += idx[d] * b.fs[d];
+      wl += pos[d] * ns[d];
     }
-    const uint64_t wl = nd_ravel(b.D, b.n, pos);
     if (mode == 0) {
       const T centre = w[wl];
-      v[off] = any ? centre - nd_interp<T>(b, tb, w, pos, odd) : centre;
+      v[off] = any ? centre - nd_interp<T>(b, tb, w, pos, odd, wl, ns) : centre;
     } else if (mode == 1) {
       if (!any) w[wl] = v[off];
     } else if (any) {
       T res = v[off];
-      res += nd_interp<T>(b, tb, w, pos, odd);
+      res += nd_interp<T>(b, tb, w, pos, odd, wl, ns);
       w[wl] = res;
     }
   }

@@ -34,7 +34,11 @@ template <typename T> struct RecomposeArgs {
 };
 
 template <typename T> __device__ __forceinline__ T dequant_one(int64_t qd, int64_t half, T qv) {
-  return qv * (T)(qd - half);
+  const int64_t d = qd - half;
+  // (T)d through the 32-bit converter when the whole wave's values fit (they practically
+  // always do): same value, a fraction of the instructions of the 64-bit conversion
+  if (__all(d == (int64_t)(int)d)) return qv * (T)(int)d;
+  return qv * (T)d;
 }
 
 template <typename T, int TC, int TF, int RCH>

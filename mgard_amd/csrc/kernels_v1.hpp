@@ -313,15 +313,28 @@ k_quantize(QuantMeta m, size_t total, const T *__restrict__ v, const int *__rest
            int prep_huffman, int64_t *__restrict__ q, unsigned long long *outlier_count,
            uint64_t *__restrict__ outlier_idx, int64_t *__restrict__ outlier_val,
            unsigned long long outlier_cap) {
-  for (size_t lin = (size_t)blockIdx.x * blockDim.x + threadIdx.x; lin < total;
-       lin += (size_t)gridDim.x * blockDim.x) {
-    const int level = m.calc_vol ? level_of(m, marks, lin) : 0;
-    const T t = v[lin];
-    int64_t qd = quantize_one(t, qz[level], m.calc_vol ? vol[level] : (T)1);
-    if (prep_huffman) {
-      qd += dict_size / 2;
-      if (!(qd >= 0 && qd < dict_size)) {
-        const unsigned long long o = atomicAdd(outlier_count, 1ULL);
+  // uniform trip count per wave so that the outlier slots of a whole wave come from one atomic
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t base = (size_t)blockIdx.x * blockDim.x; base < total; base += stride) {
+    const size_t lin = base + threadIdx.x;
+    const bool live = lin < total;
+    int64_t qd = 0;
+    bool outl = false;
+    if (live) {
+      const int level = m.calc_vol ? level_of(m, marks, lin) : 0;
+      qd = quantize_one(v[lin], qz[level], m.calc_vol ? vol[level] : (T)1);
+      if (prep_huffman) {
+        qd += dict_size / 2;
+        outl = !(qd >= 0 && qd < dict_size);
+      }
+    }
+    const unsigned long long mask = __ballot(outl);
+    if (mask) {
+      const int lane = threadIdx.x & 63;
+      unsigned long long o = 0;
+      if (lane == 0) o = atomicAdd(outlier_count, (unsigned long long)__popcll(mask));
+      o = __shfl(o, 0, 64) + __popcll(mask & ((1ULL << lane) - 1ULL));
+      if (outl) {
         if (o < outlier_cap) {
           outlier_idx[o] = lin;
           outlier_val[o] = qd;
@@ -329,7 +342,7 @@ k_quantize(QuantMeta m, size_t total, const T *__restrict__ v, const int *__rest
         qd = 0;
       }
     }
-    q[lin] = qd;
+    if (live) q[lin] = qd;
   }
 }
 
