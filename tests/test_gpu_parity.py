@@ -459,3 +459,72 @@ def test_random_shapes_bit_exact(case):
                                      outlier_idx=roi, outlier_val=rov))
     assert_bit_equal(back.cpu().numpy(), rback, "dequantize+recompose")
     h.close()
+
+
+def _compare_quantized(mg, h, o, u, ud, mode, tol, s, norm, cap):
+    """decompose+quantize on the GPU (stages fused where the library fuses them) vs the oracle."""
+    dt = u.dtype.type
+    q, oi, ov, cnt, _ = h.decompose_quantize(ud, mode, tol, s, norm=float(norm), outlier_cap=cap)
+    c = o.decompose(u)
+    rq, roi, rov, rn = o.quantize(c, mode, dt(tol), dt(s), dt(norm), outlier_cap=cap)
+    del c
+    assert cnt == rn and cnt <= cap
+    assert np.array_equal(q.cpu().numpy(), rq)
+    gi, gv = _outlier_set(oi.cpu().numpy(), ov.cpu().numpy())
+    ri, rv = _outlier_set(roi, rov)
+    assert np.array_equal(gi, ri) and np.array_equal(gv, rv)
+    return q, oi, ov
+
+
+def test_config0_1d_2pow20_f64():
+    """BASELINE.json configs[0] shape and type (1-D 2^20 float64, uniform grid, s=inf, tolerance
+    1e-3*maxabs) through the MGARD-X path: an even, non-dyadic size, so every level applies the
+    ghost-node rule. Bit-exact integers vs the oracle + round trip within the tolerance."""
+    torch, mg = _gpu()
+    n = 1 << 20
+    rng = np.random.default_rng(20260101)
+    i = np.arange(n) / n
+    u = np.sin(2 * np.pi * 5 * i) + 0.1 * np.sin(2 * np.pi * 50 * i) + 1e-3 * rng.uniform(-1, 1, n)
+    h = mg.Hierarchy((n,), np.float64)
+    o = oracle.Hierarchy((n,), np.float64)
+    ud = torch.from_numpy(u).cuda()
+    tol = 1e-3 * float(np.max(np.abs(u)))
+    q, oi, ov = _compare_quantized(mg, h, o, u, ud, mg.ABS, tol, np.inf, 1.0, n // 4)
+    back = h.dequantize_recompose(q.clone(), mg.ABS, tol, np.inf, 1.0, outlier_idx=oi, outlier_val=ov)
+    assert float((back - ud).abs().max().item()) <= tol
+    h.close()
+
+
+def test_config2_512cube_f64_nonuniform_s0():
+    """BASELINE.json configs[2] at full size: 512^3 float64, non-uniform coordinates, s=0
+    (volume-weighted quantizers, non-constant mass matrix and Thomas coefficients). ABS mode as
+    SURVEY.md section 9 caveat 1 prescribes (the L2 norm is not bit-reproducible)."""
+    torch, mg = _gpu()
+    shape = (512, 512, 512)
+    if _host_mem_gb() < 40:
+        pytest.skip("not enough host memory for the full-size oracle run")
+    u = smooth_field(shape, np.float64)
+    coords = nonuniform_coords(shape, np.float64)
+    h = mg.Hierarchy(shape, np.float64, coords=coords)
+    o = oracle.Hierarchy(shape, np.float64, coords=coords)
+    ud = torch.from_numpy(u).cuda()
+    _compare_quantized(mg, h, o, u, ud, mg.ABS, 1e-3, 0.0, 1.0, u.size // 8)
+    h.close()
+
+
+@pytest.mark.parametrize("shape", [(8, 128, 128, 128), (8, 64, 200, 96)])
+def test_config3_4d_slab(shape):
+    """BASELINE.json configs[3]: one rank's 4-D slab (8 x n^3 float32; the level count is limited
+    by the short dimension, l_target = 3) at a size the oracle finishes in seconds; generic N-D
+    kernels, bit-exact integers + round trip."""
+    torch, mg = _gpu()
+    u = smooth_field(shape, np.float32)
+    h = mg.Hierarchy(shape, np.float32)
+    o = oracle.Hierarchy(shape, np.float32)
+    assert h.l_target == 3
+    ud = torch.from_numpy(u).cuda()
+    nrm = float(np.max(np.abs(u)))
+    q, oi, ov = _compare_quantized(mg, h, o, u, ud, mg.REL, 1e-3, np.inf, nrm, u.size // 2)
+    back = h.dequantize_recompose(q.clone(), mg.REL, 1e-3, np.inf, nrm, outlier_idx=oi, outlier_val=ov)
+    assert float((back - ud).abs().max().item()) <= 1e-3 * nrm
+    h.close()
