@@ -21,6 +21,7 @@
 #include "kernels_v1.hpp"
 #include "kernels_ipk.hpp"
 #include "kernels_fused.hpp"
+#include "kernels_emit.hpp"
 #include "kernels_tail.hpp"
 #include "kernels_recompose.hpp"
 #include "kernels_nd.hpp"
@@ -61,6 +62,15 @@ struct mgh_hierarchy {
   bool force_v1 = false;  // MGH_FORCE_V1=1: run the one-thread-per-element kernels only
   bool force_nd = false;  // MGH_FORCE_ND=1: run the generic N-D kernels also for D <= 3 (cross-check)
   std::string prof_filter;  // empty = every kernel
+  // second stream for the coefficient/quantize passes that run beside the correction chain
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> fork_ev;  // one per level
+  hipEvent_t join_ev = nullptr;
+  unsigned emit_bpc = 2;   // MGH_EMIT_BPC: workgroups per CU of the (persistent) emit pass
+  unsigned emit_cch = 32;  // MGH_EMIT_CCH: cells per march of the emit pass
+  // MGH_SPLIT: 0 = never split a level (default: measured within 5% of the split schedules
+  // and single-stream), 1 = split the biggest size class, 2 = also the mid-size class
+  int split = 0;
   std::map<std::string, ProfileEntry> prof;
   size_t device_bytes = 0;
 };
@@ -461,12 +471,48 @@ QuantParams<T> make_quant_params(mgh_hierarchy *h, int ebtype, double tol, doubl
   return qp;
 }
 
+// Size class of a level for the fused kernels: 2 = plenty of tiles (long marches, RCH = 16),
+// 1 = mid-size (RCH = 4), 0 = few tiles (one coarse plane per workgroup).
+inline int level_class(const Box3 &b) {
+  constexpr int TC = 8, TF = 32;
+  const size_t gx = (b.m[2] + TF - 1) / TF, gy = (b.m[1] + TC - 1) / TC;
+  if (gx * gy * ((b.m[0] + 15) / 16) >= 2048) return 2;
+  if (gx * gy * ((b.m[0] + 3) / 4) >= 256) return 1;
+  return 0;
+}
+
+// Does level l run split (load-vector pass on the caller's stream, coefficient/quantize pass on
+// the side stream)? Only the quantizing path splits.
+template <typename T> bool level_is_split(const mgh_hierarchy *h, int l) {
+  const int c = level_class(DS<T>(h)->lt[l].box);
+  return (h->split >= 1 && c == 2) || (h->split >= 2 && c == 1);
+}
+
+inline int ensure_side_stream(mgh_hierarchy *h) {
+  if (h->side) return MGH_SUCCESS;
+  int lo = 0, hi = 0;
+  HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  // lowest priority: the latency-bound chain on the caller's stream gets the CUs it asks for
+  HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo));
+  HIP_TRY(hipEventCreateWithFlags(&h->join_ev, hipEventDisableTiming));
+  h->fork_ev.resize(h->L + 1, nullptr);
+  for (auto &e : h->fork_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return MGH_SUCCESS;
+}
+
 // Level loop on the fused kernels (3 active dims): per level one fused
 // coefficient/quantize/load-vector pass, three Thomas solves (the last one adds
 // the correction into the coarse nodal array), then the head.
-template <typename T, int OUT>
+//
+// OUT_Q, big levels: the pass is split (kernels_emit.hpp). The caller's stream carries only
+// what the next level waits for -- load vector + coarse nodes, Thomas solves -- and the
+// coefficient/quantize pass of level l starts on the side stream as soon as that level's
+// nodal input (and the quantizers) exist; the caller's stream joins the side stream at the
+// end. `norm_in_first`: the top-level pass also reduces abs-max(input) into ds->scalar, and
+// `after_first` (the quantizer set-up that consumes it) is issued right behind it.
+template <typename T, int OUT, typename AfterFirst>
 int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams<T> *qp,
-                    hipStream_t s) {
+                    hipStream_t s, bool norm_in_first, AfterFirst &&after_first) {
   auto *ds = DS<T>(h);
   const int L = h->L;
   const size_t fI = ds->full_I, fJ = ds->full_J;
@@ -497,6 +543,7 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
       break;
     }
   }
+  bool forked = false;
   for (int l = L; l > l_tail; l--) {
     const LevelTables<T> &t = ds->lt[l];
     const Box3 &b = t.box;
@@ -516,25 +563,70 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
       A.quantizer = qp->qz[l];
       A.volume = qp->vol[l];
     }
-    // long marches (RCH = 16: 9% r-halo) when there are plenty of tiles, short ones
-    // (RCH = 4) on the small levels where the march length is pure latency
     const unsigned gx = (b.m[2] + TF - 1) / TF, gy = (b.m[1] + TC - 1) / TC;
-    if ((size_t)gx * gy * ((b.m[0] + 15) / 16) >= 2048) {
-      const dim3 grid(gx, gy, (b.m[0] + 15) / 16);
-      TRY(launch(h, OUT == OUT_Q ? "level_fused_q" : "level_fused", s, [&] {
-        k_level_fused<T, OUT, TC, TF, 16, false><<<grid, 256, 0, s>>>(A);
+    const int cls = level_class(b);
+    const bool split = OUT == OUT_Q && level_is_split<T>(h, l);
+    if (split) {
+      TRY(ensure_side_stream(h));
+      A.absmax_bits = (l == L && norm_in_first) ? ds->scalar : nullptr;
+      if (cls == 2) {
+        const dim3 grid(gx, gy, (b.m[0] + 15) / 16);
+        TRY(launch(h, "level_load", s, [&] {
+          k_level_fused<T, OUT_NONE, TC, TF, 16, false><<<grid, 256, 0, s>>>(A);
+        }));
+      } else {
+        const dim3 grid(gx, gy, (b.m[0] + 3) / 4);
+        TRY(launch(h, "level_load_small", s, [&] {
+          k_level_fused<T, OUT_NONE, TC, TF, 4, false><<<grid, 256, 0, s>>>(A);
+        }));
+      }
+      A.absmax_bits = nullptr;
+      if (l == L) TRY(after_first());
+      // fork: everything the emit pass reads (nodal input of level l, quantizers) is ordered
+      // before this point of the caller's stream
+      const bool serial = std::getenv("MGH_SPLIT_SERIAL") != nullptr;  // (experiments)
+      hipStream_t es = serial ? s : h->side;
+      if (!serial) {
+        HIP_TRY(hipEventRecord(h->fork_ev[l], s));
+        HIP_TRY(hipStreamWaitEvent(h->side, h->fork_ev[l], 0));
+      }
+      // emit pass: persistent, a bounded number of workgroups per CU (kernels_emit.hpp)
+      const unsigned nstrip = (b.m[2] - 1 + 63) / 64;
+      const unsigned ncch = std::max(1u, (b.m[1] + h->emit_cch - 1) / h->emit_cch);
+      const unsigned cch = (b.m[1] + ncch - 1) / ncch;
+      const unsigned nwork = nstrip * ncch * ((b.m[0] + 3) / 4);
+      const unsigned eblocks = std::min(nwork, 256u * h->emit_bpc);
+      const char *ename = cls == 2 ? "level_emit_q" : "level_emit_q_small";
+      if (nstrip > 0)
+        TRY(launch(h, ename, es, [&] {
+          k_level_emit<T, OUT_Q, 2><<<eblocks, 256, 0, es>>>(A, nstrip, ncch, cch, nwork);
+        }));
+      const unsigned lblocks = std::min(256u, (b.m[0] * b.m[1] + 255) / 256);
+      TRY(launch(h, "level_emit_lastcol", es, [&] {
+        k_level_emit_lastcol<T, OUT_Q><<<lblocks, 256, 0, es>>>(A);
       }));
-    } else if ((size_t)gx * gy * ((b.m[0] + 3) / 4) >= 256) {
-      const dim3 grid(gx, gy, (b.m[0] + 3) / 4);
-      TRY(launch(h, OUT == OUT_Q ? "level_fused_q_small" : "level_fused_small", s, [&] {
-        k_level_fused<T, OUT, TC, TF, 4, false><<<grid, 256, 0, s>>>(A);
-      }));
+      forked = true;
     } else {
-      // few tiles: the march length is the whole cost -> one coarse plane per block
-      const dim3 grid(gx, gy, b.m[0]);
-      TRY(launch(h, OUT == OUT_Q ? "level_fused_q_small" : "level_fused_small", s, [&] {
-        k_level_fused<T, OUT, TC, TF, 1, true><<<grid, 256, 0, s>>>(A);
-      }));
+      if (l == L) TRY(after_first());
+      // long marches (RCH = 16: 9% r-halo) when there are plenty of tiles, short ones
+      // (RCH = 4) on the small levels where the march length is pure latency
+      if (cls == 2) {
+        const dim3 grid(gx, gy, (b.m[0] + 15) / 16);
+        TRY(launch(h, OUT == OUT_Q ? "level_fused_q" : "level_fused", s, [&] {
+          k_level_fused<T, OUT, TC, TF, 16, false><<<grid, 256, 0, s>>>(A);
+        }));
+      } else if (cls == 1) {
+        const dim3 grid(gx, gy, (b.m[0] + 3) / 4);
+        TRY(launch(h, OUT == OUT_Q ? "level_fused_q_small" : "level_fused_small", s, [&] {
+          k_level_fused<T, OUT, TC, TF, 4, false><<<grid, 256, 0, s>>>(A);
+        }));
+      } else {
+        // few tiles: the march length is the whole cost -> one coarse plane per block
+        const dim3 grid(gx, gy, b.m[0]);
+        TRY(launch(h, OUT == OUT_Q ? "level_fused_q_small" : "level_fused_small", s, [&] {
+          k_level_fused<T, OUT, TC, TF, 1, true><<<grid, 256, 0, s>>>(A);
+        }));
+      }
     }
     TRY(ipk_launch<T>(h, 2, b.m, ds->t3, t.thomas[2], nullptr, +1, s));
     TRY(ipk_launch<T>(h, 1, b.m, ds->t3, t.thomas[1], nullptr, +1, s));
@@ -543,6 +635,7 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
     sJ = b.m[2];
     sI = (size_t)b.m[1] * b.m[2];
   }
+  if (L <= l_tail) TRY(after_first());
   if (l_tail >= 1) {
     TailArgs<T> TA{};
     TA.nlevels = l_tail;
@@ -583,7 +676,17 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
       k_head_out<T, OUT><<<1, 256, 0, s>>>((int)b.m[0], (int)b.m[1], (int)b.m[2], ds->nodal[0], A);
     }));
   }
+  if (forked) {
+    HIP_TRY(hipEventRecord(h->join_ev, h->side));
+    HIP_TRY(hipStreamWaitEvent(s, h->join_ev, 0));
+  }
   return MGH_SUCCESS;
+}
+
+template <typename T, int OUT>
+int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams<T> *qp,
+                    hipStream_t s) {
+  return decompose_fused<T, OUT>(h, data, coeff, qp, s, false, [] { return (int)MGH_SUCCESS; });
 }
 
 inline bool fused_ok(const mgh_hierarchy *h) { return h->D == 3 && h->L >= 1; }
@@ -1063,8 +1166,14 @@ int fused_q_entry_device(mgh_hierarchy *h, const T *data, int ebtype, double tol
                          uint64_t dict_size, int prep_huffman, int64_t *q, uint64_t *ocount,
                          uint64_t *oidx, int64_t *oval, uint64_t ocap, hipStream_t st) {
   auto *ds = DS<T>(h);
-  if (!d_norm && ebtype == MGH_REL) TRY(norm_launch<T>(h, data, s, st));
-  TRY(make_qparams_launch<T>(h, d_norm, ebtype, tol, s, decomposed, nsub, st));
+  // s = inf, REL, no norm given, top level split: abs-max(input) comes out of the top level's
+  // load-vector pass (it reads every input element anyway) -- no separate norm pass
+  const bool need_norm = !d_norm && ebtype == MGH_REL;
+  const bool norm_in_first = need_norm && (T)s == std::numeric_limits<T>::infinity() &&
+                             h->L >= 1 && level_is_split<T>(h, h->L);
+  if (norm_in_first) HIP_TRY(hipMemsetAsync(ds->scalar, 0, 8, st));
+  else if (need_norm) TRY(norm_launch<T>(h, data, s, st));
+  auto qparams = [&] { return make_qparams_launch<T>(h, d_norm, ebtype, tol, s, decomposed, nsub, st); };
   QuantParams<T> qp;
   qp.d_qp = ds->qz;
   qp.dict_size = (int64_t)dict_size;
@@ -1074,7 +1183,7 @@ int fused_q_entry_device(mgh_hierarchy *h, const T *data, int ebtype, double tol
   qp.oidx = oidx;
   qp.oval = oval;
   qp.ocap = ocap;
-  TRY((decompose_fused<T, OUT_Q>(h, data, nullptr, &qp, st)));
+  TRY((decompose_fused<T, OUT_Q>(h, data, nullptr, &qp, st, norm_in_first, qparams)));
   if (h_norm_out) {
     T nv = 0;
     HIP_TRY(hipMemcpyAsync(&nv, ds->normval, sizeof(T), hipMemcpyDeviceToHost, st));
@@ -1115,6 +1224,12 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->force_v1 = e && e[0] == '1';
     const char *e2 = std::getenv("MGH_FORCE_ND");
     h->force_nd = e2 && e2[0] == '1';
+    const char *e3 = std::getenv("MGH_SPLIT");
+    if (e3 && e3[0] >= '0' && e3[0] <= '2') h->split = e3[0] - '0';
+    const char *e4 = std::getenv("MGH_EMIT_BPC");
+    if (e4 && std::atoi(e4) > 0) h->emit_bpc = (unsigned)std::atoi(e4);
+    const char *e5 = std::getenv("MGH_EMIT_CCH");
+    if (e5 && std::atoi(e5) > 0) h->emit_cch = (unsigned)std::atoi(e5);
     if (h->force_nd) h->force_v1 = true;  // keeps the fused entry points off
   }
   h->dtype = dtype;
@@ -1159,6 +1274,9 @@ void mgh_hierarchy_destroy(mgh_hierarchy *h) {
       (void)hipEventDestroy(ev.first);
       (void)hipEventDestroy(ev.second);
     }
+  for (hipEvent_t e : h->fork_ev) (void)hipEventDestroy(e);
+  if (h->join_ev) (void)hipEventDestroy(h->join_ev);
+  if (h->side) (void)hipStreamDestroy(h->side);
   if (h->dtype == MGH_FLOAT) destroy_state<float>(h); else destroy_state<double>(h);
   delete h;
 }

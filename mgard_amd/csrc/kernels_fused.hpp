@@ -59,9 +59,13 @@ template <typename T> struct FusedArgs {
   uint64_t *outlier_idx;
   int64_t *outlier_val;
   unsigned long long outlier_cap;
+  // OUT_NONE only: abs-max of the level's input (bit pattern, atomicMax), or nullptr
+  unsigned long long *absmax_bits;
 };
 
-enum { OUT_T = 0, OUT_Q = 1 };
+// OUT_NONE: coarse nodes + load vector only; the coefficients of the level are produced by
+// k_level_emit (kernels_emit.hpp) on another stream
+enum { OUT_T = 0, OUT_Q = 1, OUT_NONE = 2 };
 
 template <typename T>
 __device__ __forceinline__ T mass_apply(T a, T b, T c, T d, T e, const T (&w)[9]) {
@@ -165,7 +169,9 @@ k_level_fused(FusedArgs<T> A) {
     A.volume = A.qp[A.nlev + A.level];
   }
   const int tid = threadIdx.x;
-  const int F0 = blockIdx.x * TF, C0 = blockIdx.y * TC, R0 = blockIdx.z * RCH;
+  // r-chunks in reverse launch order: whatever ran before this kernel (the norm reduction,
+  // the level above) leaves the END of the level's input in the memory-side cache
+  const int F0 = blockIdx.x * TF, C0 = blockIdx.y * TC, R0 = (gridDim.z - 1 - blockIdx.z) * RCH;
   const int nr = A.n[0], nc = A.n[1], nf = A.n[2];
   const int mr = A.m[0], mc = A.m[1], mf = A.m[2];
   const int c_lo = 2 * C0 - 2, f_lo = 2 * F0 - 2;
@@ -221,6 +227,7 @@ k_level_fused(FusedArgs<T> A) {
     gval[k] = e < WC * WF && Pc >= 0 && Pc <= Pmax_c && Pf >= 0 && Pf <= Pmax_f;
     goff[k] = gval[k] ? (uint32_t)(min(Pc, nc - 1) * (int)A.uJ + min(Pf, nf - 1)) : 0u;
   }
+  T amax = 0;  // OUT_NONE: abs-max over everything this thread reads (max is idempotent)
   auto fetch = [&](int p, T(&reg)[NL]) {
     const bool pv = p >= 0 && p <= Pmax_r;
     const T *base = A.u + (size_t)min(max(p, 0), nr - 1) * A.uI;
@@ -230,8 +237,13 @@ k_level_fused(FusedArgs<T> A) {
   auto stash = [&](int p, const T(&reg)[NL]) {
     T *dst = raw[(p + 6) % 3];
 #pragma unroll
-    for (int k = 0; k < NL; k++)
+    for (int k = 0; k < NL; k++) {
       if (lidx[k] >= 0) dst[lidx[k]] = reg[k];
+      if (OUT == OUT_NONE) {  // here, not in fetch(): the loads stay in flight until now
+        const T a = abs_t(reg[k]);
+        amax = a > amax ? a : amax;
+      }
+    }
   };
 
   // ---- cells: a cell is the 2x2 group of window nodes (lc0 + {0,1}, lf0 + {0,1}) with even
@@ -360,7 +372,7 @@ k_level_fused(FusedArgs<T> A) {
 #pragma unroll
         for (int k = 0; k < 4; k++)
           if (on[k]) A.coef[lin[k]] = cv[k];
-      } else {
+      } else if (OUT == OUT_Q) {
         emit_quantized<T, 4>(A, cv, lin, on);
       }
     }
@@ -449,6 +461,19 @@ k_level_fused(FusedArgs<T> A) {
       __syncthreads();
       phase_c(t1s2[0]);
       phase_d(p + 1);
+    }
+  }
+  if (OUT == OUT_NONE && A.absmax_bits) {
+    for (int off = 32; off > 0; off >>= 1) {
+      const T o = __shfl_down(amax, off, 64);
+      amax = o > amax ? o : amax;
+    }
+    if ((tid & 63) == 0) {
+      // non-negative IEEE values order like their bit patterns; the plain load keeps the
+      // tens of thousands of waves from queueing on one atomic once the maximum has settled
+      unsigned long long bits;
+      if (sizeof(T) == 4) bits = __float_as_uint((float)amax); else bits = __double_as_longlong((double)amax);
+      if (bits > __atomic_load_n(A.absmax_bits, __ATOMIC_RELAXED)) atomicMax(A.absmax_bits, bits);
     }
   }
 #undef LI

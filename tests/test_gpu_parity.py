@@ -528,3 +528,33 @@ def test_config3_4d_slab(shape):
     back = h.dequantize_recompose(q.clone(), mg.REL, 1e-3, np.inf, nrm, outlier_idx=oi, outlier_val=ov)
     assert float((back - ud).abs().max().item()) <= 1e-3 * nrm
     h.close()
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("split", ["1", "2"])
+@pytest.mark.parametrize("shape,mode,s", [((257, 300, 258), "REL", np.inf), ((200, 130, 513), "ABS", 0.0),
+                                          ((129, 512, 130), "REL", np.inf)])
+def test_split_stream_schedule_bit_exact(shape, mode, s, split, dt, monkeypatch):
+    """MGH_SPLIT=1/2: big levels run as a load-vector pass on the caller's stream (with the
+    abs-max of the input fused into the top level's pass) plus an LDS-free coefficient/quantize
+    pass on a second stream (kernels_emit.hpp). Same integers, outliers and norm as the oracle."""
+    torch, mg = _gpu()
+    monkeypatch.setenv("MGH_SPLIT", split)
+    u = smooth_field(shape, dt, noise=3e-3)
+    h = mg.Hierarchy(shape, dt)
+    o = oracle.Hierarchy(shape, dt)
+    ud = torch.from_numpy(u).cuda()
+    m = mg.REL if mode == "REL" else mg.ABS
+    q, oi, ov, cnt, nrm = h.decompose_quantize(ud, m, 1e-3, s, outlier_cap=u.size)
+    if mode == "REL":
+        assert nrm == float(np.max(np.abs(u)))
+    else:
+        nrm = 1.0
+    rq, roi, rov, rn = o.quantize(o.decompose(u), oracle.REL if mode == "REL" else oracle.ABS,
+                                  dt(1e-3), dt(s), dt(nrm), outlier_cap=u.size)
+    assert cnt == rn
+    assert np.array_equal(q.cpu().numpy(), rq)
+    gi, gv = _outlier_set(oi.cpu().numpy(), ov.cpu().numpy())
+    ri, rv = _outlier_set(roi, rov)
+    assert np.array_equal(gi, ri) and np.array_equal(gv, rv)
+    h.close()
