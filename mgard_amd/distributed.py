@@ -50,3 +50,67 @@ def split_slowest(shape, world_size, rank):
     base, rem = divmod(n, world_size)
     start = rank * base + min(rank, rem)
     return start, start + base + (1 if rank < rem else 0)
+
+
+def scatter_slabs(full, shape, src=0, group=None, device=None, dtype=None):
+    """Block scatter of the domain decomposition (reference: DomainDecomposer::copy_subdomain,
+    DomainDecomposer.hpp:649-845, across devices): rank `src` holds the whole array `full`
+    (shape `shape`, C order) and sends every other rank its contiguous slab along the slowest
+    dimension with point-to-point sends (RCCL send/recv over xGMI with backend "nccl"; there is
+    no halo, subdomains share no nodes). Returns this rank's slab. `full` is only read on `src`;
+    the other ranks pass None and must give `dtype`."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return full
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = split_slowest(shape, world, rank)
+    if rank == src:
+        reqs = []
+        for r in range(world):
+            if r == src:
+                continue
+            a, b = split_slowest(shape, world, r)
+            reqs.append(dist.isend(full[a:b].contiguous(), dst=r, group=group))
+        mine = full[lo:hi].clone()
+        for q in reqs:
+            q.wait()
+        return mine
+    mine = torch.empty((hi - lo,) + tuple(shape[1:]), dtype=dtype, device=device)
+    dist.recv(mine, src=src, group=group)
+    return mine
+
+
+def gather_payloads(payload, dst=0, group=None):
+    """Payload gather: every rank's compressed subdomain (a 1-D uint8 tensor of its own length)
+    ends up on `dst`, in subdomain-id (= rank) order, the way the reference concatenates
+    `[u64 size][payload]` per subdomain (GPUPipelines.hpp:189-193). Lengths travel first (one
+    small all-gather), the bytes by point-to-point sends. Returns the list of payloads on `dst`,
+    None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [payload]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = torch.tensor([payload.numel()], dtype=torch.int64, device=payload.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    if rank != dst:
+        dist.send(payload.contiguous(), dst=dst, group=group)
+        return None
+    out = []
+    for r in range(world):
+        if r == dst:
+            out.append(payload)
+        else:
+            buf = torch.empty(int(sizes[r].item()), dtype=payload.dtype, device=payload.device)
+            dist.recv(buf, src=r, group=group)
+            out.append(buf)
+    return out
+
+
+def frame_payloads(payloads):
+    """`[u64 LE compressed_size][payload]` per subdomain, concatenated in id order
+    (GPUPipelines.hpp:189-193)."""
+    import struct
+    return b"".join(struct.pack("<Q", len(p)) + bytes(p) for p in payloads)

@@ -81,3 +81,40 @@ def test_split_slowest():
     assert [mdist.split_slowest((10, 3), 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert mdist.local_abs_tol(mdist.REL, 2.0, 1e-3, float("inf"), 8) == 2e-3
     assert mdist.local_abs_tol(mdist.ABS, 2.0, 1e-3, float("inf"), 8) == 1e-3
+
+
+def _sg_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    from mgard_amd import distributed as mdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shape = (11, 6, 7)
+    full = torch.arange(11 * 6 * 7, dtype=torch.float32).reshape(shape) if rank == 0 else None
+    slab = mdist.scatter_slabs(full, shape, src=0, dtype=torch.float32)
+    lo, hi = mdist.split_slowest(shape, world, rank)
+    ok = torch.equal(slab, torch.arange(11 * 6 * 7, dtype=torch.float32).reshape(shape)[lo:hi])
+    payload = torch.full((5 + 3 * rank,), rank + 1, dtype=torch.uint8)
+    got = mdist.gather_payloads(payload, dst=0)
+    framed = mdist.frame_payloads([g.numpy().tobytes() for g in got]) if rank == 0 else b""
+    out.put((rank, ok, framed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_slab_scatter_and_payload_gather():
+    import struct
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sg_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict((r[0], r) for r in (out.get(timeout=120) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1]
+    assert res[0][2] == struct.pack("<Q", 5) + b"\x01" * 5 + struct.pack("<Q", 8) + b"\x02" * 8
