@@ -1,0 +1,158 @@
+/* mgard_hip_compress.h -- C ABI of the HIGH-LEVEL path: whole-array compress / decompress with
+ * domain decomposition, the lossless stage and the self-describing container, on top of the
+ * low-level entry points of mgard_hip.h. Same shared library (libmgard_hip.so).
+ *
+ * What each entry point replaces in the reference (MGARD-X):
+ *   mgh_compress / mgh_decompress   mgard_x::compress / decompress
+ *                                   (include/compress_x.hpp:31-100, 109-154;
+ *                                    CompressionHighLevel.hpp:47-330, 478-640)
+ *   mgh_config                      mgard_x::Config (Config/Config.h:10-42, defaults Config.cpp:14-43)
+ *   mgh_metadata_* / mgh_infer_*    Metadata<..>::Serialize / Deserialize, infer_shape,
+ *                                   infer_data_type (Metadata/Metadata.hpp:226-262)
+ *   mgh_huffman_*                   ComposedLosslessCompressor::Compress/Serialize and
+ *                                   Deserialize/Decompress (Lossless/Lossless.hpp:70-118)
+ *
+ * Output container (byte-compatible with the reference, see mgard_amd/csrc/format.hpp):
+ *   "MGARD" | u64 LE header_size | u32 LE crc32 | proto3 Header | per subdomain:
+ *   [u64 compressed_size][payload]   (GPUPipelines.hpp:189-193), payload = the Huffman record
+ *   of Huffman.hpp:163-239 (optionally [u64 size][zstd frame] around it, Zstd.hpp:69-90), or the
+ *   raw subdomain when compression would not shrink it (GPUPipelines.hpp:136-155).
+ *
+ * Conventions as in mgard_hip.h. `original_data`, `compressed_data`, `decompressed_data` may be
+ * host or device pointers (detected like MemoryManager::IsDevicePointer); when the output is not
+ * pre-allocated the library allocates it in the same memory space as the input
+ * (CompressionHighLevel.hpp:149-162): host outputs with malloc (release with free), device
+ * outputs with hipMalloc (release with hipFree / mgh_free_device).
+ */
+#ifndef MGARD_HIP_COMPRESS_H
+#define MGARD_HIP_COMPRESS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "mgard_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGH_ERR_OUTPUT_TOO_LARGE (-7) /* cf. compress_status_type::OutputTooLargeFailure */
+#define MGH_ERR_FORMAT (-8)           /* malformed / unsupported compressed stream */
+
+typedef enum mgh_domain_decomposition { /* domain_decomposition_type, Utilities/Types.h:50 */
+  MGH_DD_MAXDIM = 0,
+  MGH_DD_BLOCK = 1,
+  MGH_DD_VARIABLE = 2
+} mgh_domain_decomposition;
+
+typedef enum mgh_lossless { /* lossless_type, Utilities/Types.h:33-38 */
+  MGH_LOSSLESS_HUFFMAN = 0,
+  MGH_LOSSLESS_HUFFMAN_LZ4 = 1, /* not supported: MGH_ERR_INVALID_ARGUMENT */
+  MGH_LOSSLESS_HUFFMAN_ZSTD = 2,
+  MGH_LOSSLESS_CPU = 3 /* not supported */
+} mgh_lossless;
+
+/* The fields of mgard_x::Config this path reads; mgh_config_default() fills the reference's
+ * defaults (Config.cpp:14-43). */
+typedef struct mgh_config {
+  int dev_id;
+  int domain_decomposition;      /* mgh_domain_decomposition */
+  int domain_decomposition_dim;  /* Variable */
+  const uint64_t *domain_decomposition_sizes; /* Variable: extent of every subdomain */
+  uint64_t num_domain_decomposition_sizes;
+  uint64_t block_size;           /* Block */
+  double estimate_outlier_ratio;
+  uint64_t huff_dict_size;
+  uint64_t huff_block_size;
+  int lossless;                  /* mgh_lossless */
+  int zstd_compress_level;
+  int normalize_coordinates;
+  uint64_t max_larget_level;
+  uint64_t max_memory_footprint; /* bytes of device memory the call may plan with */
+  int auto_pin_host_buffers;
+} mgh_config;
+
+void mgh_config_default(mgh_config *config);
+
+/* mgard_x::compress. coords: NULL (uniform) or D host arrays of the data type. If
+ * output_pre_allocated, *compressed_size carries the capacity in and the size out. */
+int mgh_compress(int D, int dtype, const uint64_t *shape, double tol, double s,
+                 int error_bound_type, const void *original_data, void **compressed_data,
+                 size_t *compressed_size, const void *const *coords, const mgh_config *config,
+                 int output_pre_allocated);
+
+/* mgard_x::decompress. Shape and type come from the header (query them first with
+ * mgh_infer_shape / mgh_infer_data_type to pre-allocate). */
+int mgh_decompress(const void *compressed_data, size_t compressed_size,
+                   void **decompressed_data, const mgh_config *config,
+                   int output_pre_allocated);
+
+/* infer_shape / infer_data_type (Metadata.hpp:244-247). compressed_data: host or device. */
+int mgh_infer_shape(const void *compressed_data, size_t compressed_size, int *D_out,
+                    uint64_t *shape_out /* [MGH_MAX_DIM] */);
+int mgh_infer_data_type(const void *compressed_data, size_t compressed_size, int *dtype_out);
+
+void mgh_free_device(void *p);
+/* release_cache (compress_x.hpp:159): drops this thread's cached hierarchies and buffers. */
+void mgh_release_cache(void);
+/* Synchronous copy between any two of host / device memory (hipMemcpyDefault); lets a host
+ * language without HIP bindings read the buffers the contexts own. */
+int mgh_memcpy(void *dst, const void *src, size_t bytes);
+
+/* ---- header (metadata) on its own: host only, no device needed -------------------------- */
+typedef struct mgh_header_info {
+  uint64_t version[3];
+  int dtype;
+  int D;
+  uint64_t shape[MGH_MAX_DIM];
+  int uniform;
+  const double *coords[MGH_MAX_DIM]; /* !uniform: serialize reads them; parse points them into
+                                        the caller's coords_storage */
+  int error_bound_type; /* mgh_error_bound */
+  double tol, s, norm;
+  int domain_decomposed;
+  int dd_method; /* mgh_domain_decomposition */
+  uint64_t dd_dim, dd_size;
+  uint64_t l_target;
+  int reorder;
+  int lossless; /* mgh_lossless */
+  uint64_t huff_dict_size, huff_block_size;
+} mgh_header_info;
+
+/* Returns the number of bytes written (or needed when out == NULL), negative on error. */
+int64_t mgh_metadata_serialize(const mgh_header_info *info, uint8_t *out, uint64_t capacity);
+/* Parses preamble + header; *metadata_size_out = offset of the first subdomain record. */
+int mgh_metadata_parse(const uint8_t *data, uint64_t size, mgh_header_info *info,
+                       double *coords_storage, uint64_t coords_capacity,
+                       uint64_t *metadata_size_out);
+
+/* ---- lossless stage on its own (device pointers) ----------------------------------------- */
+/* Host only: the canonical code built from a histogram, as it goes into the payload --
+ * code[s] = (length << 56) | value (0: unused symbol), first[64] / entry[64] / keys[dict] with
+ * the meaning Decode.hpp:52-106 gives them (reference GetCodebook.hpp:23-147 produces the
+ * same three tables on the device). */
+int mgh_huffman_codebook(const uint32_t *freq, uint64_t dict_size, uint64_t *code_out,
+                         uint64_t *first_out /* [64] */, uint64_t *entry_out /* [64] */,
+                         uint64_t *keys_out /* [dict_size] */);
+
+typedef struct mgh_lossless_ctx mgh_lossless_ctx;
+int mgh_lossless_create(mgh_lossless_ctx **out, int dev_id);
+void mgh_lossless_destroy(mgh_lossless_ctx *ctx);
+/* Quantized symbols (int64 in [0, dict_size)) + outlier list -> serialized payload in a host
+ * buffer owned by the context (valid until the next call); *size_out bytes. */
+int mgh_lossless_compress(mgh_lossless_ctx *ctx, const int64_t *d_quantized, uint64_t n,
+                          uint64_t dict_size, uint64_t chunk_size, int lossless, int zstd_level,
+                          const uint64_t *d_outlier_idx, const int64_t *d_outlier_val,
+                          uint64_t outlier_count, const uint8_t **h_payload_out,
+                          uint64_t *size_out, void *stream);
+/* Inverse: payload (host) -> d_quantized [n], outlier list in device buffers owned by the
+ * context (*d_outlier_idx_out / *d_outlier_val_out, *outlier_count_out entries). */
+int mgh_lossless_decompress(mgh_lossless_ctx *ctx, const uint8_t *h_payload, uint64_t size,
+                            int lossless, int64_t *d_quantized, uint64_t n,
+                            const uint64_t **d_outlier_idx_out, const int64_t **d_outlier_val_out,
+                            uint64_t *outlier_count_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGARD_HIP_COMPRESS_H */

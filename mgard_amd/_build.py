@@ -10,13 +10,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # MGARD_HIP_LIB: developer override to A/B two builds of the library in one session
 LIB = os.environ.get("MGARD_HIP_LIB", os.path.join(HERE, "libmgard_hip.so"))
-SOURCES = ["capi.hip"]
+SOURCES = ["capi.hip", "highlevel.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-               "-shared", "-Wall"]
+               "-shared", "-Wall", "-ldl"]
 
 
 def _deps():
-    out = [os.path.join(HERE, "..", "include", "mgard_hip.h")]
+    out = [os.path.join(HERE, "..", "include", "mgard_hip.h"),
+           os.path.join(HERE, "..", "include", "mgard_hip_compress.h")]
     for f in os.listdir(CSRC):
         if f.endswith((".hip", ".hpp", ".h", ".cpp")):
             out.append(os.path.join(CSRC, f))

@@ -1202,6 +1202,9 @@ extern "C" {
 
 const char *mgh_last_error(void) { return g_last_error.c_str(); }
 
+/* (internal: lets the high-level translation unit report through the same channel) */
+void mgh_set_last_error_(const char *msg) { g_last_error = msg ? msg : ""; }
+
 int mgh_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -1,0 +1,1266 @@
+// High-level path of libmgard_hip.so: whole-array compress / decompress (SURVEY.md section 8b
+// "high-level", 8f ranks 2-4) on top of the low-level C ABI of capi.hip:
+//   domain decomposition + double-buffered subdomain pipeline
+//     (reference DomainDecomposer.hpp:72-470, 649-845; GPUPipelines.hpp:69-207, 330-520),
+//   Huffman [+ Zstd] lossless stage (huffman.hpp; Lossless.hpp:70-118, Zstd.hpp:69-128),
+//   self-describing container (format.hpp; Metadata.cpp:249-462).
+// Host code is C++; everything exported is extern "C" (include/mgard_hip_compress.h).
+#include "../../include/mgard_hip_compress.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "format.hpp"
+#include "huffman.hpp"
+
+extern "C" void mgh_set_last_error_(const char *msg);  // capi.hip
+
+namespace {
+
+using namespace mgh;
+
+int hl_fail(int code, const std::string &msg) {
+  mgh_set_last_error_(msg.c_str());
+  return code;
+}
+
+#define HL_HIP(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess)                                                                  \
+      return hl_fail(_e == hipErrorOutOfMemory ? MGH_ERR_OUT_OF_MEMORY : MGH_ERR_DEVICE,   \
+                     std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+  } while (0)
+#define HL_TRY(expr)                       \
+  do {                                     \
+    int _rc = (expr);                      \
+    if (_rc != MGH_SUCCESS) return _rc;    \
+  } while (0)
+
+// MemoryManager::IsDevicePointer
+bool is_device_pointer(const void *p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return a.type == hipMemoryTypeDevice;
+}
+
+bool is_registered_host(const void *p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
+// grow-only device buffer
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return MGH_SUCCESS;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    HL_HIP(hipMalloc(&p, bytes));
+    cap = bytes;
+    return MGH_SUCCESS;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+// ---- Zstd through the system library (libzstd.so.1), resolved at first use -----------------
+struct ZstdApi {
+  void *lib = nullptr;
+  size_t (*compressBound)(size_t) = nullptr;
+  size_t (*compress)(void *, size_t, const void *, size_t, int) = nullptr;
+  size_t (*decompress)(void *, size_t, const void *, size_t) = nullptr;
+  unsigned (*isError)(size_t) = nullptr;
+  bool tried = false;
+  bool load() {
+    if (tried) return lib != nullptr;
+    tried = true;
+    for (const char *name : {"libzstd.so.1", "libzstd.so"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) return false;
+    compressBound = (size_t(*)(size_t))dlsym(lib, "ZSTD_compressBound");
+    compress = (size_t(*)(void *, size_t, const void *, size_t, int))dlsym(lib, "ZSTD_compress");
+    decompress = (size_t(*)(void *, size_t, const void *, size_t))dlsym(lib, "ZSTD_decompress");
+    isError = (unsigned (*)(size_t))dlsym(lib, "ZSTD_isError");
+    if (!compressBound || !compress || !decompress || !isError) {
+      dlclose(lib);
+      lib = nullptr;
+    }
+    return lib != nullptr;
+  }
+};
+ZstdApi g_zstd;
+
+// ---- serialized Huffman record: offsets with natural alignment (Huffman.hpp:163-239) --------
+inline size_t align_up(size_t off, size_t a) { return (off + a - 1) / a * a; }
+
+struct PayloadLayout {
+  size_t primary_count = 0, huffmeta = 0, decodebook_size = 0, decodebook = 0, ddata_size = 0,
+         ddata = 0, outlier_count = 0, outlier_idx = 0, outliers = 0, total = 0;
+  // offsets of: primary_count, dict_size, chunk_size, huffmeta_size are fixed (0, 8, 12, 16)
+  void compute(size_t nchunk, size_t dict, size_t units, size_t noutlier) {
+    size_t off = 0;
+    primary_count = off; off += 8;
+    off += 4;  // dict_size (int)
+    off += 4;  // chunk_size (int)
+    off = align_up(off, 8); off += 8;  // huffmeta_size
+    huffmeta = off; off += 8 * 2 * nchunk;
+    decodebook_size = off; off += 8;
+    decodebook = off; off += 8 * (2 * 64) + 8 * dict;
+    off = align_up(off, 8);
+    ddata_size = off; off += 8;
+    off = align_up(off, 8);
+    ddata = off; off += 8 * units;
+    outlier_count = off; off += 8;
+    outlier_idx = off; off += 8 * noutlier;
+    outliers = off; off += 8 * noutlier;
+    total = off;
+  }
+};
+
+} // namespace
+
+// ---- lossless context ----------------------------------------------------------------------
+struct mgh_lossless_ctx {
+  int dev = 0;
+  DevBuf freq, code, bits, entry, total, units, tables, oidx, oval;
+  std::vector<uint8_t> host;   // serialized payload
+  std::vector<uint8_t> host2;  // zstd scratch
+};
+
+namespace {
+
+int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint64_t dict,
+                      uint64_t chunk, int lossless, int zstd_level, const uint64_t *d_oidx,
+                      const int64_t *d_oval, uint64_t ocount, hipStream_t st) {
+  if (lossless != MGH_LOSSLESS_HUFFMAN && lossless != MGH_LOSSLESS_HUFFMAN_ZSTD)
+    return hl_fail(MGH_ERR_INVALID_ARGUMENT, "lossless: only Huffman and Huffman_Zstd are supported");
+  if (n == 0 || dict == 0 || dict > 16384 || chunk == 0 || chunk > (1u << 30))
+    return hl_fail(MGH_ERR_INVALID_ARGUMENT, "lossless: n, dict_size (<= 16384) or chunk_size");
+  if (lossless == MGH_LOSSLESS_HUFFMAN_ZSTD && !g_zstd.load())
+    return hl_fail(MGH_ERR_INVALID_ARGUMENT, "lossless: libzstd.so.1 not found");
+  const size_t nchunk = (n - 1) / chunk + 1;
+  HL_TRY(c->freq.ensure(dict * 4));
+  HL_TRY(c->code.ensure(dict * 8));
+  HL_TRY(c->bits.ensure(nchunk * 8));
+  HL_TRY(c->entry.ensure(nchunk * 8));
+  HL_TRY(c->total.ensure(8));
+  HL_HIP(hipMemsetAsync(c->freq.p, 0, dict * 4, st));
+  const unsigned hblocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+  huff::k_histogram<<<hblocks, 256, dict * 4, st>>>(d_q, n, (int)dict, (unsigned *)c->freq.p);
+  HL_HIP(hipGetLastError());
+  std::vector<unsigned> freq(dict);
+  HL_HIP(hipMemcpyAsync(freq.data(), c->freq.p, dict * 4, hipMemcpyDeviceToHost, st));
+  HL_HIP(hipStreamSynchronize(st));
+  huff::Codebook cb;
+  try {
+    cb = huff::build_codebook(freq);
+  } catch (const std::exception &e) {
+    return hl_fail(MGH_ERR_INVALID_ARGUMENT, e.what());
+  }
+  HL_HIP(hipMemcpyAsync(c->code.p, cb.code.data(), dict * 8, hipMemcpyHostToDevice, st));
+  huff::k_chunk_bits<<<(unsigned)nchunk, 256, 0, st>>>(d_q, n, (int)chunk, (const uint64_t *)c->code.p,
+                                                       (unsigned long long *)c->bits.p);
+  huff::k_unit_offsets<<<1, 1024, 0, st>>>((const unsigned long long *)c->bits.p, nchunk,
+                                           (unsigned long long *)c->entry.p,
+                                           (unsigned long long *)c->total.p);
+  HL_HIP(hipGetLastError());
+  unsigned long long units = 0;
+  HL_HIP(hipMemcpyAsync(&units, c->total.p, 8, hipMemcpyDeviceToHost, st));
+  HL_HIP(hipStreamSynchronize(st));
+  HL_TRY(c->units.ensure(std::max<size_t>(units, 1) * 8));
+  HL_HIP(hipMemsetAsync(c->units.p, 0, units * 8, st));
+  huff::k_encode<<<(unsigned)nchunk, 256, 0, st>>>(d_q, n, (int)chunk, (const uint64_t *)c->code.p,
+                                                   (const unsigned long long *)c->entry.p,
+                                                   (unsigned long long *)c->units.p);
+  HL_HIP(hipGetLastError());
+  // ---- serialize (Huffman.hpp:163-239) ----
+  PayloadLayout L;
+  L.compute(nchunk, dict, units, ocount);
+  std::vector<uint8_t> &out = c->host;
+  out.assign(L.total, 0);
+  auto put64 = [&](size_t off, uint64_t v) { std::memcpy(out.data() + off, &v, 8); };
+  auto put32 = [&](size_t off, int32_t v) { std::memcpy(out.data() + off, &v, 4); };
+  put64(L.primary_count, n);
+  put32(8, (int32_t)dict);
+  put32(12, (int32_t)chunk);
+  put64(16, 2 * nchunk);
+  HL_HIP(hipMemcpyAsync(out.data() + L.huffmeta, c->bits.p, nchunk * 8, hipMemcpyDeviceToHost, st));
+  HL_HIP(hipMemcpyAsync(out.data() + L.huffmeta + nchunk * 8, c->entry.p, nchunk * 8,
+                        hipMemcpyDeviceToHost, st));
+  put64(L.decodebook_size, 8 * (2 * 64) + 8 * dict);
+  std::memcpy(out.data() + L.decodebook, cb.first.data(), 8 * 64);
+  std::memcpy(out.data() + L.decodebook + 8 * 64, cb.entry.data(), 8 * 64);
+  std::memcpy(out.data() + L.decodebook + 8 * 128, cb.keys.data(), 8 * dict);
+  put64(L.ddata_size, units);
+  if (units)
+    HL_HIP(hipMemcpyAsync(out.data() + L.ddata, c->units.p, units * 8, hipMemcpyDeviceToHost, st));
+  put64(L.outlier_count, ocount);
+  if (ocount) {
+    HL_HIP(hipMemcpyAsync(out.data() + L.outlier_idx, d_oidx, ocount * 8, hipMemcpyDeviceToHost, st));
+    HL_HIP(hipMemcpyAsync(out.data() + L.outliers, d_oval, ocount * 8, hipMemcpyDeviceToHost, st));
+  }
+  HL_HIP(hipStreamSynchronize(st));
+  if (lossless == MGH_LOSSLESS_HUFFMAN_ZSTD) {
+    // [size_t input_count][zstd frame] (Zstd.hpp:69-90)
+    const size_t bound = g_zstd.compressBound(out.size());
+    c->host2.resize(bound + 8);
+    const size_t got = g_zstd.compress(c->host2.data() + 8, bound, out.data(), out.size(), zstd_level);
+    if (g_zstd.isError(got)) return hl_fail(MGH_ERR_DEVICE, "ZSTD_compress failed");
+    const uint64_t in_size = out.size();
+    std::memcpy(c->host2.data(), &in_size, 8);
+    c->host2.resize(got + 8);
+    c->host.swap(c->host2);
+  }
+  return MGH_SUCCESS;
+}
+
+int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t size, int lossless,
+                        int64_t *d_q, uint64_t n, uint64_t *ocount_out, hipStream_t st) {
+  const uint8_t *p = payload;
+  uint64_t psize = size;
+  if (lossless == MGH_LOSSLESS_HUFFMAN_ZSTD) {
+    if (!g_zstd.load()) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "lossless: libzstd.so.1 not found");
+    if (size < 8) return hl_fail(MGH_ERR_FORMAT, "zstd record truncated");
+    uint64_t raw = 0;
+    std::memcpy(&raw, payload, 8);
+    if (raw > ((uint64_t)1 << 40)) return hl_fail(MGH_ERR_FORMAT, "zstd record: implausible size");
+    c->host2.resize(raw);
+    const size_t got = g_zstd.decompress(c->host2.data(), raw, payload + 8, size - 8);
+    if (g_zstd.isError(got) || got != raw) return hl_fail(MGH_ERR_FORMAT, "ZSTD_decompress failed");
+    p = c->host2.data();
+    psize = raw;
+  } else if (lossless != MGH_LOSSLESS_HUFFMAN) {
+    return hl_fail(MGH_ERR_INVALID_ARGUMENT, "lossless: only Huffman and Huffman_Zstd are supported");
+  }
+  auto need = [&](size_t off, size_t bytes) { return off + bytes <= psize; };
+  if (!need(0, 24)) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
+  uint64_t primary = 0, huffmeta_size = 0;
+  int32_t dict = 0, chunk = 0;
+  std::memcpy(&primary, p, 8);
+  std::memcpy(&dict, p + 8, 4);
+  std::memcpy(&chunk, p + 12, 4);
+  std::memcpy(&huffmeta_size, p + 16, 8);
+  if (primary != n || dict <= 0 || chunk <= 0 || huffmeta_size != 2 * ((n - 1) / (uint64_t)chunk + 1))
+    return hl_fail(MGH_ERR_FORMAT, "Huffman record: header does not match the subdomain");
+  const size_t nchunk = huffmeta_size / 2;
+  size_t off = 24;
+  const size_t o_meta = off;
+  off += 8 * huffmeta_size;
+  if (!need(off, 8)) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
+  uint64_t dbsize = 0;
+  std::memcpy(&dbsize, p + off, 8);
+  off += 8;
+  if (dbsize != 8 * 128 + 8 * (uint64_t)dict) return hl_fail(MGH_ERR_FORMAT, "Huffman record: decodebook size");
+  const size_t o_db = off;
+  off += dbsize;
+  off = align_up(off, 8);
+  if (!need(off, 8)) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
+  uint64_t units = 0;
+  std::memcpy(&units, p + off, 8);
+  off += 8;
+  off = align_up(off, 8);
+  const size_t o_data = off;
+  if (units > (psize - off) / 8) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
+  off += 8 * units;
+  if (!need(off, 8)) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
+  uint64_t ocount = 0;
+  std::memcpy(&ocount, p + off, 8);
+  off += 8;
+  if (ocount > (psize - off) / 16) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
+  const size_t o_oidx = off, o_oval = off + 8 * ocount;
+  // the chunk entries must stay inside the unit array (they index it in the decoder)
+  {
+    const uint64_t *bits = reinterpret_cast<const uint64_t *>(p + o_meta);
+    const uint64_t *ent = bits + nchunk;
+    for (size_t k = 0; k < nchunk; k++)
+      if (ent[k] > units || (bits[k] + 63) / 64 > units - ent[k])
+        return hl_fail(MGH_ERR_FORMAT, "Huffman record: chunk outside the code stream");
+  }
+  HL_TRY(c->bits.ensure(nchunk * 8));
+  HL_TRY(c->entry.ensure(nchunk * 8));
+  HL_TRY(c->tables.ensure(dbsize));
+  HL_TRY(c->units.ensure(std::max<size_t>(units, 1) * 8));
+  HL_TRY(c->oidx.ensure(std::max<size_t>(ocount, 1) * 8));
+  HL_TRY(c->oval.ensure(std::max<size_t>(ocount, 1) * 8));
+  HL_HIP(hipMemcpyAsync(c->bits.p, p + o_meta, nchunk * 8, hipMemcpyHostToDevice, st));
+  HL_HIP(hipMemcpyAsync(c->entry.p, p + o_meta + nchunk * 8, nchunk * 8, hipMemcpyHostToDevice, st));
+  HL_HIP(hipMemcpyAsync(c->tables.p, p + o_db, dbsize, hipMemcpyHostToDevice, st));
+  if (units) HL_HIP(hipMemcpyAsync(c->units.p, p + o_data, units * 8, hipMemcpyHostToDevice, st));
+  if (ocount) {
+    HL_HIP(hipMemcpyAsync(c->oidx.p, p + o_oidx, ocount * 8, hipMemcpyHostToDevice, st));
+    HL_HIP(hipMemcpyAsync(c->oval.p, p + o_oval, ocount * 8, hipMemcpyHostToDevice, st));
+  }
+  const unsigned long long *tab = (const unsigned long long *)c->tables.p;
+  huff::k_decode<<<(unsigned)((nchunk + 63) / 64), 64, 0, st>>>(
+      (const unsigned long long *)c->units.p, (const unsigned long long *)c->bits.p,
+      (const unsigned long long *)c->entry.p, nchunk, chunk, n, tab, tab + 64, tab + 128, d_q);
+  HL_HIP(hipGetLastError());
+  // the host payload may go away when we return
+  HL_HIP(hipStreamSynchronize(st));
+  *ocount_out = ocount;
+  return MGH_SUCCESS;
+}
+
+// ---- domain decomposition (host logic) ------------------------------------------------------
+struct Decomposer {
+  int D = 0;
+  std::vector<uint64_t> shape;
+  bool decomposed = false;
+  int method = MGH_DD_MAXDIM;
+  uint64_t dim = 0, size = 0;        // MaxDim: (dim, size); Block: size; Variable: dim
+  std::vector<uint64_t> var_sizes;   // Variable
+  uint64_t num = 1;
+
+  std::vector<uint64_t> dim_num_subdomain() const {  // DomainDecomposer.hpp:90-103
+    std::vector<uint64_t> r(D, 1);
+    if (method == MGH_DD_MAXDIM || method == MGH_DD_VARIABLE) r[dim] = num;
+    else for (int d = 0; d < D; d++) r[d] = (shape[d] - 1) / size + 1;
+    return r;
+  }
+  std::vector<uint64_t> dim_subdomain_id(uint64_t id) const {  // :105-113
+    const auto nd = dim_num_subdomain();
+    std::vector<uint64_t> r(D);
+    for (int d = D - 1; d >= 0; d--) {
+      r[d] = id % nd[d];
+      id /= nd[d];
+    }
+    return r;
+  }
+  std::vector<uint64_t> subdomain_shape(uint64_t id) const {  // :124-168
+    if (!decomposed) return shape;
+    std::vector<uint64_t> r = shape;
+    if (method == MGH_DD_MAXDIM) {
+      r[dim] = id < shape[dim] / size ? size : shape[dim] % size;
+    } else if (method == MGH_DD_BLOCK) {
+      const auto sid = dim_subdomain_id(id);
+      for (int d = 0; d < D; d++) r[d] = sid[d] < shape[d] / size ? size : shape[d] % size;
+    } else {
+      r[dim] = var_sizes[id];
+    }
+    return r;
+  }
+  std::vector<uint64_t> subdomain_offset(uint64_t id) const {  // :115-122, 690-700
+    std::vector<uint64_t> r(D, 0);
+    if (!decomposed) return r;
+    if (method == MGH_DD_MAXDIM) {
+      r[dim] = id * size;
+    } else if (method == MGH_DD_BLOCK) {
+      const auto sid = dim_subdomain_id(id);
+      for (int d = 0; d < D; d++) r[d] = sid[d] * size;
+    } else {
+      for (uint64_t k = 0; k < id; k++) r[dim] += var_sizes[k];
+    }
+    return r;
+  }
+  uint64_t max_subdomain_elems() const {
+    uint64_t m = 0;
+    for (uint64_t id = 0; id < num; id++) {
+      uint64_t c = 1;
+      for (uint64_t e : subdomain_shape(id)) c *= e;
+      m = std::max(m, c);
+    }
+    return m;
+  }
+};
+
+// device bytes one subdomain of this shape needs in this implementation (two input buffers
+// for the prefetch, hierarchy workspace, quantized output, outlier lists, code stream)
+size_t estimate_footprint(const std::vector<uint64_t> &shape, size_t elem, double outlier_ratio,
+                          bool prefetch) {
+  double n = 1;
+  for (uint64_t e : shape) n *= (double)e;
+  double b = n * elem * (prefetch ? 2 : 1);  // input buffer(s)
+  b += n * elem * 0.45;                      // level buffers + load vector (+ tables)
+  b += n * 8;                                // quantized integers
+  b += n * 16 * outlier_ratio;               // outlier idx + values
+  b += n * 2;                                // code stream (typical) + chunk tables
+  return (size_t)b + (64u << 20);
+}
+
+int make_decomposer(Decomposer &dd, int D, const uint64_t *shape, size_t elem, const mgh_config &cfg) {
+  dd.D = D;
+  dd.shape.assign(shape, shape + D);
+  size_t free_b = 0, total_b = 0;
+  HL_HIP(hipMemGetInfo(&free_b, &total_b));
+  const size_t avail = std::min<size_t>(free_b, cfg.max_memory_footprint);
+  auto need = [&](const std::vector<uint64_t> &s, bool prefetch) {
+    return estimate_footprint(s, elem, cfg.estimate_outlier_ratio, prefetch) >= avail;
+  };
+  dd.method = cfg.domain_decomposition;
+  if (!need(dd.shape, false) && dd.method != MGH_DD_BLOCK && dd.method != MGH_DD_VARIABLE) {
+    dd.decomposed = false;  // DomainDecomposer.hpp:303-311
+    dd.dim = 0;
+    dd.size = shape[0];
+    dd.num = 1;
+    return MGH_SUCCESS;
+  }
+  dd.decomposed = true;
+  if (dd.method == MGH_DD_MAXDIM) {  // :209-236
+    uint64_t mx = 0;
+    for (int d = 0; d < D; d++)
+      if (shape[d] > mx) {
+        mx = shape[d];
+        dd.dim = d;
+      }
+    std::vector<uint64_t> cs = dd.shape;
+    bool prefetch = false;
+    while (need(cs, prefetch)) {
+      if (cs[dd.dim] <= 3) return hl_fail(MGH_ERR_OUT_OF_MEMORY, "domain decomposition: not enough device memory");
+      cs[dd.dim] = (cs[dd.dim] - 1) / 2 + 1;
+      prefetch = (shape[dd.dim] - 1) / cs[dd.dim] + 1 > 1;
+    }
+    dd.size = cs[dd.dim];
+    dd.num = (shape[dd.dim] - 1) / dd.size + 1;
+  } else if (dd.method == MGH_DD_BLOCK) {  // :238-263, 335-349
+    dd.size = cfg.block_size;
+    if (dd.size < 3) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "block_size");
+    for (;;) {
+      std::vector<uint64_t> cs(D, dd.size);
+      uint64_t cnt = 1;
+      for (int d = 0; d < D; d++) cnt *= (shape[d] - 1) / dd.size + 1;
+      if (!need(cs, cnt > 1)) break;
+      if (dd.size <= 3) return hl_fail(MGH_ERR_OUT_OF_MEMORY, "domain decomposition: not enough device memory");
+      dd.size = (dd.size - 1) / 2 + 1;
+    }
+    dd.num = 1;
+    for (int d = 0; d < D; d++) dd.num *= (shape[d] - 1) / dd.size + 1;
+  } else if (dd.method == MGH_DD_VARIABLE) {  // :350-357
+    if (cfg.domain_decomposition_dim < 0 || cfg.domain_decomposition_dim >= D ||
+        !cfg.domain_decomposition_sizes || !cfg.num_domain_decomposition_sizes)
+      return hl_fail(MGH_ERR_INVALID_ARGUMENT, "Variable domain decomposition needs dim and sizes");
+    dd.dim = cfg.domain_decomposition_dim;
+    dd.var_sizes.assign(cfg.domain_decomposition_sizes,
+                        cfg.domain_decomposition_sizes + cfg.num_domain_decomposition_sizes);
+    uint64_t sum = 0;
+    for (uint64_t v : dd.var_sizes) sum += v;
+    if (sum != shape[dd.dim]) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "Variable sizes do not add up to the extent");
+    dd.num = dd.var_sizes.size();
+    dd.size = dd.var_sizes[0];
+  } else {
+    return hl_fail(MGH_ERR_INVALID_ARGUMENT, "domain_decomposition");
+  }
+  for (uint64_t id = 0; id < dd.num; id++)
+    for (uint64_t e : dd.subdomain_shape(id))
+      if (e < 3) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "domain decomposition leaves a subdomain with fewer than 3 nodes in a dimension");
+  return MGH_SUCCESS;
+}
+
+// copy_subdomain (DomainDecomposer.hpp:649-845): dense subdomain buffer <-> its box inside the
+// full array (host or device), as few strided copies as the box allows.
+int copy_subdomain(const Decomposer &dd, uint64_t id, size_t elem, void *sub, const void *full_c,
+                   void *full_m, bool to_sub, hipStream_t st) {
+  const int D = dd.D;
+  const auto ext = dd.subdomain_shape(id), off = dd.subdomain_offset(id);
+  // merge trailing dimensions the box spans completely
+  int k = D - 1;
+  while (k > 0 && ext[k] == dd.shape[k]) k--;
+  // width = ext[k] * prod(shape[k+1:]) contiguous elements; rows along dim k-1
+  size_t inner = 1;
+  for (int d = k + 1; d < D; d++) inner *= dd.shape[d];
+  const size_t width = ext[k] * inner * elem;        // bytes per contiguous run
+  const size_t full_pitch = dd.shape[k] * inner * elem;  // distance between runs (dim k-1)
+  const size_t rows = k >= 1 ? ext[k - 1] : 1;
+  // outer dims 0 .. k-2
+  std::vector<uint64_t> idx(std::max(k - 1, 0), 0);
+  std::vector<size_t> fstride(D);  // element strides of the full array
+  {
+    size_t s = 1;
+    for (int d = D - 1; d >= 0; d--) {
+      fstride[d] = s;
+      s *= dd.shape[d];
+    }
+  }
+  size_t sub_off = 0;
+  const size_t sub_block = rows * width;
+  for (;;) {
+    size_t fo = off[k] * fstride[k];
+    if (k >= 1) fo += off[k - 1] * fstride[k - 1];
+    for (int d = 0; d < k - 1; d++) fo += (off[d] + idx[d]) * fstride[d];
+    char *sp = (char *)sub + sub_off;
+    if (to_sub) {
+      const char *fp = (const char *)full_c + fo * elem;
+      HL_HIP(hipMemcpy2DAsync(sp, width, fp, full_pitch, width, rows, hipMemcpyDefault, st));
+    } else {
+      char *fp = (char *)full_m + fo * elem;
+      HL_HIP(hipMemcpy2DAsync(fp, full_pitch, sp, width, width, rows, hipMemcpyDefault, st));
+    }
+    sub_off += sub_block;
+    int d = k - 2;
+    while (d >= 0) {
+      if (++idx[d] < ext[d]) break;
+      idx[d] = 0;
+      d--;
+    }
+    if (d < 0) break;
+  }
+  return MGH_SUCCESS;
+}
+
+// ---- per-thread cache: hierarchies, device buffers, lossless context
+// (CompressorCache, CompressionLowLevel/CompressorCache.hpp:139-142) -------------------------
+struct HlCache {
+  std::map<std::vector<uint64_t>, mgh_hierarchy *> hier;  // key: dtype, normalize, max_level, shape...
+  DevBuf in[2], q, ocount, oidx, oval;
+  mgh_lossless_ctx *ll = nullptr;
+  hipStream_t streams[3] = {nullptr, nullptr, nullptr};
+  int dev = -1;
+  void release() {
+    for (auto &kv : hier) mgh_hierarchy_destroy(kv.second);
+    hier.clear();
+    in[0].release();
+    in[1].release();
+    q.release();
+    ocount.release();
+    oidx.release();
+    oval.release();
+    if (ll) mgh_lossless_destroy(ll);
+    ll = nullptr;
+    for (auto &s : streams) {
+      if (s) (void)hipStreamDestroy(s);
+      s = nullptr;
+    }
+    dev = -1;
+  }
+  ~HlCache() { release(); }
+};
+thread_local HlCache g_cache;
+
+int cache_prepare(int dev) {
+  if (g_cache.dev != dev) {
+    g_cache.release();
+    HL_HIP(hipSetDevice(dev));
+    for (auto &s : g_cache.streams) HL_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    HL_TRY(mgh_lossless_create(&g_cache.ll, dev));
+    g_cache.dev = dev;
+  }
+  return MGH_SUCCESS;
+}
+
+// Hierarchy of a subdomain (DomainDecomposer::subdomain_hierarchy, :265-301). Uniform ones
+// are cached by shape (at most 4 alive); non-uniform ones are built per subdomain.
+int get_hierarchy(mgh_hierarchy **out, bool *owned, int dtype, const std::vector<uint64_t> &shape,
+                  const std::vector<std::vector<double>> *coords, const std::vector<uint64_t> &off,
+                  const mgh_config &cfg) {
+  const int D = (int)shape.size();
+  if (!coords) {
+    std::vector<uint64_t> key = {(uint64_t)dtype, (uint64_t)cfg.normalize_coordinates, cfg.max_larget_level};
+    key.insert(key.end(), shape.begin(), shape.end());
+    auto it = g_cache.hier.find(key);
+    if (it != g_cache.hier.end()) {
+      *out = it->second;
+      *owned = false;
+      return MGH_SUCCESS;
+    }
+    if (g_cache.hier.size() >= 4) {
+      for (auto &kv : g_cache.hier) mgh_hierarchy_destroy(kv.second);
+      g_cache.hier.clear();
+    }
+    mgh_hierarchy *h = nullptr;
+    HL_TRY(mgh_hierarchy_create(&h, D, shape.data(), dtype, nullptr, cfg.normalize_coordinates,
+                                cfg.max_larget_level, cfg.dev_id));
+    g_cache.hier[key] = h;
+    *out = h;
+    *owned = false;
+    return MGH_SUCCESS;
+  }
+  // slice of the coordinate arrays, converted to the data type
+  std::vector<std::vector<float>> cf(D);
+  std::vector<std::vector<double>> cd(D);
+  const void *ptrs[MGH_MAX_DIM];
+  for (int d = 0; d < D; d++) {
+    const double *src = (*coords)[d].data() + off[d];
+    if (dtype == MGH_FLOAT) {
+      cf[d].assign(src, src + shape[d]);
+      ptrs[d] = cf[d].data();
+    } else {
+      cd[d].assign(src, src + shape[d]);
+      ptrs[d] = cd[d].data();
+    }
+  }
+  HL_TRY(mgh_hierarchy_create(out, D, shape.data(), dtype, ptrs, cfg.normalize_coordinates,
+                              cfg.max_larget_level, cfg.dev_id));
+  *owned = true;
+  return MGH_SUCCESS;
+}
+
+// calc_local_abs_tol (ErrorToleranceCalculator.hpp:134-155), in the data type
+template <typename T> T local_abs_tol(int ebtype, T norm, T tol, T s, uint64_t nsub) {
+  if (ebtype == MGH_REL) {
+    if (s == std::numeric_limits<T>::infinity()) return tol * norm;
+    return std::sqrt((tol * norm) * (tol * norm) / (T)nsub);
+  }
+  if (s == std::numeric_limits<T>::infinity()) return tol;
+  return std::sqrt((tol * tol) / (T)nsub);
+}
+
+int header_from(const Decomposer &dd, int dtype, int ebtype, double tol, double s, double norm,
+                const std::vector<std::vector<double>> *coords, const mgh_config &cfg, fmt::Header &h) {
+  h = fmt::Header();
+  h.is_double = dtype == MGH_DOUBLE;
+  h.shape = dd.shape;
+  h.uniform = coords == nullptr;
+  if (coords) h.coords = *coords;
+  h.rel = ebtype == MGH_REL;
+  h.tol = tol;
+  h.s = s;
+  h.norm = norm;
+  if (dd.decomposed) {
+    h.dd_method = dd.method == MGH_DD_MAXDIM ? fmt::DD_MAX_DIMENSION
+                  : dd.method == MGH_DD_BLOCK ? fmt::DD_BLOCK : fmt::DD_VARIABLE;
+  } else {
+    h.dd_method = fmt::DD_NOOP;
+  }
+  h.dd_dim = dd.dim;
+  h.dd_size = dd.size;
+  h.hierarchy = fmt::HIER_MULTIDIM;
+  h.l_target = 0;  // never filled by the reference (Metadata.hpp:78-113)
+  h.reorder = false;
+  h.compressor = cfg.lossless == MGH_LOSSLESS_HUFFMAN ? fmt::COMP_X_HUFFMAN : fmt::COMP_X_HUFFMAN_ZSTD;
+  h.huff_dict_size = cfg.huff_dict_size;
+  h.huff_block_size = cfg.huff_block_size;
+  h.backend = fmt::DEV_X_HIP;
+  return MGH_SUCCESS;
+}
+
+template <typename T>
+int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double s_d, int ebtype,
+                  const void *original, void **compressed, size_t *compressed_size,
+                  const void *const *coords_in, const mgh_config &cfg, bool prealloc) {
+  HL_TRY(cache_prepare(cfg.dev_id));
+  const T tol = (T)tol_d, s = (T)s_d;
+  size_t total = 1;
+  for (int d = 0; d < D; d++) total *= shape[d];
+  const size_t elem = sizeof(T);
+  const bool in_dev = is_device_pointer(original);
+  Decomposer dd;
+  HL_TRY(make_decomposer(dd, D, shape, elem, cfg));
+  std::vector<std::vector<double>> coords;
+  if (coords_in) {
+    coords.resize(D);
+    for (int d = 0; d < D; d++) {
+      const T *c = static_cast<const T *>(coords_in[d]);
+      coords[d].assign(c, c + shape[d]);
+    }
+  }
+  const std::vector<std::vector<double>> *cptr = coords_in ? &coords : nullptr;
+  // output buffer, same memory space as the input (CompressionHighLevel.hpp:147-162)
+  size_t cap;
+  if (!prealloc) {
+    cap = total * elem + (size_t)1e6;
+    if (in_dev) HL_HIP(hipMalloc(compressed, cap));
+    else if (!(*compressed = std::malloc(cap))) return hl_fail(MGH_ERR_OUT_OF_MEMORY, "malloc");
+  } else {
+    cap = *compressed_size;
+  }
+  const bool out_dev = is_device_pointer(*compressed);
+  // pin the host input for asynchronous prefetch (auto_pin_host_buffers)
+  bool pinned_here = false;
+  if (!in_dev && cfg.auto_pin_host_buffers && !is_registered_host(original)) {
+    if (hipHostRegister(const_cast<void *>(original), total * elem, hipHostRegisterDefault) == hipSuccess)
+      pinned_here = true;
+    else
+      (void)hipGetLastError();
+  }
+  auto cleanup = [&](int rc) {
+    if (pinned_here) (void)hipHostUnregister(const_cast<void *>(original));
+    if (rc != MGH_SUCCESS && !prealloc) {
+      if (in_dev) (void)hipFree(*compressed); else std::free(*compressed);
+      *compressed = nullptr;
+    }
+    return rc;
+  };
+  const uint64_t max_elems = dd.max_subdomain_elems();
+  const uint64_t ocap = std::max<uint64_t>(1, (uint64_t)(cfg.estimate_outlier_ratio * (double)max_elems));
+  int rc;
+  auto ensure_all = [&]() -> int {
+    HL_TRY(g_cache.in[0].ensure(max_elems * elem));
+    if (dd.num > 1) HL_TRY(g_cache.in[1].ensure(max_elems * elem));
+    HL_TRY(g_cache.q.ensure(max_elems * 8));
+    HL_TRY(g_cache.ocount.ensure(8));
+    HL_TRY(g_cache.oidx.ensure(ocap * 8));
+    HL_TRY(g_cache.oval.ensure(ocap * 8));
+    return MGH_SUCCESS;
+  };
+  if ((rc = ensure_all()) != MGH_SUCCESS) return cleanup(rc);
+
+  // norm of the whole domain when it is decomposed (calc_norm_decomposed_w_prefetch)
+  T norm = 1;
+  T local_tol = tol;
+  int local_eb = ebtype;
+  if (dd.decomposed) {
+    if (ebtype == MGH_REL) {
+      double acc = 0;
+      int buf = 0;
+      if ((rc = copy_subdomain(dd, 0, elem, g_cache.in[0].p, original, nullptr, true, g_cache.streams[0])) != MGH_SUCCESS)
+        return cleanup(rc);
+      for (uint64_t id = 0; id < dd.num; id++) {
+        const int nb = (buf + 1) % 2;
+        if (id + 1 < dd.num &&
+            (rc = copy_subdomain(dd, id + 1, elem, g_cache.in[nb].p, original, nullptr, true, g_cache.streams[1])) != MGH_SUCCESS)
+          return cleanup(rc);
+        mgh_hierarchy *h = nullptr;
+        bool owned = false;
+        const auto sshape = dd.subdomain_shape(id);
+        if ((rc = get_hierarchy(&h, &owned, dtype, sshape, nullptr, dd.subdomain_offset(id), cfg)) != MGH_SUCCESS)
+          return cleanup(rc);
+        double ln = 0;
+        rc = mgh_norm(h, g_cache.in[buf].p, s_d, &ln, g_cache.streams[0]);
+        if (rc != MGH_SUCCESS) return cleanup(rc);
+        uint64_t cnt = 1;
+        for (uint64_t e : sshape) cnt *= e;
+        if (s == std::numeric_limits<T>::infinity()) acc = std::max(acc, ln);
+        else acc += ln * ln * (cfg.normalize_coordinates ? (double)cnt : 1.0);  // un-normalised square
+        // mgh_norm returned a host value, so streams[0] is idle; the prefetch must have landed
+        if (hipStreamSynchronize(g_cache.streams[1]) != hipSuccess) return cleanup(hl_fail(MGH_ERR_DEVICE, "sync"));
+        buf = nb;
+      }
+      if (s == std::numeric_limits<T>::infinity()) norm = (T)acc;
+      else norm = (T)(cfg.normalize_coordinates ? std::sqrt(acc / (double)total) : std::sqrt(acc));
+    }
+    local_tol = local_abs_tol<T>(ebtype, norm, tol, s, dd.num);
+    local_eb = MGH_ABS;  // CompressionHighLevel.hpp:135-138
+  }
+
+  // metadata size is known up front: the header does not depend on the payloads, except for
+  // the norm of a non-decomposed REL run, whose encoding has a fixed length (a non-zero double)
+  fmt::Header hdr;
+  header_from(dd, dtype, ebtype, tol_d, s_d, ebtype == MGH_REL ? (dd.decomposed ? (double)norm : 1.0) : 0.0, cptr, cfg, hdr);
+  const size_t meta_size = fmt::serialize_metadata(hdr).size();
+  if (meta_size > cap) return cleanup(hl_fail(MGH_ERR_OUTPUT_TOO_LARGE, "output buffer too small for the header"));
+  size_t byte_offset = meta_size;
+
+  // ---- subdomain pipeline (compress_pipeline_gpu, GPUPipelines.hpp:69-207) ----
+  int buf = 0, qi = 0;
+  if ((rc = copy_subdomain(dd, 0, elem, g_cache.in[0].p, original, nullptr, true, g_cache.streams[0])) != MGH_SUCCESS)
+    return cleanup(rc);
+  for (uint64_t id = 0; id < dd.num; id++) {
+    const int nb = (buf + 1) % 2, nq = (qi + 1) % 3;
+    hipStream_t st = g_cache.streams[qi];
+    if (id + 1 < dd.num &&
+        (rc = copy_subdomain(dd, id + 1, elem, g_cache.in[nb].p, original, nullptr, true, g_cache.streams[nq])) != MGH_SUCCESS)
+      return cleanup(rc);
+    const auto sshape = dd.subdomain_shape(id);
+    uint64_t n = 1;
+    for (uint64_t e : sshape) n *= e;
+    mgh_hierarchy *h = nullptr;
+    bool owned = false;
+    if ((rc = get_hierarchy(&h, &owned, dtype, sshape, cptr, dd.subdomain_offset(id), cfg)) != MGH_SUCCESS)
+      return cleanup(rc);
+    double norm_out = (double)norm;
+    rc = hipMemsetAsync(g_cache.ocount.p, 0, 8, st) == hipSuccess ? MGH_SUCCESS : hl_fail(MGH_ERR_DEVICE, "memset");
+    if (rc == MGH_SUCCESS)
+      rc = mgh_decompose_quantize(h, g_cache.in[buf].p, local_eb, (double)local_tol, s_d,
+                                  local_eb == MGH_REL ? 0.0 : (double)norm,
+                                  local_eb == MGH_REL ? &norm_out : nullptr, cfg.huff_dict_size, 1,
+                                  (int64_t *)g_cache.q.p, (uint64_t *)g_cache.ocount.p,
+                                  (uint64_t *)g_cache.oidx.p, (int64_t *)g_cache.oval.p, ocap, nullptr, st);
+    uint64_t ocount = 0;
+    if (rc == MGH_SUCCESS) {
+      if (hipMemcpyAsync(&ocount, g_cache.ocount.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipStreamSynchronize(st) != hipSuccess)
+        rc = hl_fail(MGH_ERR_DEVICE, "outlier count");
+      else if (ocount > ocap)
+        rc = hl_fail(MGH_ERR_INVALID_ARGUMENT, "more outliers than estimate_outlier_ratio allows");
+    }
+    if (rc == MGH_SUCCESS && local_eb == MGH_REL) norm = (T)norm_out;
+    if (rc == MGH_SUCCESS)
+      rc = lossless_compress(g_cache.ll, (const int64_t *)g_cache.q.p, n, cfg.huff_dict_size,
+                             cfg.huff_block_size, cfg.lossless, cfg.zstd_compress_level,
+                             (const uint64_t *)g_cache.oidx.p, (const int64_t *)g_cache.oval.p, ocount, st);
+    if (owned) mgh_hierarchy_destroy(h);
+    if (rc != MGH_SUCCESS) return cleanup(rc);
+    const std::vector<uint8_t> &payload = g_cache.ll->host;
+    uint64_t csize = payload.size();
+    const bool raw = (double)(n * elem) / (double)csize < 1.0;  // GPUPipelines.hpp:136-155
+    if (raw) csize = n * elem;
+    if (csize > cap - byte_offset || cap - byte_offset - csize < 8)
+      return cleanup(hl_fail(MGH_ERR_OUTPUT_TOO_LARGE, "Output too large"));
+    char *dst = (char *)*compressed + byte_offset;
+    if (out_dev) {
+      rc = hipMemcpyAsync(dst, &csize, 8, hipMemcpyHostToDevice, st) == hipSuccess ? MGH_SUCCESS : MGH_ERR_DEVICE;
+    } else {
+      std::memcpy(dst, &csize, 8);
+    }
+    dst += 8;
+    if (rc == MGH_SUCCESS) {
+      if (raw) {
+        // the dense subdomain itself (re-fetched: decompose_quantize does not modify its input,
+        // so the buffer still holds it)
+        rc = hipMemcpyAsync(dst, g_cache.in[buf].p, csize, hipMemcpyDefault, st) == hipSuccess ? MGH_SUCCESS : MGH_ERR_DEVICE;
+      } else if (out_dev) {
+        rc = hipMemcpyAsync(dst, payload.data(), csize, hipMemcpyHostToDevice, st) == hipSuccess ? MGH_SUCCESS : MGH_ERR_DEVICE;
+      } else {
+        std::memcpy(dst, payload.data(), csize);
+      }
+    }
+    if (rc == MGH_SUCCESS && hipStreamSynchronize(st) != hipSuccess) rc = MGH_ERR_DEVICE;
+    if (rc != MGH_SUCCESS) return cleanup(hl_fail(rc, "writing the subdomain record"));
+    byte_offset += 8 + csize;
+    buf = nb;
+    qi = nq;
+  }
+  // header (with the norm the pipeline computed for a non-decomposed REL run)
+  header_from(dd, dtype, ebtype, tol_d, s_d, ebtype == MGH_REL ? (double)norm : 0.0, cptr, cfg, hdr);
+  const std::vector<uint8_t> meta = fmt::serialize_metadata(hdr);
+  if (meta.size() != meta_size) return cleanup(hl_fail(MGH_ERR_FORMAT, "metadata size changed"));
+  if (out_dev) {
+    if (hipMemcpy(*compressed, meta.data(), meta.size(), hipMemcpyHostToDevice) != hipSuccess)
+      return cleanup(hl_fail(MGH_ERR_DEVICE, "writing the header"));
+  } else {
+    std::memcpy(*compressed, meta.data(), meta.size());
+  }
+  *compressed_size = byte_offset;
+  return cleanup(MGH_SUCCESS);
+}
+
+int decomposer_from_header(const fmt::Header &hd, const mgh_config &cfg, Decomposer &dd) {
+  dd.D = (int)hd.shape.size();
+  dd.shape = hd.shape;
+  dd.decomposed = hd.dd_method != fmt::DD_NOOP;
+  dd.dim = hd.dd_dim;
+  dd.size = hd.dd_size;
+  dd.num = 1;
+  if (!dd.decomposed) return MGH_SUCCESS;
+  if (dd.dim >= (uint64_t)dd.D || dd.size == 0) return hl_fail(MGH_ERR_FORMAT, "header: domain decomposition");
+  if (hd.dd_method == fmt::DD_MAX_DIMENSION) {
+    dd.method = MGH_DD_MAXDIM;
+    dd.num = (dd.shape[dd.dim] - 1) / dd.size + 1;
+  } else if (hd.dd_method == fmt::DD_BLOCK) {
+    dd.method = MGH_DD_BLOCK;
+    for (int d = 0; d < dd.D; d++) dd.num *= (dd.shape[d] - 1) / dd.size + 1;
+  } else if (hd.dd_method == fmt::DD_VARIABLE) {
+    // the header records one size only; like the reference the caller's config supplies the
+    // list (DomainDecomposer.hpp:448-452)
+    dd.method = MGH_DD_VARIABLE;
+    if (!cfg.domain_decomposition_sizes || !cfg.num_domain_decomposition_sizes)
+      return hl_fail(MGH_ERR_INVALID_ARGUMENT, "Variable domain decomposition: pass the sizes in the config");
+    dd.var_sizes.assign(cfg.domain_decomposition_sizes,
+                        cfg.domain_decomposition_sizes + cfg.num_domain_decomposition_sizes);
+    uint64_t sum = 0;
+    for (uint64_t v : dd.var_sizes) sum += v;
+    if (sum != dd.shape[dd.dim]) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "Variable sizes do not add up to the extent");
+    dd.num = dd.var_sizes.size();
+  } else {
+    return hl_fail(MGH_ERR_FORMAT, "header: unknown domain decomposition");
+  }
+  return MGH_SUCCESS;
+}
+
+// first bytes of a (host or device) stream on the host
+int fetch_host(const void *data, size_t size, size_t want, std::vector<uint8_t> &out) {
+  want = std::min(want, size);
+  out.resize(want);
+  if (is_device_pointer(data)) HL_HIP(hipMemcpy(out.data(), data, want, hipMemcpyDeviceToHost));
+  else std::memcpy(out.data(), data, want);
+  return MGH_SUCCESS;
+}
+
+int read_header(const void *data, size_t size, fmt::Header &hd, size_t &meta_size) {
+  std::vector<uint8_t> pre;
+  HL_TRY(fetch_host(data, size, fmt::kPreambleSize, pre));
+  if (pre.size() < fmt::kPreambleSize) return hl_fail(MGH_ERR_FORMAT, "stream shorter than the preamble");
+  uint64_t hs = 0;
+  for (int i = 0; i < 8; i++) hs |= (uint64_t)pre[5 + i] << (8 * i);
+  if (hs > size - fmt::kPreambleSize) return hl_fail(MGH_ERR_FORMAT, "header: truncated");
+  std::vector<uint8_t> all;
+  HL_TRY(fetch_host(data, size, fmt::kPreambleSize + hs, all));
+  try {
+    meta_size = fmt::parse_metadata(all.data(), all.size(), hd);
+  } catch (const std::exception &e) {
+    return hl_fail(MGH_ERR_FORMAT, e.what());
+  }
+  return MGH_SUCCESS;
+}
+
+template <typename T>
+int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compressed, size_t csize_total,
+                    void **out, const mgh_config &cfg_in, bool prealloc) {
+  mgh_config cfg = cfg_in;
+  HL_TRY(cache_prepare(cfg.dev_id));
+  const int dtype = hd.is_double ? MGH_DOUBLE : MGH_FLOAT;
+  const size_t elem = sizeof(T);
+  size_t total = 1;
+  for (uint64_t e : hd.shape) total *= e;
+  Decomposer dd;
+  HL_TRY(decomposer_from_header(hd, cfg, dd));
+  for (uint64_t id = 0; id < dd.num; id++)
+    for (uint64_t e : dd.subdomain_shape(id))
+      if (e < 3) return hl_fail(MGH_ERR_FORMAT, "header: subdomain with fewer than 3 nodes");
+  int lossless;
+  if (hd.compressor == fmt::COMP_X_HUFFMAN) lossless = MGH_LOSSLESS_HUFFMAN;
+  else if (hd.compressor == fmt::COMP_X_HUFFMAN_ZSTD) lossless = MGH_LOSSLESS_HUFFMAN_ZSTD;
+  else return hl_fail(MGH_ERR_FORMAT, "this lossless compressor is not supported");
+  if (hd.hierarchy != fmt::HIER_MULTIDIM) return hl_fail(MGH_ERR_FORMAT, "only the multi-dimensional decomposition is supported");
+  if (hd.reorder) return hl_fail(MGH_ERR_FORMAT, "reordered (shuffled) streams are not supported");
+  const bool in_dev = is_device_pointer(compressed);
+  if (!prealloc) {
+    if (in_dev) HL_HIP(hipMalloc(out, total * elem));
+    else if (!(*out = std::malloc(total * elem))) return hl_fail(MGH_ERR_OUT_OF_MEMORY, "malloc");
+  }
+  auto cleanup = [&](int rc) {
+    if (rc != MGH_SUCCESS && !prealloc) {
+      if (in_dev) (void)hipFree(*out); else std::free(*out);
+      *out = nullptr;
+    }
+    return rc;
+  };
+  const uint64_t max_elems = dd.max_subdomain_elems();
+  int rc;
+  auto ensure_all = [&]() -> int {
+    HL_TRY(g_cache.in[0].ensure(max_elems * elem));
+    HL_TRY(g_cache.q.ensure(max_elems * 8));
+    return MGH_SUCCESS;
+  };
+  if ((rc = ensure_all()) != MGH_SUCCESS) return cleanup(rc);
+  const T tol = (T)hd.tol, s = (T)hd.s, norm = (T)hd.norm;
+  T local_tol = tol;
+  int local_eb = hd.rel ? MGH_REL : MGH_ABS;
+  if (dd.decomposed) {  // CompressionHighLevel.hpp:513-522
+    local_tol = local_abs_tol<T>(local_eb, norm, tol, s, dd.num);
+    local_eb = MGH_ABS;
+  }
+  const std::vector<std::vector<double>> *cptr = hd.uniform ? nullptr : &hd.coords;
+  size_t byte_offset = meta_size;
+  hipStream_t st = g_cache.streams[0];
+  std::vector<uint8_t> hostbuf;
+  for (uint64_t id = 0; id < dd.num; id++) {
+    if (csize_total - byte_offset < 8) return cleanup(hl_fail(MGH_ERR_FORMAT, "subdomain record truncated"));
+    std::vector<uint8_t> sz;
+    if ((rc = fetch_host((const char *)compressed + byte_offset, 8, 8, sz)) != MGH_SUCCESS) return cleanup(rc);
+    uint64_t csize = 0;
+    std::memcpy(&csize, sz.data(), 8);
+    byte_offset += 8;
+    if (csize > csize_total - byte_offset) return cleanup(hl_fail(MGH_ERR_FORMAT, "subdomain record truncated"));
+    const auto sshape = dd.subdomain_shape(id);
+    uint64_t n = 1;
+    for (uint64_t e : sshape) n *= e;
+    const char *rec = (const char *)compressed + byte_offset;
+    if ((double)(n * elem) / (double)csize > 1.0) {  // GPUPipelines.hpp:414-417
+      const uint8_t *payload;
+      if (in_dev) {
+        hostbuf.resize(csize);
+        if (hipMemcpy(hostbuf.data(), rec, csize, hipMemcpyDeviceToHost) != hipSuccess)
+          return cleanup(hl_fail(MGH_ERR_DEVICE, "reading the subdomain record"));
+        payload = hostbuf.data();
+      } else {
+        payload = (const uint8_t *)rec;
+      }
+      uint64_t ocount = 0;
+      rc = lossless_decompress(g_cache.ll, payload, csize, lossless, (int64_t *)g_cache.q.p, n, &ocount, st);
+      if (rc != MGH_SUCCESS) return cleanup(rc);
+      mgh_hierarchy *h = nullptr;
+      bool owned = false;
+      if ((rc = get_hierarchy(&h, &owned, dtype, sshape, cptr, dd.subdomain_offset(id), cfg)) != MGH_SUCCESS)
+        return cleanup(rc);
+      rc = mgh_dequantize_recompose(h, (int64_t *)g_cache.q.p, local_eb, (double)local_tol, (double)s,
+                                    (double)norm, hd.huff_dict_size, 1, (const uint64_t *)g_cache.ll->oidx.p,
+                                    (const int64_t *)g_cache.ll->oval.p, ocount, g_cache.in[0].p, st);
+      if (owned) {
+        (void)hipStreamSynchronize(st);
+        mgh_hierarchy_destroy(h);
+      }
+      if (rc != MGH_SUCCESS) return cleanup(rc);
+    } else {
+      if (csize != n * elem) return cleanup(hl_fail(MGH_ERR_FORMAT, "raw subdomain record has the wrong size"));
+      if (hipMemcpyAsync(g_cache.in[0].p, rec, csize, hipMemcpyDefault, st) != hipSuccess)
+        return cleanup(hl_fail(MGH_ERR_DEVICE, "reading the raw subdomain"));
+    }
+    if ((rc = copy_subdomain(dd, id, elem, g_cache.in[0].p, nullptr, *out, false, st)) != MGH_SUCCESS)
+      return cleanup(rc);
+    if (hipStreamSynchronize(st) != hipSuccess) return cleanup(hl_fail(MGH_ERR_DEVICE, "sync"));
+    byte_offset += csize;
+  }
+  return cleanup(MGH_SUCCESS);
+}
+
+int check_config(const mgh_config *cfg) {
+  if (!cfg) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "config is NULL (use mgh_config_default)");
+  if (cfg->lossless != MGH_LOSSLESS_HUFFMAN && cfg->lossless != MGH_LOSSLESS_HUFFMAN_ZSTD)
+    return hl_fail(MGH_ERR_INVALID_ARGUMENT, "lossless: only Huffman and Huffman_Zstd are supported");
+  if (cfg->huff_dict_size < 2 || cfg->huff_dict_size > 16384 || cfg->huff_block_size == 0)
+    return hl_fail(MGH_ERR_INVALID_ARGUMENT, "huff_dict_size (2..16384) / huff_block_size");
+  int ndev = mgh_device_count();
+  if (ndev <= 0) return hl_fail(MGH_ERR_NO_DEVICE, "no HIP device");
+  if (cfg->dev_id < 0 || cfg->dev_id >= ndev) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "dev_id");
+  return MGH_SUCCESS;
+}
+
+} // namespace
+
+extern "C" {
+
+void mgh_config_default(mgh_config *c) {
+  if (!c) return;
+  std::memset(c, 0, sizeof(*c));
+  c->dev_id = 0;
+  c->domain_decomposition = MGH_DD_MAXDIM;
+  c->domain_decomposition_dim = 0;
+  c->block_size = 256;
+  c->estimate_outlier_ratio = 1.0;
+  c->huff_dict_size = 8192;
+  c->huff_block_size = 1024 * 20;
+  c->lossless = MGH_LOSSLESS_HUFFMAN;
+  c->zstd_compress_level = 3;
+  c->normalize_coordinates = 1;
+  c->max_larget_level = std::numeric_limits<uint64_t>::max();
+  c->max_memory_footprint = std::numeric_limits<uint64_t>::max();
+  c->auto_pin_host_buffers = 1;
+}
+
+int mgh_compress(int D, int dtype, const uint64_t *shape, double tol, double s, int ebtype,
+                 const void *original_data, void **compressed_data, size_t *compressed_size,
+                 const void *const *coords, const mgh_config *config, int output_pre_allocated) {
+  if (!shape || !original_data || !compressed_data || !compressed_size)
+    return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (D < 1 || D > MGH_MAX_DIM) return hl_fail(MGH_ERR_UNSUPPORTED_DIMENSION, "D must be 1..5");
+  if (dtype != MGH_FLOAT && dtype != MGH_DOUBLE) return hl_fail(MGH_ERR_UNSUPPORTED_DTYPE, "dtype");
+  if (ebtype != MGH_REL && ebtype != MGH_ABS) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "error_bound_type");
+  if (output_pre_allocated && !*compressed_data) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "pre-allocated output is NULL");
+  HL_TRY(check_config(config));
+  if (hipSetDevice(config->dev_id) != hipSuccess) return hl_fail(MGH_ERR_DEVICE, "hipSetDevice");
+  try {
+    if (dtype == MGH_FLOAT)
+      return compress_impl<float>(D, dtype, shape, tol, s, ebtype, original_data, compressed_data,
+                                  compressed_size, coords, *config, output_pre_allocated != 0);
+    return compress_impl<double>(D, dtype, shape, tol, s, ebtype, original_data, compressed_data,
+                                 compressed_size, coords, *config, output_pre_allocated != 0);
+  } catch (const std::exception &e) {
+    return hl_fail(MGH_ERR_DEVICE, e.what());
+  }
+}
+
+int mgh_decompress(const void *compressed_data, size_t compressed_size, void **decompressed_data,
+                   const mgh_config *config, int output_pre_allocated) {
+  if (!compressed_data || !decompressed_data) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (output_pre_allocated && !*decompressed_data) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "pre-allocated output is NULL");
+  mgh_config def;
+  if (!config) {
+    mgh_config_default(&def);
+    config = &def;
+  }
+  int ndev = mgh_device_count();
+  if (ndev <= 0) return hl_fail(MGH_ERR_NO_DEVICE, "no HIP device");
+  if (hipSetDevice(config->dev_id) != hipSuccess) return hl_fail(MGH_ERR_DEVICE, "hipSetDevice");
+  fmt::Header hd;
+  size_t meta_size = 0;
+  HL_TRY(read_header(compressed_data, compressed_size, hd, meta_size));
+  if (hd.shape.empty() || hd.shape.size() > MGH_MAX_DIM) return hl_fail(MGH_ERR_UNSUPPORTED_DIMENSION, "header: dimension");
+  if (!hd.quantized) return hl_fail(MGH_ERR_FORMAT, "not a compressed (quantized) stream");
+  try {
+    if (hd.is_double)
+      return decompress_impl<double>(hd, meta_size, compressed_data, compressed_size, decompressed_data,
+                                     *config, output_pre_allocated != 0);
+    return decompress_impl<float>(hd, meta_size, compressed_data, compressed_size, decompressed_data,
+                                  *config, output_pre_allocated != 0);
+  } catch (const std::exception &e) {
+    return hl_fail(MGH_ERR_DEVICE, e.what());
+  }
+}
+
+int mgh_infer_shape(const void *data, size_t size, int *D_out, uint64_t *shape_out) {
+  if (!data || !D_out || !shape_out) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");
+  fmt::Header hd;
+  size_t ms = 0;
+  HL_TRY(read_header(data, size, hd, ms));
+  if (hd.shape.size() > MGH_MAX_DIM) return hl_fail(MGH_ERR_UNSUPPORTED_DIMENSION, "header: dimension");
+  *D_out = (int)hd.shape.size();
+  for (size_t d = 0; d < hd.shape.size(); d++) shape_out[d] = hd.shape[d];
+  return MGH_SUCCESS;
+}
+
+int mgh_infer_data_type(const void *data, size_t size, int *dtype_out) {
+  if (!data || !dtype_out) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");
+  fmt::Header hd;
+  size_t ms = 0;
+  HL_TRY(read_header(data, size, hd, ms));
+  *dtype_out = hd.is_double ? MGH_DOUBLE : MGH_FLOAT;
+  return MGH_SUCCESS;
+}
+
+void mgh_free_device(void *p) {
+  if (p) (void)hipFree(p);
+}
+
+void mgh_release_cache(void) { g_cache.release(); }
+
+int mgh_memcpy(void *dst, const void *src, size_t bytes) {
+  if (!dst || !src) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");
+  HL_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
+  return MGH_SUCCESS;
+}
+
+int64_t mgh_metadata_serialize(const mgh_header_info *in, uint8_t *out, uint64_t capacity) {
+  if (!in || in->D < 1 || in->D > MGH_MAX_DIM) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "header info");
+  fmt::Header h;
+  for (int i = 0; i < 3; i++) h.version[i] = in->version[i];
+  h.is_double = in->dtype == MGH_DOUBLE;
+  h.shape.assign(in->shape, in->shape + in->D);
+  h.uniform = in->uniform != 0;
+  if (!h.uniform)
+    for (int d = 0; d < in->D; d++) {
+      if (!in->coords[d]) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "coords");
+      h.coords.emplace_back(in->coords[d], in->coords[d] + in->shape[d]);
+    }
+  h.rel = in->error_bound_type == MGH_REL;
+  h.tol = in->tol;
+  h.s = in->s;
+  h.norm = in->norm;
+  h.dd_method = !in->domain_decomposed ? fmt::DD_NOOP
+                : in->dd_method == MGH_DD_MAXDIM ? fmt::DD_MAX_DIMENSION
+                : in->dd_method == MGH_DD_BLOCK ? fmt::DD_BLOCK : fmt::DD_VARIABLE;
+  h.dd_dim = in->dd_dim;
+  h.dd_size = in->dd_size;
+  h.l_target = in->l_target;
+  h.reorder = in->reorder != 0;
+  h.compressor = in->lossless == MGH_LOSSLESS_HUFFMAN ? fmt::COMP_X_HUFFMAN
+                 : in->lossless == MGH_LOSSLESS_HUFFMAN_LZ4 ? fmt::COMP_X_HUFFMAN_LZ4
+                 : in->lossless == MGH_LOSSLESS_HUFFMAN_ZSTD ? fmt::COMP_X_HUFFMAN_ZSTD
+                 : fmt::COMP_CPU_HUFFMAN_ZSTD;
+  h.huff_dict_size = in->lossless == MGH_LOSSLESS_CPU ? 0 : in->huff_dict_size;
+  h.huff_block_size = in->lossless == MGH_LOSSLESS_CPU ? 0 : in->huff_block_size;
+  const std::vector<uint8_t> b = fmt::serialize_metadata(h);
+  if (out) {
+    if (capacity < b.size()) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "capacity");
+    std::memcpy(out, b.data(), b.size());
+  }
+  return (int64_t)b.size();
+}
+
+int mgh_metadata_parse(const uint8_t *data, uint64_t size, mgh_header_info *out, double *cstore,
+                       uint64_t ccap, uint64_t *metadata_size_out) {
+  if (!data || !out) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");
+  fmt::Header h;
+  size_t ms = 0;
+  try {
+    ms = fmt::parse_metadata(data, size, h);
+  } catch (const std::exception &e) {
+    return hl_fail(MGH_ERR_FORMAT, e.what());
+  }
+  if (h.shape.empty() || h.shape.size() > MGH_MAX_DIM) return hl_fail(MGH_ERR_UNSUPPORTED_DIMENSION, "header: dimension");
+  std::memset(out, 0, sizeof(*out));
+  for (int i = 0; i < 3; i++) out->version[i] = h.version[i];
+  out->dtype = h.is_double ? MGH_DOUBLE : MGH_FLOAT;
+  out->D = (int)h.shape.size();
+  for (int d = 0; d < out->D; d++) out->shape[d] = h.shape[d];
+  out->uniform = h.uniform ? 1 : 0;
+  if (!h.uniform) {
+    uint64_t need = 0;
+    for (uint64_t n : h.shape) need += n;
+    if (!cstore || ccap < need) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "coords_storage too small");
+    uint64_t off = 0;
+    for (int d = 0; d < out->D; d++) {
+      std::memcpy(cstore + off, h.coords[d].data(), h.coords[d].size() * 8);
+      out->coords[d] = cstore + off;
+      off += h.shape[d];
+    }
+  }
+  out->error_bound_type = h.rel ? MGH_REL : MGH_ABS;
+  out->tol = h.tol;
+  out->s = h.s;
+  out->norm = h.norm;
+  out->domain_decomposed = h.dd_method != fmt::DD_NOOP;
+  out->dd_method = h.dd_method == fmt::DD_BLOCK ? MGH_DD_BLOCK
+                   : h.dd_method == fmt::DD_VARIABLE ? MGH_DD_VARIABLE : MGH_DD_MAXDIM;
+  out->dd_dim = h.dd_dim;
+  out->dd_size = h.dd_size;
+  out->l_target = h.l_target;
+  out->reorder = h.reorder ? 1 : 0;
+  out->lossless = h.compressor == fmt::COMP_X_HUFFMAN ? MGH_LOSSLESS_HUFFMAN
+                  : h.compressor == fmt::COMP_X_HUFFMAN_LZ4 ? MGH_LOSSLESS_HUFFMAN_LZ4
+                  : h.compressor == fmt::COMP_X_HUFFMAN_ZSTD ? MGH_LOSSLESS_HUFFMAN_ZSTD : MGH_LOSSLESS_CPU;
+  out->huff_dict_size = h.huff_dict_size;
+  out->huff_block_size = h.huff_block_size;
+  if (metadata_size_out) *metadata_size_out = ms;
+  return MGH_SUCCESS;
+}
+
+int mgh_huffman_codebook(const uint32_t *freq, uint64_t dict_size, uint64_t *code_out,
+                         uint64_t *first_out, uint64_t *entry_out, uint64_t *keys_out) {
+  if (!freq || !dict_size || !code_out || !first_out || !entry_out || !keys_out)
+    return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");
+  try {
+    const huff::Codebook cb = huff::build_codebook(std::vector<unsigned>(freq, freq + dict_size));
+    std::memcpy(code_out, cb.code.data(), dict_size * 8);
+    std::memcpy(first_out, cb.first.data(), 64 * 8);
+    std::memcpy(entry_out, cb.entry.data(), 64 * 8);
+    std::memcpy(keys_out, cb.keys.data(), dict_size * 8);
+  } catch (const std::exception &e) {
+    return hl_fail(MGH_ERR_INVALID_ARGUMENT, e.what());
+  }
+  return MGH_SUCCESS;
+}
+
+int mgh_lossless_create(mgh_lossless_ctx **out, int dev_id) {
+  if (!out) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");
+  *out = new mgh_lossless_ctx();
+  (*out)->dev = dev_id;
+  return MGH_SUCCESS;
+}
+
+void mgh_lossless_destroy(mgh_lossless_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->dev);
+  for (DevBuf *b : {&c->freq, &c->code, &c->bits, &c->entry, &c->total, &c->units, &c->tables, &c->oidx, &c->oval})
+    b->release();
+  delete c;
+}
+
+int mgh_lossless_compress(mgh_lossless_ctx *ctx, const int64_t *d_q, uint64_t n, uint64_t dict,
+                          uint64_t chunk, int lossless, int zstd_level, const uint64_t *d_oidx,
+                          const int64_t *d_oval, uint64_t ocount, const uint8_t **payload_out,
+                          uint64_t *size_out, void *stream) {
+  if (!ctx || !d_q || !payload_out || !size_out) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (hipSetDevice(ctx->dev) != hipSuccess) return hl_fail(MGH_ERR_DEVICE, "hipSetDevice");
+  try {
+    HL_TRY(lossless_compress(ctx, d_q, n, dict, chunk, lossless, zstd_level, d_oidx, d_oval, ocount,
+                             (hipStream_t)stream));
+  } catch (const std::exception &e) {
+    return hl_fail(MGH_ERR_DEVICE, e.what());
+  }
+  *payload_out = ctx->host.data();
+  *size_out = ctx->host.size();
+  return MGH_SUCCESS;
+}
+
+int mgh_lossless_decompress(mgh_lossless_ctx *ctx, const uint8_t *payload, uint64_t size, int lossless,
+                            int64_t *d_q, uint64_t n, const uint64_t **oidx_out,
+                            const int64_t **oval_out, uint64_t *ocount_out, void *stream) {
+  if (!ctx || !payload || !d_q || !ocount_out) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (hipSetDevice(ctx->dev) != hipSuccess) return hl_fail(MGH_ERR_DEVICE, "hipSetDevice");
+  try {
+    HL_TRY(lossless_decompress(ctx, payload, size, lossless, d_q, n, ocount_out, (hipStream_t)stream));
+  } catch (const std::exception &e) {
+    return hl_fail(MGH_ERR_DEVICE, e.what());
+  }
+  if (oidx_out) *oidx_out = (const uint64_t *)ctx->oidx.p;
+  if (oval_out) *oval_out = (const int64_t *)ctx->oval.p;
+  return MGH_SUCCESS;
+}
+
+} // extern "C"

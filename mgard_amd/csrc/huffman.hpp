@@ -1,0 +1,293 @@
+// Huffman stage of the lossless compressor for gfx950.
+//
+// Produces / consumes the reference's serialized Huffman payload
+// (include/mgard-x/Lossless/ParallelHuffman/Huffman.hpp:163-239, Deserialize :283-370):
+//
+//   size_t primary_count | int dict_size | int chunk_size | size_t huffmeta_size (= 2 nchunk)
+//   size_t bits_per_chunk[nchunk] | size_t word_entry[nchunk]
+//   size_t decodebook_size | u8 decodebook[ 8*64 first | 8*64 entry | 8*dict keys ]
+//   size_t ddata_size | u64 ddata[ddata_size]           (each member naturally aligned)
+//   u64 outlier_count | u64 outlier_idx[count] | i64 outliers[count]
+//
+// with H = u64 code units filled MSB first, every chunk of `chunk_size` symbols starting on a
+// unit boundary (Deflate.hpp:33-76, Condense.hpp), and a canonical code described by
+// first[l] / entry[l] / keys[] exactly as Decode.hpp:52-106 consumes it: a code of length l is
+// recognised by v >= first[l], its symbol is keys[entry[l] + v - first[l]], unused lengths carry
+// first = 2^64-1 (GenerateCW.hpp:77-83). The stock decoder therefore reads these payloads.
+//
+// How it is built here (not a port of the reference's kernels): histogram with LDS privatised
+// bins; code lengths on the host (8192 symbols: microseconds) with the classic two-queue
+// construction, codes assigned longest-first so that first[] has the property above; encoding
+// in two passes over the symbols -- per-chunk bit totals, a scan for the unit offsets, then
+// every workgroup writes its chunk straight into its final (condensed) position, each thread
+// packing a run of symbols in registers and touching shared units with atomicOr only at the
+// two ends of its run. Decoding is one lane per chunk, as the format dictates (chunks are the
+// only entry points into the bit stream).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstring>
+#include <queue>
+#include <stdexcept>
+#include <vector>
+
+namespace mgh {
+namespace huff {
+
+constexpr int kUnitBits = 64;
+constexpr int kMaxCodeBits = 56;  // codeword representation: length in the top byte
+
+// ---------------------------------------------------------------------------------------
+// host: code construction
+// ---------------------------------------------------------------------------------------
+struct Codebook {
+  std::vector<uint64_t> code;  // [dict]: (len << 56) | value, 0 for unused symbols
+  std::vector<uint64_t> first, entry;  // [64]
+  std::vector<uint64_t> keys;          // [dict]: symbols in decreasing-frequency / code order
+  int max_len = 0;
+};
+
+inline Codebook build_codebook(const std::vector<unsigned> &freq) {
+  const int dict = (int)freq.size();
+  Codebook cb;
+  cb.code.assign(dict, 0);
+  cb.first.assign(kUnitBits, ~(uint64_t)0);
+  cb.entry.assign(kUnitBits, 0);
+  cb.keys.assign(dict, 0);
+  // symbols by decreasing frequency (ties: increasing symbol) -- the order of keys[]
+  std::vector<int> order;
+  for (int i = 0; i < dict; i++)
+    if (freq[i]) order.push_back(i);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return freq[a] > freq[b]; });
+  const int nz = (int)order.size();
+  // fill keys with the used symbols first, then the unused ones (any order)
+  {
+    int k = 0;
+    for (int s : order) cb.keys[k++] = (uint64_t)s;
+    for (int i = 0; i < dict; i++)
+      if (!freq[i]) cb.keys[k++] = (uint64_t)i;
+  }
+  if (nz == 0) return cb;
+  std::vector<int> len(nz, 0);
+  if (nz == 1) {
+    len[0] = 1;
+  } else {
+    // Huffman tree with two queues over the leaves sorted by increasing weight
+    struct Node { uint64_t w; int l, r; };
+    std::vector<Node> nodes;
+    nodes.reserve(2 * nz);
+    for (int i = nz - 1; i >= 0; i--) nodes.push_back({freq[order[i]], -1, -1});  // increasing
+    size_t leaf = 0, inner = (size_t)nz, inner_end = (size_t)nz;
+    auto take = [&]() -> int {
+      if (leaf < (size_t)nz && (inner >= inner_end || nodes[leaf].w <= nodes[inner].w)) return (int)leaf++;
+      return (int)inner++;
+    };
+    for (int k = 0; k < nz - 1; k++) {
+      const int a = take(), b = take();
+      nodes.push_back({nodes[a].w + nodes[b].w, a, b});
+      inner_end++;
+    }
+    std::vector<int> depth(nodes.size(), 0);
+    for (int i = (int)nodes.size() - 1; i >= nz; i--) {
+      depth[nodes[i].l] = depth[i] + 1;
+      depth[nodes[i].r] = depth[i] + 1;
+    }
+    for (int i = 0; i < nz; i++) len[nz - 1 - i] = depth[i];  // leaf i = order[nz-1-i]
+  }
+  // lengths are non-decreasing along `order` up to ties in the tree; canonical assignment
+  // needs symbols grouped by length: stable sort of the key order by length
+  std::vector<int> idx(nz);
+  for (int i = 0; i < nz; i++) idx[i] = i;
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return len[a] < len[b]; });
+  std::vector<uint64_t> count(kUnitBits + 1, 0);
+  for (int i = 0; i < nz; i++) {
+    if (len[i] > kMaxCodeBits)
+      throw std::runtime_error("Huffman: codeword longer than 56 bits");
+    count[len[i]]++;
+    cb.max_len = std::max(cb.max_len, len[i]);
+  }
+  {
+    int k = 0;
+    std::vector<uint64_t> keys2(cb.keys);
+    for (int i : idx) keys2[k++] = (uint64_t)order[i];
+    cb.keys = keys2;
+  }
+  // first[l]: longest codes start at 0, every shorter length continues above the prefixes of
+  // the longer ones: first[l] = ceil((first[l+1] + count[l+1]) / 2)
+  std::vector<uint64_t> first(kUnitBits + 2, 0);
+  first[cb.max_len] = 0;
+  for (int l = cb.max_len - 1; l >= 1; l--) first[l] = (first[l + 1] + count[l + 1] + 1) / 2;
+  uint64_t e = 0;
+  for (int l = 1; l < kUnitBits; l++) {
+    cb.entry[l] = e;
+    if (l <= cb.max_len && count[l]) cb.first[l] = first[l];
+    e += l <= cb.max_len ? count[l] : 0;
+  }
+  // codes: the j-th symbol of length l (in keys order) gets first[l] + j
+  std::vector<uint64_t> next(first);
+  for (int i : idx) {
+    const int l = len[i];
+    cb.code[order[i]] = ((uint64_t)l << kMaxCodeBits) | next[l]++;
+  }
+  return cb;
+}
+
+// ---------------------------------------------------------------------------------------
+// device kernels
+// ---------------------------------------------------------------------------------------
+// Histogram of the symbols (int64 values in [0, dict)); bins privatised in LDS.
+__global__ void __launch_bounds__(256)
+k_histogram(const int64_t *__restrict__ q, size_t n, int dict, unsigned *__restrict__ freq) {
+  extern __shared__ unsigned bins[];
+  for (int i = threadIdx.x; i < dict; i += 256) bins[i] = 0;
+  __syncthreads();
+  const size_t nth = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += nth) {
+    const uint64_t s = (uint64_t)q[i];
+    if (s < (uint64_t)dict) atomicAdd(&bins[s], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < dict; i += 256)
+    if (bins[i]) atomicAdd(&freq[i], bins[i]);
+}
+
+// bits of every chunk (one workgroup per chunk)
+__global__ void __launch_bounds__(256)
+k_chunk_bits(const int64_t *__restrict__ q, size_t n, int chunk, const uint64_t *__restrict__ code,
+             unsigned long long *__restrict__ bits) {
+  const size_t base = (size_t)blockIdx.x * chunk;
+  const size_t cnt = min((size_t)chunk, n - base);
+  unsigned long long s = 0;
+  for (size_t i = threadIdx.x; i < cnt; i += 256) s += code[q[base + i]] >> kMaxCodeBits;
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  __shared__ unsigned long long w[4];
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) bits[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
+}
+
+// entry[c] = sum_{k<c} ceil(bits[k] / 64); total units in *total (one workgroup)
+__global__ void __launch_bounds__(1024)
+k_unit_offsets(const unsigned long long *__restrict__ bits, size_t nchunk,
+               unsigned long long *__restrict__ entry, unsigned long long *__restrict__ total) {
+  __shared__ unsigned long long part[1024];
+  const size_t per = (nchunk + 1023) / 1024;
+  const size_t lo = min(nchunk, threadIdx.x * per), hi = min(nchunk, lo + per);
+  unsigned long long s = 0;
+  for (size_t i = lo; i < hi; i++) s += (bits[i] + 63) / 64;
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const unsigned long long v = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  unsigned long long run = part[threadIdx.x] - s;
+  for (size_t i = lo; i < hi; i++) {
+    entry[i] = run;
+    run += (bits[i] + 63) / 64;
+  }
+  if (threadIdx.x == 1023) *total = part[1023];
+}
+
+// Write the bit stream of every chunk at its final position (units pre-zeroed). One workgroup
+// per chunk; thread t packs the symbols [t*run, (t+1)*run) of the chunk.
+__global__ void __launch_bounds__(256)
+k_encode(const int64_t *__restrict__ q, size_t n, int chunk, const uint64_t *__restrict__ code,
+         const unsigned long long *__restrict__ entry, unsigned long long *__restrict__ out) {
+  const size_t base = (size_t)blockIdx.x * chunk;
+  const size_t cnt = min((size_t)chunk, n - base);
+  const size_t run = (cnt + 255) / 256;
+  const size_t lo = min(cnt, threadIdx.x * run), hi = min(cnt, lo + run);
+  unsigned long long s = 0;
+  for (size_t i = lo; i < hi; i++) s += code[q[base + i]] >> kMaxCodeBits;
+  // exclusive scan of the per-thread bit counts
+  __shared__ unsigned long long sc[256];
+  sc[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const unsigned long long v = threadIdx.x >= (unsigned)off ? sc[threadIdx.x - off] : 0;
+    __syncthreads();
+    sc[threadIdx.x] += v;
+    __syncthreads();
+  }
+  unsigned long long pos = sc[threadIdx.x] - s;  // first bit of this thread's run
+  if (lo >= hi || s == 0) return;
+  unsigned long long *dst = out + entry[blockIdx.x];
+  size_t w = pos / kUnitBits;
+  int room = kUnitBits - (int)(pos % kUnitBits);  // free bits in the current unit
+  unsigned long long acc = 0;
+  bool first_unit = true;
+  auto flush = [&](bool last) {
+    // the first and the last unit of a run may be shared with the neighbouring runs
+    if (first_unit || last) atomicOr(&dst[w], acc);
+    else dst[w] = acc;
+    first_unit = false;
+  };
+  for (size_t i = lo; i < hi; i++) {
+    const uint64_t c = code[q[base + i]];
+    const int len = (int)(c >> kMaxCodeBits);
+    const unsigned long long val = c & (((uint64_t)1 << kMaxCodeBits) - 1);
+    if (len <= room) {
+      room -= len;
+      acc |= val << room;
+      if (room == 0) {
+        flush(false);
+        w++;
+        acc = 0;
+        room = kUnitBits;
+      }
+    } else {
+      const int rest = len - room;
+      acc |= val >> rest;
+      flush(false);
+      w++;
+      room = kUnitBits - rest;
+      acc = val << room;
+    }
+  }
+  if (room != kUnitBits) flush(true);
+}
+
+// Canonical decoding, one lane per chunk (Decode.hpp:52-106 semantics).
+__global__ void __launch_bounds__(64)
+k_decode(const unsigned long long *__restrict__ units, const unsigned long long *__restrict__ bits,
+         const unsigned long long *__restrict__ entry_of_chunk, size_t nchunk, int chunk, size_t n,
+         const unsigned long long *__restrict__ first, const unsigned long long *__restrict__ entry,
+         const unsigned long long *__restrict__ keys, int64_t *__restrict__ q) {
+  __shared__ unsigned long long sfirst[64], sentry[64];
+  sfirst[threadIdx.x] = first[threadIdx.x];
+  sentry[threadIdx.x] = entry[threadIdx.x];
+  __syncthreads();
+  const size_t c = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (c >= nchunk) return;
+  const unsigned long long *src = units + entry_of_chunk[c];
+  const unsigned long long total = bits[c];
+  int64_t *dst = q + c * (size_t)chunk;
+  const size_t cap = min((size_t)chunk, n - c * (size_t)chunk);
+  unsigned long long cur = 0, i = 0;
+  size_t produced = 0;
+  while (i < total && produced < cap) {
+    unsigned long long v = 0;
+    int l = 0;
+    bool hit = false;
+    while (i < total && l < 63) {
+      if ((i & 63) == 0) cur = src[i >> 6];
+      v = (v << 1) | ((cur >> (63 - (i & 63))) & 1ull);
+      i++;
+      l++;
+      if (v >= sfirst[l]) {
+        hit = true;
+        break;
+      }
+    }
+    if (!hit) break;  // truncated / corrupt stream: stop instead of indexing out of range
+    dst[produced++] = (int64_t)keys[sentry[l] + v - sfirst[l]];
+  }
+}
+
+} // namespace huff
+} // namespace mgh

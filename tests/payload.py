@@ -1,0 +1,81 @@
+"""Independent (pure Python / numpy) reader of the container and of the serialized Huffman
+record, written from the format description only (reference Huffman.hpp:163-239,
+Decode.hpp:52-106, GPUPipelines.hpp:189-193): used by the tests to check what the library
+writes without going through the library's own decoder."""
+import struct
+
+import numpy as np
+
+
+def _align(off, a):
+    return (off + a - 1) // a * a
+
+
+def parse_huffman_record(b):
+    """dict with primary_count, dict_size, chunk_size, bits[], entry[], first[64], entry_tab[64],
+    keys[dict], units[], outlier_idx[], outliers[]."""
+    off = 0
+    primary, = struct.unpack_from("<Q", b, off); off += 8
+    dict_size, chunk = struct.unpack_from("<ii", b, off); off += 8
+    off = _align(off, 8)
+    hm, = struct.unpack_from("<Q", b, off); off += 8
+    meta = np.frombuffer(b, dtype="<u8", count=hm, offset=off); off += 8 * hm
+    dbs, = struct.unpack_from("<Q", b, off); off += 8
+    assert dbs == 8 * 128 + 8 * dict_size
+    first = np.frombuffer(b, dtype="<u8", count=64, offset=off)
+    entry_tab = np.frombuffer(b, dtype="<u8", count=64, offset=off + 512)
+    keys = np.frombuffer(b, dtype="<u8", count=dict_size, offset=off + 1024)
+    off += dbs
+    off = _align(off, 8)
+    nunits, = struct.unpack_from("<Q", b, off); off += 8
+    off = _align(off, 8)
+    units = np.frombuffer(b, dtype="<u8", count=nunits, offset=off); off += 8 * nunits
+    oc, = struct.unpack_from("<Q", b, off); off += 8
+    oidx = np.frombuffer(b, dtype="<u8", count=oc, offset=off); off += 8 * oc
+    oval = np.frombuffer(b, dtype="<i8", count=oc, offset=off); off += 8 * oc
+    assert off == len(b), (off, len(b))
+    nchunk = hm // 2
+    return dict(primary_count=primary, dict_size=dict_size, chunk_size=chunk, bits=meta[:nchunk],
+                entry=meta[nchunk:], first=first, entry_tab=entry_tab, keys=keys, units=units,
+                outlier_idx=oidx, outliers=oval)
+
+
+def decode_huffman_record(rec, max_chunks=None):
+    """Bit-serial canonical decoding exactly as Decode.hpp:52-106 states it (slow: for small
+    inputs). Returns the symbols as int64."""
+    first = [int(x) for x in rec["first"]]
+    entry = [int(x) for x in rec["entry_tab"]]
+    keys = rec["keys"]
+    n, chunk = rec["primary_count"], rec["chunk_size"]
+    out = np.zeros(n, dtype=np.int64)
+    nchunk = len(rec["bits"]) if max_chunks is None else min(max_chunks, len(rec["bits"]))
+    for c in range(nchunk):
+        total = int(rec["bits"][c])
+        base = int(rec["entry"][c])
+        nun = (total + 63) // 64
+        bits = np.unpackbits(rec["units"][base:base + nun].astype(">u8").view(np.uint8))
+        i, k = 0, c * chunk
+        while i < total:
+            v, l = int(bits[i]), 1
+            i += 1
+            while v < first[l]:
+                v = (v << 1) | int(bits[i])
+                i += 1
+                l += 1
+            out[k] = keys[entry[l] + v - first[l]]
+            k += 1
+        assert k == min(n, (c + 1) * chunk), (c, k)
+    return out
+
+
+def split_container(buf, metadata_size):
+    """[(size, payload bytes)] of the subdomain records behind the header."""
+    b = bytes(buf)
+    off, out = metadata_size, []
+    while off < len(b):
+        size, = struct.unpack_from("<Q", b, off)
+        off += 8
+        out.append(b[off:off + size])
+        off += size
+    assert off == len(b)
+    return out

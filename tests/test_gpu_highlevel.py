@@ -1,0 +1,262 @@
+"""GPU tests of the high-level path (include/mgard_hip_compress.h): lossless stage, container,
+domain decomposition and the whole-array compress / decompress round trip, all through the C
+ABI. The serialized records are additionally read back by an independent pure-Python reader
+(tests/payload.py) written from the format description."""
+import numpy as np
+import pytest
+
+import oracle
+from tests import payload as pl
+from tests.util import nonuniform_coords, smooth_field
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    import torch
+    import mgard_amd
+    from mgard_amd import highlevel as hl
+    return torch, mgard_amd, hl
+
+
+def _symbols(n, seed=3, width=6.0, dict_size=8192):
+    rng = np.random.default_rng(seed)
+    q = np.rint(rng.normal(0, width, n)).astype(np.int64) + dict_size // 2
+    return np.clip(q, 0, dict_size - 1)
+
+
+@pytest.mark.parametrize("lossless", ["HUFFMAN", "HUFFMAN_ZSTD"])
+@pytest.mark.parametrize("n,chunk", [(1, 20480), (777, 64), (20480, 20480), (20481, 20480), (300001, 4096)])
+def test_lossless_roundtrip_and_record_layout(n, chunk, lossless):
+    torch, mg, hl = _mods()
+    mode = getattr(hl, lossless)
+    q = _symbols(n)
+    oi = np.array([0, n // 2, n - 1][:min(3, n)], dtype=np.int64)
+    oi = np.unique(oi)
+    ov = np.array([-70000, 123456, 8192][:len(oi)], dtype=np.int64)
+    q[oi] = 0
+    ctx = hl.Lossless()
+    qd = torch.from_numpy(q).cuda()
+    rec = ctx.compress(qd, 8192, chunk, mode, 3, torch.from_numpy(oi).cuda(), torch.from_numpy(ov).cuda())
+    if mode == hl.HUFFMAN:
+        r = pl.parse_huffman_record(rec)
+        assert r["primary_count"] == n and r["dict_size"] == 8192 and r["chunk_size"] == chunk
+        nchunk = (n - 1) // chunk + 1
+        assert len(r["bits"]) == nchunk
+        words = (r["bits"].astype(np.int64) + 63) // 64
+        assert np.array_equal(r["entry"], np.concatenate([[0], np.cumsum(words)[:-1]]).astype(np.uint64))
+        assert len(r["units"]) == int(words.sum())
+        assert np.array_equal(r["outlier_idx"].astype(np.int64), oi) and np.array_equal(r["outliers"], ov)
+        if n <= 30000:
+            assert np.array_equal(pl.decode_huffman_record(r), q)   # independent decoder
+    back, bi, bv = ctx.decompress(rec, n, mode)
+    assert np.array_equal(back.cpu().numpy(), q)
+    assert np.array_equal(bi.cpu().numpy(), oi) and np.array_equal(bv.cpu().numpy(), ov)
+    ctx.close()
+
+
+def test_lossless_single_symbol_and_full_dictionary():
+    torch, mg, hl = _mods()
+    ctx = hl.Lossless()
+    for q in (np.full(5000, 4096, np.int64), np.arange(8192, dtype=np.int64).repeat(3)):
+        rec = ctx.compress(torch.from_numpy(q).cuda(), 8192, 1024)
+        assert np.array_equal(pl.decode_huffman_record(pl.parse_huffman_record(rec)), q)
+        back, _, _ = ctx.decompress(rec, q.size)
+        assert np.array_equal(back.cpu().numpy(), q)
+    ctx.close()
+
+
+def test_lossless_rejects_damaged_records():
+    torch, mg, hl = _mods()
+    ctx = hl.Lossless()
+    q = _symbols(50000)
+    rec = bytearray(ctx.compress(torch.from_numpy(q).cuda(), 8192, 4096))
+    with pytest.raises(mg.MgardHipError):
+        ctx.decompress(bytes(rec[:100]), q.size)
+    with pytest.raises(mg.MgardHipError):
+        ctx.decompress(bytes(rec), q.size + 1)
+    bad = bytearray(rec)
+    bad[24 + 8 * 13 + 8 * 13 - 1] = 0x7f   # a chunk entry far outside the code stream
+    with pytest.raises(mg.MgardHipError):
+        ctx.decompress(bytes(bad), q.size)
+    ctx.close()
+
+
+def _err(u, v, s, shape):
+    if np.isinf(s):
+        return float(np.max(np.abs(u.astype(np.float64) - v.astype(np.float64))))
+    return float(np.sqrt(np.mean((u.astype(np.float64) - v.astype(np.float64)) ** 2)))
+
+
+def _norm(u, s):
+    return float(np.max(np.abs(u))) if np.isinf(s) else float(np.sqrt(np.mean(u.astype(np.float64) ** 2)))
+
+
+@pytest.mark.parametrize("where", ["host", "device"])
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("shape,s,mode,lossless", [
+    ((65, 70, 129), np.inf, "REL", "HUFFMAN"), ((100, 36, 260), 0.0, "REL", "HUFFMAN_ZSTD"),
+    ((1025,), np.inf, "ABS", "HUFFMAN"), ((129, 200), 1.0, "ABS", "HUFFMAN"),
+    ((6, 20, 17, 33), np.inf, "REL", "HUFFMAN"), ((3, 4, 5, 6, 7), np.inf, "ABS", "HUFFMAN_ZSTD")])
+def test_compress_decompress_roundtrip(shape, s, mode, lossless, dt, where):
+    torch, mg, hl = _mods()
+    u = smooth_field(shape, dt)
+    tol = 1e-3
+    cfg = hl.Config(lossless=getattr(hl, lossless))
+    src = u if where == "host" else torch.from_numpy(u).cuda()
+    buf = hl.compress(src, tol, s, mg.REL if mode == "REL" else mg.ABS, config=cfg)
+    raw = buf if where == "host" else buf.cpu().numpy()
+    m = hl.metadata_parse(bytes(raw[:4096]) if raw.size > 4096 else bytes(raw))
+    assert m["shape"] == list(shape) and m["tol"] == tol and m["lossless"] == getattr(hl, lossless)
+    assert m["domain_decomposed"] is False and m["dict_size"] == 8192 and m["block_size"] == 20480
+    if mode == "REL":
+        assert abs(m["norm"] - _norm(u, s)) <= 1e-5 * _norm(u, s)
+        if np.isinf(s):
+            assert dt(m["norm"]) == dt(np.max(np.abs(u)))
+    if u.nbytes > (1 << 20):
+        assert raw.size < u.nbytes                  # it does compress (the 64 KiB decodebook
+                                                    # makes tiny arrays fall back to raw storage)
+    assert hl.infer(buf) == (tuple(shape), hl.DOUBLE if dt == np.float64 else hl.FLOAT)
+    v = hl.decompress(buf)
+    v = v if where == "host" else v.cpu().numpy()
+    assert v.shape == tuple(shape) and v.dtype == dt
+    bound = tol * (_norm(u, s) if mode == "REL" else 1.0)
+    assert _err(u, v, s, shape) <= bound * (1 + 1e-6)
+
+
+def test_container_records_hold_the_quantized_coefficients():
+    """The single record of a non-decomposed stream decodes (independent reader) to exactly the
+    integers the low-level path produces, outliers included."""
+    torch, mg, hl = _mods()
+    shape = (65, 40, 65)
+    u = smooth_field(shape, np.float32, noise=2e-3)
+    tol = 1e-2
+    buf = hl.compress(u, tol, np.inf, mg.REL, config=hl.Config(huff_dict_size=2048, huff_block_size=4096))
+    m = hl.metadata_parse(bytes(buf))
+    assert m["dict_size"] == 2048 and m["block_size"] == 4096
+    recs = pl.split_container(buf, m["metadata_size"])
+    assert len(recs) == 1 and len(recs[0]) < u.nbytes
+    r = pl.parse_huffman_record(recs[0])
+    h = mg.Hierarchy(shape, np.float32)
+    q, oi, ov, cnt, nrm = h.decompose_quantize(torch.from_numpy(u).cuda(), mg.REL, tol, np.inf,
+                                               dict_size=2048)
+    assert cnt > 0
+    assert np.array_equal(pl.decode_huffman_record(r), q.cpu().numpy().reshape(-1))
+    a = np.argsort(r["outlier_idx"])
+    b = np.argsort(oi.cpu().numpy())
+    assert np.array_equal(r["outlier_idx"][a].astype(np.int64), oi.cpu().numpy()[b])
+    assert np.array_equal(r["outliers"][a], ov.cpu().numpy()[b])
+    h.close()
+
+
+@pytest.mark.parametrize("s", [np.inf, 0.0])
+@pytest.mark.parametrize("kind", ["maxdim_auto", "block", "variable"])
+def test_domain_decomposition(kind, s):
+    torch, mg, hl = _mods()
+    shape = (66, 300, 80)
+    u = smooth_field(shape, np.float32)
+    tol = 1e-2
+    if kind == "maxdim_auto":
+        # a memory budget that only fits a fraction of the array forces a MaxDim split
+        cfg = hl.Config(max_memory_footprint=(64 << 20) + 30 * u.nbytes // 8)
+    elif kind == "block":
+        cfg = hl.Config(domain_decomposition=hl.DD_BLOCK, block_size=50)
+    else:
+        cfg = hl.Config(domain_decomposition=hl.DD_VARIABLE, domain_decomposition_dim=1,
+                        domain_decomposition_sizes=[100, 60, 140])
+    buf = hl.compress(u, tol, s, mg.REL, config=cfg)
+    m = hl.metadata_parse(bytes(buf))
+    assert m["domain_decomposed"]
+    recs = pl.split_container(buf, m["metadata_size"])
+    if kind == "maxdim_auto":
+        assert m["dd_method"] == hl.DD_MAXDIM and m["dd_dim"] == 1
+        assert len(recs) == (300 - 1) // m["dd_size"] + 1 and len(recs) > 1
+    elif kind == "block":
+        assert m["dd_method"] == hl.DD_BLOCK and m["dd_size"] == 50 and len(recs) == 2 * 6 * 2
+    else:
+        assert m["dd_method"] == hl.DD_VARIABLE and len(recs) == 3
+    nrm = _norm(u, s)
+    assert abs(m["norm"] - nrm) <= 1e-5 * nrm
+    v = hl.decompress(buf, config=cfg)
+    assert _err(u, v, s, shape) <= tol * nrm * (1 + 1e-6)
+    # subdomain extents in record order (last decomposed dimension fastest,
+    # DomainDecomposer.hpp:105-113); every record is the Huffman record of its subdomain, or the
+    # raw subdomain where that is smaller (GPUPipelines.hpp:136-155)
+    def pieces(n, size):
+        return [size] * (n // size) + ([n % size] if n % size else [])
+    if kind == "maxdim_auto":
+        sizes = [66 * p * 80 for p in pieces(300, m["dd_size"])]
+    elif kind == "block":
+        sizes = [a * b * c for a in pieces(66, 50) for b in pieces(300, 50) for c in pieces(80, 50)]
+    else:
+        sizes = [66 * p * 80 for p in (100, 60, 140)]
+    assert len(sizes) == len(recs) and sum(sizes) == u.size
+    n_huff = 0
+    for r, n in zip(recs, sizes):
+        if len(r) == 4 * n:
+            continue
+        assert len(r) < 4 * n and pl.parse_huffman_record(r)["primary_count"] == n
+        n_huff += 1
+    assert n_huff > 0
+
+
+def test_nonuniform_coordinates_roundtrip():
+    torch, mg, hl = _mods()
+    shape = (33, 50, 65)
+    u = smooth_field(shape, np.float64)
+    coords = nonuniform_coords(shape, np.float64)
+    buf = hl.compress(u, 1e-4, 0.0, mg.ABS, coords=coords)
+    m = hl.metadata_parse(bytes(buf))
+    assert not m["uniform"]
+    for got, ref in zip(m["coords"], coords):
+        assert np.array_equal(got, ref)
+    v = hl.decompress(buf)
+    # same integers as the low-level path on the same hierarchy => same reconstruction
+    h = mg.Hierarchy(shape, np.float64, coords=coords)
+    q, oi, ov, cnt, _ = h.decompose_quantize(torch.from_numpy(u).cuda(), mg.ABS, 1e-4, 0.0, norm=1.0)
+    w = h.dequantize_recompose(q, mg.ABS, 1e-4, 0.0, 1.0, outlier_idx=oi, outlier_val=ov).cpu().numpy()
+    assert np.array_equal(v, w)
+    h.close()
+
+
+def test_incompressible_subdomain_is_stored_raw():
+    torch, mg, hl = _mods()
+    rng = np.random.default_rng(1)
+    for shape in [(40, 41, 42), (5, 12, 13, 14)]:
+        u = rng.standard_normal(shape).astype(np.float32) * 1e6
+        buf = hl.compress(u, 1e-9, np.inf, mg.ABS)
+        m = hl.metadata_parse(bytes(buf))
+        recs = pl.split_container(buf, m["metadata_size"])
+        assert len(recs) == 1 and len(recs[0]) == u.nbytes      # GPUPipelines.hpp:136-155
+        assert np.array_equal(np.frombuffer(recs[0], np.float32).reshape(shape), u)
+        assert np.array_equal(hl.decompress(buf), u)
+
+
+def test_output_too_large_and_bad_arguments():
+    torch, mg, hl = _mods()
+    u = smooth_field((65, 65, 65), np.float32)
+    with pytest.raises(mg.MgardHipError, match="-7"):
+        hl.compress(u, 1e-6, np.inf, mg.REL, out_capacity=2000)
+    with pytest.raises(mg.MgardHipError):
+        hl.compress(u, 1e-3, np.inf, mg.REL, config=hl.Config(lossless=hl.HUFFMAN_LZ4))
+    with pytest.raises(mg.MgardHipError):
+        hl.compress(smooth_field((2, 65, 65), np.float32), 1e-3)
+    buf = hl.compress(u, 1e-3, np.inf, mg.REL)
+    bad = buf.copy()
+    bad[len(bad) // 2:] = 0
+    with pytest.raises(mg.MgardHipError):
+        hl.decompress(bad[:len(bad) - 40])
+    hl.release_cache()
+
+
+def test_matches_reference_error_semantics_at_benchmark_size():
+    """512^3 float32, REL 1e-3, s = inf, device-resident: end-to-end compress + decompress through
+    the container; the error bound holds and the stream is much smaller than the input."""
+    torch, mg, hl = _mods()
+    u = smooth_field((512, 512, 512), np.float32)
+    ud = torch.from_numpy(u).cuda()
+    buf = hl.compress(ud, 1e-3, np.inf, mg.REL)
+    assert buf.numel() < u.nbytes / 3     # (the 1e-3 noise of the synthetic field is incompressible)
+    v = hl.decompress(buf)
+    nrm = float(np.max(np.abs(u)))
+    assert float((v - ud).abs().max().item()) <= 1e-3 * nrm
