@@ -149,11 +149,41 @@ struct PayloadLayout {
 struct mgh_lossless_ctx {
   int dev = 0;
   DevBuf freq, code, bits, entry, total, units, tables, oidx, oval;
-  std::vector<uint8_t> host;   // serialized payload
+  std::vector<uint8_t> host;   // serialized payload (when assembled on the host)
   std::vector<uint8_t> host2;  // zstd scratch
+  // the record of the last compress call in pieces: everything before the code units sits in
+  // `head`, the units and the outlier lists are still on the device
+  std::vector<uint8_t> head;
+  PayloadLayout lay;
+  uint64_t n_units = 0, n_outliers = 0;
+  const uint64_t *d_oidx = nullptr;
+  const int64_t *d_oval = nullptr;
+  bool on_host = false;  // Huffman_Zstd: the whole record is in `host`
+  size_t record_size() const { return on_host ? host.size() : lay.total; }
 };
 
 namespace {
+
+// Copy the record of the last lossless_compress() to dst (host or device memory, record_size()
+// bytes). Asynchronous on st where the memory kinds allow it.
+int record_write(mgh_lossless_ctx *c, void *dst, hipStream_t st) {
+  char *d = (char *)dst;
+  if (c->on_host) {
+    HL_HIP(hipMemcpyAsync(d, c->host.data(), c->host.size(), hipMemcpyDefault, st));
+    return MGH_SUCCESS;
+  }
+  const PayloadLayout &L = c->lay;
+  HL_HIP(hipMemcpyAsync(d, c->head.data(), c->head.size(), hipMemcpyDefault, st));
+  if (c->n_units)
+    HL_HIP(hipMemcpyAsync(d + L.ddata, c->units.p, c->n_units * 8, hipMemcpyDefault, st));
+  // (the count travels from a member that outlives the asynchronous copy)
+  HL_HIP(hipMemcpyAsync(d + L.outlier_count, &c->n_outliers, 8, hipMemcpyDefault, st));
+  if (c->n_outliers) {
+    HL_HIP(hipMemcpyAsync(d + L.outlier_idx, c->d_oidx, c->n_outliers * 8, hipMemcpyDefault, st));
+    HL_HIP(hipMemcpyAsync(d + L.outliers, c->d_oval, c->n_outliers * 8, hipMemcpyDefault, st));
+  }
+  return MGH_SUCCESS;
+}
 
 int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint64_t dict,
                       uint64_t chunk, int lossless, int zstd_level, const uint64_t *d_oidx,
@@ -199,11 +229,12 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
                                                    (const unsigned long long *)c->entry.p,
                                                    (unsigned long long *)c->units.p);
   HL_HIP(hipGetLastError());
-  // ---- serialize (Huffman.hpp:163-239) ----
-  PayloadLayout L;
+  // ---- serialize (Huffman.hpp:163-239): the small leading part on the host, the code units
+  // and the outlier lists stay where they are until record_write() ----
+  PayloadLayout &L = c->lay;
   L.compute(nchunk, dict, units, ocount);
-  std::vector<uint8_t> &out = c->host;
-  out.assign(L.total, 0);
+  std::vector<uint8_t> &out = c->head;
+  out.assign(L.ddata, 0);
   auto put64 = [&](size_t off, uint64_t v) { std::memcpy(out.data() + off, &v, 8); };
   auto put32 = [&](size_t off, int32_t v) { std::memcpy(out.data() + off, &v, 4); };
   put64(L.primary_count, n);
@@ -218,85 +249,101 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
   std::memcpy(out.data() + L.decodebook + 8 * 64, cb.entry.data(), 8 * 64);
   std::memcpy(out.data() + L.decodebook + 8 * 128, cb.keys.data(), 8 * dict);
   put64(L.ddata_size, units);
-  if (units)
-    HL_HIP(hipMemcpyAsync(out.data() + L.ddata, c->units.p, units * 8, hipMemcpyDeviceToHost, st));
-  put64(L.outlier_count, ocount);
-  if (ocount) {
-    HL_HIP(hipMemcpyAsync(out.data() + L.outlier_idx, d_oidx, ocount * 8, hipMemcpyDeviceToHost, st));
-    HL_HIP(hipMemcpyAsync(out.data() + L.outliers, d_oval, ocount * 8, hipMemcpyDeviceToHost, st));
-  }
   HL_HIP(hipStreamSynchronize(st));
+  c->n_units = units;
+  c->n_outliers = ocount;
+  c->d_oidx = d_oidx;
+  c->d_oval = d_oval;
+  c->on_host = false;
   if (lossless == MGH_LOSSLESS_HUFFMAN_ZSTD) {
-    // [size_t input_count][zstd frame] (Zstd.hpp:69-90)
-    const size_t bound = g_zstd.compressBound(out.size());
-    c->host2.resize(bound + 8);
-    const size_t got = g_zstd.compress(c->host2.data() + 8, bound, out.data(), out.size(), zstd_level);
+    // [size_t input_count][zstd frame] (Zstd.hpp:69-90): needs the whole record on the host
+    std::vector<uint8_t> &full = c->host2;
+    full.resize(L.total);
+    HL_TRY(record_write(c, full.data(), st));
+    HL_HIP(hipStreamSynchronize(st));
+    const size_t bound = g_zstd.compressBound(full.size());
+    c->host.resize(bound + 8);
+    const size_t got = g_zstd.compress(c->host.data() + 8, bound, full.data(), full.size(), zstd_level);
     if (g_zstd.isError(got)) return hl_fail(MGH_ERR_DEVICE, "ZSTD_compress failed");
-    const uint64_t in_size = out.size();
-    std::memcpy(c->host2.data(), &in_size, 8);
-    c->host2.resize(got + 8);
-    c->host.swap(c->host2);
+    const uint64_t in_size = full.size();
+    std::memcpy(c->host.data(), &in_size, 8);
+    c->host.resize(got + 8);
+    c->on_host = true;
   }
   return MGH_SUCCESS;
 }
 
+// `payload` may be host or device memory: only the small leading part of the record is brought
+// to the host, the code units and outlier lists go device-to-device (or host-to-device).
 int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t size, int lossless,
                         int64_t *d_q, uint64_t n, uint64_t *ocount_out, hipStream_t st) {
   const uint8_t *p = payload;
   uint64_t psize = size;
+  bool on_dev = is_device_pointer(payload);
   if (lossless == MGH_LOSSLESS_HUFFMAN_ZSTD) {
     if (!g_zstd.load()) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "lossless: libzstd.so.1 not found");
     if (size < 8) return hl_fail(MGH_ERR_FORMAT, "zstd record truncated");
+    const uint8_t *src = payload;
+    if (on_dev) {
+      c->host.resize(size);
+      HL_HIP(hipMemcpy(c->host.data(), payload, size, hipMemcpyDeviceToHost));
+      src = c->host.data();
+    }
     uint64_t raw = 0;
-    std::memcpy(&raw, payload, 8);
+    std::memcpy(&raw, src, 8);
     if (raw > ((uint64_t)1 << 40)) return hl_fail(MGH_ERR_FORMAT, "zstd record: implausible size");
     c->host2.resize(raw);
-    const size_t got = g_zstd.decompress(c->host2.data(), raw, payload + 8, size - 8);
+    const size_t got = g_zstd.decompress(c->host2.data(), raw, src + 8, size - 8);
     if (g_zstd.isError(got) || got != raw) return hl_fail(MGH_ERR_FORMAT, "ZSTD_decompress failed");
     p = c->host2.data();
     psize = raw;
+    on_dev = false;
   } else if (lossless != MGH_LOSSLESS_HUFFMAN) {
     return hl_fail(MGH_ERR_INVALID_ARGUMENT, "lossless: only Huffman and Huffman_Zstd are supported");
   }
-  auto need = [&](size_t off, size_t bytes) { return off + bytes <= psize; };
+  // host copy of bytes [off, off + bytes) of the record
+  std::vector<uint8_t> &head = c->head;
+  auto need = [&](size_t off, size_t bytes) { return off <= psize && bytes <= psize - off; };
+  auto fetch = [&](size_t upto) -> int {  // make head cover [0, upto)
+    if (head.size() >= upto) return MGH_SUCCESS;
+    const size_t have = head.size();
+    head.resize(upto);
+    if (on_dev) HL_HIP(hipMemcpy(head.data() + have, p + have, upto - have, hipMemcpyDeviceToHost));
+    else std::memcpy(head.data() + have, p + have, upto - have);
+    return MGH_SUCCESS;
+  };
+  head.clear();
   if (!need(0, 24)) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
+  HL_TRY(fetch(24));
   uint64_t primary = 0, huffmeta_size = 0;
   int32_t dict = 0, chunk = 0;
-  std::memcpy(&primary, p, 8);
-  std::memcpy(&dict, p + 8, 4);
-  std::memcpy(&chunk, p + 12, 4);
-  std::memcpy(&huffmeta_size, p + 16, 8);
-  if (primary != n || dict <= 0 || chunk <= 0 || huffmeta_size != 2 * ((n - 1) / (uint64_t)chunk + 1))
+  std::memcpy(&primary, head.data(), 8);
+  std::memcpy(&dict, head.data() + 8, 4);
+  std::memcpy(&chunk, head.data() + 12, 4);
+  std::memcpy(&huffmeta_size, head.data() + 16, 8);
+  if (primary != n || dict <= 0 || dict > 16384 || chunk <= 0 ||
+      huffmeta_size != 2 * ((n - 1) / (uint64_t)chunk + 1))
     return hl_fail(MGH_ERR_FORMAT, "Huffman record: header does not match the subdomain");
   const size_t nchunk = huffmeta_size / 2;
-  size_t off = 24;
-  const size_t o_meta = off;
-  off += 8 * huffmeta_size;
-  if (!need(off, 8)) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
-  uint64_t dbsize = 0;
-  std::memcpy(&dbsize, p + off, 8);
-  off += 8;
+  PayloadLayout L;
+  L.compute(nchunk, (size_t)dict, 0, 0);
+  if (!need(0, L.ddata)) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
+  HL_TRY(fetch(L.ddata));
+  uint64_t dbsize = 0, units = 0;
+  std::memcpy(&dbsize, head.data() + L.decodebook_size, 8);
   if (dbsize != 8 * 128 + 8 * (uint64_t)dict) return hl_fail(MGH_ERR_FORMAT, "Huffman record: decodebook size");
-  const size_t o_db = off;
-  off += dbsize;
-  off = align_up(off, 8);
-  if (!need(off, 8)) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
-  uint64_t units = 0;
-  std::memcpy(&units, p + off, 8);
-  off += 8;
-  off = align_up(off, 8);
-  const size_t o_data = off;
-  if (units > (psize - off) / 8) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
-  off += 8 * units;
-  if (!need(off, 8)) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
+  std::memcpy(&units, head.data() + L.ddata_size, 8);
+  if (units > (psize - L.ddata) / 8) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
+  const size_t o_oc = L.ddata + 8 * units;
+  if (!need(o_oc, 8)) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
   uint64_t ocount = 0;
-  std::memcpy(&ocount, p + off, 8);
-  off += 8;
-  if (ocount > (psize - off) / 16) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
-  const size_t o_oidx = off, o_oval = off + 8 * ocount;
+  if (on_dev) HL_HIP(hipMemcpy(&ocount, p + o_oc, 8, hipMemcpyDeviceToHost));
+  else std::memcpy(&ocount, p + o_oc, 8);
+  if (ocount > (psize - o_oc - 8) / 16) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
+  const size_t o_oidx = o_oc + 8, o_oval = o_oidx + 8 * ocount;
   // the chunk entries must stay inside the unit array (they index it in the decoder)
   {
-    const uint64_t *bits = reinterpret_cast<const uint64_t *>(p + o_meta);
+    const uint64_t *bits = reinterpret_cast<const uint64_t *>(head.data() + L.huffmeta);
     const uint64_t *ent = bits + nchunk;
     for (size_t k = 0; k < nchunk; k++)
       if (ent[k] > units || (bits[k] + 63) / 64 > units - ent[k])
@@ -305,21 +352,22 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
   HL_TRY(c->bits.ensure(nchunk * 8));
   HL_TRY(c->entry.ensure(nchunk * 8));
   HL_TRY(c->tables.ensure(dbsize));
-  HL_TRY(c->units.ensure(std::max<size_t>(units, 1) * 8));
+  HL_TRY(c->units.ensure((units + 1) * 8));
   HL_TRY(c->oidx.ensure(std::max<size_t>(ocount, 1) * 8));
   HL_TRY(c->oval.ensure(std::max<size_t>(ocount, 1) * 8));
-  HL_HIP(hipMemcpyAsync(c->bits.p, p + o_meta, nchunk * 8, hipMemcpyHostToDevice, st));
-  HL_HIP(hipMemcpyAsync(c->entry.p, p + o_meta + nchunk * 8, nchunk * 8, hipMemcpyHostToDevice, st));
-  HL_HIP(hipMemcpyAsync(c->tables.p, p + o_db, dbsize, hipMemcpyHostToDevice, st));
-  if (units) HL_HIP(hipMemcpyAsync(c->units.p, p + o_data, units * 8, hipMemcpyHostToDevice, st));
+  HL_HIP(hipMemcpyAsync(c->bits.p, head.data() + L.huffmeta, nchunk * 8, hipMemcpyHostToDevice, st));
+  HL_HIP(hipMemcpyAsync(c->entry.p, head.data() + L.huffmeta + nchunk * 8, nchunk * 8, hipMemcpyHostToDevice, st));
+  HL_HIP(hipMemcpyAsync(c->tables.p, head.data() + L.decodebook, dbsize, hipMemcpyHostToDevice, st));
+  if (units) HL_HIP(hipMemcpyAsync(c->units.p, p + L.ddata, units * 8, hipMemcpyDefault, st));
+  HL_HIP(hipMemsetAsync((char *)c->units.p + units * 8, 0, 8, st));  // (the decoder peeks one unit ahead)
   if (ocount) {
-    HL_HIP(hipMemcpyAsync(c->oidx.p, p + o_oidx, ocount * 8, hipMemcpyHostToDevice, st));
-    HL_HIP(hipMemcpyAsync(c->oval.p, p + o_oval, ocount * 8, hipMemcpyHostToDevice, st));
+    HL_HIP(hipMemcpyAsync(c->oidx.p, p + o_oidx, ocount * 8, hipMemcpyDefault, st));
+    HL_HIP(hipMemcpyAsync(c->oval.p, p + o_oval, ocount * 8, hipMemcpyDefault, st));
   }
   const unsigned long long *tab = (const unsigned long long *)c->tables.p;
   huff::k_decode<<<(unsigned)((nchunk + 63) / 64), 64, 0, st>>>(
       (const unsigned long long *)c->units.p, (const unsigned long long *)c->bits.p,
-      (const unsigned long long *)c->entry.p, nchunk, chunk, n, tab, tab + 64, tab + 128, d_q);
+      (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, tab, tab + 64, tab + 128, d_q);
   HL_HIP(hipGetLastError());
   // the host payload may go away when we return
   HL_HIP(hipStreamSynchronize(st));
@@ -795,8 +843,7 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
                              (const uint64_t *)g_cache.oidx.p, (const int64_t *)g_cache.oval.p, ocount, st);
     if (owned) mgh_hierarchy_destroy(h);
     if (rc != MGH_SUCCESS) return cleanup(rc);
-    const std::vector<uint8_t> &payload = g_cache.ll->host;
-    uint64_t csize = payload.size();
+    uint64_t csize = g_cache.ll->record_size();
     const bool raw = (double)(n * elem) / (double)csize < 1.0;  // GPUPipelines.hpp:136-155
     if (raw) csize = n * elem;
     if (csize > cap - byte_offset || cap - byte_offset - csize < 8)
@@ -813,10 +860,8 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
         // the dense subdomain itself (re-fetched: decompose_quantize does not modify its input,
         // so the buffer still holds it)
         rc = hipMemcpyAsync(dst, g_cache.in[buf].p, csize, hipMemcpyDefault, st) == hipSuccess ? MGH_SUCCESS : MGH_ERR_DEVICE;
-      } else if (out_dev) {
-        rc = hipMemcpyAsync(dst, payload.data(), csize, hipMemcpyHostToDevice, st) == hipSuccess ? MGH_SUCCESS : MGH_ERR_DEVICE;
       } else {
-        std::memcpy(dst, payload.data(), csize);
+        rc = record_write(g_cache.ll, dst, st);
       }
     }
     if (rc == MGH_SUCCESS && hipStreamSynchronize(st) != hipSuccess) rc = MGH_ERR_DEVICE;
@@ -948,7 +993,6 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
   const std::vector<std::vector<double>> *cptr = hd.uniform ? nullptr : &hd.coords;
   size_t byte_offset = meta_size;
   hipStream_t st = g_cache.streams[0];
-  std::vector<uint8_t> hostbuf;
   for (uint64_t id = 0; id < dd.num; id++) {
     if (csize_total - byte_offset < 8) return cleanup(hl_fail(MGH_ERR_FORMAT, "subdomain record truncated"));
     std::vector<uint8_t> sz;
@@ -962,15 +1006,7 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
     for (uint64_t e : sshape) n *= e;
     const char *rec = (const char *)compressed + byte_offset;
     if ((double)(n * elem) / (double)csize > 1.0) {  // GPUPipelines.hpp:414-417
-      const uint8_t *payload;
-      if (in_dev) {
-        hostbuf.resize(csize);
-        if (hipMemcpy(hostbuf.data(), rec, csize, hipMemcpyDeviceToHost) != hipSuccess)
-          return cleanup(hl_fail(MGH_ERR_DEVICE, "reading the subdomain record"));
-        payload = hostbuf.data();
-      } else {
-        payload = (const uint8_t *)rec;
-      }
+      const uint8_t *payload = (const uint8_t *)rec;
       uint64_t ocount = 0;
       rc = lossless_decompress(g_cache.ll, payload, csize, lossless, (int64_t *)g_cache.q.p, n, &ocount, st);
       if (rc != MGH_SUCCESS) return cleanup(rc);
@@ -1242,6 +1278,11 @@ int mgh_lossless_compress(mgh_lossless_ctx *ctx, const int64_t *d_q, uint64_t n,
                              (hipStream_t)stream));
   } catch (const std::exception &e) {
     return hl_fail(MGH_ERR_DEVICE, e.what());
+  }
+  if (!ctx->on_host) {
+    ctx->host.resize(ctx->lay.total);
+    HL_TRY(record_write(ctx, ctx->host.data(), (hipStream_t)stream));
+    HL_HIP(hipStreamSynchronize((hipStream_t)stream));
   }
   *payload_out = ctx->host.data();
   *size_out = ctx->host.size();

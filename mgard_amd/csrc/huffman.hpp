@@ -252,15 +252,43 @@ k_encode(const int64_t *__restrict__ q, size_t n, int chunk, const uint64_t *__r
   if (room != kUnitBits) flush(true);
 }
 
-// Canonical decoding, one lane per chunk (Decode.hpp:52-106 semantics).
+// Canonical decoding, one lane per chunk (the chunks are the only entry points of the stream);
+// semantics of Decode.hpp:52-106: a code of length l is recognised by v >= first[l] and stands
+// for keys[entry[l] + v - first[l]]. Codes of up to kTableBits bits are resolved with one
+// lookup in a prefix table the workgroup builds in LDS from first / entry / keys (lengths with
+// first = 2^64-1 are unused, the number of codes of a length is entry[l+1] - entry[l]); longer
+// codes continue bit by bit from the same 64-bit window. `units` must be readable one element
+// past the stream (the window peeks ahead).
+constexpr int kTableBits = 12;
+
 __global__ void __launch_bounds__(64)
 k_decode(const unsigned long long *__restrict__ units, const unsigned long long *__restrict__ bits,
          const unsigned long long *__restrict__ entry_of_chunk, size_t nchunk, int chunk, size_t n,
-         const unsigned long long *__restrict__ first, const unsigned long long *__restrict__ entry,
-         const unsigned long long *__restrict__ keys, int64_t *__restrict__ q) {
+         int dict, const unsigned long long *__restrict__ first,
+         const unsigned long long *__restrict__ entry, const unsigned long long *__restrict__ keys,
+         int64_t *__restrict__ q) {
   __shared__ unsigned long long sfirst[64], sentry[64];
+  __shared__ unsigned table[1 << kTableBits];  // (length << 16) | symbol, 0 = longer code
   sfirst[threadIdx.x] = first[threadIdx.x];
   sentry[threadIdx.x] = entry[threadIdx.x];
+  for (int i = threadIdx.x; i < (1 << kTableBits); i += 64) table[i] = 0;
+  __syncthreads();
+  for (int l = 1; l <= kTableBits; l++) {
+    if (sfirst[l] == ~0ull) continue;
+    if (sentry[l] >= (unsigned long long)dict) continue;
+    unsigned long long cnt = (l + 1 < 64 ? sentry[l + 1] : (unsigned long long)dict) - sentry[l];
+    cnt = min(cnt, (unsigned long long)dict - sentry[l]);  // (damaged tables must not spin here)
+    cnt = min(cnt, 1ull << l);
+    const int span = 1 << (kTableBits - l);
+    // codes first[l] .. first[l] + cnt - 1, each covering `span` table slots
+    for (unsigned long long j = threadIdx.x; j < cnt * span; j += 64) {
+      const unsigned long long code = sfirst[l] + j / span;
+      const unsigned long long slot = (code << (kTableBits - l)) + j % span;
+      const unsigned long long k = sentry[l] + j / span;
+      if (slot < (1u << kTableBits) && k < (unsigned long long)dict)
+        table[slot] = ((unsigned)l << 16) | (unsigned)(keys[k] & 0xffff);
+    }
+  }
   __syncthreads();
   const size_t c = (size_t)blockIdx.x * 64 + threadIdx.x;
   if (c >= nchunk) return;
@@ -268,24 +296,41 @@ k_decode(const unsigned long long *__restrict__ units, const unsigned long long 
   const unsigned long long total = bits[c];
   int64_t *dst = q + c * (size_t)chunk;
   const size_t cap = min((size_t)chunk, n - c * (size_t)chunk);
-  unsigned long long cur = 0, i = 0;
+  unsigned long long i = 0, cw = 0;
+  unsigned long long cur = total ? src[0] : 0, nxt = total ? src[1] : 0;
   size_t produced = 0;
   while (i < total && produced < cap) {
-    unsigned long long v = 0;
-    int l = 0;
-    bool hit = false;
-    while (i < total && l < 63) {
-      if ((i & 63) == 0) cur = src[i >> 6];
-      v = (v << 1) | ((cur >> (63 - (i & 63))) & 1ull);
-      i++;
-      l++;
-      if (v >= sfirst[l]) {
-        hit = true;
-        break;
+    const int sh = (int)(i & 63);
+    const unsigned long long win = sh ? (cur << sh) | (nxt >> (64 - sh)) : cur;
+    const unsigned e = table[win >> (64 - kTableBits)];
+    int l;
+    unsigned long long sym;
+    if (e) {
+      l = (int)(e >> 16);
+      sym = e & 0xffff;
+    } else {
+      bool hit = false;
+      for (l = kTableBits + 1; l <= 56; l++) {
+        const unsigned long long v = win >> (64 - l);
+        if (v >= sfirst[l]) {
+          const unsigned long long k = sentry[l] + v - sfirst[l];
+          if (k < (unsigned long long)dict) {
+            sym = keys[k];
+            hit = true;
+          }
+          break;
+        }
       }
+      if (!hit) break;  // corrupt stream: stop instead of indexing out of range
     }
-    if (!hit) break;  // truncated / corrupt stream: stop instead of indexing out of range
-    dst[produced++] = (int64_t)keys[sentry[l] + v - sfirst[l]];
+    if (i + l > total) break;
+    dst[produced++] = (int64_t)sym;
+    i += l;
+    if ((i >> 6) != cw) {
+      cw++;
+      cur = nxt;
+      nxt = src[cw + 1];
+    }
   }
 }
 
