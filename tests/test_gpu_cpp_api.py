@@ -10,14 +10,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_cpp_lowlevel_roundtrip(tmp_path):
+@pytest.mark.parametrize("prog", ["lowlevel_roundtrip", "highlevel_roundtrip"])
+def test_cpp_roundtrip(tmp_path, prog):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    exe = str(tmp_path / "lowlevel_roundtrip")
+    exe = str(tmp_path / prog)
     lib = os.path.join(ROOT, "mgard_amd", "libmgard_hip.so")
     assert os.path.exists(lib), "libmgard_hip.so is not built"
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17",
                            "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "cpp", "lowlevel_roundtrip.cpp"),
+                           os.path.join(ROOT, "tests", "cpp", prog + ".cpp"),
                            "-L", os.path.dirname(lib), "-lmgard_hip",
                            "-Wl,-rpath," + os.path.dirname(lib), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
@@ -27,7 +28,8 @@ def test_cpp_lowlevel_roundtrip(tmp_path):
 
 def test_cpp_header_compiles_on_host():
     """No GPU needed: the header-only mirror must compile as plain C++17 against the C ABI."""
-    src = '#include "mgard_hip.hpp"\nint main() { mgard_hip::Config c; return c.dev_id; }\n'
+    src = ('#include "mgard_hip.hpp"\n#include "compress_hip.hpp"\n'
+           'int main() { mgard_hip::HighLevelConfig c; return c.dev_id; }\n')
     p = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
                         "-x", "c++", "-"], input=src, text=True, capture_output=True)
     assert p.returncode == 0, p.stderr
