@@ -365,9 +365,20 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
     HL_HIP(hipMemcpyAsync(c->oval.p, p + o_oval, ocount * 8, hipMemcpyDefault, st));
   }
   const unsigned long long *tab = (const unsigned long long *)c->tables.p;
-  huff::k_decode<<<(unsigned)((nchunk + 63) / 64), 64, 0, st>>>(
+  // prefix table as large as LDS allows next to the 16-bit keys (15 bits for dict = 8192)
+  int tb = 15;
+  const size_t lds_keys_ring = ((size_t)dict * 2 + 7) / 8 * 8 + 16 * 64 * 8;
+  while (tb > 8 && ((size_t)4 << tb) + lds_keys_ring > 154 * 1024) tb--;
+  const size_t lds = ((size_t)4 << tb) + lds_keys_ring;
+  static bool once = false;
+  if (!once) {
+    HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_decode),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    once = true;
+  }
+  huff::k_decode<<<(unsigned)((nchunk + 63) / 64), 64, lds, st>>>(
       (const unsigned long long *)c->units.p, (const unsigned long long *)c->bits.p,
-      (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, tab, tab + 64, tab + 128, d_q);
+      (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, tb, tab, tab + 64, tab + 128, d_q);
   HL_HIP(hipGetLastError());
   // the host payload may go away when we return
   HL_HIP(hipStreamSynchronize(st));

@@ -254,82 +254,121 @@ k_encode(const int64_t *__restrict__ q, size_t n, int chunk, const uint64_t *__r
 
 // Canonical decoding, one lane per chunk (the chunks are the only entry points of the stream);
 // semantics of Decode.hpp:52-106: a code of length l is recognised by v >= first[l] and stands
-// for keys[entry[l] + v - first[l]]. Codes of up to kTableBits bits are resolved with one
+// for keys[entry[l] + v - first[l]]. Codes of up to `tb` bits are resolved with one
 // lookup in a prefix table the workgroup builds in LDS from first / entry / keys (lengths with
 // first = 2^64-1 are unused, the number of codes of a length is entry[l+1] - entry[l]); longer
 // codes continue bit by bit from the same 64-bit window. `units` must be readable one element
 // past the stream (the window peeks ahead).
-constexpr int kTableBits = 12;
-
+// The table has 2^tb entries (tb chosen by the host so that table + keys fit in LDS: 15 bits
+// for the default dictionary); dynamic LDS = 4 * 2^tb + 2 * dict (rounded up to 8) + 8 KiB.
 __global__ void __launch_bounds__(64)
 k_decode(const unsigned long long *__restrict__ units, const unsigned long long *__restrict__ bits,
          const unsigned long long *__restrict__ entry_of_chunk, size_t nchunk, int chunk, size_t n,
-         int dict, const unsigned long long *__restrict__ first,
+         int dict, int tb, const unsigned long long *__restrict__ first,
          const unsigned long long *__restrict__ entry, const unsigned long long *__restrict__ keys,
          int64_t *__restrict__ q) {
   __shared__ unsigned long long sfirst[64], sentry[64];
-  __shared__ unsigned table[1 << kTableBits];  // (length << 16) | symbol, 0 = longer code
+  extern __shared__ unsigned dyn_lds[];
+  unsigned *table = dyn_lds;  // (length << 16) | symbol, 0 = longer code
+  unsigned short *skeys = reinterpret_cast<unsigned short *>(dyn_lds + (1u << tb));  // [dict]
+  // [16][64] staged code units, behind the keys (8-byte aligned)
+  unsigned long long *ring = reinterpret_cast<unsigned long long *>(
+      dyn_lds + (1u << tb) + (((unsigned)dict * 2 + 7) / 8) * 2);
   sfirst[threadIdx.x] = first[threadIdx.x];
   sentry[threadIdx.x] = entry[threadIdx.x];
-  for (int i = threadIdx.x; i < (1 << kTableBits); i += 64) table[i] = 0;
+  for (unsigned i = threadIdx.x; i < (1u << tb); i += 64) table[i] = 0;
+  for (int i = threadIdx.x; i < dict; i += 64) skeys[i] = (unsigned short)keys[i];
   __syncthreads();
-  for (int l = 1; l <= kTableBits; l++) {
+  for (int l = 1; l <= tb; l++) {
     if (sfirst[l] == ~0ull) continue;
     if (sentry[l] >= (unsigned long long)dict) continue;
     unsigned long long cnt = (l + 1 < 64 ? sentry[l + 1] : (unsigned long long)dict) - sentry[l];
     cnt = min(cnt, (unsigned long long)dict - sentry[l]);  // (damaged tables must not spin here)
     cnt = min(cnt, 1ull << l);
-    const int span = 1 << (kTableBits - l);
+    const unsigned span = 1u << (tb - l);
     // codes first[l] .. first[l] + cnt - 1, each covering `span` table slots
     for (unsigned long long j = threadIdx.x; j < cnt * span; j += 64) {
       const unsigned long long code = sfirst[l] + j / span;
-      const unsigned long long slot = (code << (kTableBits - l)) + j % span;
+      const unsigned long long slot = (code << (tb - l)) + j % span;
       const unsigned long long k = sentry[l] + j / span;
-      if (slot < (1u << kTableBits) && k < (unsigned long long)dict)
-        table[slot] = ((unsigned)l << 16) | (unsigned)(keys[k] & 0xffff);
+      if (slot < (1ull << tb) && k < (unsigned long long)dict)
+        table[slot] = ((unsigned)l << 16) | (unsigned)skeys[k];
     }
   }
   __syncthreads();
-  const size_t c = (size_t)blockIdx.x * 64 + threadIdx.x;
-  if (c >= nchunk) return;
+  const size_t c0 = (size_t)blockIdx.x * 64 + threadIdx.x;
+  const bool have = c0 < nchunk;  // (idle lanes stay in the loop: it uses wave votes)
+  const size_t c = have ? c0 : nchunk - 1;
   const unsigned long long *src = units + entry_of_chunk[c];
-  const unsigned long long total = bits[c];
+  const unsigned long long total = have ? bits[c] : 0;
   int64_t *dst = q + c * (size_t)chunk;
   const size_t cap = min((size_t)chunk, n - c * (size_t)chunk);
+  const unsigned long long nun = (total + 63) / 64;  // (src[nun] exists: the stream is padded)
+  // Code units reach the lanes through a per-lane ring in LDS that ALL lanes top up together,
+  // kRing loads in flight each: a wave waits for its youngest outstanding load, and nearly every
+  // iteration some lane crosses a unit boundary, so a load per crossing would stall the wave
+  // every iteration (measured: 0.7 us per symbol step).
+  constexpr int kRing = 16;
+  const int lane = threadIdx.x;
+  unsigned long long filled = 0;  // units [0, filled) of this lane's stream have been staged
+  auto refill = [&](unsigned long long cw) {
+    unsigned long long tmp[kRing];
+#pragma unroll
+    for (int k = 0; k < kRing; k++) {
+      const unsigned long long idx = filled + k;
+      tmp[k] = (idx < cw + kRing && idx <= nun) ? src[idx] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kRing; k++) {
+      const unsigned long long idx = filled + k;
+      if (idx < cw + kRing && idx <= nun) ring[(idx % kRing) * 64 + lane] = tmp[k];
+    }
+    filled = min(cw + kRing, nun + 1);
+  };
   unsigned long long i = 0, cw = 0;
-  unsigned long long cur = total ? src[0] : 0, nxt = total ? src[1] : 0;
+  refill(0);
+  unsigned long long cur = ring[lane], nxt = ring[64 + lane];
   size_t produced = 0;
-  while (i < total && produced < cap) {
-    const int sh = (int)(i & 63);
-    const unsigned long long win = sh ? (cur << sh) | (nxt >> (64 - sh)) : cur;
-    const unsigned e = table[win >> (64 - kTableBits)];
-    int l;
-    unsigned long long sym;
-    if (e) {
-      l = (int)(e >> 16);
-      sym = e & 0xffff;
-    } else {
-      bool hit = false;
-      for (l = kTableBits + 1; l <= 56; l++) {
-        const unsigned long long v = win >> (64 - l);
-        if (v >= sfirst[l]) {
-          const unsigned long long k = sentry[l] + v - sfirst[l];
-          if (k < (unsigned long long)dict) {
-            sym = keys[k];
-            hit = true;
+  bool live = total > 0;
+  while (__any(live)) {
+    // invariant at the top: units cw .. cw+2 are staged (one crossing can happen below)
+    if (__any(live && cw + 2 >= filled && filled <= nun)) refill(cw);
+    if (live) {
+      const int sh = (int)(i & 63);
+      const unsigned long long win = sh ? (cur << sh) | (nxt >> (64 - sh)) : cur;
+      const unsigned e = table[win >> (64 - tb)];
+      int l = 0;
+      unsigned long long sym = 0;
+      bool hit = e != 0;
+      if (hit) {
+        l = (int)(e >> 16);
+        sym = e & 0xffff;
+      } else {
+        for (l = tb + 1; l <= 56; l++) {
+          const unsigned long long v = win >> (64 - l);
+          if (v >= sfirst[l]) {
+            const unsigned long long k = sentry[l] + v - sfirst[l];
+            if (k < (unsigned long long)dict) {
+              sym = skeys[k];
+              hit = true;
+            }
+            break;
           }
-          break;
         }
       }
-      if (!hit) break;  // corrupt stream: stop instead of indexing out of range
-    }
-    if (i + l > total) break;
-    dst[produced++] = (int64_t)sym;
-    i += l;
-    if ((i >> 6) != cw) {
-      cw++;
-      cur = nxt;
-      nxt = src[cw + 1];
+      // (a miss or an overrun means a corrupt stream: stop instead of indexing out of range)
+      if (!hit || i + l > total) {
+        live = false;
+      } else {
+        dst[produced++] = (int64_t)sym;
+        i += l;
+        if ((i >> 6) != cw) {
+          cw++;
+          cur = nxt;
+          nxt = ring[((cw + 1) % kRing) * 64 + lane];
+        }
+        live = i < total && produced < cap;
+      }
     }
   }
 }
