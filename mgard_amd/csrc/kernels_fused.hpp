@@ -145,14 +145,13 @@ __device__ __forceinline__ void emit_quantized(const FusedArgs<T> &A, const T (&
 // on the small levels, where a block's march is pure latency; on the big levels occupancy
 // matters more (PAIR = false).
 template <typename T, int OUT, int TC, int TF, int RCH, bool PAIR>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(TC * TF)
 k_level_fused(FusedArgs<T> A) {
   constexpr int WC = 2 * TC + 3;
   constexpr int WF = 2 * TF + 3;
   constexpr int HF = TF + 2;     // even-f slots of a window row (odd-f slots: TF + 1)
   constexpr int ROW = 2 * HF;    // LDS row: [0,HF) even f, [HF, HF+TF+1) odd f (stride-1 access)
-  constexpr int NT = 256;
-  static_assert(TC * TF == NT, "one owned cell / one c-sweep output per thread");
+  constexpr int NT = TC * TF;  // one owned cell / one c-sweep output per thread
   constexpr int NH = (TC + 2) * (TF + 2) - TC * TF;  // halo cells
   static_assert(NH <= NT, "halo cells are handled in one extra pass");
   __shared__ T raw[3][WC * ROW];

@@ -260,3 +260,35 @@ def test_matches_reference_error_semantics_at_benchmark_size():
     v = hl.decompress(buf)
     nrm = float(np.max(np.abs(u)))
     assert float((v - ud).abs().max().item()) <= 1e-3 * nrm
+
+
+def test_decompress_survives_random_damage():
+    """Bit flips anywhere in a valid stream (header, chunk tables, decodebook, code units, outlier
+    lists, record sizes): mgh_decompress either reports an error or returns an array -- it never
+    crashes, hangs or reads outside its buffers."""
+    torch, mg, hl = _mods()
+    u = smooth_field((40, 50, 66), np.float32)
+    cfg = hl.Config(huff_dict_size=1024, huff_block_size=1024, domain_decomposition=hl.DD_BLOCK,
+                    block_size=33)
+    good = hl.compress(u, 1e-2, np.inf, mg.REL, config=cfg)
+    assert _err(u, hl.decompress(good, config=cfg), np.inf, u.shape) <= 1e-2 * float(np.max(np.abs(u))) * 1.000001
+    rng = np.random.default_rng(11)
+    outcomes = {"error": 0, "array": 0}
+    for trial in range(60):
+        bad = good.copy()
+        if trial % 3 == 0:      # damage the structured front part of a record
+            m = hl.metadata_parse(bytes(good))
+            pos = m["metadata_size"] + int(rng.integers(0, 9000))
+        else:
+            pos = int(rng.integers(0, bad.size))
+        bad[pos % bad.size] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        if trial % 10 == 9:
+            bad = bad[:int(rng.integers(20, bad.size))]
+        try:
+            v = hl.decompress(bad, config=cfg)
+            assert v.shape == u.shape
+            outcomes["array"] += 1
+        except mg.MgardHipError:
+            outcomes["error"] += 1
+    assert outcomes["error"] > 0 and outcomes["array"] > 0
+    hl.release_cache()

@@ -20,3 +20,7 @@ tc, buf = t(lambda: hl.compress(u, 1e-3, np.inf, mg.REL), 2)
 td, v = t(lambda: hl.decompress(buf), 2)
 print("huffman       host  : compress %.1f ms (%.2f GB/s)  decompress %.1f ms (%.2f GB/s)" % (
     tc * 1e3, u.nbytes / tc / 1e9, td * 1e3, u.nbytes / td / 1e9))
+for pin in (1, 0):
+    cfg = hl.Config(auto_pin_host_buffers=pin)
+    tc, buf = t(lambda: hl.compress(u, 1e-3, np.inf, mg.REL, config=cfg), 2)
+    print("host compress, auto_pin_host_buffers=%d: %.1f ms" % (pin, tc * 1e3))
