@@ -108,6 +108,11 @@ template <typename T> struct DeviceState {
   T *scratch_full = nullptr;       // lazily allocated full-size copy
   T *qz = nullptr;                 // 2*(L+1): quantizers, volumes
   unsigned long long *scalar = nullptr;  // 8-byte device scalar (norm / counters)
+  // fused device-norm path: fscal[slot] is zero on entry, the other slot is zeroed by
+  // k_make_qparams for the next call; `fscal_dirty` marks a call that died in between
+  unsigned long long *fscal = nullptr;
+  int scalar_slot = 0;
+  bool fscal_dirty = false;
   T *normval = nullptr;                  // norm as T, written by k_make_qparams
   QuantMeta qmeta;
   size_t full_I = 0, full_J = 0;   // strides of the full array in the 3-D view
@@ -200,6 +205,8 @@ template <typename T> int build_device_state(mgh_hierarchy *h) {
     HIP_TRY(hipMemcpy(ds->marks, marks.data(), marks.size() * sizeof(int), hipMemcpyHostToDevice));
     TRY(dev_alloc(h, &ds->qz, (size_t)2 * (L + 1)));
     TRY(dev_alloc(h, &ds->scalar, (size_t)2));
+    TRY(dev_alloc(h, &ds->fscal, (size_t)2));
+    HIP_TRY(hipMemset(ds->fscal, 0, 16));
     TRY(dev_alloc(h, &ds->normval, (size_t)2));
     return MGH_SUCCESS;
   }
@@ -281,6 +288,8 @@ template <typename T> int build_device_state(mgh_hierarchy *h) {
   }
   TRY(dev_alloc(h, &ds->qz, (size_t)2 * (L + 1)));
   TRY(dev_alloc(h, &ds->scalar, (size_t)2));
+  TRY(dev_alloc(h, &ds->fscal, (size_t)2));
+  HIP_TRY(hipMemset(ds->fscal, 0, 16));
   TRY(dev_alloc(h, &ds->normval, (size_t)2));
   ds->full_J = hh->shape[D - 1];
   ds->full_I = (D >= 2 ? hh->shape[D - 2] : 1) * ds->full_J;
@@ -302,6 +311,7 @@ template <typename T> void destroy_state(mgh_hierarchy *h) {
     (void)hipFree(ds->nd_b);
     (void)hipFree(ds->qz);
     (void)hipFree(ds->scalar);
+    (void)hipFree(ds->fscal);
     (void)hipFree(ds->normval);
     delete ds;
   }
@@ -568,7 +578,7 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
     const bool split = OUT == OUT_Q && level_is_split<T>(h, l);
     if (split) {
       TRY(ensure_side_stream(h));
-      A.absmax_bits = (l == L && norm_in_first) ? ds->scalar : nullptr;
+      A.absmax_bits = (l == L && norm_in_first) ? ds->fscal + ds->scalar_slot : nullptr;
       if (cls == 2) {
         const dim3 grid(gx, gy, (b.m[0] + 15) / 16);
         TRY(launch(h, "level_load", s, [&] {
@@ -1063,12 +1073,12 @@ template <typename T> int norm_launch(mgh_hierarchy *h, const T *data, double s,
 
 // Quantizer table on the device from a device-resident norm (no host round trip).
 template <typename T>
-int make_qparams_launch(mgh_hierarchy *h, const T *d_norm, int ebtype, double tol, double s,
-                        int decomposed, uint64_t nsub, hipStream_t st) {
+int fill_qparam_args(mgh_hierarchy *h, const T *d_norm, int ebtype, double tol, double s,
+                     int decomposed, uint64_t nsub, uint64_t *reset_count, QParamArgs<T> &P) {
   auto *ds = DS<T>(h);
   auto *hh = HH<T>(h);
   if (h->L + 1 > kMaxLevels) return fail(MGH_ERR_INVALID_ARGUMENT, "too many levels");
-  QParamArgs<T> P{};
+  P = QParamArgs<T>{};
   P.d_norm = d_norm;
   P.scalar = ds->scalar;
   P.s_is_inf = ((T)s == std::numeric_limits<T>::infinity()) ? 1 : 0;
@@ -1083,6 +1093,15 @@ int make_qparams_launch(mgh_hierarchy *h, const T *d_norm, int ebtype, double to
   for (int l = 0; l <= h->L; l++) P.vol[l] = P.s_is_inf ? (T)1 : hh->level_volume(l, false);
   P.qp = ds->qz;
   P.norm_out = ds->normval;
+  P.reset_count = (unsigned long long *)reset_count;
+  return MGH_SUCCESS;
+}
+
+template <typename T>
+int make_qparams_launch(mgh_hierarchy *h, const T *d_norm, int ebtype, double tol, double s,
+                        int decomposed, uint64_t nsub, uint64_t *reset_count, hipStream_t st) {
+  QParamArgs<T> P;
+  TRY(fill_qparam_args<T>(h, d_norm, ebtype, tol, s, decomposed, nsub, reset_count, P));
   return launch(h, "make_qparams", st, [&] { k_make_qparams<T><<<1, 64, 0, st>>>(P); });
 }
 
@@ -1171,9 +1190,31 @@ int fused_q_entry_device(mgh_hierarchy *h, const T *data, int ebtype, double tol
   const bool need_norm = !d_norm && ebtype == MGH_REL;
   const bool norm_in_first = need_norm && (T)s == std::numeric_limits<T>::infinity() &&
                              h->L >= 1 && level_is_split<T>(h, h->L);
-  if (norm_in_first) HIP_TRY(hipMemsetAsync(ds->scalar, 0, 8, st));
-  else if (need_norm) TRY(norm_launch<T>(h, data, s, st));
-  auto qparams = [&] { return make_qparams_launch<T>(h, d_norm, ebtype, tol, s, decomposed, nsub, st); };
+  // The norm scalar has two slots used alternately: this call reduces into scalar[slot] (zero on
+  // entry) and k_make_qparams zeroes the other one for the next call, together with the outlier
+  // counter -- two memset launches less per step.
+  if (ds->fscal_dirty) HIP_TRY(hipMemsetAsync(ds->fscal, 0, 16, st));
+  ds->fscal_dirty = true;
+  unsigned long long *slot = ds->fscal + ds->scalar_slot;
+  unsigned long long *other = ds->fscal + (1 - ds->scalar_slot);
+  if (need_norm && !norm_in_first) {
+    const size_t total = h->total;
+    const unsigned grid = (unsigned)std::min<size_t>((total + 1023) / 1024, 256 * 8);
+    if ((T)s == std::numeric_limits<T>::infinity())
+      TRY(launch(h, "absmax", st, [&] { k_absmax<T><<<grid, 256, 0, st>>>(data, total, slot); }));
+    else
+      TRY(launch(h, "sqsum", st, [&] { k_sqsum<T><<<grid, 256, 0, st>>>(data, total, (double *)slot); }));
+  }
+  auto qparams = [&] {
+    QParamArgs<T> P;
+    TRY(fill_qparam_args<T>(h, d_norm, ebtype, tol, s, decomposed, nsub, ocount, P));
+    P.scalar = slot;
+    P.zero_next = other;
+    TRY(launch(h, "make_qparams", st, [&] { k_make_qparams<T><<<1, 64, 0, st>>>(P); }));
+    ds->scalar_slot = 1 - ds->scalar_slot;
+    ds->fscal_dirty = false;
+    return (int)MGH_SUCCESS;
+  };
   QuantParams<T> qp;
   qp.d_qp = ds->qz;
   qp.dict_size = (int64_t)dict_size;
@@ -1370,7 +1411,6 @@ int mgh_decompose_quantize(mgh_hierarchy *h, const void *d_data, int error_bound
     // the norm and the quantizers stay on the device: no host round trip inside the call
     if (prep_huffman && (!d_outlier_count || (outlier_capacity && (!d_outlier_idx || !d_outlier_val))))
       return fail(MGH_ERR_INVALID_ARGUMENT, "outlier buffers required with prep_huffman");
-    if (d_outlier_count) HIP_TRY(hipMemsetAsync(d_outlier_count, 0, sizeof(uint64_t), (hipStream_t)stream));
     return DISPATCH(h,
                     fused_q_entry_device<float>(h, (const float *)d_data, error_bound_type, tol, s,
                                                 nullptr, 0, 1, h_norm_out, dict_size, prep_huffman,
@@ -1423,11 +1463,11 @@ int mgh_norm_device(mgh_hierarchy *h, const void *d_data, double s, void *d_norm
   if (h->dtype == MGH_FLOAT) {
     TRY(norm_launch<float>(h, (const float *)d_data, s, st));
     // ABS/undecomposed parameters are irrelevant here: only the norm conversion is wanted
-    TRY(make_qparams_launch<float>(h, nullptr, MGH_ABS, 1.0, s, 0, 1, st));
+    TRY(make_qparams_launch<float>(h, nullptr, MGH_ABS, 1.0, s, 0, 1, nullptr, st));
     HIP_TRY(hipMemcpyAsync(d_norm_out, DS<float>(h)->normval, sizeof(float), hipMemcpyDeviceToDevice, st));
   } else {
     TRY(norm_launch<double>(h, (const double *)d_data, s, st));
-    TRY(make_qparams_launch<double>(h, nullptr, MGH_ABS, 1.0, s, 0, 1, st));
+    TRY(make_qparams_launch<double>(h, nullptr, MGH_ABS, 1.0, s, 0, 1, nullptr, st));
     HIP_TRY(hipMemcpyAsync(d_norm_out, DS<double>(h)->normval, sizeof(double), hipMemcpyDeviceToDevice, st));
   }
   return MGH_SUCCESS;
@@ -1444,7 +1484,6 @@ int mgh_decompose_quantize_dn(mgh_hierarchy *h, const void *d_data, int error_bo
   if (prep_huffman && (!d_outlier_count || (outlier_capacity && (!d_outlier_idx || !d_outlier_val))))
     return fail(MGH_ERR_INVALID_ARGUMENT, "outlier buffers required with prep_huffman");
   HIP_TRY(hipSetDevice(h->device));
-  if (d_outlier_count) HIP_TRY(hipMemsetAsync(d_outlier_count, 0, sizeof(uint64_t), (hipStream_t)stream));
   return DISPATCH(h,
                   fused_q_entry_device<float>(h, (const float *)d_data, error_bound_type, tol, s,
                                               (const float *)d_norm, 1, num_subdomains, nullptr,

@@ -530,10 +530,14 @@ template <typename T> struct QParamArgs {
   T vol[kMaxLevels];
   T *qp;
   T *norm_out;
+  // launches saved: the outlier counter of this call and the norm scalar of the NEXT call
+  // (the two scalar slots alternate) are zeroed here instead of by memsets
+  unsigned long long *reset_count;
+  unsigned long long *zero_next;
 };
 
-template <typename T> __global__ void k_make_qparams(QParamArgs<T> P) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+template <typename T>
+__device__ __forceinline__ void make_qparams_body(const QParamArgs<T> &P) {
   T norm;
   if (P.d_norm) {
     norm = *P.d_norm;
@@ -569,6 +573,13 @@ template <typename T> __global__ void k_make_qparams(QParamArgs<T> P) {
     P.qp[l] = q;
     P.qp[P.nlev + l] = P.vol[l];
   }
+  if (P.reset_count) *P.reset_count = 0;
+  if (P.zero_next) *P.zero_next = 0;
+}
+
+template <typename T> __global__ void k_make_qparams(QParamArgs<T> P) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  make_qparams_body<T>(P);
 }
 
 } // namespace mgh
