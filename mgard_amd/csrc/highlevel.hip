@@ -225,9 +225,22 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
   HL_HIP(hipStreamSynchronize(st));
   HL_TRY(c->units.ensure(std::max<size_t>(units, 1) * 8));
   HL_HIP(hipMemsetAsync(c->units.p, 0, units * 8, st));
-  huff::k_encode<<<(unsigned)nchunk, 256, 0, st>>>(d_q, n, (int)chunk, (const uint64_t *)c->code.p,
-                                                   (const unsigned long long *)c->entry.p,
-                                                   (unsigned long long *)c->units.p);
+  const size_t enc_lds = dict * 8 + chunk * 2;
+  if (enc_lds <= 150 * 1024) {
+    static bool once = false;
+    if (!once) {
+      HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_encode_lds),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+      once = true;
+    }
+    huff::k_encode_lds<<<(unsigned)nchunk, 256, enc_lds, st>>>(
+        d_q, n, (int)chunk, (int)dict, (const uint64_t *)c->code.p,
+        (const unsigned long long *)c->entry.p, (unsigned long long *)c->units.p);
+  } else {
+    huff::k_encode<<<(unsigned)nchunk, 256, 0, st>>>(d_q, n, (int)chunk, (const uint64_t *)c->code.p,
+                                                     (const unsigned long long *)c->entry.p,
+                                                     (unsigned long long *)c->units.p);
+  }
   HL_HIP(hipGetLastError());
   // ---- serialize (Huffman.hpp:163-239): the small leading part on the host, the code units
   // and the outlier lists stay where they are until record_write() ----

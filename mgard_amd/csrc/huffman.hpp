@@ -252,6 +252,71 @@ k_encode(const int64_t *__restrict__ q, size_t n, int chunk, const uint64_t *__r
   if (room != kUnitBits) flush(true);
 }
 
+// Same as k_encode with the chunk's symbols (16 bit) and the code table staged in LDS: the
+// symbols are read from HBM once, coalesced, instead of every lane walking its own run, and the
+// per-symbol table lookups never leave the CU. Dynamic LDS: 8 * dict + 2 * chunk bytes.
+__global__ void __launch_bounds__(256)
+k_encode_lds(const int64_t *__restrict__ q, size_t n, int chunk, int dict,
+             const uint64_t *__restrict__ code, const unsigned long long *__restrict__ entry,
+             unsigned long long *__restrict__ out) {
+  extern __shared__ unsigned long long enc_lds[];
+  unsigned long long *scode = enc_lds;
+  unsigned short *ssym = reinterpret_cast<unsigned short *>(enc_lds + dict);
+  const size_t base = (size_t)blockIdx.x * chunk;
+  const size_t cnt = min((size_t)chunk, n - base);
+  for (int i = threadIdx.x; i < dict; i += 256) scode[i] = code[i];
+  for (size_t i = threadIdx.x; i < cnt; i += 256) ssym[i] = (unsigned short)q[base + i];
+  __syncthreads();
+  const size_t run = (cnt + 255) / 256;
+  const size_t lo = min(cnt, threadIdx.x * run), hi = min(cnt, lo + run);
+  unsigned long long s = 0;
+  for (size_t i = lo; i < hi; i++) s += scode[ssym[i]] >> kMaxCodeBits;
+  __shared__ unsigned long long sc[256];
+  sc[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const unsigned long long v = threadIdx.x >= (unsigned)off ? sc[threadIdx.x - off] : 0;
+    __syncthreads();
+    sc[threadIdx.x] += v;
+    __syncthreads();
+  }
+  unsigned long long pos = sc[threadIdx.x] - s;
+  if (lo >= hi || s == 0) return;
+  unsigned long long *dst = out + entry[blockIdx.x];
+  size_t w = pos / kUnitBits;
+  int room = kUnitBits - (int)(pos % kUnitBits);
+  unsigned long long acc = 0;
+  bool first_unit = true;
+  auto flush = [&](bool last) {
+    if (first_unit || last) atomicOr(&dst[w], acc);
+    else dst[w] = acc;
+    first_unit = false;
+  };
+  for (size_t i = lo; i < hi; i++) {
+    const uint64_t c = scode[ssym[i]];
+    const int len = (int)(c >> kMaxCodeBits);
+    const unsigned long long val = c & (((uint64_t)1 << kMaxCodeBits) - 1);
+    if (len <= room) {
+      room -= len;
+      acc |= val << room;
+      if (room == 0) {
+        flush(false);
+        w++;
+        acc = 0;
+        room = kUnitBits;
+      }
+    } else {
+      const int rest = len - room;
+      acc |= val >> rest;
+      flush(false);
+      w++;
+      room = kUnitBits - rest;
+      acc = val << room;
+    }
+  }
+  if (room != kUnitBits) flush(true);
+}
+
 // Canonical decoding, one lane per chunk (the chunks are the only entry points of the stream);
 // semantics of Decode.hpp:52-106: a code of length l is recognised by v >= first[l] and stands
 // for keys[entry[l] + v - first[l]]. Codes of up to `tb` bits are resolved with one
