@@ -389,9 +389,24 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
                                hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     once = true;
   }
-  huff::k_decode<<<(unsigned)((nchunk + 63) / 64), 64, lds, st>>>(
-      (const unsigned long long *)c->units.p, (const unsigned long long *)c->bits.p,
-      (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, tb, tab, tab + 64, tab + 128, d_q);
+  static const bool serial_decode = std::getenv("MGH_HUFF_SERIAL_DECODE") != nullptr;  // cross-check
+  if (!serial_decode && (size_t)chunk >= 1024) {
+    // parallel decoding inside the chunks (one wave per chunk)
+    static bool once2 = false;
+    if (!once2) {
+      HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_decode_par),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+      once2 = true;
+    }
+    huff::k_decode_par<<<(unsigned)((nchunk + huff::kParWaves - 1) / huff::kParWaves),
+                         64 * huff::kParWaves, lds, st>>>(
+        (const unsigned long long *)c->units.p, (const unsigned long long *)c->bits.p,
+        (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, tb, tab, tab + 64, tab + 128, d_q);
+  } else {
+    huff::k_decode<<<(unsigned)((nchunk + 63) / 64), 64, lds, st>>>(
+        (const unsigned long long *)c->units.p, (const unsigned long long *)c->bits.p,
+        (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, tb, tab, tab + 64, tab + 128, d_q);
+  }
   HL_HIP(hipGetLastError());
   // the host payload may go away when we return
   HL_HIP(hipStreamSynchronize(st));

@@ -438,5 +438,140 @@ k_decode(const unsigned long long *__restrict__ units, const unsigned long long 
   }
 }
 
+// Parallel decoding INSIDE a chunk (the serial kernel above needs 20480 dependent steps per
+// chunk). One wave per chunk, 16 chunks per workgroup sharing the LDS tables. The chunk's bit
+// stream is cut into 64 equal subsequences, one per lane:
+//   1. every lane decodes its subsequence speculatively from the cut (lane 0's start is a true
+//      code boundary, the others probably are not) and remembers where it ended;
+//   2. a lane whose start differs from the end of its left neighbour restarts from that end;
+//      repeated until no lane changes. Huffman streams re-synchronise within a few symbols, so
+//      in practice one or two rounds; at most 64 (every round fixes at least the first wrong
+//      lane), and then every start is a true boundary;
+//   3. symbol counts are prefix-summed across the wave and every lane decodes its subsequence
+//      once more, now writing the symbols to their final positions.
+// Same tables and semantics as k_decode. Dynamic LDS as for k_decode without the unit ring.
+constexpr int kParWaves = 16;
+
+__global__ void __launch_bounds__(64 * kParWaves)
+k_decode_par(const unsigned long long *__restrict__ units, const unsigned long long *__restrict__ bits,
+             const unsigned long long *__restrict__ entry_of_chunk, size_t nchunk, int chunk, size_t n,
+             int dict, int tb, const unsigned long long *__restrict__ first,
+             const unsigned long long *__restrict__ entry, const unsigned long long *__restrict__ keys,
+             int64_t *__restrict__ q) {
+  __shared__ unsigned long long sfirst[64], sentry[64];
+  extern __shared__ unsigned dyn_lds[];
+  unsigned *table = dyn_lds;
+  unsigned short *skeys = reinterpret_cast<unsigned short *>(dyn_lds + (1u << tb));
+  constexpr int NT = 64 * kParWaves;
+  if (threadIdx.x < 64) {
+    sfirst[threadIdx.x] = first[threadIdx.x];
+    sentry[threadIdx.x] = entry[threadIdx.x];
+  }
+  for (unsigned i = threadIdx.x; i < (1u << tb); i += NT) table[i] = 0;
+  for (int i = threadIdx.x; i < dict; i += NT) skeys[i] = (unsigned short)keys[i];
+  __syncthreads();
+  for (int l = 1; l <= tb; l++) {
+    if (sfirst[l] == ~0ull) continue;
+    if (sentry[l] >= (unsigned long long)dict) continue;
+    unsigned long long cnt = (l + 1 < 64 ? sentry[l + 1] : (unsigned long long)dict) - sentry[l];
+    cnt = min(cnt, (unsigned long long)dict - sentry[l]);
+    cnt = min(cnt, 1ull << l);
+    const unsigned span = 1u << (tb - l);
+    for (unsigned long long j = threadIdx.x; j < cnt * span; j += NT) {
+      const unsigned long long code = sfirst[l] + j / span;
+      const unsigned long long slot = (code << (tb - l)) + j % span;
+      const unsigned long long k = sentry[l] + j / span;
+      if (slot < (1ull << tb) && k < (unsigned long long)dict)
+        table[slot] = ((unsigned)l << 16) | (unsigned)skeys[k];
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const size_t c = (size_t)blockIdx.x * kParWaves + (threadIdx.x >> 6);
+  if (c >= nchunk) return;  // (whole wave; no block-wide barrier follows)
+  const unsigned long long *src = units + entry_of_chunk[c];
+  const unsigned long long total = bits[c];
+  int64_t *dst = q + c * (size_t)chunk;
+  const unsigned long long cap = min((size_t)chunk, n - c * (size_t)chunk);
+  const unsigned long long nun = (total + 63) / 64;
+  const unsigned long long B = (total + 63) / 64;  // bits per subsequence (ceil(total / 64))
+  const unsigned long long lim = min(((unsigned long long)lane + 1) * B, total);
+
+  // decode from bit `start` while the position is below `lim`; optionally store the symbols at
+  // out[0 .. max_out). Returns the end position, *count = symbols decoded.
+  auto run = [&](unsigned long long start, unsigned long long *count, int64_t *out,
+                 unsigned long long max_out) {
+    unsigned long long pos = start, cnt = 0;
+    if (pos >= lim) {
+      *count = 0;
+      return pos;
+    }
+    unsigned long long cw = pos >> 6;
+    unsigned long long cur = src[min(cw, nun)], nxt = src[min(cw + 1, nun)];
+    while (pos < lim) {
+      const int sh = (int)(pos & 63);
+      const unsigned long long win = sh ? (cur << sh) | (nxt >> (64 - sh)) : cur;
+      const unsigned e = table[win >> (64 - tb)];
+      int l = 0;
+      unsigned long long sym = 0;
+      bool hit = e != 0;
+      if (hit) {
+        l = (int)(e >> 16);
+        sym = e & 0xffff;
+      } else {
+        for (l = tb + 1; l <= 56; l++) {
+          const unsigned long long v = win >> (64 - l);
+          if (v >= sfirst[l]) {
+            const unsigned long long k = sentry[l] + v - sfirst[l];
+            if (k < (unsigned long long)dict) {
+              sym = skeys[k];
+              hit = true;
+            }
+            break;
+          }
+        }
+      }
+      if (!hit || pos + l > total) {  // corrupt stream (or a speculative start that runs off the
+        pos = total;                  // end): give up on this subsequence
+        break;
+      }
+      if (out && cnt < max_out) out[cnt] = (int64_t)sym;
+      cnt++;
+      pos += l;
+      if ((pos >> 6) != cw) {
+        cw++;
+        cur = nxt;
+        nxt = src[min(cw + 1, nun)];
+      }
+    }
+    *count = cnt;
+    return pos;
+  };
+
+  unsigned long long s = min((unsigned long long)lane * B, total), cnt = 0;
+  unsigned long long e = run(s, &cnt, nullptr, 0);
+  for (int it = 0; it < 64; it++) {
+    unsigned long long pe = __shfl_up(e, 1, 64);
+    if (lane == 0) pe = 0;
+    const bool changed = s != pe;
+    if (!__any(changed)) break;
+    if (changed) {
+      s = pe;
+      e = run(s, &cnt, nullptr, 0);
+    }
+  }
+  // exclusive prefix sum of the symbol counts
+  unsigned long long off = cnt;
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long v = __shfl_up(off, d, 64);
+    if (lane >= d) off += v;
+  }
+  off -= cnt;
+  if (off < cap) {
+    unsigned long long c2 = 0;
+    (void)run(s, &c2, dst + off, cap - off);
+  }
+}
+
 } // namespace huff
 } // namespace mgh
