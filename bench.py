@@ -291,7 +291,14 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        # RCCL prints a version banner through C stdio, which would otherwise be flushed at exit,
+        # AFTER the result: push everything out first so that the JSON line is the last line
+        import ctypes
         sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(result), flush=True)
 
 
