@@ -409,6 +409,24 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
   });
 }
 
+// f-solve and c-solve of a compact (m0, m1, m2) box: one launch when a coarse plane fits in LDS
+// (every level but the biggest), else the two tiled kernels.
+template <typename T>
+int ipk_fc_launch(mgh_hierarchy *h, const uint32_t *m, T *x, const T *tt_f, const T *tt_c,
+                  hipStream_t s) {
+  const uint32_t pitch = m[2] | 1u;
+  if ((size_t)m[1] * pitch * sizeof(T) <= 150 * 1024 && m[1] <= 1024 && m[2] <= 1024) {
+    static bool once = false;
+    if (!once) { TRY(allow_big_lds(k_ipk_plane_fc<T>)); once = true; }
+    return launch(h, "ipk_fc", s, [&] {
+      k_ipk_plane_fc<T><<<m[0], 256, (size_t)m[1] * pitch * sizeof(T), s>>>(m[1], m[2], pitch, x,
+                                                                              tt_f, tt_c);
+    });
+  }
+  TRY(ipk_launch<T>(h, 2, m, x, tt_f, nullptr, +1, s));
+  return ipk_launch<T>(h, 1, m, x, tt_c, nullptr, +1, s);
+}
+
 // ---- correction = IPK(LPK(coefficients)) then +/- into nodal[l-1] --------------
 // CalcCorrection3D (Correction/CalcCorrection3D.hpp:26-185) + AddND/SubtractND.
 template <typename T>
@@ -638,8 +656,7 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
         }));
       }
     }
-    TRY(ipk_launch<T>(h, 2, b.m, ds->t3, t.thomas[2], nullptr, +1, s));
-    TRY(ipk_launch<T>(h, 1, b.m, ds->t3, t.thomas[1], nullptr, +1, s));
+    TRY(ipk_fc_launch<T>(h, b.m, ds->t3, t.thomas[2], t.thomas[1], s));
     TRY(ipk_launch<T>(h, 0, b.m, ds->t3, t.thomas[0], ds->nodal[l - 1], +1, s));
     src = ds->nodal[l - 1];
     sJ = b.m[2];
@@ -989,8 +1006,7 @@ int dequantize_recompose_fused(mgh_hierarchy *h, int64_t *q, int ebtype, double 
         k_level_loadvec_q<T, TC, TF, 1><<<dim3(gx, gy, b.m[0]), 256, 0, st>>>(A);
       }));
     }
-    TRY(ipk_launch<T>(h, 2, b.m, ds->t3, t.thomas[2], nullptr, -1, st));
-    TRY(ipk_launch<T>(h, 1, b.m, ds->t3, t.thomas[1], nullptr, -1, st));
+    TRY(ipk_fc_launch<T>(h, b.m, ds->t3, t.thomas[2], t.thomas[1], st));
     TRY(ipk_launch<T>(h, 0, b.m, ds->t3, t.thomas[0], ds->nodal[l - 1], -1, st));
     A.fine = (l == L) ? data : ds->nodal[l];
     A.fJ = (l == L) ? ds->full_J : b.n[2];

@@ -183,4 +183,26 @@ k_ipk_lds_strided(uint32_t n_outer, uint32_t n_inner, size_t outer_stride, size_
   }
 }
 
+// f-solve and c-solve of one coarse r-plane in ONE workgroup (both are independent per plane):
+// the plane sits in LDS with an odd row pitch, rows are solved by one lane each (lane t walks
+// row t: conflict-free because the pitch is odd), then columns (lane t walks column t). One
+// launch and one pass over HBM instead of two for every level whose coarse plane fits in LDS
+// -- on those levels a launch is mostly dispatch latency.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_ipk_plane_fc(uint32_t m1, uint32_t m2, uint32_t pitch, T *__restrict__ x,
+               const T *__restrict__ tt_f, const T *__restrict__ tt_c) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T *sm = reinterpret_cast<T *>(smem_raw);
+  T *g = x + (size_t)blockIdx.x * m1 * m2;
+  const uint32_t total = m1 * m2;
+  for (uint32_t e = threadIdx.x; e < total; e += 256) sm[(e / m2) * pitch + e % m2] = g[e];
+  __syncthreads();
+  for (uint32_t r = threadIdx.x; r < m1; r += 256) thomas_lds<T>(sm + r * pitch, 1, m2, tt_f);
+  __syncthreads();
+  for (uint32_t c = threadIdx.x; c < m2; c += 256) thomas_lds<T>(sm + c, pitch, m1, tt_c);
+  __syncthreads();
+  for (uint32_t e = threadIdx.x; e < total; e += 256) g[e] = sm[(e / m2) * pitch + e % m2];
+}
+
 } // namespace mgh
