@@ -960,7 +960,7 @@ int dequantize_recompose_fused(mgh_hierarchy *h, int64_t *q, int ebtype, double 
   const int L = h->L;
   if (prep_huffman && ocount) {
     TRY(launch(h, "outlier_restore", st, [&] {
-      k_outlier_restore<<<(unsigned)((ocount + 255) / 256), 256, 0, st>>>(q, oidx, oval, ocount);
+      k_outlier_restore<<<(unsigned)((ocount + 255) / 256), 256, 0, st>>>(q, h->total, oidx, oval, ocount);
     }));
   }
   std::vector<T> qz(L + 1);
@@ -1064,7 +1064,7 @@ int dequantize_impl(mgh_hierarchy *h, int64_t *q, int ebtype, double tol, double
   const size_t total = h->total;
   if (prep_huffman && ocount) {
     TRY(launch(h, "outlier_restore", st, [&] {
-      k_outlier_restore<<<(unsigned)((ocount + 255) / 256), 256, 0, st>>>(q, oidx, oval, ocount);
+      k_outlier_restore<<<(unsigned)((ocount + 255) / 256), 256, 0, st>>>(q, h->total, oidx, oval, ocount);
     }));
   }
   const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);

@@ -634,9 +634,17 @@ struct HlCache {
     }
     dev = -1;
   }
-  ~HlCache() { release(); }
 };
-thread_local HlCache g_cache;
+// Deliberately never destroyed automatically: a thread_local destructor would run HIP calls at
+// thread / process exit, possibly after the HIP runtime has started to tear itself down. The
+// resources are returned by mgh_release_cache() (like mgard_x::release_cache); a thread that
+// exits without calling it leaves them to process teardown.
+thread_local HlCache *g_cache_ptr = nullptr;
+inline HlCache &hl_cache() {
+  if (!g_cache_ptr) g_cache_ptr = new HlCache();
+  return *g_cache_ptr;
+}
+#define g_cache (hl_cache())
 
 int cache_prepare(int dev) {
   if (g_cache.dev != dev) {
@@ -1182,7 +1190,9 @@ void mgh_free_device(void *p) {
   if (p) (void)hipFree(p);
 }
 
-void mgh_release_cache(void) { g_cache.release(); }
+void mgh_release_cache(void) {
+  if (g_cache_ptr) g_cache_ptr->release();
+}
 
 int mgh_memcpy(void *dst, const void *src, size_t bytes) {
   if (!dst || !src) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");

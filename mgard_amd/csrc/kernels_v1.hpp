@@ -363,10 +363,12 @@ k_dequantize(QuantMeta m, size_t total, const int64_t *__restrict__ q,
 
 // OutlierRestore (LinearQuantization.hpp:304-350)
 __global__ void __launch_bounds__(256)
-k_outlier_restore(int64_t *__restrict__ q, const uint64_t *__restrict__ idx,
+k_outlier_restore(int64_t *__restrict__ q, uint64_t total, const uint64_t *__restrict__ idx,
                   const int64_t *__restrict__ val, uint64_t count) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < count) q[idx[t]] = val[t];
+  // (an index outside the array can only come from a damaged stream: skip it, never write
+  // out of bounds)
+  if (t < count && idx[t] < total) q[idx[t]] = val[t];
 }
 
 // ---------------------------------------------------------------------------

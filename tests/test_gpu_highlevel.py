@@ -274,14 +274,19 @@ def test_decompress_survives_random_damage():
     assert _err(u, hl.decompress(good, config=cfg), np.inf, u.shape) <= 1e-2 * float(np.max(np.abs(u))) * 1.000001
     rng = np.random.default_rng(11)
     outcomes = {"error": 0, "array": 0}
-    for trial in range(60):
+    m = hl.metadata_parse(bytes(good))
+    for trial in range(150):
         bad = good.copy()
         if trial % 3 == 0:      # damage the structured front part of a record
-            m = hl.metadata_parse(bytes(good))
             pos = m["metadata_size"] + int(rng.integers(0, 9000))
+        elif trial % 3 == 1:    # ... or its tail (outlier count / indices / values)
+            pos = bad.size - 1 - int(rng.integers(0, 4000))
         else:
             pos = int(rng.integers(0, bad.size))
         bad[pos % bad.size] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        if trial % 7 == 0:      # a burst of garbage
+            a = int(rng.integers(0, bad.size - 64))
+            bad[a:a + 64] = rng.integers(0, 256, 64, dtype=np.uint8)
         if trial % 10 == 9:
             bad = bad[:int(rng.integers(20, bad.size))]
         try:
