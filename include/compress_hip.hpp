@@ -42,7 +42,7 @@ struct HighLevelConfig : Config {
   lossless_type lossless = lossless_type::Huffman;
   int zstd_compress_level = 3;
   SIZE max_memory_footprint = std::numeric_limits<SIZE>::max();
-  bool auto_pin_host_buffers = true;
+  bool auto_pin_host_buffers = false;  // (reference: true; see mgh_config_default in highlevel.hip)
 };
 
 namespace detail {

@@ -69,7 +69,7 @@ typedef struct mgh_config {
   int normalize_coordinates;
   uint64_t max_larget_level;
   uint64_t max_memory_footprint; /* bytes of device memory the call may plan with */
-  int auto_pin_host_buffers;
+  int auto_pin_host_buffers; /* default 0 here (reference: 1), see mgh_config_default */
 } mgh_config;
 
 void mgh_config_default(mgh_config *config);

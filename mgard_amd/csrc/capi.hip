@@ -127,6 +127,17 @@ template <typename T> DeviceState<T> *DS(const mgh_hierarchy *h) {
 
 // ---- profiled launch -------------------------------------------------------
 template <typename F> int launch(mgh_hierarchy *h, const char *name, hipStream_t s, F &&f) {
+  // MGH_DEBUG_SYNC=1: name every launch on stderr and synchronise behind it, so that a GPU
+  // memory fault can be attributed to a kernel (developer aid)
+  static const bool debug_sync = std::getenv("MGH_DEBUG_SYNC") != nullptr;
+  if (debug_sync) {
+    std::fprintf(stderr, "[mgh] %s\n", name);
+    std::fflush(stderr);
+    f();
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return MGH_SUCCESS;
+  }
   if (!h->profiling || (!h->prof_filter.empty() && h->prof_filter != name)) {
     f();
     HIP_TRY(hipGetLastError());

@@ -30,6 +30,16 @@ namespace {
 
 using namespace mgh;
 
+// MGH_DEBUG_SYNC=1: name the stages on stderr and synchronise (developer aid, see capi.hip)
+inline void hl_debug(const char *what) {
+  static const bool on = std::getenv("MGH_DEBUG_SYNC") != nullptr;
+  if (on) {
+    (void)hipDeviceSynchronize();
+    std::fprintf(stderr, "[mgh-hl] %s\n", what);
+    std::fflush(stderr);
+  }
+}
+
 int hl_fail(int code, const std::string &msg) {
   mgh_set_last_error_(msg.c_str());
   return code;
@@ -200,6 +210,7 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
   HL_TRY(c->bits.ensure(nchunk * 8));
   HL_TRY(c->entry.ensure(nchunk * 8));
   HL_TRY(c->total.ensure(8));
+  hl_debug("lossless_compress: begin");
   HL_HIP(hipMemsetAsync(c->freq.p, 0, dict * 4, st));
   const unsigned hblocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
   huff::k_histogram<<<hblocks, 256, dict * 4, st>>>(d_q, n, (int)dict, (unsigned *)c->freq.p);
@@ -213,6 +224,7 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
   } catch (const std::exception &e) {
     return hl_fail(MGH_ERR_INVALID_ARGUMENT, e.what());
   }
+  hl_debug("lossless_compress: histogram done");
   HL_HIP(hipMemcpyAsync(c->code.p, cb.code.data(), dict * 8, hipMemcpyHostToDevice, st));
   huff::k_chunk_bits<<<(unsigned)nchunk, 256, 0, st>>>(d_q, n, (int)chunk, (const uint64_t *)c->code.p,
                                                        (unsigned long long *)c->bits.p);
@@ -223,6 +235,7 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
   unsigned long long units = 0;
   HL_HIP(hipMemcpyAsync(&units, c->total.p, 8, hipMemcpyDeviceToHost, st));
   HL_HIP(hipStreamSynchronize(st));
+  hl_debug("lossless_compress: chunk bits + offsets done");
   HL_TRY(c->units.ensure(std::max<size_t>(units, 1) * 8));
   HL_HIP(hipMemsetAsync(c->units.p, 0, units * 8, st));
   const size_t enc_lds = dict * 8 + chunk * 2;
@@ -242,6 +255,7 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
                                                      (unsigned long long *)c->units.p);
   }
   HL_HIP(hipGetLastError());
+  hl_debug("lossless_compress: encode launched");
   // ---- serialize (Huffman.hpp:163-239): the small leading part on the host, the code units
   // and the outlier lists stay where they are until record_write() ----
   PayloadLayout &L = c->lay;
@@ -377,6 +391,7 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
     HL_HIP(hipMemcpyAsync(c->oidx.p, p + o_oidx, ocount * 8, hipMemcpyDefault, st));
     HL_HIP(hipMemcpyAsync(c->oval.p, p + o_oval, ocount * 8, hipMemcpyDefault, st));
   }
+  hl_debug("lossless_decompress: uploads done");
   const unsigned long long *tab = (const unsigned long long *)c->tables.p;
   // prefix table as large as LDS allows next to the 16-bit keys (15 bits for dict = 8192)
   int tb = 15;
@@ -408,6 +423,7 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
         (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, tb, tab, tab + 64, tab + 128, d_q);
   }
   HL_HIP(hipGetLastError());
+  hl_debug("lossless_decompress: decode launched");
   // the host payload may go away when we return
   HL_HIP(hipStreamSynchronize(st));
   *ocount_out = ocount;
@@ -562,6 +578,7 @@ int make_decomposer(Decomposer &dd, int D, const uint64_t *shape, size_t elem, c
 // full array (host or device), as few strided copies as the box allows.
 int copy_subdomain(const Decomposer &dd, uint64_t id, size_t elem, void *sub, const void *full_c,
                    void *full_m, bool to_sub, hipStream_t st) {
+  hl_debug(to_sub ? "copy_subdomain: to subdomain" : "copy_subdomain: to original");
   const int D = dd.D;
   const auto ext = dd.subdomain_shape(id), off = dd.subdomain_offset(id);
   // merge trailing dimensions the box spans completely
@@ -1113,7 +1130,12 @@ void mgh_config_default(mgh_config *c) {
   c->normalize_coordinates = 1;
   c->max_larget_level = std::numeric_limits<uint64_t>::max();
   c->max_memory_footprint = std::numeric_limits<uint64_t>::max();
-  c->auto_pin_host_buffers = 1;
+  // The reference defaults to true. Here it is opt-in: on ROCm 7.0 registering and unregistering
+  // caller memory (hipHostRegister / hipHostUnregister) was observed to leave the runtime
+  // treating later allocations at the same addresses as pinned -- a copy into such a buffer
+  // then dies with a GPU memory fault (1 in 3 runs of the test suite). Without registration
+  // host buffers go through the runtime's pageable-copy path, measured within 20 %.
+  c->auto_pin_host_buffers = 0;
 }
 
 int mgh_compress(int D, int dtype, const uint64_t *shape, double tol, double s, int ebtype,
