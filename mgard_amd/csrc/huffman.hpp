@@ -344,23 +344,25 @@ k_decode(const unsigned long long *__restrict__ units, const unsigned long long 
   for (unsigned i = threadIdx.x; i < (1u << tb); i += 64) table[i] = 0;
   for (int i = threadIdx.x; i < dict; i += 64) skeys[i] = (unsigned short)keys[i];
   __syncthreads();
-  for (int l = 1; l <= tb; l++) {
-    if (sfirst[l] == ~0ull) continue;
-    if (sentry[l] >= (unsigned long long)dict) continue;
-    unsigned long long cnt = (l + 1 < 64 ? sentry[l + 1] : (unsigned long long)dict) - sentry[l];
-    cnt = min(cnt, (unsigned long long)dict - sentry[l]);  // (damaged tables must not spin here)
-    cnt = min(cnt, 1ull << l);
-    const unsigned span = 1u << (tb - l);
-    // codes first[l] .. first[l] + cnt - 1, each covering `span` table slots
-    for (unsigned long long j = threadIdx.x; j < cnt * span; j += 64) {
-      const unsigned long long code = sfirst[l] + j / span;
-      const unsigned long long slot = (code << (tb - l)) + j % span;
-      const unsigned long long k = sentry[l] + j / span;
-      if (slot < (1ull << tb) && k < (unsigned long long)dict)
-        table[slot] = ((unsigned)l << 16) | (unsigned)skeys[k];
+  // (longest codes first: should a foreign stream's entry[] make a length look longer than it
+  // is, the surplus slots are rewritten by the shorter, valid codes that own them)
+  for (int l = tb; l >= 1; l--) {
+    if (sfirst[l] != ~0ull && sentry[l] < (unsigned long long)dict) {
+      unsigned long long cnt = (l + 1 < 64 ? sentry[l + 1] : (unsigned long long)dict) - sentry[l];
+      cnt = min(cnt, (unsigned long long)dict - sentry[l]);  // (damaged tables must not spin here)
+      cnt = min(cnt, 1ull << l);
+      const unsigned span = 1u << (tb - l);
+      // codes first[l] .. first[l] + cnt - 1, each covering `span` table slots
+      for (unsigned long long j = threadIdx.x; j < cnt * span; j += 64) {
+        const unsigned long long code = sfirst[l] + j / span;
+        const unsigned long long slot = (code << (tb - l)) + j % span;
+        const unsigned long long k = sentry[l] + j / span;
+        if (slot < (1ull << tb) && k < (unsigned long long)dict)
+          table[slot] = ((unsigned)l << 16) | (unsigned)skeys[k];
+      }
     }
+    __syncthreads();
   }
-  __syncthreads();
   const size_t c0 = (size_t)blockIdx.x * 64 + threadIdx.x;
   const bool have = c0 < nchunk;  // (idle lanes stay in the loop: it uses wave votes)
   const size_t c = have ? c0 : nchunk - 1;
@@ -470,22 +472,24 @@ k_decode_par(const unsigned long long *__restrict__ units, const unsigned long l
   for (unsigned i = threadIdx.x; i < (1u << tb); i += NT) table[i] = 0;
   for (int i = threadIdx.x; i < dict; i += NT) skeys[i] = (unsigned short)keys[i];
   __syncthreads();
-  for (int l = 1; l <= tb; l++) {
-    if (sfirst[l] == ~0ull) continue;
-    if (sentry[l] >= (unsigned long long)dict) continue;
-    unsigned long long cnt = (l + 1 < 64 ? sentry[l + 1] : (unsigned long long)dict) - sentry[l];
-    cnt = min(cnt, (unsigned long long)dict - sentry[l]);
-    cnt = min(cnt, 1ull << l);
-    const unsigned span = 1u << (tb - l);
-    for (unsigned long long j = threadIdx.x; j < cnt * span; j += NT) {
-      const unsigned long long code = sfirst[l] + j / span;
-      const unsigned long long slot = (code << (tb - l)) + j % span;
-      const unsigned long long k = sentry[l] + j / span;
-      if (slot < (1ull << tb) && k < (unsigned long long)dict)
-        table[slot] = ((unsigned)l << 16) | (unsigned)skeys[k];
+  // (longest codes first: should a foreign stream's entry[] make a length look longer than it
+  // is, the surplus slots are rewritten by the shorter, valid codes that own them)
+  for (int l = tb; l >= 1; l--) {
+    if (sfirst[l] != ~0ull && sentry[l] < (unsigned long long)dict) {
+      unsigned long long cnt = (l + 1 < 64 ? sentry[l + 1] : (unsigned long long)dict) - sentry[l];
+      cnt = min(cnt, (unsigned long long)dict - sentry[l]);
+      cnt = min(cnt, 1ull << l);
+      const unsigned span = 1u << (tb - l);
+      for (unsigned long long j = threadIdx.x; j < cnt * span; j += NT) {
+        const unsigned long long code = sfirst[l] + j / span;
+        const unsigned long long slot = (code << (tb - l)) + j % span;
+        const unsigned long long k = sentry[l] + j / span;
+        if (slot < (1ull << tb) && k < (unsigned long long)dict)
+          table[slot] = ((unsigned)l << 16) | (unsigned)skeys[k];
+      }
     }
+    __syncthreads();
   }
-  __syncthreads();
   const int lane = threadIdx.x & 63;
   const size_t c = (size_t)blockIdx.x * kParWaves + (threadIdx.x >> 6);
   if (c >= nchunk) return;  // (whole wave; no block-wide barrier follows)
