@@ -623,7 +623,7 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
       if (l == L) TRY(after_first());
       // fork: everything the emit pass reads (nodal input of level l, quantizers) is ordered
       // before this point of the caller's stream
-      const bool serial = std::getenv("MGH_SPLIT_SERIAL") != nullptr;  // (experiments)
+      static const bool serial = std::getenv("MGH_SPLIT_SERIAL") != nullptr;  // (experiments)
       hipStream_t es = serial ? s : h->side;
       if (!serial) {
         HIP_TRY(hipEventRecord(h->fork_ev[l], s));
