@@ -142,6 +142,50 @@ inline compress_status_type decompress(const void *compressed_data, size_t compr
                     output_pre_allocated);
 }
 
+// The remaining stages of the reference's LOW-LEVEL Compressor (Compressor.h:39-78):
+// LosslessCompress + Serialize, Deserialize + LosslessDecompress, and Compress / Decompress that
+// chain all stages (Compressor.hpp:193-272). The serialized record is the subdomain payload of
+// the container (Huffman.hpp:163-239); it lives in host memory owned by this object.
+template <DIM D, typename T> class LosslessCompressor {
+public:
+  explicit LosslessCompressor(Compressor<D, T> &c, HighLevelConfig config = HighLevelConfig())
+      : c_(&c), config_(config) {
+    check(mgh_lossless_create(&ctx_, config.dev_id), "LosslessCompressor");
+  }
+  ~LosslessCompressor() { mgh_lossless_destroy(ctx_); }
+  LosslessCompressor(const LosslessCompressor &) = delete;
+  LosslessCompressor &operator=(const LosslessCompressor &) = delete;
+
+  // LosslessCompress + Serialize: quantized_array() and the outlier list of the Compressor ->
+  // record bytes (valid until the next call)
+  void LosslessCompress(SIZE n, SIZE outlier_count, const Byte *&data, SIZE &size, void *queue = nullptr) {
+    const uint8_t *p = nullptr;
+    uint64_t sz = 0;
+    check(mgh_lossless_compress(ctx_, c_->quantized_array(), n, config_.huff_dict_size,
+                                config_.huff_block_size, (int)config_.lossless,
+                                config_.zstd_compress_level, c_->outlier_indexes(), c_->outliers(),
+                                outlier_count, &p, &sz, queue),
+          "LosslessCompress");
+    data = p;
+    size = sz;
+  }
+  // Deserialize + LosslessDecompress: record bytes -> quantized_array(); the outlier list comes
+  // back in device buffers owned by this object
+  void LosslessDecompress(const Byte *data, SIZE size, SIZE n, const ATOMIC_IDX *&outlier_idx,
+                          const QUANTIZED_INT *&outliers, SIZE &outlier_count, void *queue = nullptr) {
+    uint64_t cnt = 0;
+    check(mgh_lossless_decompress(ctx_, data, size, (int)config_.lossless, c_->quantized_array(), n,
+                                  &outlier_idx, &outliers, &cnt, queue),
+          "LosslessDecompress");
+    outlier_count = cnt;
+  }
+
+private:
+  Compressor<D, T> *c_;
+  HighLevelConfig config_;
+  mgh_lossless_ctx *ctx_ = nullptr;
+};
+
 // release_cache (compress_x.hpp:159)
 inline compress_status_type release_cache(HighLevelConfig = HighLevelConfig()) {
   mgh_release_cache();
