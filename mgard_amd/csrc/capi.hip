@@ -911,6 +911,10 @@ int decompose_impl(mgh_hierarchy *h, const T *data, T *coeff, hipStream_t s) {
 }
 
 
+template <typename T, typename QT>
+int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> &level_qv, T *data,
+                     hipStream_t st);
+
 template <typename T>
 int recompose_impl(mgh_hierarchy *h, const T *coeff, T *data, hipStream_t s) {
   auto *ds = DS<T>(h);
@@ -931,6 +935,14 @@ int recompose_impl(mgh_hierarchy *h, const T *coeff, T *data, hipStream_t s) {
   if (L == 0) {
     HIP_TRY(hipMemcpyAsync(data, coeff, h->total * sizeof(T), hipMemcpyDeviceToDevice, s));
     return MGH_SUCCESS;
+  }
+  if (fused_ok(h) && !h->force_v1) {
+    // the level loop of the fused decompression, reading floating-point coefficients
+    RecomposeArgs<T> A{};
+    A.coef = C;
+    A.dI = fI;
+    A.dJ = fJ;
+    return recompose_levels<T, T>(h, A, std::vector<T>(L + 1, (T)1), data, s);
   }
   const dim3 blk(64, 4, 1);
   {
@@ -960,7 +972,61 @@ int recompose_impl(mgh_hierarchy *h, const T *coeff, T *data, hipStream_t s) {
 // Fused decompression: outlier restore, then per level (coarse to fine) the load vector
 // straight from the quantized coefficients, three Thomas solves subtracting the correction
 // from the coarse nodes, and the node restore with the dequantizer fused in
-// (Compressor::Decompress lines 256-257 = Dequantize + Recompose).
+// (Compressor::Decompress lines 256-257 = Dequantize + Recompose). With QT = T the same level
+// loop runs on floating-point coefficients (Compressor::Recompose on its own).
+template <typename T, typename QT>
+int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> &level_qv, T *data,
+                     hipStream_t st) {
+  auto *ds = DS<T>(h);
+  const int L = h->L;
+  {
+    const Box3 &b = ds->lt[1].box;
+    A.qv = level_qv[0];
+    TRY(launch(h, "head_in", st, [&] {
+      k_head_in_q<T, QT><<<1, 256, 0, st>>>((int)b.m[0], (int)b.m[1], (int)b.m[2], A, ds->nodal[0]);
+    }));
+  }
+  constexpr int TC = 8, TF = 32;
+  for (int l = 1; l <= L; l++) {
+    const LevelTables<T> &t = ds->lt[l];
+    const Box3 &b = t.box;
+    for (int k = 0; k < 3; k++) {
+      A.n[k] = (int)b.n[k];
+      A.m[k] = (int)b.m[k];
+      A.ratio[k] = t.ratio[k];
+      A.mass[k] = t.mass[k];
+    }
+    A.qv = level_qv[l];
+    A.load = ds->t3;
+    A.coarse = ds->nodal[l - 1];
+    const unsigned gx = (b.m[2] + TF - 1) / TF, gy = (b.m[1] + TC - 1) / TC;
+    if ((size_t)gx * gy * ((b.m[0] + 15) / 16) >= 2048) {
+      TRY(launch(h, "loadvec_q", st, [&] {
+        k_level_loadvec_q<T, QT, TC, TF, 16><<<dim3(gx, gy, (b.m[0] + 15) / 16), 256, 0, st>>>(A);
+      }));
+    } else if ((size_t)gx * gy * ((b.m[0] + 3) / 4) >= 256) {
+      TRY(launch(h, "loadvec_q_small", st, [&] {
+        k_level_loadvec_q<T, QT, TC, TF, 4><<<dim3(gx, gy, (b.m[0] + 3) / 4), 256, 0, st>>>(A);
+      }));
+    } else {
+      TRY(launch(h, "loadvec_q_small", st, [&] {
+        k_level_loadvec_q<T, QT, TC, TF, 1><<<dim3(gx, gy, b.m[0]), 256, 0, st>>>(A);
+      }));
+    }
+    TRY(ipk_fc_launch<T>(h, b.m, ds->t3, t.thomas[2], t.thomas[1], st));
+    TRY(ipk_launch<T>(h, 0, b.m, ds->t3, t.thomas[0], ds->nodal[l - 1], -1, st));
+    A.fine = (l == L) ? data : ds->nodal[l];
+    A.fJ = (l == L) ? ds->full_J : b.n[2];
+    A.fI = (l == L) ? ds->full_I : (size_t)b.n[1] * b.n[2];
+    const dim3 blk(64, 4, 1);
+    TRY(launch(h, "restore_q", st, [&] {
+      // one 64-lane wave per fine row, 4 rows per block
+      k_level_restore_q<T, QT><<<dim3(1, (b.n[1] + 3) / 4, b.n[0]), blk, 0, st>>>(A);
+    }));
+  }
+  return MGH_SUCCESS;
+}
+
 template <typename T>
 int dequantize_recompose_fused(mgh_hierarchy *h, int64_t *q, int ebtype, double tol, double s,
                                double norm, uint64_t dict_size, int prep_huffman,
@@ -982,53 +1048,9 @@ int dequantize_recompose_fused(mgh_hierarchy *h, int64_t *q, int ebtype, double 
   A.dI = ds->full_I;
   A.dJ = ds->full_J;
   A.half = prep_huffman ? (int64_t)(dict_size / 2) : 0;
-  auto qv = [&](int l) { return qz[l] * (calc_vol ? hh->level_volume(l, true) : (T)1); };
-  {
-    const Box3 &b = ds->lt[1].box;
-    A.qv = qv(0);
-    TRY(launch(h, "head_in", st, [&] {
-      k_head_in_q<T><<<1, 256, 0, st>>>((int)b.m[0], (int)b.m[1], (int)b.m[2], A, ds->nodal[0]);
-    }));
-  }
-  constexpr int TC = 8, TF = 32;
-  for (int l = 1; l <= L; l++) {
-    const LevelTables<T> &t = ds->lt[l];
-    const Box3 &b = t.box;
-    for (int k = 0; k < 3; k++) {
-      A.n[k] = (int)b.n[k];
-      A.m[k] = (int)b.m[k];
-      A.ratio[k] = t.ratio[k];
-      A.mass[k] = t.mass[k];
-    }
-    A.qv = qv(l);
-    A.load = ds->t3;
-    A.coarse = ds->nodal[l - 1];
-    const unsigned gx = (b.m[2] + TF - 1) / TF, gy = (b.m[1] + TC - 1) / TC;
-    if ((size_t)gx * gy * ((b.m[0] + 15) / 16) >= 2048) {
-      TRY(launch(h, "loadvec_q", st, [&] {
-        k_level_loadvec_q<T, TC, TF, 16><<<dim3(gx, gy, (b.m[0] + 15) / 16), 256, 0, st>>>(A);
-      }));
-    } else if ((size_t)gx * gy * ((b.m[0] + 3) / 4) >= 256) {
-      TRY(launch(h, "loadvec_q_small", st, [&] {
-        k_level_loadvec_q<T, TC, TF, 4><<<dim3(gx, gy, (b.m[0] + 3) / 4), 256, 0, st>>>(A);
-      }));
-    } else {
-      TRY(launch(h, "loadvec_q_small", st, [&] {
-        k_level_loadvec_q<T, TC, TF, 1><<<dim3(gx, gy, b.m[0]), 256, 0, st>>>(A);
-      }));
-    }
-    TRY(ipk_fc_launch<T>(h, b.m, ds->t3, t.thomas[2], t.thomas[1], st));
-    TRY(ipk_launch<T>(h, 0, b.m, ds->t3, t.thomas[0], ds->nodal[l - 1], -1, st));
-    A.fine = (l == L) ? data : ds->nodal[l];
-    A.fJ = (l == L) ? ds->full_J : b.n[2];
-    A.fI = (l == L) ? ds->full_I : (size_t)b.n[1] * b.n[2];
-    const dim3 blk(64, 4, 1);
-    TRY(launch(h, "restore_q", st, [&] {
-      // one 64-lane wave per fine row, 4 rows per block
-      k_level_restore_q<T><<<dim3(1, (b.n[1] + 3) / 4, b.n[0]), blk, 0, st>>>(A);
-    }));
-  }
-  return MGH_SUCCESS;
+  std::vector<T> level_qv(L + 1);
+  for (int l = 0; l <= L; l++) level_qv[l] = qz[l] * (calc_vol ? hh->level_volume(l, true) : (T)1);
+  return recompose_levels<T, int64_t>(h, A, level_qv, data, st);
 }
 
 template <typename T>

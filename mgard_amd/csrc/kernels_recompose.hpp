@@ -22,6 +22,7 @@ namespace mgh {
 template <typename T> struct RecomposeArgs {
   int n[3], m[3];
   const int64_t *q;  // quantized coefficients, reordered layout, strides (dI, dJ, 1)
+  const T *coef;     // ... or the coefficients themselves (kernels instantiated with QT = T)
   size_t dI, dJ;
   const T *coarse;   // compact (m0, m1, m2), corrected coarse nodes (restore only)
   T *load;           // compact (m0, m1, m2) (loadvec only)
@@ -41,7 +42,19 @@ template <typename T> __device__ __forceinline__ T dequant_one(int64_t qd, int64
   return qv * (T)d;
 }
 
-template <typename T, int TC, int TF, int RCH>
+// The kernels read the level's coefficients either as quantized integers (QT = int64_t, the
+// dequantizer is applied on the fly) or as floating-point coefficients (QT = T: Recompose on
+// its own, Compressor::Recompose).
+template <typename T> __device__ __forceinline__ const int64_t *qsrc(const RecomposeArgs<T> &A, int64_t) { return A.q; }
+template <typename T> __device__ __forceinline__ const T *qsrc(const RecomposeArgs<T> &A, T) { return A.coef; }
+template <typename T> __device__ __forceinline__ int64_t qmissing(const RecomposeArgs<T> &A, int64_t) { return A.half; }
+template <typename T> __device__ __forceinline__ T qmissing(const RecomposeArgs<T> &, T) { return (T)0; }
+template <typename T> __device__ __forceinline__ T qdecode(const RecomposeArgs<T> &A, int64_t v) {
+  return dequant_one<T>(v, A.half, A.qv);
+}
+template <typename T> __device__ __forceinline__ T qdecode(const RecomposeArgs<T> &, T v) { return v; }
+
+template <typename T, typename QT, int TC, int TF, int RCH>
 __global__ void __launch_bounds__(256)
 k_level_loadvec_q(RecomposeArgs<T> A) {
   constexpr int WC = 2 * TC + 3;
@@ -98,16 +111,16 @@ k_level_loadvec_q(RecomposeArgs<T> A) {
     lds[k] = e < WC * WF ? LI(lc, lf) : -1;
     evn[k] = !(lc & 1) && !(lf & 1);
   }
-  auto fetch = [&](int p, int64_t(&reg)[NL]) {
+  auto fetch = [&](int p, QT(&reg)[NL]) {
     const bool pv = p >= 0 && p <= Pmax_r && p != ghost_r;
     const bool p_odd = p & 1;
     const int oi = p_odd ? mr + (p - 1) / 2 : p / 2;
-    const int64_t *base = A.q + (size_t)(pv ? oi : 0) * A.dI;
+    const QT *base = qsrc<T>(A, QT()) + (size_t)(pv ? oi : 0) * A.dI;
 #pragma unroll
     for (int k = 0; k < NL; k++)
-      reg[k] = (pv && qoff[k] != kNone && (p_odd || !evn[k])) ? base[qoff[k]] : A.half;
+      reg[k] = (pv && qoff[k] != kNone && (p_odd || !evn[k])) ? base[qoff[k]] : qmissing<T>(A, QT());
   };
-  int64_t cur[NL], nxt[NL];
+  QT cur[NL], nxt[NL];
   fetch(r_lo, cur);
   for (int p = r_lo; p <= r_hi; p++) {
     if (p < r_hi) fetch(p + 1, nxt);
@@ -115,7 +128,7 @@ k_level_loadvec_q(RecomposeArgs<T> A) {
     // a missing value was fetched as `half`, which dequantizes to exactly 0)
 #pragma unroll
     for (int k = 0; k < NL; k++)
-      if (lds[k] >= 0) Cs[lds[k]] = dequant_one<T>(cur[k], A.half, A.qv);
+      if (lds[k] >= 0) Cs[lds[k]] = qdecode<T>(A, cur[k]);
     __syncthreads();
     for (int lc = jc; lc < WC; lc += TC) {
       const T *row = Cs + lc * ROW;
@@ -153,7 +166,7 @@ k_level_loadvec_q(RecomposeArgs<T> A) {
 // t = lane, lane + 64, ...: consecutive lanes read consecutive quantized values in both the
 // coarse-f and the coefficient-f part of the reordered row and consecutive coarse nodes, and
 // write 8 contiguous bytes each. Row-level index math is done once per wave.
-template <typename T>
+template <typename T, typename QT>
 __global__ void __launch_bounds__(256)
 k_level_restore_q(RecomposeArgs<T> A) {
   const int nr = A.n[0], nc = A.n[1], nf = A.n[2];
@@ -172,7 +185,7 @@ k_level_restore_q(RecomposeArgs<T> A) {
   const size_t mJ = mf, mI = (size_t)mc * mf;
   const int r0 = ro ? (rp - 1) / 2 : i, c0 = co ? (cp - 1) / 2 : j;
   const T rr = ro ? A.ratio[0][rp - 1] : (T)0, rc = co ? A.ratio[1][cp - 1] : (T)0;
-  const int64_t *qrow = A.q + (size_t)i * A.dI + (size_t)j * A.dJ;
+  const QT *qrow = qsrc<T>(A, QT()) + (size_t)i * A.dI + (size_t)j * A.dJ;
   T *out = A.fine + (size_t)rp * A.fI + (size_t)cp * A.fJ;
   const bool pure_coarse = !ro && !co;
   const T *rows[2][2];
@@ -211,13 +224,13 @@ k_level_restore_q(RecomposeArgs<T> A) {
     const T iO = ro ? lerp_ref(hO[0], hO[1], rr) : hO[0];
     // E: coarse node (pure copy) unless r or c is odd
     T vE = iE;
-    if (!pure_coarse) vE = dequant_one<T>(qrow[t], A.half, A.qv) + iE;
+    if (!pure_coarse) vE = qdecode<T>(A, qrow[t]) + iE;
     T vO = iO;  // (pure coarse last node of an even-sized dim: iO = row[mf-1])
     if (hasO) {
       if (fo)
-        vO = dequant_one<T>(qrow[mf + t], A.half, A.qv) + iO;
+        vO = qdecode<T>(A, qrow[mf + t]) + iO;
       else if (!pure_coarse)
-        vO = dequant_one<T>(qrow[mf - 1], A.half, A.qv) + iO;
+        vO = qdecode<T>(A, qrow[mf - 1]) + iO;
     }
     // the pair is contiguous: one 2-element store when the row start allows it
     T *dst = out + 2 * t;
@@ -231,13 +244,13 @@ k_level_restore_q(RecomposeArgs<T> A) {
   }
 }
 
-template <typename T>
+template <typename T, typename QT>
 __global__ void __launch_bounds__(256)
 k_head_in_q(int m0, int m1, int m2, RecomposeArgs<T> A, T *__restrict__ nodal) {
   const int total = m0 * m1 * m2;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const int k = e % m2, j = (e / m2) % m1, i = e / (m2 * m1);
-    nodal[e] = dequant_one<T>(A.q[(size_t)i * A.dI + (size_t)j * A.dJ + k], A.half, A.qv);
+    nodal[e] = qdecode<T>(A, qsrc<T>(A, QT())[(size_t)i * A.dI + (size_t)j * A.dJ + k]);
   }
 }
 
