@@ -56,6 +56,7 @@ struct mgh_hierarchy {
   int device = 0;
   int D = 0, L = 0;
   uint64_t total = 0;
+  uint64_t plane_elems = 0;  // product of the two fastest dimensions
   void *host = nullptr;  // HostHierarchy<T>*
   void *impl = nullptr;  // DeviceState<T>*
   bool profiling = false;
@@ -727,7 +728,11 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
   return decompose_fused<T, OUT>(h, data, coeff, qp, s, false, [] { return (int)MGH_SUCCESS; });
 }
 
-inline bool fused_ok(const mgh_hierarchy *h) { return h->D == 3 && h->L >= 1; }
+// The fused kernels index inside an r-plane with 32-bit offsets (and the emit pass with 32-bit
+// byte offsets): planes of 2^29 elements or more go through the one-thread-per-element kernels.
+inline bool fused_ok(const mgh_hierarchy *h) {
+  return h->D == 3 && h->L >= 1 && h->plane_elems < ((uint64_t)1 << 29);
+}
 
 
 // ---- N-D path (D = 4, 5): in place on `v` (full array, reordered as levels proceed) -------
@@ -1350,6 +1355,7 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     return fail(MGH_ERR_INVALID_ARGUMENT,
                 "invalid shape: every dimension must have at least 3 nodes");
   }
+  h->plane_elems = shape[D - 1] * (D >= 2 ? shape[D - 2] : 1);
   int rc = DISPATCH(h, build_device_state<float>(h), build_device_state<double>(h));
   if (rc != MGH_SUCCESS) {
     mgh_hierarchy_destroy(h);
