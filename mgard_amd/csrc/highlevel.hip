@@ -481,6 +481,24 @@ struct Decomposer {
     }
     return r;
   }
+  // A subdomain is one contiguous run of the full array when it spans every dimension but the
+  // slowest completely; then it can be used in place (no copy) if the array is device memory.
+  bool contiguous(uint64_t id) const {
+    const auto ext = subdomain_shape(id);
+    for (int d = 1; d < D; d++)
+      if (ext[d] != shape[d]) return false;
+    return true;
+  }
+  uint64_t linear_offset(uint64_t id) const {
+    uint64_t inner = 1;
+    for (int d = 1; d < D; d++) inner *= shape[d];
+    return subdomain_offset(id)[0] * inner;
+  }
+  bool all_contiguous() const {
+    for (uint64_t id = 0; id < num; id++)
+      if (!contiguous(id)) return false;
+    return true;
+  }
   uint64_t max_subdomain_elems() const {
     uint64_t m = 0;
     for (uint64_t id = 0; id < num; id++) {
@@ -599,6 +617,12 @@ int copy_subdomain(const Decomposer &dd, uint64_t id, size_t elem, void *sub, co
       fstride[d] = s;
       s *= dd.shape[d];
     }
+  }
+  if (k == 0) {  // one contiguous run
+    const size_t fo = off[0] * fstride[0];
+    if (to_sub) HL_HIP(hipMemcpyAsync(sub, (const char *)full_c + fo * elem, width, hipMemcpyDefault, st));
+    else HL_HIP(hipMemcpyAsync((char *)full_m + fo * elem, sub, width, hipMemcpyDefault, st));
+    return MGH_SUCCESS;
   }
   size_t sub_off = 0;
   const size_t sub_block = rows * width;
@@ -809,10 +833,22 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
   };
   const uint64_t max_elems = dd.max_subdomain_elems();
   const uint64_t ocap = std::max<uint64_t>(1, (uint64_t)(cfg.estimate_outlier_ratio * (double)max_elems));
+  // device-resident input whose subdomains are contiguous slabs: compress them where they are
+  const bool zero_copy = in_dev && dd.all_contiguous();
+  auto sub_in = [&](uint64_t id, int buf) -> const void * {
+    return zero_copy ? (const void *)((const char *)original + dd.linear_offset(id) * elem)
+                     : (const void *)g_cache.in[buf].p;
+  };
+  auto fetch_sub = [&](uint64_t id, int buf, hipStream_t stream) -> int {
+    if (zero_copy) return MGH_SUCCESS;
+    return copy_subdomain(dd, id, elem, g_cache.in[buf].p, original, nullptr, true, stream);
+  };
   int rc;
   auto ensure_all = [&]() -> int {
-    HL_TRY(g_cache.in[0].ensure(max_elems * elem));
-    if (dd.num > 1) HL_TRY(g_cache.in[1].ensure(max_elems * elem));
+    if (!zero_copy) {
+      HL_TRY(g_cache.in[0].ensure(max_elems * elem));
+      if (dd.num > 1) HL_TRY(g_cache.in[1].ensure(max_elems * elem));
+    }
     HL_TRY(g_cache.q.ensure(max_elems * 8));
     HL_TRY(g_cache.ocount.ensure(8));
     HL_TRY(g_cache.oidx.ensure(ocap * 8));
@@ -829,12 +865,11 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
     if (ebtype == MGH_REL) {
       double acc = 0;
       int buf = 0;
-      if ((rc = copy_subdomain(dd, 0, elem, g_cache.in[0].p, original, nullptr, true, g_cache.streams[0])) != MGH_SUCCESS)
+      if ((rc = fetch_sub(0, 0, g_cache.streams[0])) != MGH_SUCCESS)
         return cleanup(rc);
       for (uint64_t id = 0; id < dd.num; id++) {
         const int nb = (buf + 1) % 2;
-        if (id + 1 < dd.num &&
-            (rc = copy_subdomain(dd, id + 1, elem, g_cache.in[nb].p, original, nullptr, true, g_cache.streams[1])) != MGH_SUCCESS)
+        if (id + 1 < dd.num && (rc = fetch_sub(id + 1, nb, g_cache.streams[1])) != MGH_SUCCESS)
           return cleanup(rc);
         mgh_hierarchy *h = nullptr;
         bool owned = false;
@@ -842,7 +877,7 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
         if ((rc = get_hierarchy(&h, &owned, dtype, sshape, nullptr, dd.subdomain_offset(id), cfg)) != MGH_SUCCESS)
           return cleanup(rc);
         double ln = 0;
-        rc = mgh_norm(h, g_cache.in[buf].p, s_d, &ln, g_cache.streams[0]);
+        rc = mgh_norm(h, sub_in(id, buf), s_d, &ln, g_cache.streams[0]);
         if (rc != MGH_SUCCESS) return cleanup(rc);
         uint64_t cnt = 1;
         for (uint64_t e : sshape) cnt *= e;
@@ -869,13 +904,12 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
 
   // ---- subdomain pipeline (compress_pipeline_gpu, GPUPipelines.hpp:69-207) ----
   int buf = 0, qi = 0;
-  if ((rc = copy_subdomain(dd, 0, elem, g_cache.in[0].p, original, nullptr, true, g_cache.streams[0])) != MGH_SUCCESS)
+  if ((rc = fetch_sub(0, 0, g_cache.streams[0])) != MGH_SUCCESS)
     return cleanup(rc);
   for (uint64_t id = 0; id < dd.num; id++) {
     const int nb = (buf + 1) % 2, nq = (qi + 1) % 3;
     hipStream_t st = g_cache.streams[qi];
-    if (id + 1 < dd.num &&
-        (rc = copy_subdomain(dd, id + 1, elem, g_cache.in[nb].p, original, nullptr, true, g_cache.streams[nq])) != MGH_SUCCESS)
+    if (id + 1 < dd.num && (rc = fetch_sub(id + 1, nb, g_cache.streams[nq])) != MGH_SUCCESS)
       return cleanup(rc);
     const auto sshape = dd.subdomain_shape(id);
     uint64_t n = 1;
@@ -887,7 +921,7 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
     double norm_out = (double)norm;
     rc = hipMemsetAsync(g_cache.ocount.p, 0, 8, st) == hipSuccess ? MGH_SUCCESS : hl_fail(MGH_ERR_DEVICE, "memset");
     if (rc == MGH_SUCCESS)
-      rc = mgh_decompose_quantize(h, g_cache.in[buf].p, local_eb, (double)local_tol, s_d,
+      rc = mgh_decompose_quantize(h, sub_in(id, buf), local_eb, (double)local_tol, s_d,
                                   local_eb == MGH_REL ? 0.0 : (double)norm,
                                   local_eb == MGH_REL ? &norm_out : nullptr, cfg.huff_dict_size, 1,
                                   (int64_t *)g_cache.q.p, (uint64_t *)g_cache.ocount.p,
@@ -923,7 +957,7 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
       if (raw) {
         // the dense subdomain itself (re-fetched: decompose_quantize does not modify its input,
         // so the buffer still holds it)
-        rc = hipMemcpyAsync(dst, g_cache.in[buf].p, csize, hipMemcpyDefault, st) == hipSuccess ? MGH_SUCCESS : MGH_ERR_DEVICE;
+        rc = hipMemcpyAsync(dst, sub_in(id, buf), csize, hipMemcpyDefault, st) == hipSuccess ? MGH_SUCCESS : MGH_ERR_DEVICE;
       } else {
         rc = record_write(g_cache.ll, dst, st);
       }
@@ -1041,8 +1075,10 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
   };
   const uint64_t max_elems = dd.max_subdomain_elems();
   int rc;
+  // device-resident output whose subdomains are contiguous slabs: reconstruct them in place
+  const bool zero_copy = is_device_pointer(*out) && dd.all_contiguous();
   auto ensure_all = [&]() -> int {
-    HL_TRY(g_cache.in[0].ensure(max_elems * elem));
+    if (!zero_copy) HL_TRY(g_cache.in[0].ensure(max_elems * elem));
     HL_TRY(g_cache.q.ensure(max_elems * 8));
     return MGH_SUCCESS;
   };
@@ -1069,6 +1105,7 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
     uint64_t n = 1;
     for (uint64_t e : sshape) n *= e;
     const char *rec = (const char *)compressed + byte_offset;
+    void *sub = zero_copy ? (void *)((char *)*out + dd.linear_offset(id) * elem) : g_cache.in[0].p;
     if ((double)(n * elem) / (double)csize > 1.0) {  // GPUPipelines.hpp:414-417
       const uint8_t *payload = (const uint8_t *)rec;
       uint64_t ocount = 0;
@@ -1080,7 +1117,7 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
         return cleanup(rc);
       rc = mgh_dequantize_recompose(h, (int64_t *)g_cache.q.p, local_eb, (double)local_tol, (double)s,
                                     (double)norm, hd.huff_dict_size, 1, (const uint64_t *)g_cache.ll->oidx.p,
-                                    (const int64_t *)g_cache.ll->oval.p, ocount, g_cache.in[0].p, st);
+                                    (const int64_t *)g_cache.ll->oval.p, ocount, sub, st);
       if (owned) {
         (void)hipStreamSynchronize(st);
         mgh_hierarchy_destroy(h);
@@ -1088,10 +1125,10 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
       if (rc != MGH_SUCCESS) return cleanup(rc);
     } else {
       if (csize != n * elem) return cleanup(hl_fail(MGH_ERR_FORMAT, "raw subdomain record has the wrong size"));
-      if (hipMemcpyAsync(g_cache.in[0].p, rec, csize, hipMemcpyDefault, st) != hipSuccess)
+      if (hipMemcpyAsync(sub, rec, csize, hipMemcpyDefault, st) != hipSuccess)
         return cleanup(hl_fail(MGH_ERR_DEVICE, "reading the raw subdomain"));
     }
-    if ((rc = copy_subdomain(dd, id, elem, g_cache.in[0].p, nullptr, *out, false, st)) != MGH_SUCCESS)
+    if (!zero_copy && (rc = copy_subdomain(dd, id, elem, sub, nullptr, *out, false, st)) != MGH_SUCCESS)
       return cleanup(rc);
     if (hipStreamSynchronize(st) != hipSuccess) return cleanup(hl_fail(MGH_ERR_DEVICE, "sync"));
     byte_offset += csize;
