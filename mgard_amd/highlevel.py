@@ -199,9 +199,11 @@ def _as_ptr(a):
     return C.c_void_p(a.ctypes.data), dt, a.shape, a
 
 
-def compress(data, tol, s=INF, mode=REL, coords=None, config=None, out_capacity=None):
+def compress(data, tol, s=INF, mode=REL, coords=None, config=None, out_capacity=None, out=None):
     """mgard_x::compress. `data`: numpy array (host) or cuda tensor (device). Returns the
-    compressed stream as a numpy uint8 array (host input) or a cuda uint8 tensor (device input)."""
+    compressed stream as a numpy uint8 array (host input) or a cuda uint8 tensor (device input).
+    `out`: optional pre-allocated uint8 buffer of the same kind to write into (its size is the
+    capacity)."""
     import torch
     L = _hl()
     cfg = config if config is not None else Config()
@@ -221,7 +223,10 @@ def compress(data, tol, s=INF, mode=REL, coords=None, config=None, out_capacity=
     on_device = isinstance(data, torch.Tensor) and data.is_cuda
     nbytes = int(np.prod(shape)) * (4 if dt == FLOAT else 8)
     cap = int(out_capacity) if out_capacity is not None else nbytes + 1000000
-    if on_device:
+    if out is not None:
+        cap = int(out.numel()) if on_device else int(out.size)
+        optr = C.c_void_p(out.data_ptr()) if on_device else C.c_void_p(out.ctypes.data)
+    elif on_device:
         out = torch.empty(cap, dtype=torch.uint8, device=data.device)
         optr = C.c_void_p(out.data_ptr())
     else:
