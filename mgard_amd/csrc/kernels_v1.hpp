@@ -234,23 +234,64 @@ k_ipk(uint32_t n0, uint32_t n1, uint32_t n2, T *__restrict__ x, const T *__restr
     base = pb * sJ + pa; st = sI;
   }
   T *p = x + base;
+  // The loads of a pencil do not depend on the recurrence: issue them U at a time ahead of the
+  // dependent chain (a load per step would expose the full memory latency at every step --
+  // this kernel serves the pencils that are too long for the LDS-staged solves).
+  constexpr uint32_t U = 8;
   T prev = 0;
-  for (uint32_t i = 0; i < n; i++) {
-    T cur = p[i * st];
+  uint32_t i = 0;
+  for (; i + U <= n; i += U) {
+    T v[U], m[U];
+#pragma unroll
+    for (uint32_t u = 0; u < U; u++) {
+      v[u] = p[(size_t)(i + u) * st];
+      m[u] = tt[i + u];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < U; u++) {
+      v[u] = v[u] - prev * m[u];
+      prev = v[u];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < U; u++) p[(size_t)(i + u) * st] = v[u];
+  }
+  for (; i < n; i++) {
+    T cur = p[(size_t)i * st];
     cur = cur - prev * tt[i];
-    p[i * st] = cur;
+    p[(size_t)i * st] = cur;
     prev = cur;
   }
   prev = 0;
-  for (uint32_t kk = 0; kk < n; kk++) {
-    const uint32_t i = n - 1 - kk;
-    T cur = p[i * st];
-    cur = (cur - tt[n + i] * prev) / tt[2 * n + i];
-    if (add_to) {
-      T *q = add_to + base + i * st;
-      if (sign > 0) *q += cur; else *q -= cur;
+  T *q = add_to ? add_to + base : nullptr;
+  int64_t k = (int64_t)n - 1;
+  for (; k >= (int64_t)U - 1; k -= U) {
+    T v[U], am[U], bm[U], o[U];
+#pragma unroll
+    for (uint32_t u = 0; u < U; u++) {
+      v[u] = p[(size_t)(k - u) * st];
+      am[u] = tt[n + (k - u)];
+      bm[u] = tt[2 * n + (k - u)];
+      o[u] = q ? q[(size_t)(k - u) * st] : (T)0;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < U; u++) {
+      v[u] = (v[u] - am[u] * prev) / bm[u];
+      prev = v[u];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < U; u++) {
+      if (q) q[(size_t)(k - u) * st] = sign > 0 ? o[u] + v[u] : o[u] - v[u];
+      else p[(size_t)(k - u) * st] = v[u];
+    }
+  }
+  for (; k >= 0; k--) {
+    T cur = p[(size_t)k * st];
+    cur = (cur - tt[n + k] * prev) / tt[2 * n + k];
+    if (q) {
+      T *qq = q + (size_t)k * st;
+      if (sign > 0) *qq += cur; else *qq -= cur;
     } else {
-      p[i * st] = cur;
+      p[(size_t)k * st] = cur;
     }
     prev = cur;
   }
