@@ -430,9 +430,10 @@ int ipk_fc_launch(mgh_hierarchy *h, const uint32_t *m, T *x, const T *tt_f, cons
   if ((size_t)m[1] * pitch * sizeof(T) <= 150 * 1024 && m[1] <= 1024 && m[2] <= 1024) {
     static bool once = false;
     if (!once) { TRY(allow_big_lds(k_ipk_plane_fc<T>)); once = true; }
+    const uint32_t magic = (uint32_t)((((uint64_t)1 << 32) + m[2] - 1) / m[2]);  // e / m2, e < 2^32 / m2
     return launch(h, "ipk_fc", s, [&] {
-      k_ipk_plane_fc<T><<<m[0], 256, (size_t)m[1] * pitch * sizeof(T), s>>>(m[1], m[2], pitch, x,
-                                                                              tt_f, tt_c);
+      k_ipk_plane_fc<T><<<m[0], 256, (size_t)m[1] * pitch * sizeof(T), s>>>(m[1], m[2], pitch, magic,
+                                                                              x, tt_f, tt_c);
     });
   }
   TRY(ipk_launch<T>(h, 2, m, x, tt_f, nullptr, +1, s));

@@ -135,12 +135,12 @@ k_tail(TailArgs<T> A) {
     }
     __syncthreads();
     // ---- Thomas solves in LDS: f, c, r ----
-    for (uint32_t p = tid; p < m0 * m1; p += NT) thomas_lds<T>(T3 + (size_t)p * m2, 1, m2, L.thomas[2]);
+    for (uint32_t p = tid; p < m0 * m1; p += NT) thomas_lds<T, false>(T3 + (size_t)p * m2, 1, m2, L.thomas[2]);
     __syncthreads();
     for (uint32_t p = tid; p < m0 * m2; p += NT)
-      thomas_lds<T>(T3 + (size_t)(p / m2) * m1 * m2 + (p % m2), m2, m1, L.thomas[1]);
+      thomas_lds<T, false>(T3 + (size_t)(p / m2) * m1 * m2 + (p % m2), m2, m1, L.thomas[1]);
     __syncthreads();
-    for (uint32_t p = tid; p < m1 * m2; p += NT) thomas_lds<T>(T3 + p, m1 * m2, m0, L.thomas[0]);
+    for (uint32_t p = tid; p < m1 * m2; p += NT) thomas_lds<T, false>(T3 + p, m1 * m2, m0, L.thomas[0]);
     __syncthreads();
     // ---- apply the correction (AddND); the corrected coarse nodes are the next level ----
     for (uint32_t e = tid; e < mtot; e += NT) Y[e] += T3[e];
