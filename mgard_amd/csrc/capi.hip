@@ -386,7 +386,7 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
     const size_t outer_stride = (size_t)m[1] * m[2];
     const size_t stride = axis == 1 ? (size_t)m[2] : (size_t)m[1] * m[2];
     const size_t lds = best_w * pencil_bytes;
-    const unsigned blocks = (npencil + best_w - 1) / best_w;
+    const unsigned blocks = ((npencil + best_w - 1) / best_w + 7) / 8 * 8;  // XCD-contiguous tile ranges
 #define MGH_STRIDED(W)                                                                        \
   {                                                                                           \
     static bool once = false;                                                                 \

@@ -234,7 +234,7 @@ k_ipk_lds_contig(uint32_t npencil, uint32_t n, uint32_t pad, uint32_t magic, uin
 // [0, n_outer * n_inner): base = (p / n_inner) * outer_stride + p % n_inner; consecutive
 // positions are `stride` elements apart. Where the VN pencils of a thread are not
 // neighbours in memory (the tile crosses an outer boundary, or the end of the range)
-// the thread falls back to element accesses.
+// the thread falls back to element accesses. Launch with a grid padded to a multiple of 8.
 template <typename T, int W>
 __global__ void __launch_bounds__(256)
 k_ipk_lds_strided(uint32_t n_outer, uint32_t n_inner, size_t outer_stride, size_t stride,
@@ -252,7 +252,12 @@ k_ipk_lds_strided(uint32_t n_outer, uint32_t n_inner, size_t outer_stride, size_
   const uint32_t npencil = n_outer * n_inner;
   const uint32_t cv = threadIdx.x % WV;
   const uint32_t r0 = threadIdx.x / WV;
-  const uint32_t p = blockIdx.x * W + cv * VN;  // first pencil of this thread
+  // workgroups go round-robin to the 8 XCDs (own L2 each): give every XCD a contiguous range of
+  // tiles, so that the cache lines two neighbouring tiles share are fetched by one L2
+  const uint32_t per = (gridDim.x + 7) / 8;
+  const uint32_t bid = (blockIdx.x % 8) * per + blockIdx.x / 8;
+  if ((uint64_t)bid * W >= (uint64_t)n_outer * n_inner) return;  // grid is padded to a multiple of 8
+  const uint32_t p = bid * W + cv * VN;  // first pencil of this thread
   const bool rows_live = r0 < (uint32_t)RW;
   const uint32_t po = p / n_inner;
   const bool vec = p + VN - 1 < npencil && (p + VN - 1) / n_inner == po;
@@ -294,7 +299,7 @@ k_ipk_lds_strided(uint32_t n_outer, uint32_t n_inner, size_t outer_stride, size_
     }
   }
   __syncthreads();
-  if ((MGH_IPK_PHASES & 2) && threadIdx.x < W && blockIdx.x * W + threadIdx.x < npencil)
+  if ((MGH_IPK_PHASES & 2) && threadIdx.x < W && bid * W + threadIdx.x < npencil)
     thomas_lds<T>(sm + threadIdx.x, W, n, tt);
   __syncthreads();
   if ((MGH_IPK_PHASES & 4) && rows_live) {
