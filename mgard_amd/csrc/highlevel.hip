@@ -158,7 +158,8 @@ struct PayloadLayout {
 // ---- lossless context ----------------------------------------------------------------------
 struct mgh_lossless_ctx {
   int dev = 0;
-  DevBuf freq, code, bits, entry, total, units, tables, oidx, oval;
+  DevBuf freq, code, bits, entry, total, units, tables, oidx, oval, state;
+  bool overflow = false;  // the code stream did not fit into cap_units: treat as incompressible
   std::vector<uint8_t> host;   // serialized payload (when assembled on the host)
   std::vector<uint8_t> host2;  // zstd scratch
   // the record of the last compress call in pieces: everything before the code units sits in
@@ -169,7 +170,7 @@ struct mgh_lossless_ctx {
   const uint64_t *d_oidx = nullptr;
   const int64_t *d_oval = nullptr;
   bool on_host = false;  // Huffman_Zstd: the whole record is in `host`
-  size_t record_size() const { return on_host ? host.size() : lay.total; }
+  size_t record_size() const { return overflow ? ~(size_t)0 : (on_host ? host.size() : lay.total); }
 };
 
 namespace {
@@ -195,9 +196,14 @@ int record_write(mgh_lossless_ctx *c, void *dst, hipStream_t st) {
   return MGH_SUCCESS;
 }
 
+// ocount: number of outliers, or (d_ocount != nullptr) read from the device together with the
+// results of the encoder (one host synchronisation less) and checked against ocap.
+// cap_units: upper bound for the code stream the caller is interested in (0: worst case).
 int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint64_t dict,
                       uint64_t chunk, int lossless, int zstd_level, const uint64_t *d_oidx,
-                      const int64_t *d_oval, uint64_t ocount, hipStream_t st) {
+                      const int64_t *d_oval, uint64_t ocount, hipStream_t st,
+                      const uint64_t *d_ocount = nullptr, uint64_t ocap = ~(uint64_t)0,
+                      uint64_t cap_units = 0) {
   if (lossless != MGH_LOSSLESS_HUFFMAN && lossless != MGH_LOSSLESS_HUFFMAN_ZSTD)
     return hl_fail(MGH_ERR_INVALID_ARGUMENT, "lossless: only Huffman and Huffman_Zstd are supported");
   if (n == 0 || dict == 0 || dict > 16384 || chunk == 0 || chunk > (1u << 30))
@@ -226,62 +232,84 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
   }
   hl_debug("lossless_compress: histogram done");
   HL_HIP(hipMemcpyAsync(c->code.p, cb.code.data(), dict * 8, hipMemcpyHostToDevice, st));
-  huff::k_chunk_bits<<<(unsigned)nchunk, 256, 0, st>>>(d_q, n, (int)chunk, (const uint64_t *)c->code.p,
-                                                       (unsigned long long *)c->bits.p);
-  huff::k_unit_offsets<<<1, 1024, 0, st>>>((const unsigned long long *)c->bits.p, nchunk,
-                                           (unsigned long long *)c->entry.p,
-                                           (unsigned long long *)c->total.p);
-  HL_HIP(hipGetLastError());
-  unsigned long long units = 0;
-  HL_HIP(hipMemcpyAsync(&units, c->total.p, 8, hipMemcpyDeviceToHost, st));
-  HL_HIP(hipStreamSynchronize(st));
-  hl_debug("lossless_compress: chunk bits + offsets done");
-  HL_TRY(c->units.ensure(std::max<size_t>(units, 1) * 8));
-  HL_HIP(hipMemsetAsync(c->units.p, 0, units * 8, st));
-  const size_t enc_lds = dict * 8 + chunk * 2;
-  if (enc_lds <= 150 * 1024) {
-    static bool once = false;
-    if (!once) {
-      HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_encode_lds),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-      once = true;
-    }
-    huff::k_encode_lds<<<(unsigned)nchunk, 256, enc_lds, st>>>(
-        d_q, n, (int)chunk, (int)dict, (const uint64_t *)c->code.p,
-        (const unsigned long long *)c->entry.p, (unsigned long long *)c->units.p);
-  } else {
-    huff::k_encode<<<(unsigned)nchunk, 256, 0, st>>>(d_q, n, (int)chunk, (const uint64_t *)c->code.p,
-                                                     (const unsigned long long *)c->entry.p,
-                                                     (unsigned long long *)c->units.p);
-  }
-  HL_HIP(hipGetLastError());
-  hl_debug("lossless_compress: encode launched");
   // ---- serialize (Huffman.hpp:163-239): the small leading part on the host, the code units
   // and the outlier lists stay where they are until record_write() ----
   PayloadLayout &L = c->lay;
-  L.compute(nchunk, dict, units, ocount);
+  L.compute(nchunk, dict, 0, 0);  // (the offsets before the code units do not depend on the counts)
   std::vector<uint8_t> &out = c->head;
   out.assign(L.ddata, 0);
+  auto fetch_meta = [&]() -> int {  // bits_per_chunk[] and word_entry[] into the head
+    HL_HIP(hipMemcpyAsync(out.data() + L.huffmeta, c->bits.p, nchunk * 8, hipMemcpyDeviceToHost, st));
+    HL_HIP(hipMemcpyAsync(out.data() + L.huffmeta + nchunk * 8, c->entry.p, nchunk * 8,
+                          hipMemcpyDeviceToHost, st));
+    if (d_ocount) HL_HIP(hipMemcpyAsync(&ocount, d_ocount, 8, hipMemcpyDeviceToHost, st));
+    return MGH_SUCCESS;
+  };
+  unsigned long long units = 0;
+  const size_t enc_lds = dict * 8 + chunk * 2;
+  if (enc_lds <= 140 * 1024) {
+    // one pass: bit counts, unit offsets (decoupled look-back) and packing in the same kernel.
+    // The stream is written into a buffer of cap_units; more than that means "not compressible".
+    const unsigned long long worst = n + nchunk;  // a code is shorter than a unit
+    const unsigned long long cap = cap_units ? std::min<unsigned long long>(cap_units, worst) : worst;
+    HL_TRY(c->units.ensure(std::max<size_t>(cap, 1) * 8 + 8));
+    HL_TRY(c->state.ensure((3 + nchunk) * 8));
+    HL_HIP(hipMemsetAsync(c->state.p, 0, (3 + nchunk) * 8, st));
+    static bool once = false;
+    if (!once) {
+      HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_encode_chain),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      once = true;
+    }
+    huff::k_encode_chain<<<(unsigned)nchunk, huff::kEncThreads, enc_lds, st>>>(
+        d_q, n, (int)chunk, (int)dict, nchunk, (const uint64_t *)c->code.p,
+        (unsigned long long *)c->state.p, (unsigned long long *)c->bits.p,
+        (unsigned long long *)c->entry.p, (unsigned long long *)c->units.p, cap);
+    HL_HIP(hipGetLastError());
+    unsigned long long st3[3] = {0, 0, 0};
+    HL_HIP(hipMemcpyAsync(st3, c->state.p, 24, hipMemcpyDeviceToHost, st));
+    HL_TRY(fetch_meta());
+    HL_HIP(hipStreamSynchronize(st));
+    units = st3[1];
+    c->overflow = st3[2] != 0;
+  } else {
+    huff::k_chunk_bits<<<(unsigned)nchunk, 256, 0, st>>>(d_q, n, (int)chunk, (const uint64_t *)c->code.p,
+                                                         (unsigned long long *)c->bits.p);
+    huff::k_unit_offsets<<<1, 1024, 0, st>>>((const unsigned long long *)c->bits.p, nchunk,
+                                             (unsigned long long *)c->entry.p,
+                                             (unsigned long long *)c->total.p);
+    HL_HIP(hipGetLastError());
+    HL_HIP(hipMemcpyAsync(&units, c->total.p, 8, hipMemcpyDeviceToHost, st));
+    HL_TRY(fetch_meta());
+    HL_HIP(hipStreamSynchronize(st));
+    HL_TRY(c->units.ensure(std::max<size_t>(units, 1) * 8 + 8));
+    HL_HIP(hipMemsetAsync(c->units.p, 0, units * 8, st));
+    huff::k_encode<<<(unsigned)nchunk, 256, 0, st>>>(d_q, n, (int)chunk, (const uint64_t *)c->code.p,
+                                                     (const unsigned long long *)c->entry.p,
+                                                     (unsigned long long *)c->units.p);
+    HL_HIP(hipGetLastError());
+    c->overflow = false;
+  }
+  hl_debug("lossless_compress: encode launched");
+  if (ocount > ocap) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "more outliers than estimate_outlier_ratio allows");
+  c->on_host = false;
+  if (c->overflow) return MGH_SUCCESS;  // record_size() says "larger than anything"
+  L.compute(nchunk, dict, units, ocount);
   auto put64 = [&](size_t off, uint64_t v) { std::memcpy(out.data() + off, &v, 8); };
   auto put32 = [&](size_t off, int32_t v) { std::memcpy(out.data() + off, &v, 4); };
   put64(L.primary_count, n);
   put32(8, (int32_t)dict);
   put32(12, (int32_t)chunk);
   put64(16, 2 * nchunk);
-  HL_HIP(hipMemcpyAsync(out.data() + L.huffmeta, c->bits.p, nchunk * 8, hipMemcpyDeviceToHost, st));
-  HL_HIP(hipMemcpyAsync(out.data() + L.huffmeta + nchunk * 8, c->entry.p, nchunk * 8,
-                        hipMemcpyDeviceToHost, st));
   put64(L.decodebook_size, 8 * (2 * 64) + 8 * dict);
   std::memcpy(out.data() + L.decodebook, cb.first.data(), 8 * 64);
   std::memcpy(out.data() + L.decodebook + 8 * 64, cb.entry.data(), 8 * 64);
   std::memcpy(out.data() + L.decodebook + 8 * 128, cb.keys.data(), 8 * dict);
   put64(L.ddata_size, units);
-  HL_HIP(hipStreamSynchronize(st));
   c->n_units = units;
   c->n_outliers = ocount;
   c->d_oidx = d_oidx;
   c->d_oval = d_oval;
-  c->on_host = false;
   if (lossless == MGH_LOSSLESS_HUFFMAN_ZSTD) {
     // [size_t input_count][zstd frame] (Zstd.hpp:69-90): needs the whole record on the host
     std::vector<uint8_t> &full = c->host2;
@@ -926,19 +954,12 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
                                   local_eb == MGH_REL ? &norm_out : nullptr, cfg.huff_dict_size, 1,
                                   (int64_t *)g_cache.q.p, (uint64_t *)g_cache.ocount.p,
                                   (uint64_t *)g_cache.oidx.p, (int64_t *)g_cache.oval.p, ocap, nullptr, st);
-    uint64_t ocount = 0;
-    if (rc == MGH_SUCCESS) {
-      if (hipMemcpyAsync(&ocount, g_cache.ocount.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
-          hipStreamSynchronize(st) != hipSuccess)
-        rc = hl_fail(MGH_ERR_DEVICE, "outlier count");
-      else if (ocount > ocap)
-        rc = hl_fail(MGH_ERR_INVALID_ARGUMENT, "more outliers than estimate_outlier_ratio allows");
-    }
     if (rc == MGH_SUCCESS && local_eb == MGH_REL) norm = (T)norm_out;
-    if (rc == MGH_SUCCESS)
+    if (rc == MGH_SUCCESS)  // (the outlier count is read back together with the encoder's results)
       rc = lossless_compress(g_cache.ll, (const int64_t *)g_cache.q.p, n, cfg.huff_dict_size,
                              cfg.huff_block_size, cfg.lossless, cfg.zstd_compress_level,
-                             (const uint64_t *)g_cache.oidx.p, (const int64_t *)g_cache.oval.p, ocount, st);
+                             (const uint64_t *)g_cache.oidx.p, (const int64_t *)g_cache.oval.p, 0, st,
+                             (const uint64_t *)g_cache.ocount.p, ocap, n * elem / 8 + 1);
     if (owned) mgh_hierarchy_destroy(h);
     if (rc != MGH_SUCCESS) return cleanup(rc);
     uint64_t csize = g_cache.ll->record_size();
@@ -1370,7 +1391,7 @@ int mgh_lossless_create(mgh_lossless_ctx **out, int dev_id) {
 void mgh_lossless_destroy(mgh_lossless_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->dev);
-  for (DevBuf *b : {&c->freq, &c->code, &c->bits, &c->entry, &c->total, &c->units, &c->tables, &c->oidx, &c->oval})
+  for (DevBuf *b : {&c->freq, &c->code, &c->bits, &c->entry, &c->total, &c->units, &c->tables, &c->oidx, &c->oval, &c->state})
     b->release();
   delete c;
 }

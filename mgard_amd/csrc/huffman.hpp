@@ -252,10 +252,12 @@ k_encode(const int64_t *__restrict__ q, size_t n, int chunk, const uint64_t *__r
   if (room != kUnitBits) flush(true);
 }
 
+constexpr int kEncThreads = 1024;  // one workgroup per CU (LDS): fill it with waves
+
 // Same as k_encode with the chunk's symbols (16 bit) and the code table staged in LDS: the
 // symbols are read from HBM once, coalesced, instead of every lane walking its own run, and the
 // per-symbol table lookups never leave the CU. Dynamic LDS: 8 * dict + 2 * chunk bytes.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kEncThreads)
 k_encode_lds(const int64_t *__restrict__ q, size_t n, int chunk, int dict,
              const uint64_t *__restrict__ code, const unsigned long long *__restrict__ entry,
              unsigned long long *__restrict__ out) {
@@ -264,17 +266,17 @@ k_encode_lds(const int64_t *__restrict__ q, size_t n, int chunk, int dict,
   unsigned short *ssym = reinterpret_cast<unsigned short *>(enc_lds + dict);
   const size_t base = (size_t)blockIdx.x * chunk;
   const size_t cnt = min((size_t)chunk, n - base);
-  for (int i = threadIdx.x; i < dict; i += 256) scode[i] = code[i];
-  for (size_t i = threadIdx.x; i < cnt; i += 256) ssym[i] = (unsigned short)q[base + i];
+  for (int i = threadIdx.x; i < dict; i += kEncThreads) scode[i] = code[i];
+  for (size_t i = threadIdx.x; i < cnt; i += kEncThreads) ssym[i] = (unsigned short)q[base + i];
   __syncthreads();
-  const size_t run = (cnt + 255) / 256;
+  const size_t run = (cnt + kEncThreads - 1) / kEncThreads;
   const size_t lo = min(cnt, threadIdx.x * run), hi = min(cnt, lo + run);
   unsigned long long s = 0;
   for (size_t i = lo; i < hi; i++) s += scode[ssym[i]] >> kMaxCodeBits;
-  __shared__ unsigned long long sc[256];
+  __shared__ unsigned long long sc[kEncThreads];
   sc[threadIdx.x] = s;
   __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
+  for (int off = 1; off < kEncThreads; off <<= 1) {
     const unsigned long long v = threadIdx.x >= (unsigned)off ? sc[threadIdx.x - off] : 0;
     __syncthreads();
     sc[threadIdx.x] += v;
@@ -283,6 +285,130 @@ k_encode_lds(const int64_t *__restrict__ q, size_t n, int chunk, int dict,
   unsigned long long pos = sc[threadIdx.x] - s;
   if (lo >= hi || s == 0) return;
   unsigned long long *dst = out + entry[blockIdx.x];
+  size_t w = pos / kUnitBits;
+  int room = kUnitBits - (int)(pos % kUnitBits);
+  unsigned long long acc = 0;
+  bool first_unit = true;
+  auto flush = [&](bool last) {
+    if (first_unit || last) atomicOr(&dst[w], acc);
+    else dst[w] = acc;
+    first_unit = false;
+  };
+  for (size_t i = lo; i < hi; i++) {
+    const uint64_t c = scode[ssym[i]];
+    const int len = (int)(c >> kMaxCodeBits);
+    const unsigned long long val = c & (((uint64_t)1 << kMaxCodeBits) - 1);
+    if (len <= room) {
+      room -= len;
+      acc |= val << room;
+      if (room == 0) {
+        flush(false);
+        w++;
+        acc = 0;
+        room = kUnitBits;
+      }
+    } else {
+      const int rest = len - room;
+      acc |= val >> rest;
+      flush(false);
+      w++;
+      room = kUnitBits - rest;
+      acc = val << room;
+    }
+  }
+  if (room != kUnitBits) flush(true);
+}
+
+// One pass over the symbols instead of two (k_chunk_bits + k_encode_lds): the unit offset of a
+// chunk is the sum of the unit counts of all chunks before it, which a workgroup obtains while
+// its symbols sit in LDS by a decoupled look-back over a status word per chunk (the single-pass
+// prefix scan of Merrill & Garland): chunks are handed out in ticket order, so every
+// predecessor of a running workgroup is running or done and the wait is bounded; a workgroup
+// publishes (AGGREGATE | its own units) as soon as it has counted its bits, and
+// (INCLUSIVE | units up to and including itself) once it knows its offset. Status words, ticket
+// and overflow flag are read and written with device-scope atomic read-modify-writes only (the
+// XCDs do not share an L2).
+//   state: [0] ticket counter, [1] total units (written by the last chunk), [2] overflow flag,
+//          [3 + c] status of chunk c; all zero before the launch.
+// A workgroup zeroes its units before packing (threads meet in shared units with atomicOr);
+// nothing is written beyond cap_units: the overflow flag tells the caller that the stream did not
+// fit (bits[] / entry[] / total are still right).
+constexpr unsigned long long kStAggregate = 1ull << 62, kStInclusive = 2ull << 62,
+                             kStValue = (1ull << 62) - 1;
+
+__global__ void __launch_bounds__(kEncThreads)
+k_encode_chain(const int64_t *__restrict__ q, size_t n, int chunk, int dict, size_t nchunk,
+               const uint64_t *__restrict__ code, unsigned long long *__restrict__ state,
+               unsigned long long *__restrict__ bits, unsigned long long *__restrict__ entry,
+               unsigned long long *__restrict__ out, unsigned long long cap_units) {
+  extern __shared__ unsigned long long enc_lds[];
+  unsigned long long *scode = enc_lds;
+  unsigned short *ssym = reinterpret_cast<unsigned short *>(enc_lds + dict);
+  __shared__ unsigned long long sc[kEncThreads];
+  __shared__ unsigned long long sh_id, sh_entry;
+  if (threadIdx.x == 0) sh_id = atomicAdd(&state[0], 1ull);
+  for (int i = threadIdx.x; i < dict; i += kEncThreads) scode[i] = code[i];
+  __syncthreads();
+  const size_t id = (size_t)sh_id;
+  const size_t base = id * chunk;
+  const size_t cnt = min((size_t)chunk, n - base);
+  for (size_t i = threadIdx.x; i < cnt; i += kEncThreads) ssym[i] = (unsigned short)q[base + i];
+  __syncthreads();
+  const size_t run = (cnt + kEncThreads - 1) / kEncThreads;
+  const size_t lo = min(cnt, threadIdx.x * run), hi = min(cnt, lo + run);
+  unsigned long long s = 0;
+  for (size_t i = lo; i < hi; i++) s += scode[ssym[i]] >> kMaxCodeBits;
+  sc[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < kEncThreads; off <<= 1) {
+    const unsigned long long v = threadIdx.x >= (unsigned)off ? sc[threadIdx.x - off] : 0;
+    __syncthreads();
+    sc[threadIdx.x] += v;
+    __syncthreads();
+  }
+  const unsigned long long chunk_bits = sc[kEncThreads - 1];
+  const unsigned long long my_units = (chunk_bits + kUnitBits - 1) / kUnitBits;
+  if (threadIdx.x < 64) {  // wave 0: publish, look back, publish
+    const int lane = threadIdx.x;
+    unsigned long long excl = 0;
+    if (id > 0) {
+      if (lane == 0) atomicExch(&state[3 + id], kStAggregate | my_units);
+      long long p = (long long)id - 1;  // first predecessor this round looks at
+      while (true) {
+        const long long mine = p - lane;
+        unsigned long long st = kStInclusive;  // lanes before chunk 0 terminate the walk
+        if (mine >= 0) st = atomicAdd(&state[3 + mine], 0ull);
+        const unsigned long long ready = __ballot((st >> 62) != 0);
+        const unsigned long long incl = __ballot((st >> 62) == 2);
+        // usable prefix of lanes: all ready up to (and including) the first inclusive one
+        const int first_unready = ready == ~0ull ? 64 : __ffsll((long long)~ready) - 1;
+        const int first_incl = incl ? __ffsll((long long)incl) - 1 : 64;
+        const int upto = min(first_unready, first_incl + 1);  // lanes [0, upto) are added
+        unsigned long long v = lane < upto && mine >= 0 ? (st & kStValue) : 0;
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        excl += __shfl(v, 0, 64);
+        if (first_incl < upto) break;  // reached an inclusive prefix
+        p -= upto;                     // (upto == 0: spin on the same predecessor)
+        if (upto == 0) __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    if (lane == 0) {
+      atomicExch(&state[3 + id], kStInclusive | (excl + my_units));
+      bits[id] = chunk_bits;
+      entry[id] = excl;
+      if (id == nchunk - 1) state[1] = excl + my_units;
+      if (excl + my_units > cap_units) atomicExch(&state[2], 1ull);
+      sh_entry = excl;
+    }
+  }
+  __syncthreads();
+  const unsigned long long e0 = sh_entry;
+  if (e0 + my_units > cap_units) return;
+  unsigned long long *dst = out + e0;
+  for (size_t i = threadIdx.x; i < my_units; i += kEncThreads) dst[i] = 0;
+  __syncthreads();
+  unsigned long long pos = sc[threadIdx.x] - s;
+  if (lo >= hi || s == 0) return;
   size_t w = pos / kUnitBits;
   int room = kUnitBits - (int)(pos % kUnitBits);
   unsigned long long acc = 0;
