@@ -425,6 +425,7 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
   int tb = 15;
   const size_t lds_keys_ring = ((size_t)dict * 2 + 7) / 8 * 8 + 16 * 64 * 8;
   while (tb > 8 && ((size_t)4 << tb) + lds_keys_ring > 154 * 1024) tb--;
+  if (const char *e = std::getenv("MGH_HUFF_TB")) tb = std::max(8, std::min(tb, atoi(e)));  // developer switch
   const size_t lds = ((size_t)4 << tb) + lds_keys_ring;
   static bool once = false;
   if (!once) {
@@ -441,8 +442,13 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
       once2 = true;
     }
+    // 14-bit prefix table at most, so that the write-out staging (4 KiB per wave) fits beside it
+    while (tb > 8 && ((size_t)4 << tb) + ((size_t)dict + 3) / 4 * 8 + huff::kParWaves * 64 * huff::kParBatch * 2 >
+                         150 * 1024)
+      tb--;
+    const size_t lds_par = ((size_t)4 << tb) + ((size_t)dict + 3) / 4 * 8 + huff::kParWaves * 64 * huff::kParBatch * 2;
     huff::k_decode_par<<<(unsigned)((nchunk + huff::kParWaves - 1) / huff::kParWaves),
-                         64 * huff::kParWaves, lds, st>>>(
+                         64 * huff::kParWaves, lds_par, st>>>(
         (const unsigned long long *)c->units.p, (const unsigned long long *)c->bits.p,
         (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, tb, tab, tab + 64, tab + 128, d_q);
   } else {

@@ -578,7 +578,11 @@ k_decode(const unsigned long long *__restrict__ units, const unsigned long long 
 //   3. symbol counts are prefix-summed across the wave and every lane decodes its subsequence
 //      once more, now writing the symbols to their final positions.
 // Same tables and semantics as k_decode. Dynamic LDS as for k_decode without the unit ring.
+#ifndef MGH_DEC_ROUNDS
+#define MGH_DEC_ROUNDS 64
+#endif
 constexpr int kParWaves = 16;
+constexpr int kParBatch = 32;  // symbols a lane decodes between two write-outs
 
 __global__ void __launch_bounds__(64 * kParWaves)
 k_decode_par(const unsigned long long *__restrict__ units, const unsigned long long *__restrict__ bits,
@@ -590,6 +594,8 @@ k_decode_par(const unsigned long long *__restrict__ units, const unsigned long l
   extern __shared__ unsigned dyn_lds[];
   unsigned *table = dyn_lds;
   unsigned short *skeys = reinterpret_cast<unsigned short *>(dyn_lds + (1u << tb));
+  // per wave: kParBatch symbols of every lane, staged for the coalesced write-out
+  unsigned short *stage = skeys + (((size_t)dict + 3) / 4 * 4) + (size_t)(threadIdx.x >> 6) * (64 * kParBatch);
   constexpr int NT = 64 * kParWaves;
   if (threadIdx.x < 64) {
     sfirst[threadIdx.x] = first[threadIdx.x];
@@ -621,7 +627,7 @@ k_decode_par(const unsigned long long *__restrict__ units, const unsigned long l
   if (c >= nchunk) return;  // (whole wave; no block-wide barrier follows)
   const unsigned long long *src = units + entry_of_chunk[c];
   const unsigned long long total = bits[c];
-  int64_t *dst = q + c * (size_t)chunk;
+  int64_t *dst = q ? q + c * (size_t)chunk : nullptr;
   const unsigned long long cap = min((size_t)chunk, n - c * (size_t)chunk);
   const unsigned long long nun = (total + 63) / 64;
   const unsigned long long B = (total + 63) / 64;  // bits per subsequence (ceil(total / 64))
@@ -680,7 +686,7 @@ k_decode_par(const unsigned long long *__restrict__ units, const unsigned long l
 
   unsigned long long s = min((unsigned long long)lane * B, total), cnt = 0;
   unsigned long long e = run(s, &cnt, nullptr, 0);
-  for (int it = 0; it < 64; it++) {
+  for (int it = 0; it < MGH_DEC_ROUNDS; it++) {
     unsigned long long pe = __shfl_up(e, 1, 64);
     if (lane == 0) pe = 0;
     const bool changed = s != pe;
@@ -697,9 +703,61 @@ k_decode_par(const unsigned long long *__restrict__ units, const unsigned long l
     if (lane >= d) off += v;
   }
   off -= cnt;
-  if (off < cap) {
-    unsigned long long c2 = 0;
-    (void)run(s, &c2, dst + off, cap - off);
+  // 3. final pass: every lane decodes its subsequence again, kParBatch symbols at a time into
+  // LDS; after each batch the wave writes the 64 runs out one after the other, 8-byte elements
+  // of a run side by side (a lane storing its own symbols directly touches 64 different cache
+  // lines per store instruction: 1.1 of 2.9 ms at 512^3).
+  if (!dst) return;
+  unsigned long long pos = s, done = 0;  // bit position, symbols of this lane written so far
+  unsigned long long cw = pos >> 6;
+  unsigned long long cur = src[min(cw, nun)], nxt = src[min(cw + 1, nun)];
+  bool live = pos < lim && cnt > 0;
+  while (__any(live)) {
+    int got = 0;
+    while (live && got < kParBatch) {
+      const int sh = (int)(pos & 63);
+      const unsigned long long win = sh ? (cur << sh) | (nxt >> (64 - sh)) : cur;
+      const unsigned e = table[win >> (64 - tb)];
+      int l = 0;
+      unsigned sym = 0;
+      bool hit = e != 0;
+      if (hit) {
+        l = (int)(e >> 16);
+        sym = e & 0xffff;
+      } else {
+        for (l = tb + 1; l <= 56; l++) {
+          const unsigned long long v = win >> (64 - l);
+          if (v >= sfirst[l]) {
+            const unsigned long long k = sentry[l] + v - sfirst[l];
+            if (k < (unsigned long long)dict) {
+              sym = skeys[k];
+              hit = true;
+            }
+            break;
+          }
+        }
+      }
+      if (!hit || pos + l > total) {
+        live = false;
+        break;
+      }
+      stage[lane * kParBatch + got] = (unsigned short)sym;
+      got++;
+      pos += l;
+      if ((pos >> 6) != cw) {
+        cw++;
+        cur = nxt;
+        nxt = src[min(cw + 1, nun)];
+      }
+      live = pos < lim && done + got < cnt;
+    }
+    // write-out (LDS traffic of one wave: in order, no barrier needed)
+    for (int L = 0; L < 64; L++) {
+      const int n_L = __shfl(got, L, 64);
+      const unsigned long long o_L = __shfl(off + done, L, 64);
+      if (lane < n_L && o_L + lane < cap) dst[o_L + lane] = (int64_t)stage[L * kParBatch + lane];
+    }
+    done += got;
   }
 }
 
