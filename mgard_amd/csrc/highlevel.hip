@@ -158,7 +158,7 @@ struct PayloadLayout {
 // ---- lossless context ----------------------------------------------------------------------
 struct mgh_lossless_ctx {
   int dev = 0;
-  DevBuf freq, code, bits, entry, total, units, tables, oidx, oval, state;
+  DevBuf freq, code, bits, entry, total, units, tables, oidx, oval, state, dtable;
   bool overflow = false;  // the code stream did not fit into cap_units: treat as incompressible
   std::vector<uint8_t> host;   // serialized payload (when assembled on the host)
   std::vector<uint8_t> host2;  // zstd scratch
@@ -434,7 +434,34 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
     once = true;
   }
   static const bool serial_decode = std::getenv("MGH_HUFF_SERIAL_DECODE") != nullptr;  // cross-check
-  if (!serial_decode && (size_t)chunk >= 1024) {
+  static const bool par_decode = std::getenv("MGH_HUFF_PAR_DECODE") != nullptr;           // cross-check
+  if (!serial_decode && !par_decode && (size_t)chunk >= 1024 && (size_t)chunk <= (1u << 24) && dict <= 65536) {
+    // parallel decoding inside the chunks: two-level table from the decodebook (host, microseconds),
+    // code units through per-lane LDS rings. 16 waves per workgroup when the table leaves room.
+    const uint64_t *book = reinterpret_cast<const uint64_t *>(head.data() + L.decodebook);
+    int rtb = 12;
+    if (const char *e = std::getenv("MGH_HUFF_TB")) rtb = std::max(8, std::min(14, atoi(e)));  // developer switch
+    const size_t lds_cap = 150 * 1024;
+    const size_t per_wave = huff::decode_ring_lds(0, 1);
+    const std::vector<uint32_t> dt = huff::build_decode_table(book, book + 64, book + 128, (int)dict, rtb,
+                                                              (lds_cap - 8 * per_wave) / 4);
+    const int waves = huff::decode_ring_lds(dt.size(), 16) <= lds_cap ? 16 : 8;
+    HL_TRY(c->dtable.ensure(dt.size() * 4));
+    HL_HIP(hipMemcpyAsync(c->dtable.p, dt.data(), dt.size() * 4, hipMemcpyHostToDevice, st));
+    static bool once3 = false;
+    if (!once3) {
+      HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_decode_ring),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+      once3 = true;
+    }
+    huff::k_decode_ring<<<(unsigned)((nchunk + waves - 1) / waves), 64 * waves,
+                          huff::decode_ring_lds(dt.size(), waves), st>>>(
+        (const unsigned long long *)c->units.p, (const unsigned long long *)c->bits.p,
+        (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, rtb, (const unsigned *)c->dtable.p,
+        (unsigned)dt.size(), tab, tab + 64, tab + 128, d_q);
+    HL_HIP(hipGetLastError());
+    HL_HIP(hipStreamSynchronize(st));  // (dt goes out of scope)
+  } else if (!serial_decode && (size_t)chunk >= 1024) {
     // parallel decoding inside the chunks (one wave per chunk)
     static bool once2 = false;
     if (!once2) {
@@ -1397,7 +1424,7 @@ int mgh_lossless_create(mgh_lossless_ctx **out, int dev_id) {
 void mgh_lossless_destroy(mgh_lossless_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->dev);
-  for (DevBuf *b : {&c->freq, &c->code, &c->bits, &c->entry, &c->total, &c->units, &c->tables, &c->oidx, &c->oval, &c->state})
+  for (DevBuf *b : {&c->freq, &c->code, &c->bits, &c->entry, &c->total, &c->units, &c->tables, &c->oidx, &c->oval, &c->state, &c->dtable})
     b->release();
   delete c;
 }

@@ -31,6 +31,7 @@
 #include <cstring>
 #include <queue>
 #include <stdexcept>
+#include <type_traits>
 #include <vector>
 
 namespace mgh {
@@ -759,6 +760,311 @@ k_decode_par(const unsigned long long *__restrict__ units, const unsigned long l
     }
     done += got;
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// Two-level decoding table (host), built from the decodebook of the payload.
+//   root: 2^tb entries indexed by the next tb bits of the stream;
+//     (len << 16) | symbol          a code of len <= tb bits (replicated over its 2^(tb-len) slots)
+//     1<<31 | sub_bits << 24 | off  codes longer than tb bits with this prefix: second lookup at
+//                                   table[off + next sub_bits bits], entries (len << 16) | symbol
+//     0                             neither (unused prefix, or left to the comparison path of the
+//                                   kernel: sub-table wider than kSubBitsMax or table budget spent)
+// Codes are taken longest first, as the kernels do, so that should a foreign stream's entry[]
+// make a length look longer than it is, the shorter valid codes overwrite the surplus.
+// ---------------------------------------------------------------------------------------
+constexpr int kSubBitsMax = 11;
+
+inline std::vector<uint32_t> build_decode_table(const uint64_t *first, const uint64_t *entry,
+                                                const uint64_t *keys, int dict, int tb,
+                                                size_t max_entries) {
+  std::vector<uint32_t> t((size_t)1 << tb, 0);
+  auto count_of = [&](int l) -> uint64_t {
+    if (first[l] == ~(uint64_t)0 || entry[l] >= (uint64_t)dict) return 0;
+    uint64_t cnt = (l + 1 < 64 ? entry[l + 1] : (uint64_t)dict) - entry[l];
+    if (l + 1 < 64 && entry[l + 1] < entry[l]) cnt = 0;
+    cnt = std::min<uint64_t>(cnt, (uint64_t)dict - entry[l]);
+    cnt = std::min<uint64_t>(cnt, (uint64_t)1 << l);
+    if (first[l] >= ((uint64_t)1 << l)) return 0;
+    return std::min<uint64_t>(cnt, ((uint64_t)1 << l) - first[l]);
+  };
+  // pass 1: widest code under every root prefix that has long codes
+  std::vector<uint8_t> group_len((size_t)1 << tb, 0);
+  for (int l = tb + 1; l <= kMaxCodeBits; l++) {
+    const uint64_t cnt = count_of(l);
+    for (uint64_t j = 0; j < cnt; j++) {
+      const uint64_t prefix = (first[l] + j) >> (l - tb);
+      group_len[prefix] = (uint8_t)std::max<int>(group_len[prefix], l);
+    }
+  }
+  for (size_t pfx = 0; pfx < group_len.size(); pfx++) {
+    if (!group_len[pfx]) continue;
+    const int sb = group_len[pfx] - tb;
+    if (sb > kSubBitsMax || t.size() + ((size_t)1 << sb) > max_entries) continue;  // comparison path
+    t[pfx] = 0x80000000u | ((uint32_t)sb << 24) | (uint32_t)t.size();
+    t.resize(t.size() + ((size_t)1 << sb), 0);
+  }
+  // pass 2: fill, longest codes first
+  for (int l = kMaxCodeBits; l >= 1; l--) {
+    const uint64_t cnt = count_of(l);
+    for (uint64_t j = 0; j < cnt; j++) {
+      const uint64_t code = first[l] + j;
+      const uint32_t val = ((uint32_t)l << 16) | (uint32_t)(keys[entry[l] + j] & 0xffff);
+      if (l <= tb) {
+        const uint64_t lo = code << (tb - l);
+        for (uint64_t k = 0; k < ((uint64_t)1 << (tb - l)); k++) t[lo + k] = val;
+      } else {
+        const uint32_t r = t[code >> (l - tb)];
+        if (!(r & 0x80000000u)) continue;
+        const int sb = (int)((r >> 24) & 0x7f);
+        const size_t off = r & 0xffffff;
+        const uint64_t rest = code & (((uint64_t)1 << (l - tb)) - 1);  // the l - tb bits after the prefix
+        const uint64_t lo = rest << (sb - (l - tb));
+        for (uint64_t k = 0; k < ((uint64_t)1 << (sb - (l - tb))); k++) t[off + lo + k] = val;
+      }
+    }
+  }
+  return t;
+}
+
+// Parallel decoding inside a chunk like k_decode_par, with two changes that matter:
+//  * the code units reach a lane through a per-lane LDS ring that the whole wave tops up at
+//    wave-uniform points (every kRingStep symbols; the loads land in registers while the next
+//    symbols are decoded and are committed to the ring afterwards). In k_decode_par a lane loads
+//    its next unit when it crosses into a new one: lanes cross at different symbols, so nearly
+//    every iteration of the wave contains a load and the wave-wide wait on it;
+//  * every symbol is resolved with one or two table lookups (build_decode_table): with 64 lanes a
+//    wave almost always holds SOME lane with a code longer than the prefix table, so a search
+//    over the lengths costs the whole wave on nearly every symbol. The comparison path (slim[],
+//    below) remains for prefixes the table leaves out.
+// A lane that would run past the units it holds (codes longer than 32 bits on average) pauses
+// until the next refill.
+//   dynamic LDS: 4 * table_entries | per wave: kRingUnits * 64 * 8 (ring) + 64 * kRingBatch * 2
+//   (write-out staging); blockDim.x = 64 * waves.
+constexpr int kRingUnits = 8;   // units per lane in the ring
+constexpr int kRingFetch = 4;   // units per lane per refill
+#ifndef MGH_RING_STEP
+#define MGH_RING_STEP 8
+#endif
+constexpr int kRingStep = MGH_RING_STEP;    // symbols between two refills
+constexpr int kRingBatch = 16;  // symbols a lane stages between two write-outs (multiple of kRingStep)
+constexpr int kRecStride = 8;   // every kRecStride-th code boundary of the first pass is remembered
+
+inline size_t decode_ring_lds(size_t table_entries, int waves) {
+  return (table_entries * 4 + 7) / 8 * 8 + (size_t)waves * (kRingUnits * 64 * 8 + 64 * kRingBatch * 2);
+}
+
+__global__ void __launch_bounds__(1024)
+k_decode_ring(const unsigned long long *__restrict__ units, const unsigned long long *__restrict__ bits,
+              const unsigned long long *__restrict__ entry_of_chunk, size_t nchunk, int chunk, size_t n,
+              int dict, int tb, const unsigned *__restrict__ g_table, unsigned table_entries,
+              const unsigned long long *__restrict__ first,
+              const unsigned long long *__restrict__ entry, const unsigned long long *__restrict__ keys,
+              int64_t *__restrict__ q) {
+  __shared__ unsigned long long sfirst[64], sentry[64], slim[64];
+  __shared__ int smaxlen;
+  extern __shared__ unsigned dyn_lds[];
+  unsigned *table = dyn_lds;
+  const int nwaves = blockDim.x >> 6;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned long long *rings = reinterpret_cast<unsigned long long *>(dyn_lds + (table_entries + 1) / 2 * 2);
+  unsigned long long *ring = rings + (size_t)wave * (kRingUnits * 64);
+  unsigned short *stage = reinterpret_cast<unsigned short *>(rings + (size_t)nwaves * (kRingUnits * 64)) +
+                          (size_t)wave * (64 * kRingBatch);
+  if (threadIdx.x < 64) {
+    sfirst[threadIdx.x] = first[threadIdx.x];
+    sentry[threadIdx.x] = entry[threadIdx.x];
+  }
+  for (unsigned i = threadIdx.x; i < table_entries; i += blockDim.x) table[i] = g_table[i];
+  __syncthreads();
+  // Comparison path for what the table leaves out: with lim[l] = first[l] << (64 - l)
+  // (left-aligned lower bound of the codes of length l, 2^64-1 for unused lengths) a window w
+  // holds a code of the smallest l with w >= lim[l]; slim[l] = min over (tb, l] of lim makes
+  // that a count, len = tb + 1 + #{l in (tb, maxlen] : w < slim[l]} -- no dependent search.
+  if (threadIdx.x == 0) {
+    unsigned long long m = ~0ull;
+    int mx = 0;
+    for (int l = 1; l < 64; l++) {
+      const bool used = sfirst[l] != ~0ull && l <= kMaxCodeBits;
+      if (used) mx = l;
+      if (l > tb) {
+        if (used) m = min(m, sfirst[l] << (64 - l));
+        slim[l] = m;
+      } else {
+        slim[l] = ~0ull;
+      }
+    }
+    slim[0] = ~0ull;
+    smaxlen = mx;
+  }
+  __syncthreads();
+  const int maxlen = smaxlen;
+  const size_t c = (size_t)blockIdx.x * nwaves + wave;
+  if (c >= nchunk) return;  // (whole wave; no block-wide barrier follows)
+  const unsigned long long *src = units + entry_of_chunk[c];
+  // (bit positions inside a chunk fit 32 bits: the host sends chunks of at most 2^24 symbols here)
+  const unsigned total = (unsigned)min(bits[c], (unsigned long long)chunk * kMaxCodeBits);
+  int64_t *dst = q + c * (size_t)chunk;
+  const unsigned cap = (unsigned)min((size_t)chunk, n - c * (size_t)chunk);
+  const unsigned nun = (total + 63) / 64;  // src[nun] is readable (the window peeks ahead)
+  const unsigned B = (total + 63) / 64;    // bits per subsequence
+  const unsigned lim = min((unsigned)(lane + 1) * B, total);
+  unsigned short *rec = stage + lane * kRingBatch;  // this lane's slots of the staging area
+
+  // One pass over this lane's subsequence from bit `start`; all lanes of the wave call it
+  // together. MODE 0: count the symbols up to position lim, remember where every kRecStride-th of the
+  // first kRingBatch * kRecStride codes ended (rec[], relative to start). MODE 1: the same from a corrected start, but stop as
+  // soon as a position is reached that the remembered pass went through -- from there on the two
+  // are the same pass (Huffman streams re-synchronise within a few symbols), so its end and its
+  // remaining count are inherited. MODE 2: decode `want` symbols and write them to dst[out0...].
+  // Returns the end position, *count = symbols.
+  auto pass = [&](auto mode_tag, unsigned start, unsigned *count, unsigned want, unsigned out0,
+                  unsigned rec_start, unsigned rec_end, unsigned rec_cnt) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    unsigned pos = start, cnt = 0;
+    bool live = MODE == 2 ? (pos < lim && want > 0) : pos < lim;
+    if (MODE == 1 && live && pos == rec_start) {  // (starts on the remembered pass)
+      *count = rec_cnt;
+      pos = rec_end;
+      live = false;
+    }
+    unsigned cw = pos >> 6, hi = cw;
+#pragma unroll
+    for (int r = 0; r < kRingUnits; r++)  // initial fill of the ring
+      ring[((cw + r) % kRingUnits) * 64 + lane] = src[min(cw + r, nun)];
+    hi = cw + kRingUnits;
+    unsigned long long cur = ring[(cw % kRingUnits) * 64 + lane];
+    unsigned long long nxt = ring[((cw + 1) % kRingUnits) * 64 + lane];
+    bool have_nxt = true;
+    unsigned long long pf[kRingFetch];
+    bool pending = false;
+    int jrec = 0;           // MODE 1: next remembered boundary to compare with
+    bool inherited = !live && MODE == 1 && pos == rec_end && *count == rec_cnt && start == rec_start;
+    if (MODE == 0) {
+#pragma unroll
+      for (int k = 0; k < kRingBatch; k++) rec[k] = 0xffff;
+    }
+    while (__any(live)) {
+      int got = 0;
+      for (int rep = 0; rep < kRingBatch / kRingStep; rep++) {
+        if (live && !pending) {  // request the next units; they are committed kRingStep symbols later
+#pragma unroll
+          for (int j = 0; j < kRingFetch; j++) pf[j] = src[min(hi + j, nun)];
+          pending = true;
+        }
+        for (int k = 0; k < kRingStep; k++) {
+          if (live && !have_nxt && cw + 1 < hi) {
+            nxt = ring[((cw + 1) % kRingUnits) * 64 + lane];
+            have_nxt = true;
+          }
+          if (live && have_nxt) {
+            const int sh = (int)(pos & 63);
+            const unsigned long long win = sh ? (cur << sh) | (nxt >> (64 - sh)) : cur;
+            unsigned e = table[win >> (64 - tb)];
+            if (e & 0x80000000u) {  // second level: the next sub_bits bits
+              const int sb = (int)((e >> 24) & 0x7f);
+              e = table[(e & 0xffffff) + (unsigned)((win << tb) >> (64 - sb))];
+            }
+            int l = (int)(e >> 16);
+            unsigned sym = e & 0xffff;
+            bool hit = e != 0;
+            if (!hit) {  // not in the table
+              l = tb + 1;
+              for (int j = tb + 1; j <= maxlen; j++) l += win < slim[j] ? 1 : 0;
+              if (l <= maxlen) {
+                const unsigned long long v = win >> (64 - l);
+                const unsigned long long kk = sentry[l] + (v - sfirst[l]);
+                if (v >= sfirst[l] && kk < (unsigned long long)dict) {
+                  sym = (unsigned)keys[kk] & 0xffff;
+                  hit = true;
+                }
+              }
+            }
+            if (!hit || pos + l > total) {  // corrupt stream, or a speculative start running off the end
+              pos = total;
+              live = false;
+            } else {
+              if (MODE == 2) stage[lane * kRingBatch + got] = (unsigned short)sym;
+              got++;
+              pos += l;
+              cnt++;
+              if (MODE == 0 && cnt % kRecStride == 0 && cnt / kRecStride <= (unsigned)kRingBatch)
+                rec[cnt / kRecStride - 1] = (unsigned short)min(pos - start, 0xfffeu);
+              if ((pos >> 6) != cw) {
+                cw++;
+                cur = nxt;
+                have_nxt = cw + 1 < hi;
+                if (have_nxt) nxt = ring[((cw + 1) % kRingUnits) * 64 + lane];
+              }
+              live = MODE == 2 ? (pos < lim && cnt < want) : pos < lim;
+              if (MODE == 1 && live && pos >= rec_start) {
+                const unsigned rel = pos - rec_start;
+                if (rel == 0) {
+                  cnt += rec_cnt;
+                  pos = rec_end;
+                  live = false;
+                  inherited = true;
+                } else if (rel < 0xfffeu) {
+                  while (jrec < kRingBatch && rec[jrec] < rel) jrec++;
+                  if (jrec < kRingBatch && rec[jrec] == rel) {
+                    cnt += rec_cnt - (unsigned)(jrec + 1) * kRecStride;
+                    pos = rec_end;
+                    live = false;
+                    inherited = true;
+                  }
+                }
+              }
+            }
+          }
+        }
+        // refill point: commit the units requested before these symbols if the ring has room
+        if (pending && hi + kRingFetch <= cw + kRingUnits) {
+#pragma unroll
+          for (int j = 0; j < kRingFetch; j++) ring[((hi + j) % kRingUnits) * 64 + lane] = pf[j];
+          hi += kRingFetch;
+          pending = false;
+        }
+      }
+      if (MODE == 2) {  // write-out: run after run, 8-byte elements side by side
+        for (int L = 0; L < 64; L++) {
+          const int n_L = __shfl(got, L, 64);
+          const unsigned o_L = __shfl(out0 + cnt - got, L, 64);
+          if (lane < n_L && o_L + lane < cap) dst[o_L + lane] = (int64_t)stage[L * kRingBatch + lane];
+        }
+      }
+    }
+    if (!(MODE == 1 && inherited && start == rec_start)) *count = cnt;
+    return pos;
+  };
+  using M0 = std::integral_constant<int, 0>;
+  using M1 = std::integral_constant<int, 1>;
+  using M2 = std::integral_constant<int, 2>;
+
+  unsigned s = min((unsigned)lane * B, total), cnt = 0;
+  unsigned e = pass(M0{}, s, &cnt, 0, 0, 0, 0, 0);
+  const unsigned rs = s, re = e, rc = cnt;  // the remembered pass
+  for (int it = 0; it < 64; it++) {
+    unsigned pe = __shfl_up(e, 1, 64);
+    if (lane == 0) pe = 0;
+    const bool changed = s != pe;
+    if (!__any(changed)) break;
+    // (all lanes take part in the pass; the unchanged ones with an empty range)
+    unsigned c1 = 0;
+    const unsigned e1 = pass(M1{}, changed ? pe : total, &c1, 0, 0, rs, re, rc);
+    if (changed) {
+      s = pe;
+      e = e1;
+      cnt = c1;
+    }
+  }
+  unsigned off = cnt;
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned v = __shfl_up(off, d, 64);
+    if (lane >= d) off += v;
+  }
+  off -= cnt;
+  unsigned c2 = 0;
+  (void)pass(M2{}, s, &c2, off < cap ? cnt : 0, off, 0, 0, 0);
 }
 
 } // namespace huff
