@@ -66,6 +66,41 @@ def test_lossless_single_symbol_and_full_dictionary():
     ctx.close()
 
 
+@pytest.mark.parametrize("kind", ["wide", "skewed"])
+def test_lossless_long_codes_and_many_chunks(kind):
+    """Thousands of chunks (unit offsets by look-back across workgroups) and codes longer than
+    the decoder's root table (second-level tables) / than root + 11 bits (comparison path)."""
+    torch, mg, hl = _mods()
+    rng = np.random.default_rng(11)
+    if kind == "wide":
+        q = _symbols(3_000_000, seed=5, width=900.0)
+    else:  # Fibonacci frequencies: the deepest Huffman tree a histogram of this size can give
+        fib = [1, 1]
+        while len(fib) < 31:
+            fib.append(fib[-1] + fib[-2])
+        parts = [np.full(f, 100 + k, np.int64) for k, f in enumerate(fib)]
+        q = rng.permutation(np.concatenate(parts))
+    code = np.zeros(8192, np.uint64)
+    freq = np.bincount(q, minlength=8192).astype(np.uint32)
+    code, first, entry, keys = hl.huffman_codebook(freq)
+    lengths = (code >> np.uint64(56)).astype(np.int64)
+    assert lengths.max() > (23 if kind == "skewed" else 12)
+    ctx = hl.Lossless()
+    for chunk in (1024, 20480):
+        rec = ctx.compress(torch.from_numpy(q).cuda(), 8192, chunk)
+        r = pl.parse_huffman_record(rec)
+        words = (r["bits"].astype(np.int64) + 63) // 64
+        assert np.array_equal(r["entry"], np.concatenate([[0], np.cumsum(words)[:-1]]).astype(np.uint64))
+        assert len(r["units"]) == int(words.sum())
+        assert int(r["bits"].sum()) == int(lengths[q].sum())     # every symbol with its code length
+        back, _, _ = ctx.decompress(rec, q.size)
+        assert np.array_equal(back.cpu().numpy(), q)
+    small = q[:40000]
+    rec = ctx.compress(torch.from_numpy(small).cuda(), 8192, 2048)
+    assert np.array_equal(pl.decode_huffman_record(pl.parse_huffman_record(rec)), small)
+    ctx.close()
+
+
 def test_lossless_rejects_damaged_records():
     torch, mg, hl = _mods()
     ctx = hl.Lossless()
