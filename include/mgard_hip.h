@@ -133,6 +133,20 @@ int mgh_decompose_quantize(mgh_hierarchy *h, const void *d_data, int error_bound
                            int64_t *d_outlier_val, uint64_t outlier_capacity,
                            void *d_coeff_opt, void *stream);
 
+/* The same with the quantized values delivered as 16-bit DICTIONARY SYMBOLS (what the lossless
+ * stage consumes: q + dict_size/2 in [0, dict_size), out-of-dictionary values as symbol 0 plus an
+ * entry of the outlier list, LinearQuantization.hpp:208-241) -- the values of
+ * mgh_decompose_quantize(..., prep_huffman = 1, ...) narrowed to uint16_t, a quarter of the
+ * output bytes. An extension for callers that feed the Huffman stage directly (mgh_compress does);
+ * the reference always materialises the int64 array (QUANTIZED_INT, RuntimeX/DataTypes.h:128).
+ * dict_size <= 65536. Only where the fused kernels run (3-D, at least one level), else
+ * MGH_ERR_UNSUPPORTED_DIMENSION: use mgh_decompose_quantize there. */
+int mgh_decompose_quantize_sym16(mgh_hierarchy *h, const void *d_data, int error_bound_type,
+                                 double tol, double s, double norm, double *h_norm_out,
+                                 uint64_t dict_size, uint16_t *d_symbols,
+                                 uint64_t *d_outlier_count, uint64_t *d_outlier_idx,
+                                 int64_t *d_outlier_val, uint64_t outlier_capacity, void *stream);
+
 /* Norm that stays on the device: writes one value of the hierarchy's dtype to
  * d_norm_out (max|x| for s = +inf, else the L2 norm of this array as
  * norm_calculator defines it). ASYNCHRONOUS. For a decomposed domain the caller

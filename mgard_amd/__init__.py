@@ -23,7 +23,7 @@ SYMBOLS = [
     "mgh_l_target", "mgh_level_shape", "mgh_total_num_elems", "mgh_device_bytes",
     "mgh_hierarchy_table", "mgh_norm", "mgh_decompose", "mgh_recompose", "mgh_quantize",
     "mgh_dequantize", "mgh_decompose_quantize", "mgh_dequantize_recompose",
-    "mgh_norm_device", "mgh_decompose_quantize_dn",
+    "mgh_norm_device", "mgh_decompose_quantize_dn", "mgh_decompose_quantize_sym16",
     "mgh_profile_enable", "mgh_profile_filter", "mgh_profile_read",
 ]
 
@@ -72,6 +72,8 @@ def load_library():
                                          C.POINTER(C.c_double), u64, C.c_int, vp, vp, vp, vp, u64,
                                          vp, vp]
     L.mgh_norm_device.argtypes = [vp, vp, C.c_double, vp, vp]
+    L.mgh_decompose_quantize_sym16.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, C.c_double,
+                                               C.POINTER(C.c_double), u64, vp, vp, vp, vp, u64, vp]
     L.mgh_decompose_quantize_dn.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, vp, u64, u64,
                                             C.c_int, vp, vp, vp, vp, u64, vp]
     L.mgh_dequantize_recompose.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, C.c_double,
@@ -262,6 +264,21 @@ class Hierarchy:
         n = int(cnt.item())
         k = min(n, cap)
         return q, idx[:k], val[:k], n, nout.value
+
+    def decompose_quantize_sym16(self, data, ebtype, tol, s, norm=0.0, dict_size=8192, outlier_cap=None):
+        """mgh_decompose_quantize_sym16: (symbols uint16, outlier_idx, outlier_val, count, norm)."""
+        import torch
+        cap = self.total if outlier_cap is None else int(outlier_cap)
+        sym = torch.empty(self.shape, dtype=torch.uint16, device=data.device)
+        cnt, idx, val = self._outlier_bufs(cap)
+        nout = C.c_double()
+        _check(load_library().mgh_decompose_quantize_sym16(
+            self._h, self._chk(data), ebtype, tol, s, norm, C.byref(nout), dict_size,
+            C.c_void_p(sym.data_ptr()), C.c_void_p(cnt.data_ptr()), C.c_void_p(idx.data_ptr()),
+            C.c_void_p(val.data_ptr()), cap, _stream()))
+        n = int(cnt.item())
+        k = min(n, cap)
+        return sym, idx[:k], val[:k], n, nout.value
 
     def dequantize_recompose(self, q, ebtype, tol, s, norm, dict_size=8192, prep_huffman=True,
                              outlier_idx=None, outlier_val=None, out=None):

@@ -492,6 +492,7 @@ template <typename T> struct QuantParams {
   int64_t dict_size = 0;
   int prep_huffman = 0;
   int64_t *q = nullptr;
+  uint16_t *q16 = nullptr;  // instead of q: 16-bit dictionary symbols (mgh_decompose_quantize_sym16)
   unsigned long long *ocount = nullptr;
   uint64_t *oidx = nullptr;
   int64_t *oval = nullptr;
@@ -566,6 +567,7 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
   A.dJ = fJ;
   if (OUT == OUT_Q) {
     A.q = qp->q;
+    A.q16 = qp->q16;
     A.dict_size = qp->dict_size;
     A.prep_huffman = qp->prep_huffman;
     A.outlier_count = qp->ocount;
@@ -1238,7 +1240,8 @@ template <typename T>
 int fused_q_entry_device(mgh_hierarchy *h, const T *data, int ebtype, double tol, double s,
                          const T *d_norm, int decomposed, uint64_t nsub, double *h_norm_out,
                          uint64_t dict_size, int prep_huffman, int64_t *q, uint64_t *ocount,
-                         uint64_t *oidx, int64_t *oval, uint64_t ocap, hipStream_t st) {
+                         uint64_t *oidx, int64_t *oval, uint64_t ocap, hipStream_t st,
+                         uint16_t *q16 = nullptr) {
   auto *ds = DS<T>(h);
   // s = inf, REL, no norm given, top level split: abs-max(input) comes out of the top level's
   // load-vector pass (it reads every input element anyway) -- no separate norm pass
@@ -1275,6 +1278,7 @@ int fused_q_entry_device(mgh_hierarchy *h, const T *data, int ebtype, double tol
   qp.dict_size = (int64_t)dict_size;
   qp.prep_huffman = prep_huffman;
   qp.q = q;
+  qp.q16 = q16;
   qp.ocount = (unsigned long long *)ocount;
   qp.oidx = oidx;
   qp.oval = oval;
@@ -1453,6 +1457,49 @@ int mgh_dequantize(mgh_hierarchy *h, int64_t *d_quantized, int ebtype, double to
                   dequantize_impl<double>(h, d_quantized, ebtype, tol, s, norm, dict_size,
                                           prep_huffman, d_outlier_idx, d_outlier_val, outlier_count,
                                           (double *)d_coeff, (hipStream_t)stream));
+}
+
+int mgh_decompose_quantize_sym16(mgh_hierarchy *h, const void *d_data, int error_bound_type, double tol,
+                                 double s, double norm, double *h_norm_out, uint64_t dict_size,
+                                 uint16_t *d_symbols, uint64_t *d_outlier_count,
+                                 uint64_t *d_outlier_idx, int64_t *d_outlier_val,
+                                 uint64_t outlier_capacity, void *stream) {
+  if (!h || !d_data || !d_symbols || !d_outlier_count || (outlier_capacity && (!d_outlier_idx || !d_outlier_val)))
+    return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
+  if (dict_size == 0 || dict_size > 65536) return fail(MGH_ERR_INVALID_ARGUMENT, "dict_size must be in 1..65536");
+  HIP_TRY(hipSetDevice(h->device));
+  if (!fused_ok(h) || h->force_v1 || h->split)
+    return fail(MGH_ERR_UNSUPPORTED_DIMENSION, "16-bit symbols: only on the fused 3-D path");
+  // (the norm and the quantizers stay on the device; a given norm is uploaded first)
+  const void *d_norm = nullptr;
+  if (!(error_bound_type == MGH_REL && !(norm > 0)) && error_bound_type == MGH_REL) {
+    if (h->dtype == MGH_FLOAT) {
+      const float nv = (float)norm;
+      HIP_TRY(hipMemcpyAsync(DS<float>(h)->normval, &nv, sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+      HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+      d_norm = DS<float>(h)->normval;
+    } else {
+      const double nv = norm;
+      HIP_TRY(hipMemcpyAsync(DS<double>(h)->normval, &nv, sizeof(double), hipMemcpyHostToDevice, (hipStream_t)stream));
+      HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+      d_norm = DS<double>(h)->normval;
+    }
+    if (h_norm_out) *h_norm_out = norm;
+    h_norm_out = nullptr;
+  }
+  if (error_bound_type != MGH_REL) {  // (no norm involved)
+    if (h_norm_out) *h_norm_out = norm;
+    h_norm_out = nullptr;
+  }
+  return DISPATCH(h,
+                  fused_q_entry_device<float>(h, (const float *)d_data, error_bound_type, tol, s,
+                                              (const float *)d_norm, 0, 1, h_norm_out, dict_size, 1, nullptr,
+                                              d_outlier_count, d_outlier_idx, d_outlier_val,
+                                              outlier_capacity, (hipStream_t)stream, d_symbols),
+                  fused_q_entry_device<double>(h, (const double *)d_data, error_bound_type, tol, s,
+                                               (const double *)d_norm, 0, 1, h_norm_out, dict_size, 1, nullptr,
+                                               d_outlier_count, d_outlier_idx, d_outlier_val,
+                                               outlier_capacity, (hipStream_t)stream, d_symbols));
 }
 
 int mgh_decompose_quantize(mgh_hierarchy *h, const void *d_data, int error_bound_type, double tol, double s,

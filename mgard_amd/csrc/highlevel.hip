@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -33,10 +34,18 @@ using namespace mgh;
 // MGH_DEBUG_SYNC=1: name the stages on stderr and synchronise (developer aid, see capi.hip)
 inline void hl_debug(const char *what) {
   static const bool on = std::getenv("MGH_DEBUG_SYNC") != nullptr;
-  if (on) {
+  static const bool timing = std::getenv("MGH_HL_TIMING") != nullptr;  // + microseconds since the last mark
+  if (on || timing) {
     (void)hipDeviceSynchronize();
-    std::fprintf(stderr, "[mgh-hl] %s\n", what);
+    static auto last = std::chrono::steady_clock::now();
+    const auto now = std::chrono::steady_clock::now();
+    if (timing)
+      std::fprintf(stderr, "[mgh-hl] %8.1f us  %s\n",
+                   std::chrono::duration<double, std::micro>(now - last).count(), what);
+    else
+      std::fprintf(stderr, "[mgh-hl] %s\n", what);
     std::fflush(stderr);
+    last = std::chrono::steady_clock::now();
   }
 }
 
@@ -175,6 +184,11 @@ struct mgh_lossless_ctx {
 
 namespace {
 
+// The single-pass encoder stages code table and symbols of a chunk in LDS.
+inline bool lossless_sym16_ok(uint64_t dict, uint64_t chunk) {
+  return dict <= 65536 && dict * 8 + chunk * 2 <= 140 * 1024;
+}
+
 // Copy the record of the last lossless_compress() to dst (host or device memory, record_size()
 // bytes). Asynchronous on st where the memory kinds allow it.
 int record_write(mgh_lossless_ctx *c, void *dst, hipStream_t st) {
@@ -203,7 +217,9 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
                       uint64_t chunk, int lossless, int zstd_level, const uint64_t *d_oidx,
                       const int64_t *d_oval, uint64_t ocount, hipStream_t st,
                       const uint64_t *d_ocount = nullptr, uint64_t ocap = ~(uint64_t)0,
-                      uint64_t cap_units = 0) {
+                      uint64_t cap_units = 0, bool sym16 = false) {
+  // sym16: d_q points to uint16_t symbols (mgh_decompose_quantize_sym16) -- only with the
+  // single-pass encoder (lossless_sym16_ok)
   if (lossless != MGH_LOSSLESS_HUFFMAN && lossless != MGH_LOSSLESS_HUFFMAN_ZSTD)
     return hl_fail(MGH_ERR_INVALID_ARGUMENT, "lossless: only Huffman and Huffman_Zstd are supported");
   if (n == 0 || dict == 0 || dict > 16384 || chunk == 0 || chunk > (1u << 30))
@@ -219,7 +235,11 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
   hl_debug("lossless_compress: begin");
   HL_HIP(hipMemsetAsync(c->freq.p, 0, dict * 4, st));
   const unsigned hblocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
-  huff::k_histogram<<<hblocks, 256, dict * 4, st>>>(d_q, n, (int)dict, (unsigned *)c->freq.p);
+  if (sym16)
+    huff::k_histogram<uint16_t><<<hblocks, 256, dict * 4, st>>>((const uint16_t *)d_q, n, (int)dict,
+                                                                (unsigned *)c->freq.p);
+  else
+    huff::k_histogram<int64_t><<<hblocks, 256, dict * 4, st>>>(d_q, n, (int)dict, (unsigned *)c->freq.p);
   HL_HIP(hipGetLastError());
   std::vector<unsigned> freq(dict);
   HL_HIP(hipMemcpyAsync(freq.data(), c->freq.p, dict * 4, hipMemcpyDeviceToHost, st));
@@ -230,7 +250,7 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
   } catch (const std::exception &e) {
     return hl_fail(MGH_ERR_INVALID_ARGUMENT, e.what());
   }
-  hl_debug("lossless_compress: histogram done");
+  hl_debug("lossless_compress: histogram + codebook done");
   HL_HIP(hipMemcpyAsync(c->code.p, cb.code.data(), dict * 8, hipMemcpyHostToDevice, st));
   // ---- serialize (Huffman.hpp:163-239): the small leading part on the host, the code units
   // and the outlier lists stay where they are until record_write() ----
@@ -257,14 +277,22 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
     HL_HIP(hipMemsetAsync(c->state.p, 0, (3 + nchunk) * 8, st));
     static bool once = false;
     if (!once) {
-      HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_encode_chain),
+      HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_encode_chain<int64_t>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_encode_chain<uint16_t>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
       once = true;
     }
-    huff::k_encode_chain<<<(unsigned)nchunk, huff::kEncThreads, enc_lds, st>>>(
-        d_q, n, (int)chunk, (int)dict, nchunk, (const uint64_t *)c->code.p,
-        (unsigned long long *)c->state.p, (unsigned long long *)c->bits.p,
-        (unsigned long long *)c->entry.p, (unsigned long long *)c->units.p, cap);
+    if (sym16)
+      huff::k_encode_chain<uint16_t><<<(unsigned)nchunk, huff::kEncThreads, enc_lds, st>>>(
+          (const uint16_t *)d_q, n, (int)chunk, (int)dict, nchunk, (const uint64_t *)c->code.p,
+          (unsigned long long *)c->state.p, (unsigned long long *)c->bits.p,
+          (unsigned long long *)c->entry.p, (unsigned long long *)c->units.p, cap);
+    else
+      huff::k_encode_chain<int64_t><<<(unsigned)nchunk, huff::kEncThreads, enc_lds, st>>>(
+          d_q, n, (int)chunk, (int)dict, nchunk, (const uint64_t *)c->code.p,
+          (unsigned long long *)c->state.p, (unsigned long long *)c->bits.p,
+          (unsigned long long *)c->entry.p, (unsigned long long *)c->units.p, cap);
     HL_HIP(hipGetLastError());
     unsigned long long st3[3] = {0, 0, 0};
     HL_HIP(hipMemcpyAsync(st3, c->state.p, 24, hipMemcpyDeviceToHost, st));
@@ -273,6 +301,7 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
     units = st3[1];
     c->overflow = st3[2] != 0;
   } else {
+    if (sym16) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "lossless: 16-bit symbols need the single-pass encoder");
     huff::k_chunk_bits<<<(unsigned)nchunk, 256, 0, st>>>(d_q, n, (int)chunk, (const uint64_t *)c->code.p,
                                                          (unsigned long long *)c->bits.p);
     huff::k_unit_offsets<<<1, 1024, 0, st>>>((const unsigned long long *)c->bits.p, nchunk,
@@ -979,20 +1008,34 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
     bool owned = false;
     if ((rc = get_hierarchy(&h, &owned, dtype, sshape, cptr, dd.subdomain_offset(id), cfg)) != MGH_SUCCESS)
       return cleanup(rc);
+    hl_debug("compress: subdomain ready");
     double norm_out = (double)norm;
     rc = hipMemsetAsync(g_cache.ocount.p, 0, 8, st) == hipSuccess ? MGH_SUCCESS : hl_fail(MGH_ERR_DEVICE, "memset");
-    if (rc == MGH_SUCCESS)
+    // 16-bit symbols straight from the quantizer where the fused kernels run (a quarter of the
+    // bytes written by the quantizer and read twice by the lossless stage); int64 otherwise
+    bool sym16 = false;
+    if (rc == MGH_SUCCESS && lossless_sym16_ok(cfg.huff_dict_size, cfg.huff_block_size)) {
+      const int r16 = mgh_decompose_quantize_sym16(
+          h, sub_in(id, buf), local_eb, (double)local_tol, s_d, local_eb == MGH_REL ? 0.0 : (double)norm,
+          local_eb == MGH_REL ? &norm_out : nullptr, cfg.huff_dict_size, (uint16_t *)g_cache.q.p,
+          (uint64_t *)g_cache.ocount.p, (uint64_t *)g_cache.oidx.p, (int64_t *)g_cache.oval.p, ocap, st);
+      if (r16 == MGH_SUCCESS) sym16 = true;
+      else if (r16 != MGH_ERR_UNSUPPORTED_DIMENSION) rc = r16;
+    }
+    if (rc == MGH_SUCCESS && !sym16)
       rc = mgh_decompose_quantize(h, sub_in(id, buf), local_eb, (double)local_tol, s_d,
                                   local_eb == MGH_REL ? 0.0 : (double)norm,
                                   local_eb == MGH_REL ? &norm_out : nullptr, cfg.huff_dict_size, 1,
                                   (int64_t *)g_cache.q.p, (uint64_t *)g_cache.ocount.p,
                                   (uint64_t *)g_cache.oidx.p, (int64_t *)g_cache.oval.p, ocap, nullptr, st);
+    hl_debug("compress: decompose + quantize done");
     if (rc == MGH_SUCCESS && local_eb == MGH_REL) norm = (T)norm_out;
     if (rc == MGH_SUCCESS)  // (the outlier count is read back together with the encoder's results)
       rc = lossless_compress(g_cache.ll, (const int64_t *)g_cache.q.p, n, cfg.huff_dict_size,
                              cfg.huff_block_size, cfg.lossless, cfg.zstd_compress_level,
                              (const uint64_t *)g_cache.oidx.p, (const int64_t *)g_cache.oval.p, 0, st,
-                             (const uint64_t *)g_cache.ocount.p, ocap, n * elem / 8 + 1);
+                             (const uint64_t *)g_cache.ocount.p, ocap, n * elem / 8 + 1, sym16);
+    hl_debug("compress: lossless stage done");
     if (owned) mgh_hierarchy_destroy(h);
     if (rc != MGH_SUCCESS) return cleanup(rc);
     uint64_t csize = g_cache.ll->record_size();
@@ -1018,6 +1061,7 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
     }
     if (rc == MGH_SUCCESS && hipStreamSynchronize(st) != hipSuccess) rc = MGH_ERR_DEVICE;
     if (rc != MGH_SUCCESS) return cleanup(hl_fail(rc, "writing the subdomain record"));
+    hl_debug("compress: record written");
     byte_offset += 8 + csize;
     buf = nb;
     qi = nq;

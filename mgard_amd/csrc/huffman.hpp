@@ -59,9 +59,16 @@ inline Codebook build_codebook(const std::vector<unsigned> &freq) {
   cb.keys.assign(dict, 0);
   // symbols by decreasing frequency (ties: increasing symbol) -- the order of keys[]
   std::vector<int> order;
-  for (int i = 0; i < dict; i++)
-    if (freq[i]) order.push_back(i);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return freq[a] > freq[b]; });
+  {
+    // one integer key per used symbol: (2^32-1 - frequency) above the symbol -> plain sort
+    std::vector<uint64_t> key;
+    key.reserve(dict);
+    for (int i = 0; i < dict; i++)
+      if (freq[i]) key.push_back(((uint64_t)(0xffffffffu - freq[i]) << 32) | (uint32_t)i);
+    std::sort(key.begin(), key.end());
+    order.resize(key.size());
+    for (size_t k = 0; k < key.size(); k++) order[k] = (int)(key[k] & 0xffffffffu);
+  }
   const int nz = (int)order.size();
   // fill keys with the used symbols first, then the unused ones (any order)
   {
@@ -99,15 +106,18 @@ inline Codebook build_codebook(const std::vector<unsigned> &freq) {
   }
   // lengths are non-decreasing along `order` up to ties in the tree; canonical assignment
   // needs symbols grouped by length: stable sort of the key order by length
-  std::vector<int> idx(nz);
-  for (int i = 0; i < nz; i++) idx[i] = i;
-  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return len[a] < len[b]; });
   std::vector<uint64_t> count(kUnitBits + 1, 0);
   for (int i = 0; i < nz; i++) {
     if (len[i] > kMaxCodeBits)
       throw std::runtime_error("Huffman: codeword longer than 56 bits");
     count[len[i]]++;
     cb.max_len = std::max(cb.max_len, len[i]);
+  }
+  std::vector<int> idx(nz);  // counting sort by length, stable
+  {
+    std::vector<int> at(kUnitBits + 2, 0);
+    for (int l = 1; l <= kUnitBits; l++) at[l + 1] = at[l] + (int)count[l];
+    for (int i = 0; i < nz; i++) idx[at[len[i]]++] = i;
   }
   {
     int k = 0;
@@ -139,13 +149,30 @@ inline Codebook build_codebook(const std::vector<unsigned> &freq) {
 // device kernels
 // ---------------------------------------------------------------------------------------
 // Histogram of the symbols (int64 values in [0, dict)); bins privatised in LDS.
+template <typename SYM>  // int64_t (the reference's quantized array) or uint16_t symbols
 __global__ void __launch_bounds__(256)
-k_histogram(const int64_t *__restrict__ q, size_t n, int dict, unsigned *__restrict__ freq) {
+k_histogram(const SYM *__restrict__ q, size_t n, int dict, unsigned *__restrict__ freq) {
   extern __shared__ unsigned bins[];
   for (int i = threadIdx.x; i < dict; i += 256) bins[i] = 0;
   __syncthreads();
   const size_t nth = (size_t)gridDim.x * 256;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += nth) {
+  size_t done = 0;
+  if (sizeof(SYM) == 2 && (reinterpret_cast<uintptr_t>(q) & 15) == 0) {  // 8 symbols per load
+    const size_t nv = n / 8;
+    const uint4 *qv = reinterpret_cast<const uint4 *>(q);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += nth) {
+      const uint4 v = qv[i];
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const unsigned a = w[k] & 0xffffu, b = w[k] >> 16;
+        if (a < (unsigned)dict) atomicAdd(&bins[a], 1u);
+        if (b < (unsigned)dict) atomicAdd(&bins[b], 1u);
+      }
+    }
+    done = nv * 8;
+  }
+  for (size_t i = done + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += nth) {
     const uint64_t s = (uint64_t)q[i];
     if (s < (uint64_t)dict) atomicAdd(&bins[s], 1u);
   }
@@ -337,8 +364,9 @@ k_encode_lds(const int64_t *__restrict__ q, size_t n, int chunk, int dict,
 constexpr unsigned long long kStAggregate = 1ull << 62, kStInclusive = 2ull << 62,
                              kStValue = (1ull << 62) - 1;
 
+template <typename SYM>
 __global__ void __launch_bounds__(kEncThreads)
-k_encode_chain(const int64_t *__restrict__ q, size_t n, int chunk, int dict, size_t nchunk,
+k_encode_chain(const SYM *__restrict__ q, size_t n, int chunk, int dict, size_t nchunk,
                const uint64_t *__restrict__ code, unsigned long long *__restrict__ state,
                unsigned long long *__restrict__ bits, unsigned long long *__restrict__ entry,
                unsigned long long *__restrict__ out, unsigned long long cap_units) {
@@ -353,7 +381,15 @@ k_encode_chain(const int64_t *__restrict__ q, size_t n, int chunk, int dict, siz
   const size_t id = (size_t)sh_id;
   const size_t base = id * chunk;
   const size_t cnt = min((size_t)chunk, n - base);
-  for (size_t i = threadIdx.x; i < cnt; i += kEncThreads) ssym[i] = (unsigned short)q[base + i];
+  size_t staged = 0;
+  if (sizeof(SYM) == 2 && (reinterpret_cast<uintptr_t>(q + base) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(ssym) & 15) == 0) {  // 16-bit symbols: straight 16-byte copies
+    const uint4 *src = reinterpret_cast<const uint4 *>(q + base);
+    uint4 *dst4 = reinterpret_cast<uint4 *>(ssym);
+    for (size_t i = threadIdx.x; i < cnt / 8; i += kEncThreads) dst4[i] = src[i];
+    staged = cnt / 8 * 8;
+  }
+  for (size_t i = staged + threadIdx.x; i < cnt; i += kEncThreads) ssym[i] = (unsigned short)q[base + i];
   __syncthreads();
   const size_t run = (cnt + kEncThreads - 1) / kEncThreads;
   const size_t lo = min(cnt, threadIdx.x * run), hi = min(cnt, lo + run);

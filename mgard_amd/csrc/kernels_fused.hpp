@@ -45,6 +45,8 @@ template <typename T> struct FusedArgs {
   // coefficient output (reordered layout, strides dI, dJ, 1)
   T *coef;         // OUT_T
   int64_t *q;      // OUT_Q
+  uint16_t *q16;   // OUT_Q, instead of q: the dictionary symbols as 16-bit values (prep_huffman,
+                   // dict_size <= 65536; out-of-dictionary values go to the outlier list only)
   size_t dI, dJ;
   const T *ratio[3];  // fine-level interpolation ratios
   const T *mass[3];   // mass_table SoA [9][m]
@@ -137,7 +139,10 @@ __device__ __forceinline__ void emit_quantized(const FusedArgs<T> &A, const T (&
   }
 #pragma unroll
   for (int k = 0; k < NV; k++)
-    if (on[k]) A.q[lin[k]] = qd[k];
+    if (on[k]) {
+      if (A.q16) A.q16[lin[k]] = (uint16_t)qd[k];
+      else A.q[lin[k]] = qd[k];
+    }
 }
 
 // PAIR = true runs the (odd, even) plane pair through each phase together: 3 barriers per pair
@@ -506,7 +511,8 @@ k_head_out(int m0, int m1, int m2, const T *__restrict__ nodal, FusedArgs<T> A) 
           qd = 0;
         }
       }
-      A.q[lin] = qd;
+      if (A.q16) A.q16[lin] = (uint16_t)qd;
+      else A.q[lin] = qd;
     }
   }
 }

@@ -558,3 +558,34 @@ def test_split_stream_schedule_bit_exact(shape, mode, s, split, dt, monkeypatch)
     ri, rv = _outlier_set(roi, rov)
     assert np.array_equal(gi, ri) and np.array_equal(gv, rv)
     h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,dt,mode,tol,s,dict_size", [
+    ((65, 70, 129), np.float32, "REL", 1e-3, np.inf, 8192), ((33, 40, 36), np.float64, "ABS", 1e-4, 0.0, 8192),
+    ((129, 129, 129), np.float32, "REL", 1e-4, np.inf, 64), ((20, 17, 300), np.float32, "REL", 1e-2, 1.0, 65536)])
+def test_sym16_output_equals_the_int64_output(shape, dt, mode, tol, s, dict_size):
+    """mgh_decompose_quantize_sym16 = mgh_decompose_quantize(prep_huffman=1) narrowed to 16 bits,
+    same outlier list (the small dictionary forces many outliers)."""
+    import torch
+    import mgard_amd as mg
+    u = smooth_field(shape, dt)
+    d = torch.from_numpy(u).cuda()
+    h = mg.Hierarchy(shape, dt)
+    eb = getattr(mg, mode)
+    norm = 0.0 if (mode == "REL" and np.isinf(s)) else (float(np.sqrt(np.mean(u.astype(np.float64) ** 2))) if mode == "REL" else 0.0)
+    q, oi, ov, cnt, n1 = h.decompose_quantize(d, eb, tol, s, norm=norm, dict_size=dict_size)
+    sym, si, sv, scnt, n2 = h.decompose_quantize_sym16(d, eb, tol, s, norm=norm, dict_size=dict_size)
+    assert cnt == scnt and n1 == n2
+    assert np.array_equal(sym.cpu().numpy().astype(np.int64), q.cpu().numpy())
+    a = sorted(zip(oi.cpu().numpy().tolist(), ov.cpu().numpy().tolist()))
+    b = sorted(zip(si.cpu().numpy().tolist(), sv.cpu().numpy().tolist()))
+    assert a == b
+    if dict_size == 64:
+        assert cnt > 100
+    h.close()
+    # not on the generic paths
+    h2 = mg.Hierarchy((300, 40), np.float32)
+    with pytest.raises(mg.MgardHipError):
+        h2.decompose_quantize_sym16(torch.zeros((300, 40), device="cuda"), mg.ABS, 1e-3, np.inf)
+    h2.close()
