@@ -147,6 +147,17 @@ int mgh_decompose_quantize_sym16(mgh_hierarchy *h, const void *d_data, int error
                                  uint64_t *d_outlier_count, uint64_t *d_outlier_idx,
                                  int64_t *d_outlier_val, uint64_t outlier_capacity, void *stream);
 
+/* Inverse of mgh_decompose_quantize_sym16: dequantize + recompose from 16-bit symbols and the
+ * outlier list (found by index through a hash table: symbol 0 at an outlier's position).
+ * Same result as mgh_dequantize_recompose on the widened values. mgh_sym16_supported tells
+ * whether this hierarchy runs the two *_sym16 calls (1) or returns
+ * MGH_ERR_UNSUPPORTED_DIMENSION (0). */
+int mgh_dequantize_recompose_sym16(mgh_hierarchy *h, const uint16_t *d_symbols, int error_bound_type,
+                                   double tol, double s, double norm, uint64_t dict_size,
+                                   const uint64_t *d_outlier_idx, const int64_t *d_outlier_val,
+                                   uint64_t outlier_count, void *d_data_out, void *stream);
+int mgh_sym16_supported(const mgh_hierarchy *h);
+
 /* Norm that stays on the device: writes one value of the hierarchy's dtype to
  * d_norm_out (max|x| for s = +inf, else the L2 norm of this array as
  * norm_calculator defines it). ASYNCHRONOUS. For a decomposed domain the caller

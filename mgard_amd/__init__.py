@@ -24,6 +24,7 @@ SYMBOLS = [
     "mgh_hierarchy_table", "mgh_norm", "mgh_decompose", "mgh_recompose", "mgh_quantize",
     "mgh_dequantize", "mgh_decompose_quantize", "mgh_dequantize_recompose",
     "mgh_norm_device", "mgh_decompose_quantize_dn", "mgh_decompose_quantize_sym16",
+    "mgh_dequantize_recompose_sym16", "mgh_sym16_supported",
     "mgh_profile_enable", "mgh_profile_filter", "mgh_profile_read",
 ]
 
@@ -72,6 +73,9 @@ def load_library():
                                          C.POINTER(C.c_double), u64, C.c_int, vp, vp, vp, vp, u64,
                                          vp, vp]
     L.mgh_norm_device.argtypes = [vp, vp, C.c_double, vp, vp]
+    L.mgh_dequantize_recompose_sym16.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, C.c_double, u64,
+                                                 vp, vp, u64, vp, vp]
+    L.mgh_sym16_supported.argtypes = [vp]
     L.mgh_decompose_quantize_sym16.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, C.c_double,
                                                C.POINTER(C.c_double), u64, vp, vp, vp, vp, u64, vp]
     L.mgh_decompose_quantize_dn.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, vp, u64, u64,
@@ -279,6 +283,17 @@ class Hierarchy:
         n = int(cnt.item())
         k = min(n, cap)
         return sym, idx[:k], val[:k], n, nout.value
+
+    def dequantize_recompose_sym16(self, sym, ebtype, tol, s, norm, dict_size=8192, outlier_idx=None,
+                                   outlier_val=None, out=None):
+        import torch
+        out = torch.empty(self.shape, dtype=self.torch_dtype, device=sym.device) if out is None else out
+        n = 0 if outlier_idx is None else int(outlier_idx.numel())
+        _check(load_library().mgh_dequantize_recompose_sym16(
+            self._h, C.c_void_p(sym.data_ptr()), ebtype, tol, s, norm, dict_size,
+            C.c_void_p(outlier_idx.data_ptr() if n else 0), C.c_void_p(outlier_val.data_ptr() if n else 0),
+            n, self._chk(out), _stream()))
+        return out
 
     def dequantize_recompose(self, q, ebtype, tol, s, norm, dict_size=8192, prep_huffman=True,
                              outlier_idx=None, outlier_val=None, out=None):

@@ -115,6 +115,9 @@ template <typename T> struct DeviceState {
   int scalar_slot = 0;
   bool fscal_dirty = false;
   T *normval = nullptr;                  // norm as T, written by k_make_qparams
+  unsigned long long *oh_key = nullptr;  // outlier table of the 16-bit symbol path (grown on demand)
+  long long *oh_val = nullptr;
+  size_t oh_slots = 0;
   QuantMeta qmeta;
   size_t full_I = 0, full_J = 0;   // strides of the full array in the 3-D view
 };
@@ -325,6 +328,8 @@ template <typename T> void destroy_state(mgh_hierarchy *h) {
     (void)hipFree(ds->scalar);
     (void)hipFree(ds->fscal);
     (void)hipFree(ds->normval);
+    (void)hipFree(ds->oh_key);
+    (void)hipFree(ds->oh_val);
     delete ds;
   }
   delete HH<T>(h);
@@ -1061,6 +1066,51 @@ int dequantize_recompose_fused(mgh_hierarchy *h, int64_t *q, int ebtype, double 
   return recompose_levels<T, int64_t>(h, A, level_qv, data, st);
 }
 
+// The same from 16-bit dictionary symbols (what the Huffman decoder of the high-level path
+// delivers): no int64 array, the out-of-dictionary values are found through a hash table.
+template <typename T>
+int dequantize_recompose_fused16(mgh_hierarchy *h, const uint16_t *sym, int ebtype, double tol, double s,
+                                 double norm, uint64_t dict_size, const uint64_t *oidx,
+                                 const int64_t *oval, uint64_t ocount, T *data, hipStream_t st) {
+  auto *ds = DS<T>(h);
+  auto *hh = HH<T>(h);
+  const int L = h->L;
+  RecomposeArgs<T> A{};
+  if (ocount) {
+    size_t slots = 16;
+    while (slots < 2 * ocount) slots *= 2;
+    if (slots > ((size_t)1 << 31)) return fail(MGH_ERR_INVALID_ARGUMENT, "too many outliers");
+    if (slots > ds->oh_slots) {
+      (void)hipFree(ds->oh_key);
+      (void)hipFree(ds->oh_val);
+      ds->oh_key = nullptr;
+      ds->oh_val = nullptr;
+      ds->oh_slots = 0;
+      HIP_TRY(hipMalloc(&ds->oh_key, slots * 8));
+      HIP_TRY(hipMalloc(&ds->oh_val, slots * 8));
+      ds->oh_slots = slots;
+    }
+    HIP_TRY(hipMemsetAsync(ds->oh_key, 0, slots * 8, st));
+    TRY(launch(h, "outlier_table", st, [&] {
+      k_outlier_hash_build<<<(unsigned)((ocount + 255) / 256), 256, 0, st>>>(
+          oidx, oval, ocount, h->total, ds->oh_key, ds->oh_val, (uint32_t)(slots - 1));
+    }));
+    A.oh_key = ds->oh_key;
+    A.oh_val = ds->oh_val;
+    A.oh_mask = (uint32_t)(slots - 1);
+  }
+  std::vector<T> qz(L + 1);
+  hh->quantizers(ebtype, (T)tol, (T)s, (T)norm, false, qz.data());
+  const bool calc_vol = !((T)s == std::numeric_limits<T>::infinity());
+  A.q16 = sym;
+  A.dI = ds->full_I;
+  A.dJ = ds->full_J;
+  A.half = (int64_t)(dict_size / 2);
+  std::vector<T> level_qv(L + 1);
+  for (int l = 0; l <= L; l++) level_qv[l] = qz[l] * (calc_vol ? hh->level_volume(l, true) : (T)1);
+  return recompose_levels<T, uint16_t>(h, A, level_qv, data, st);
+}
+
 template <typename T>
 int upload_quantizers(mgh_hierarchy *h, int ebtype, double tol, double s, double norm,
                       bool reciprocal, hipStream_t st) {
@@ -1468,7 +1518,7 @@ int mgh_decompose_quantize_sym16(mgh_hierarchy *h, const void *d_data, int error
     return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
   if (dict_size == 0 || dict_size > 65536) return fail(MGH_ERR_INVALID_ARGUMENT, "dict_size must be in 1..65536");
   HIP_TRY(hipSetDevice(h->device));
-  if (!fused_ok(h) || h->force_v1 || h->split)
+  if (!mgh_sym16_supported(h))
     return fail(MGH_ERR_UNSUPPORTED_DIMENSION, "16-bit symbols: only on the fused 3-D path");
   // (the norm and the quantizers stay on the device; a given norm is uploaded first)
   const void *d_norm = nullptr;
@@ -1500,6 +1550,29 @@ int mgh_decompose_quantize_sym16(mgh_hierarchy *h, const void *d_data, int error
                                                (const double *)d_norm, 0, 1, h_norm_out, dict_size, 1, nullptr,
                                                d_outlier_count, d_outlier_idx, d_outlier_val,
                                                outlier_capacity, (hipStream_t)stream, d_symbols));
+}
+
+int mgh_sym16_supported(const mgh_hierarchy *h) {
+  return h && fused_ok(h) && !h->force_v1 && !h->split ? 1 : 0;
+}
+
+int mgh_dequantize_recompose_sym16(mgh_hierarchy *h, const uint16_t *d_symbols, int error_bound_type,
+                                   double tol, double s, double norm, uint64_t dict_size,
+                                   const uint64_t *d_outlier_idx, const int64_t *d_outlier_val,
+                                   uint64_t outlier_count, void *d_data_out, void *stream) {
+  if (!h || !d_symbols || !d_data_out || (outlier_count && (!d_outlier_idx || !d_outlier_val)))
+    return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
+  if (dict_size == 0 || dict_size > 65536) return fail(MGH_ERR_INVALID_ARGUMENT, "dict_size must be in 1..65536");
+  HIP_TRY(hipSetDevice(h->device));
+  if (!mgh_sym16_supported(h))
+    return fail(MGH_ERR_UNSUPPORTED_DIMENSION, "16-bit symbols: only on the fused 3-D path");
+  return DISPATCH(h,
+                  dequantize_recompose_fused16<float>(h, d_symbols, error_bound_type, tol, s, norm, dict_size,
+                                                      d_outlier_idx, d_outlier_val, outlier_count,
+                                                      (float *)d_data_out, (hipStream_t)stream),
+                  dequantize_recompose_fused16<double>(h, d_symbols, error_bound_type, tol, s, norm, dict_size,
+                                                       d_outlier_idx, d_outlier_val, outlier_count,
+                                                       (double *)d_data_out, (hipStream_t)stream));
 }
 
 int mgh_decompose_quantize(mgh_hierarchy *h, const void *d_data, int error_bound_type, double tol, double s,

@@ -359,8 +359,11 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
 
 // `payload` may be host or device memory: only the small leading part of the record is brought
 // to the host, the code units and outlier lists go device-to-device (or host-to-device).
+// sym16: decode to uint16_t symbols at d_q (the ring decoder only; *sym16 is cleared when another
+// decoder had to be used and d_q holds int64 values).
 int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t size, int lossless,
-                        int64_t *d_q, uint64_t n, uint64_t *ocount_out, hipStream_t st) {
+                        int64_t *d_q, uint64_t n, uint64_t *ocount_out, hipStream_t st,
+                        bool *sym16 = nullptr) {
   const uint8_t *p = payload;
   uint64_t psize = size;
   bool on_dev = is_device_pointer(payload);
@@ -479,18 +482,28 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
     HL_HIP(hipMemcpyAsync(c->dtable.p, dt.data(), dt.size() * 4, hipMemcpyHostToDevice, st));
     static bool once3 = false;
     if (!once3) {
-      HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_decode_ring),
+      HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_decode_ring<int64_t>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+      HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_decode_ring<uint16_t>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
       once3 = true;
     }
-    huff::k_decode_ring<<<(unsigned)((nchunk + waves - 1) / waves), 64 * waves,
-                          huff::decode_ring_lds(dt.size(), waves), st>>>(
-        (const unsigned long long *)c->units.p, (const unsigned long long *)c->bits.p,
-        (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, rtb, (const unsigned *)c->dtable.p,
-        (unsigned)dt.size(), tab, tab + 64, tab + 128, d_q);
+    if (sym16 && *sym16)
+      huff::k_decode_ring<uint16_t><<<(unsigned)((nchunk + waves - 1) / waves), 64 * waves,
+                                      huff::decode_ring_lds(dt.size(), waves), st>>>(
+          (const unsigned long long *)c->units.p, (const unsigned long long *)c->bits.p,
+          (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, rtb, (const unsigned *)c->dtable.p,
+          (unsigned)dt.size(), tab, tab + 64, tab + 128, (uint16_t *)d_q);
+    else
+      huff::k_decode_ring<int64_t><<<(unsigned)((nchunk + waves - 1) / waves), 64 * waves,
+                                     huff::decode_ring_lds(dt.size(), waves), st>>>(
+          (const unsigned long long *)c->units.p, (const unsigned long long *)c->bits.p,
+          (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, rtb, (const unsigned *)c->dtable.p,
+          (unsigned)dt.size(), tab, tab + 64, tab + 128, d_q);
     HL_HIP(hipGetLastError());
     HL_HIP(hipStreamSynchronize(st));  // (dt goes out of scope)
   } else if (!serial_decode && (size_t)chunk >= 1024) {
+    if (sym16) *sym16 = false;
     // parallel decoding inside the chunks (one wave per chunk)
     static bool once2 = false;
     if (!once2) {
@@ -508,6 +521,7 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
         (const unsigned long long *)c->units.p, (const unsigned long long *)c->bits.p,
         (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, tb, tab, tab + 64, tab + 128, d_q);
   } else {
+    if (sym16) *sym16 = false;
     huff::k_decode<<<(unsigned)((nchunk + 63) / 64), 64, lds, st>>>(
         (const unsigned long long *)c->units.p, (const unsigned long long *)c->bits.p,
         (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, tb, tab, tab + 64, tab + 128, d_q);
@@ -1207,15 +1221,30 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
     if ((double)(n * elem) / (double)csize > 1.0) {  // GPUPipelines.hpp:414-417
       const uint8_t *payload = (const uint8_t *)rec;
       uint64_t ocount = 0;
-      rc = lossless_decompress(g_cache.ll, payload, csize, lossless, (int64_t *)g_cache.q.p, n, &ocount, st);
-      if (rc != MGH_SUCCESS) return cleanup(rc);
       mgh_hierarchy *h = nullptr;
       bool owned = false;
       if ((rc = get_hierarchy(&h, &owned, dtype, sshape, cptr, dd.subdomain_offset(id), cfg)) != MGH_SUCCESS)
         return cleanup(rc);
-      rc = mgh_dequantize_recompose(h, (int64_t *)g_cache.q.p, local_eb, (double)local_tol, (double)s,
-                                    (double)norm, hd.huff_dict_size, 1, (const uint64_t *)g_cache.ll->oidx.p,
-                                    (const int64_t *)g_cache.ll->oval.p, ocount, sub, st);
+      // 16-bit symbols between decoder and dequantizer: measured SLOWER than int64 on this side
+      // (3.0 vs 2.9 ms at 512^3: decoder and node restore are instruction-bound, not
+      // bandwidth-bound, and the outlier look-ups of the coarse levels cost more than the
+      // outlier-restore pass they replace) -- opt-in, MGH_SYM16_DECODE=1
+      static const bool sym16_decode = std::getenv("MGH_SYM16_DECODE") != nullptr;
+      bool sym16 = sym16_decode && mgh_sym16_supported(h) && hd.huff_dict_size <= 65536;
+      rc = lossless_decompress(g_cache.ll, payload, csize, lossless, (int64_t *)g_cache.q.p, n, &ocount, st,
+                               &sym16);
+      if (rc == MGH_SUCCESS) {
+        if (sym16)
+          rc = mgh_dequantize_recompose_sym16(h, (const uint16_t *)g_cache.q.p, local_eb, (double)local_tol,
+                                              (double)s, (double)norm, hd.huff_dict_size,
+                                              (const uint64_t *)g_cache.ll->oidx.p,
+                                              (const int64_t *)g_cache.ll->oval.p, ocount, sub, st);
+        else
+          rc = mgh_dequantize_recompose(h, (int64_t *)g_cache.q.p, local_eb, (double)local_tol, (double)s,
+                                        (double)norm, hd.huff_dict_size, 1,
+                                        (const uint64_t *)g_cache.ll->oidx.p,
+                                        (const int64_t *)g_cache.ll->oval.p, ocount, sub, st);
+      }
       if (owned) {
         (void)hipStreamSynchronize(st);
         mgh_hierarchy_destroy(h);

@@ -890,13 +890,14 @@ inline size_t decode_ring_lds(size_t table_entries, int waves) {
   return (table_entries * 4 + 7) / 8 * 8 + (size_t)waves * (kRingUnits * 64 * 8 + 64 * kRingBatch * 2);
 }
 
+template <typename OUT>  // int64_t (the reference's array of quantized values) or uint16_t symbols
 __global__ void __launch_bounds__(1024)
 k_decode_ring(const unsigned long long *__restrict__ units, const unsigned long long *__restrict__ bits,
               const unsigned long long *__restrict__ entry_of_chunk, size_t nchunk, int chunk, size_t n,
               int dict, int tb, const unsigned *__restrict__ g_table, unsigned table_entries,
               const unsigned long long *__restrict__ first,
               const unsigned long long *__restrict__ entry, const unsigned long long *__restrict__ keys,
-              int64_t *__restrict__ q) {
+              OUT *__restrict__ q) {
   __shared__ unsigned long long sfirst[64], sentry[64], slim[64];
   __shared__ int smaxlen;
   extern __shared__ unsigned dyn_lds[];
@@ -940,7 +941,7 @@ k_decode_ring(const unsigned long long *__restrict__ units, const unsigned long 
   const unsigned long long *src = units + entry_of_chunk[c];
   // (bit positions inside a chunk fit 32 bits: the host sends chunks of at most 2^24 symbols here)
   const unsigned total = (unsigned)min(bits[c], (unsigned long long)chunk * kMaxCodeBits);
-  int64_t *dst = q + c * (size_t)chunk;
+  OUT *dst = q + c * (size_t)chunk;
   const unsigned cap = (unsigned)min((size_t)chunk, n - c * (size_t)chunk);
   const unsigned nun = (total + 63) / 64;  // src[nun] is readable (the window peeks ahead)
   const unsigned B = (total + 63) / 64;    // bits per subsequence
@@ -1065,7 +1066,7 @@ k_decode_ring(const unsigned long long *__restrict__ units, const unsigned long 
         for (int L = 0; L < 64; L++) {
           const int n_L = __shfl(got, L, 64);
           const unsigned o_L = __shfl(out0 + cnt - got, L, 64);
-          if (lane < n_L && o_L + lane < cap) dst[o_L + lane] = (int64_t)stage[L * kRingBatch + lane];
+          if (lane < n_L && o_L + lane < cap) dst[o_L + lane] = (OUT)stage[L * kRingBatch + lane];
         }
       }
     }

@@ -23,6 +23,11 @@ template <typename T> struct RecomposeArgs {
   int n[3], m[3];
   const int64_t *q;  // quantized coefficients, reordered layout, strides (dI, dJ, 1)
   const T *coef;     // ... or the coefficients themselves (kernels instantiated with QT = T)
+  const uint16_t *q16;  // ... or 16-bit dictionary symbols (QT = uint16_t): symbol 0 may stand for
+                        // an out-of-dictionary value, looked up by its linear index in the table
+  const unsigned long long *oh_key;  // open-addressing table: key = linear index + 1, 0 = empty
+  const long long *oh_val;           // shifted quantized value of the outlier
+  uint32_t oh_mask;                  // slots - 1 (power of two)
   size_t dI, dJ;
   const T *coarse;   // compact (m0, m1, m2), corrected coarse nodes (restore only)
   T *load;           // compact (m0, m1, m2) (loadvec only)
@@ -53,6 +58,43 @@ template <typename T> __device__ __forceinline__ T qdecode(const RecomposeArgs<T
   return dequant_one<T>(v, A.half, A.qv);
 }
 template <typename T> __device__ __forceinline__ T qdecode(const RecomposeArgs<T> &, T v) { return v; }
+
+// 16-bit symbols travel as 32-bit values (kMissing16 where a window element has no
+// coefficient) and are dequantized where they are used: d = symbol - half fits an int, same
+// conversion and product as dequant_one. Symbol 0 is looked up in the outlier table by its
+// linear index (rare: outliers and true zeros only). The loads themselves stay plain loads --
+// a lookup inside the load loop would put every load into its own basic block and serialise them.
+constexpr uint32_t kMissing16 = 0xffffffffu;
+__device__ __forceinline__ uint32_t outlier_hash(unsigned long long lin) {
+  return (uint32_t)((lin * 0x9E3779B97F4A7C15ull) >> 32);
+}
+template <typename T>
+__device__ __forceinline__ T qdecode(const RecomposeArgs<T> &A, uint32_t v, size_t lin) {
+  if (v == kMissing16) return (T)0;
+  if (v == 0 && A.oh_key) {
+    uint32_t slot = outlier_hash(lin) & A.oh_mask;
+    for (uint32_t probes = 0; probes <= A.oh_mask; probes++) {
+      const unsigned long long k = A.oh_key[slot];
+      if (k == (unsigned long long)lin + 1) return A.qv * (T)((int64_t)A.oh_val[slot] - A.half);
+      if (k == 0) break;
+      slot = (slot + 1) & A.oh_mask;
+    }
+  }
+  return A.qv * (T)((int)v - (int)A.half);
+}
+template <typename T> __device__ __forceinline__ T qdecode(const RecomposeArgs<T> &A, int64_t v, size_t) {
+  return qdecode<T>(A, v);
+}
+__device__ __forceinline__ float qdecode(const RecomposeArgs<float> &, float v, size_t) { return v; }
+__device__ __forceinline__ double qdecode(const RecomposeArgs<double> &, double v, size_t) { return v; }
+template <typename T> __device__ __forceinline__ uint32_t qload(const RecomposeArgs<T> &, const uint16_t *p) { return *p; }
+template <typename T> __device__ __forceinline__ int64_t qload(const RecomposeArgs<T> &, const int64_t *p) { return *p; }
+template <typename T> __device__ __forceinline__ T qload(const RecomposeArgs<T> &, const T *p) { return *p; }
+template <typename T> __device__ __forceinline__ const uint16_t *qsrc(const RecomposeArgs<T> &A, uint16_t) { return A.q16; }
+template <typename T> __device__ __forceinline__ uint32_t qmissing(const RecomposeArgs<T> &, uint16_t) { return kMissing16; }
+// type a loaded value travels in
+template <typename T, typename QT> struct QReg { using type = QT; };
+template <typename T> struct QReg<T, uint16_t> { using type = uint32_t; };
 
 template <typename T, typename QT, int TC, int TF, int RCH>
 __global__ void __launch_bounds__(256)
@@ -111,24 +153,28 @@ k_level_loadvec_q(RecomposeArgs<T> A) {
     lds[k] = e < WC * WF ? LI(lc, lf) : -1;
     evn[k] = !(lc & 1) && !(lf & 1);
   }
-  auto fetch = [&](int p, QT(&reg)[NL]) {
+  using QR = typename QReg<T, QT>::type;
+  auto fetch = [&](int p, QR(&reg)[NL]) {
     const bool pv = p >= 0 && p <= Pmax_r && p != ghost_r;
     const bool p_odd = p & 1;
     const int oi = p_odd ? mr + (p - 1) / 2 : p / 2;
     const QT *base = qsrc<T>(A, QT()) + (size_t)(pv ? oi : 0) * A.dI;
 #pragma unroll
     for (int k = 0; k < NL; k++)
-      reg[k] = (pv && qoff[k] != kNone && (p_odd || !evn[k])) ? base[qoff[k]] : qmissing<T>(A, QT());
+      reg[k] = (pv && qoff[k] != kNone && (p_odd || !evn[k])) ? qload<T>(A, base + qoff[k]) : qmissing<T>(A, QT());
   };
-  QT cur[NL], nxt[NL];
+  QR cur[NL], nxt[NL];
   fetch(r_lo, cur);
   for (int p = r_lo; p <= r_hi; p++) {
     if (p < r_hi) fetch(p + 1, nxt);
     // Phase A': dequantized coefficient field of the window (0 at coarse / missing nodes:
     // a missing value was fetched as `half`, which dequantizes to exactly 0)
+    {
+      const size_t pb = (size_t)((p & 1) ? mr + (p - 1) / 2 : p / 2) * A.dI;  // (index of a looked-up value)
 #pragma unroll
-    for (int k = 0; k < NL; k++)
-      if (lds[k] >= 0) Cs[lds[k]] = qdecode<T>(A, cur[k]);
+      for (int k = 0; k < NL; k++)
+        if (lds[k] >= 0) Cs[lds[k]] = qdecode(A, cur[k], pb + qoff[k]);
+    }
     __syncthreads();
     for (int lc = jc; lc < WC; lc += TC) {
       const T *row = Cs + lc * ROW;
@@ -185,7 +231,8 @@ k_level_restore_q(RecomposeArgs<T> A) {
   const size_t mJ = mf, mI = (size_t)mc * mf;
   const int r0 = ro ? (rp - 1) / 2 : i, c0 = co ? (cp - 1) / 2 : j;
   const T rr = ro ? A.ratio[0][rp - 1] : (T)0, rc = co ? A.ratio[1][cp - 1] : (T)0;
-  const QT *qrow = qsrc<T>(A, QT()) + (size_t)i * A.dI + (size_t)j * A.dJ;
+  const size_t qlin = (size_t)i * A.dI + (size_t)j * A.dJ;
+  const QT *qrow = qsrc<T>(A, QT()) + qlin;
   T *out = A.fine + (size_t)rp * A.fI + (size_t)cp * A.fJ;
   const bool pure_coarse = !ro && !co;
   const T *rows[2][2];
@@ -224,13 +271,13 @@ k_level_restore_q(RecomposeArgs<T> A) {
     const T iO = ro ? lerp_ref(hO[0], hO[1], rr) : hO[0];
     // E: coarse node (pure copy) unless r or c is odd
     T vE = iE;
-    if (!pure_coarse) vE = qdecode<T>(A, qrow[t]) + iE;
+    if (!pure_coarse) vE = qdecode(A, qload<T>(A, qrow + t), qlin + t) + iE;
     T vO = iO;  // (pure coarse last node of an even-sized dim: iO = row[mf-1])
     if (hasO) {
       if (fo)
-        vO = qdecode<T>(A, qrow[mf + t]) + iO;
+        vO = qdecode(A, qload<T>(A, qrow + mf + t), qlin + mf + t) + iO;
       else if (!pure_coarse)
-        vO = qdecode<T>(A, qrow[mf - 1]) + iO;
+        vO = qdecode(A, qload<T>(A, qrow + mf - 1), qlin + mf - 1) + iO;
     }
     // the pair is contiguous: one 2-element store when the row start allows it
     T *dst = out + 2 * t;
@@ -250,7 +297,29 @@ k_head_in_q(int m0, int m1, int m2, RecomposeArgs<T> A, T *__restrict__ nodal) {
   const int total = m0 * m1 * m2;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const int k = e % m2, j = (e / m2) % m1, i = e / (m2 * m1);
-    nodal[e] = qdecode<T>(A, qsrc<T>(A, QT())[(size_t)i * A.dI + (size_t)j * A.dJ + k]);
+    const size_t lin = (size_t)i * A.dI + (size_t)j * A.dJ + k;
+    nodal[e] = qdecode(A, qload<T>(A, qsrc<T>(A, QT()) + lin), lin);
+  }
+}
+
+// Outlier table for the 16-bit symbol path: idx -> value, open addressing with linear probing;
+// indices outside the array (damaged streams) are dropped. keys[] zero before the launch.
+__global__ void __launch_bounds__(256)
+k_outlier_hash_build(const uint64_t *__restrict__ oidx, const int64_t *__restrict__ oval, size_t count,
+                     size_t total, unsigned long long *__restrict__ keys, long long *__restrict__ vals,
+                     uint32_t mask) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const unsigned long long lin = oidx[i];
+  if (lin >= total) return;
+  uint32_t slot = outlier_hash(lin) & mask;
+  for (uint32_t probes = 0; probes <= mask; probes++) {
+    const unsigned long long prev = atomicCAS(&keys[slot], 0ull, lin + 1);
+    if (prev == 0 || prev == lin + 1) {
+      vals[slot] = oval[i];
+      return;
+    }
+    slot = (slot + 1) & mask;
   }
 }
 

@@ -583,6 +583,17 @@ def test_sym16_output_equals_the_int64_output(shape, dt, mode, tol, s, dict_size
     assert a == b
     if dict_size == 64:
         assert cnt > 100
+    # and back: the 16-bit path reconstructs the same bits as the int64 path
+    nrm = n1 if mode == "REL" else 0.0
+    v64 = h.dequantize_recompose(q.clone(), eb, tol, s, nrm, dict_size=dict_size, outlier_idx=oi, outlier_val=ov)
+    v16 = h.dequantize_recompose_sym16(sym, eb, tol, s, nrm, dict_size=dict_size, outlier_idx=si, outlier_val=sv)
+    assert np.array_equal(v64.cpu().numpy().view(np.uint8), v16.cpu().numpy().view(np.uint8))
+    # out-of-range and duplicate outlier indices (damaged stream) must not fault
+    if cnt:
+        bad_i = torch.cat([si, torch.tensor([h.total + 5, 2 ** 40], dtype=si.dtype, device=si.device), si[:1]])
+        bad_v = torch.cat([sv, torch.tensor([7, 8], dtype=sv.dtype, device=sv.device), sv[:1]])
+        h.dequantize_recompose_sym16(sym, eb, tol, s, nrm, dict_size=dict_size, outlier_idx=bad_i, outlier_val=bad_v)
+        torch.cuda.synchronize()
     h.close()
     # not on the generic paths
     h2 = mg.Hierarchy((300, 40), np.float32)
