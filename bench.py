@@ -248,6 +248,29 @@ def main():
                                 "roundtrip_linf_error": err, "tolerance_abs": TOL * nrm_host,
                                 "within_tolerance": bool(err <= TOL * nrm_host)}
         del back, q_work
+        # the same step with the quantized values delivered as 16-bit dictionary symbols (what
+        # mgh_compress feeds its Huffman stage with; an extension, never `value`: the metric
+        # is defined on the reference's int64 output)
+        try:
+            sym_out = h.decompose_quantize_sym16(d_u, mgard_amd.REL, TOL, float("inf"))
+            torch.cuda.synchronize()
+            t16 = time.perf_counter()
+            lib, hp = mgard_amd.load_library(), h._h
+            import ctypes as C
+            s_sym, s_cnt, s_idx, s_val = sym_out[0], torch.zeros(1, dtype=torch.int64, device="cuda"), oidx, oval
+            for _ in range(10):
+                lib.mgh_decompose_quantize_sym16(hp, C.c_void_p(d_u.data_ptr()), mgard_amd.REL, TOL, float("inf"),
+                                                 0.0, None, 8192, C.c_void_p(s_sym.data_ptr()),
+                                                 C.c_void_p(s_cnt.data_ptr()), C.c_void_p(s_idx.data_ptr()),
+                                                 C.c_void_p(s_val.data_ptr()), int(s_idx.numel()), None)
+            torch.cuda.synchronize()
+            s_ms = (time.perf_counter() - t16) / 10 * 1e3
+            same = bool(torch.equal(s_sym.to(torch.int64), q))
+            result["sym16_output"] = {"ms_per_step": round(s_ms, 4), "value": round(in_bytes / s_ms / 1e6, 3),
+                                      "unit": "GB/s (input)", "equals_int64_output": same}
+            del sym_out, s_sym
+        except mgard_amd.MgardHipError as e:
+            result["sym16_output"] = {"error": str(e)}
         # end to end through the container (reported separately, never
         # `value`): mgh_compress / mgh_decompress on the device-resident volume -- norm,
         # decompose, quantize, Huffman, serialisation into the MGARD-X container and back
