@@ -169,6 +169,8 @@ struct mgh_lossless_ctx {
   int dev = 0;
   DevBuf freq, code, bits, entry, total, units, tables, oidx, oval, state, dtable;
   bool overflow = false;  // the code stream did not fit into cap_units: treat as incompressible
+  std::vector<unsigned> h_freq;  // host copies that keep their storage from call to call
+  huff::Codebook codebook;
   std::vector<uint8_t> host;   // serialized payload (when assembled on the host)
   std::vector<uint8_t> host2;  // zstd scratch
   // the record of the last compress call in pieces: everything before the code units sits in
@@ -241,12 +243,15 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
   else
     huff::k_histogram<int64_t><<<hblocks, 256, dict * 4, st>>>(d_q, n, (int)dict, (unsigned *)c->freq.p);
   HL_HIP(hipGetLastError());
-  std::vector<unsigned> freq(dict);
+  hl_debug("lossless_compress: histogram kernel done");
+  std::vector<unsigned> &freq = c->h_freq;
+  freq.resize(dict);
   HL_HIP(hipMemcpyAsync(freq.data(), c->freq.p, dict * 4, hipMemcpyDeviceToHost, st));
   HL_HIP(hipStreamSynchronize(st));
-  huff::Codebook cb;
+  hl_debug("lossless_compress: histogram on the host");
+  huff::Codebook &cb = c->codebook;
   try {
-    cb = huff::build_codebook(freq);
+    huff::build_codebook(freq.data(), (int)dict, cb);
   } catch (const std::exception &e) {
     return hl_fail(MGH_ERR_INVALID_ARGUMENT, e.what());
   }

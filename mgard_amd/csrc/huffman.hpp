@@ -50,41 +50,52 @@ struct Codebook {
   int max_len = 0;
 };
 
-inline Codebook build_codebook(const std::vector<unsigned> &freq) {
-  const int dict = (int)freq.size();
-  Codebook cb;
+// Builds into `cb` (its vectors keep their capacity from call to call, as do the thread-local
+// work arrays: the construction runs once per subdomain on the critical path of mgh_compress).
+inline void build_codebook(const unsigned *freq, int dict, Codebook &cb) {
+  struct Node { uint64_t w; int l, r; };
+  static thread_local std::vector<uint64_t> key, count, first, next;
+  static thread_local std::vector<int> order, len, depth, idx, at;
+  static thread_local std::vector<Node> nodes;
+  cb.max_len = 0;
   cb.code.assign(dict, 0);
   cb.first.assign(kUnitBits, ~(uint64_t)0);
   cb.entry.assign(kUnitBits, 0);
-  cb.keys.assign(dict, 0);
-  // symbols by decreasing frequency (ties: increasing symbol) -- the order of keys[]
-  std::vector<int> order;
-  {
-    // one integer key per used symbol: (2^32-1 - frequency) above the symbol -> plain sort
-    std::vector<uint64_t> key;
-    key.reserve(dict);
-    for (int i = 0; i < dict; i++)
-      if (freq[i]) key.push_back(((uint64_t)(0xffffffffu - freq[i]) << 32) | (uint32_t)i);
-    std::sort(key.begin(), key.end());
-    order.resize(key.size());
-    for (size_t k = 0; k < key.size(); k++) order[k] = (int)(key[k] & 0xffffffffu);
+  cb.keys.resize(dict);
+  // symbols by decreasing frequency (ties: increasing symbol): one integer key per used symbol,
+  // (2^32-1 - frequency) above the symbol -> plain sort
+  key.clear();
+  key.reserve(dict);
+  for (int i = 0; i < dict; i++)
+    if (freq[i]) key.push_back(((uint64_t)(0xffffffffu - freq[i]) << 32) | (uint32_t)i);
+  const int nz = (int)key.size();
+  {  // LSD radix sort on the upper 32 bits (stable: ties stay in symbol order)
+    static thread_local std::vector<uint64_t> tmp;
+    tmp.resize(nz);
+    uint64_t *a = key.data(), *b = tmp.data();
+    for (int shift = 32; shift < 64; shift += 8) {
+      int cnt[257] = {0};
+      for (int i = 0; i < nz; i++) cnt[((a[i] >> shift) & 0xff) + 1]++;
+      for (int k = 0; k < 256; k++) cnt[k + 1] += cnt[k];
+      for (int i = 0; i < nz; i++) b[cnt[(a[i] >> shift) & 0xff]++] = a[i];
+      std::swap(a, b);
+    }  // (4 passes: the sorted keys are back in `key`)
   }
-  const int nz = (int)order.size();
-  // fill keys with the used symbols first, then the unused ones (any order)
+  order.resize(nz);
+  for (int k = 0; k < nz; k++) order[k] = (int)(key[k] & 0xffffffffu);
+  // keys[]: the used symbols in code order (filled below), then the unused ones (any order)
   {
-    int k = 0;
-    for (int s : order) cb.keys[k++] = (uint64_t)s;
+    int k = nz;
     for (int i = 0; i < dict; i++)
       if (!freq[i]) cb.keys[k++] = (uint64_t)i;
   }
-  if (nz == 0) return cb;
-  std::vector<int> len(nz, 0);
+  if (nz == 0) return;
+  len.assign(nz, 0);
   if (nz == 1) {
     len[0] = 1;
   } else {
     // Huffman tree with two queues over the leaves sorted by increasing weight
-    struct Node { uint64_t w; int l, r; };
-    std::vector<Node> nodes;
+    nodes.clear();
     nodes.reserve(2 * nz);
     for (int i = nz - 1; i >= 0; i--) nodes.push_back({freq[order[i]], -1, -1});  // increasing
     size_t leaf = 0, inner = (size_t)nz, inner_end = (size_t)nz;
@@ -97,7 +108,7 @@ inline Codebook build_codebook(const std::vector<unsigned> &freq) {
       nodes.push_back({nodes[a].w + nodes[b].w, a, b});
       inner_end++;
     }
-    std::vector<int> depth(nodes.size(), 0);
+    depth.assign(nodes.size(), 0);
     for (int i = (int)nodes.size() - 1; i >= nz; i--) {
       depth[nodes[i].l] = depth[i] + 1;
       depth[nodes[i].r] = depth[i] + 1;
@@ -105,29 +116,22 @@ inline Codebook build_codebook(const std::vector<unsigned> &freq) {
     for (int i = 0; i < nz; i++) len[nz - 1 - i] = depth[i];  // leaf i = order[nz-1-i]
   }
   // lengths are non-decreasing along `order` up to ties in the tree; canonical assignment
-  // needs symbols grouped by length: stable sort of the key order by length
-  std::vector<uint64_t> count(kUnitBits + 1, 0);
+  // needs symbols grouped by length: counting sort of the key order by length (stable)
+  count.assign(kUnitBits + 1, 0);
   for (int i = 0; i < nz; i++) {
     if (len[i] > kMaxCodeBits)
       throw std::runtime_error("Huffman: codeword longer than 56 bits");
     count[len[i]]++;
     cb.max_len = std::max(cb.max_len, len[i]);
   }
-  std::vector<int> idx(nz);  // counting sort by length, stable
-  {
-    std::vector<int> at(kUnitBits + 2, 0);
-    for (int l = 1; l <= kUnitBits; l++) at[l + 1] = at[l] + (int)count[l];
-    for (int i = 0; i < nz; i++) idx[at[len[i]]++] = i;
-  }
-  {
-    int k = 0;
-    std::vector<uint64_t> keys2(cb.keys);
-    for (int i : idx) keys2[k++] = (uint64_t)order[i];
-    cb.keys = keys2;
-  }
+  idx.resize(nz);
+  at.assign(kUnitBits + 2, 0);
+  for (int l = 1; l <= kUnitBits; l++) at[l + 1] = at[l] + (int)count[l];
+  for (int i = 0; i < nz; i++) idx[at[len[i]]++] = i;
+  for (int k = 0; k < nz; k++) cb.keys[k] = (uint64_t)order[idx[k]];
   // first[l]: longest codes start at 0, every shorter length continues above the prefixes of
   // the longer ones: first[l] = ceil((first[l+1] + count[l+1]) / 2)
-  std::vector<uint64_t> first(kUnitBits + 2, 0);
+  first.assign(kUnitBits + 2, 0);
   first[cb.max_len] = 0;
   for (int l = cb.max_len - 1; l >= 1; l--) first[l] = (first[l + 1] + count[l + 1] + 1) / 2;
   uint64_t e = 0;
@@ -137,11 +141,16 @@ inline Codebook build_codebook(const std::vector<unsigned> &freq) {
     e += l <= cb.max_len ? count[l] : 0;
   }
   // codes: the j-th symbol of length l (in keys order) gets first[l] + j
-  std::vector<uint64_t> next(first);
-  for (int i : idx) {
-    const int l = len[i];
+  next = first;
+  for (int k = 0; k < nz; k++) {
+    const int i = idx[k], l = len[i];
     cb.code[order[i]] = ((uint64_t)l << kMaxCodeBits) | next[l]++;
   }
+}
+
+inline Codebook build_codebook(const std::vector<unsigned> &freq) {
+  Codebook cb;
+  build_codebook(freq.data(), (int)freq.size(), cb);
   return cb;
 }
 
