@@ -170,6 +170,7 @@ struct mgh_lossless_ctx {
   DevBuf freq, code, bits, entry, total, units, tables, oidx, oval, state, dtable;
   bool overflow = false;  // the code stream did not fit into cap_units: treat as incompressible
   std::vector<unsigned> h_freq;  // host copies that keep their storage from call to call
+  std::vector<uint32_t> h_code32;
   huff::Codebook codebook;
   std::vector<uint8_t> host;   // serialized payload (when assembled on the host)
   std::vector<uint8_t> host2;  // zstd scratch
@@ -256,7 +257,19 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
     return hl_fail(MGH_ERR_INVALID_ARGUMENT, e.what());
   }
   hl_debug("lossless_compress: histogram + codebook done");
-  HL_HIP(hipMemcpyAsync(c->code.p, cb.code.data(), dict * 8, hipMemcpyHostToDevice, st));
+  // code table for the kernels: 32-bit entries when every code fits 27 bits (it practically
+  // always does: half the LDS of the encoder, two workgroups per CU), else 64-bit entries
+  const bool short_codes = cb.max_len <= huff::kShortCodeBits;
+  if (short_codes) {
+    std::vector<uint32_t> &c32 = c->h_code32;
+    c32.resize(dict);
+    for (uint64_t k = 0; k < dict; k++)
+      c32[k] = (uint32_t)((cb.code[k] >> huff::kMaxCodeBits) << huff::kShortCodeBits) |
+               (uint32_t)(cb.code[k] & (((uint64_t)1 << huff::kShortCodeBits) - 1));
+    HL_HIP(hipMemcpyAsync(c->code.p, c32.data(), dict * 4, hipMemcpyHostToDevice, st));
+  } else {
+    HL_HIP(hipMemcpyAsync(c->code.p, cb.code.data(), dict * 8, hipMemcpyHostToDevice, st));
+  }
   // ---- serialize (Huffman.hpp:163-239): the small leading part on the host, the code units
   // and the outlier lists stay where they are until record_write() ----
   PayloadLayout &L = c->lay;
@@ -271,8 +284,8 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
     return MGH_SUCCESS;
   };
   unsigned long long units = 0;
-  const size_t enc_lds = dict * 8 + chunk * 2;
-  if (enc_lds <= 140 * 1024) {
+  const size_t enc_lds = (dict * (short_codes ? 4 : 8) + 15) / 16 * 16 + chunk * 2;
+  if (lossless_sym16_ok(dict, chunk) && chunk <= (1u << 24)) {
     // one pass: bit counts, unit offsets (decoupled look-back) and packing in the same kernel.
     // The stream is written into a buffer of cap_units; more than that means "not compressible".
     const unsigned long long worst = n + nchunk;  // a code is shorter than a unit
@@ -282,22 +295,29 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
     HL_HIP(hipMemsetAsync(c->state.p, 0, (3 + nchunk) * 8, st));
     static bool once = false;
     if (!once) {
-      HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_encode_chain<int64_t>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-      HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_encode_chain<uint16_t>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+      const int lim = 144 * 1024;
+      HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_encode_chain<int64_t, uint64_t>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_encode_chain<uint16_t, uint64_t>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_encode_chain<int64_t, uint32_t>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_encode_chain<uint16_t, uint32_t>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lim));
       once = true;
     }
-    if (sym16)
-      huff::k_encode_chain<uint16_t><<<(unsigned)nchunk, huff::kEncThreads, enc_lds, st>>>(
-          (const uint16_t *)d_q, n, (int)chunk, (int)dict, nchunk, (const uint64_t *)c->code.p,
+    auto enc = [&](auto sym_tag, auto code_tag) {
+      using SYM = decltype(sym_tag);
+      using CODE = decltype(code_tag);
+      huff::k_encode_chain<SYM, CODE><<<(unsigned)nchunk, huff::kEncThreads, enc_lds, st>>>(
+          (const SYM *)d_q, n, (int)chunk, (int)dict, nchunk, (const CODE *)c->code.p,
           (unsigned long long *)c->state.p, (unsigned long long *)c->bits.p,
           (unsigned long long *)c->entry.p, (unsigned long long *)c->units.p, cap);
-    else
-      huff::k_encode_chain<int64_t><<<(unsigned)nchunk, huff::kEncThreads, enc_lds, st>>>(
-          d_q, n, (int)chunk, (int)dict, nchunk, (const uint64_t *)c->code.p,
-          (unsigned long long *)c->state.p, (unsigned long long *)c->bits.p,
-          (unsigned long long *)c->entry.p, (unsigned long long *)c->units.p, cap);
+    };
+    if (sym16 && short_codes) enc(uint16_t(), uint32_t());
+    else if (sym16) enc(uint16_t(), uint64_t());
+    else if (short_codes) enc(int64_t(), uint32_t());
+    else enc(int64_t(), uint64_t());
     HL_HIP(hipGetLastError());
     unsigned long long st3[3] = {0, 0, 0};
     HL_HIP(hipMemcpyAsync(st3, c->state.p, 24, hipMemcpyDeviceToHost, st));
@@ -307,6 +327,8 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
     c->overflow = st3[2] != 0;
   } else {
     if (sym16) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "lossless: 16-bit symbols need the single-pass encoder");
+    if (short_codes)  // (these kernels read 64-bit entries)
+      HL_HIP(hipMemcpyAsync(c->code.p, cb.code.data(), dict * 8, hipMemcpyHostToDevice, st));
     huff::k_chunk_bits<<<(unsigned)nchunk, 256, 0, st>>>(d_q, n, (int)chunk, (const uint64_t *)c->code.p,
                                                          (unsigned long long *)c->bits.p);
     huff::k_unit_offsets<<<1, 1024, 0, st>>>((const unsigned long long *)c->bits.p, nchunk,

@@ -289,7 +289,7 @@ k_encode(const int64_t *__restrict__ q, size_t n, int chunk, const uint64_t *__r
   if (room != kUnitBits) flush(true);
 }
 
-constexpr int kEncThreads = 1024;  // one workgroup per CU (LDS): fill it with waves
+constexpr int kEncThreads = 512;  // threads of an encoder workgroup (two workgroups per CU with 32-bit code entries)
 
 // Same as k_encode with the chunk's symbols (16 bit) and the code table staged in LDS: the
 // symbols are read from HBM once, coalesced, instead of every lane walking its own run, and the
@@ -363,8 +363,9 @@ k_encode_lds(const int64_t *__restrict__ q, size_t n, int chunk, int dict,
 // predecessor of a running workgroup is running or done and the wait is bounded; a workgroup
 // publishes (AGGREGATE | its own units) as soon as it has counted its bits, and
 // (INCLUSIVE | units up to and including itself) once it knows its offset. Status words, ticket
-// and overflow flag are read and written with device-scope atomic read-modify-writes only (the
-// XCDs do not share an L2).
+// are read and written with device-scope atomic loads / stores (the XCDs do not share an L2;
+// read-modify-writes instead serialise in the L2 channel of a status line that up to 64
+// successors poll: 0.73 -> see DESIGN.md).
 //   state: [0] ticket counter, [1] total units (written by the last chunk), [2] overflow flag,
 //          [3 + c] status of chunk c; all zero before the launch.
 // A workgroup zeroes its units before packing (threads meet in shared units with atomicOr);
@@ -373,16 +374,26 @@ k_encode_lds(const int64_t *__restrict__ q, size_t n, int chunk, int dict,
 constexpr unsigned long long kStAggregate = 1ull << 62, kStInclusive = 2ull << 62,
                              kStValue = (1ull << 62) - 1;
 
-template <typename SYM>
+// CODE: uint64_t entries (length << 56 | value) or, when no code is longer than 27 bits, uint32_t
+// entries (length << 27 | value): half the LDS, two workgroups per CU instead of one.
+template <typename CODE> struct CodeEntry;
+template <> struct CodeEntry<uint64_t> { static constexpr int shift = kMaxCodeBits; };
+template <> struct CodeEntry<uint32_t> { static constexpr int shift = 27; };
+constexpr int kShortCodeBits = 27;
+
+template <typename SYM, typename CODE>
 __global__ void __launch_bounds__(kEncThreads)
 k_encode_chain(const SYM *__restrict__ q, size_t n, int chunk, int dict, size_t nchunk,
-               const uint64_t *__restrict__ code, unsigned long long *__restrict__ state,
+               const CODE *__restrict__ code, unsigned long long *__restrict__ state,
                unsigned long long *__restrict__ bits, unsigned long long *__restrict__ entry,
                unsigned long long *__restrict__ out, unsigned long long cap_units) {
+  constexpr int SH = CodeEntry<CODE>::shift;
   extern __shared__ unsigned long long enc_lds[];
-  unsigned long long *scode = enc_lds;
-  unsigned short *ssym = reinterpret_cast<unsigned short *>(enc_lds + dict);
-  __shared__ unsigned long long sc[kEncThreads];
+  CODE *scode = reinterpret_cast<CODE *>(enc_lds);
+  unsigned short *ssym = reinterpret_cast<unsigned short *>(
+      reinterpret_cast<unsigned char *>(enc_lds) + ((size_t)dict * sizeof(CODE) + 15) / 16 * 16);
+  __shared__ unsigned sc[kEncThreads];   // bit offset of every thread's run in the chunk
+  __shared__ unsigned swave[kEncThreads / 64];
   __shared__ unsigned long long sh_id, sh_entry;
   if (threadIdx.x == 0) sh_id = atomicAdd(&state[0], 1ull);
   for (int i = threadIdx.x; i < dict; i += kEncThreads) scode[i] = code[i];
@@ -391,8 +402,8 @@ k_encode_chain(const SYM *__restrict__ q, size_t n, int chunk, int dict, size_t 
   const size_t base = id * chunk;
   const size_t cnt = min((size_t)chunk, n - base);
   size_t staged = 0;
-  if (sizeof(SYM) == 2 && (reinterpret_cast<uintptr_t>(q + base) & 15) == 0 &&
-      (reinterpret_cast<uintptr_t>(ssym) & 15) == 0) {  // 16-bit symbols: straight 16-byte copies
+  if (sizeof(SYM) == 2 && (reinterpret_cast<uintptr_t>(q + base) & 15) == 0) {
+    // 16-bit symbols: straight 16-byte copies
     const uint4 *src = reinterpret_cast<const uint4 *>(q + base);
     uint4 *dst4 = reinterpret_cast<uint4 *>(ssym);
     for (size_t i = threadIdx.x; i < cnt / 8; i += kEncThreads) dst4[i] = src[i];
@@ -402,28 +413,52 @@ k_encode_chain(const SYM *__restrict__ q, size_t n, int chunk, int dict, size_t 
   __syncthreads();
   const size_t run = (cnt + kEncThreads - 1) / kEncThreads;
   const size_t lo = min(cnt, threadIdx.x * run), hi = min(cnt, lo + run);
-  unsigned long long s = 0;
-  for (size_t i = lo; i < hi; i++) s += scode[ssym[i]] >> kMaxCodeBits;
-  sc[threadIdx.x] = s;
-  __syncthreads();
-  for (int off = 1; off < kEncThreads; off <<= 1) {
-    const unsigned long long v = threadIdx.x >= (unsigned)off ? sc[threadIdx.x - off] : 0;
-    __syncthreads();
-    sc[threadIdx.x] += v;
-    __syncthreads();
+  // The code entries of the run are kept in registers between the counting and the packing
+  // (default chunk: 40 symbols per thread): the table look-ups of a thread are then independent
+  // LDS reads in flight together, and the packing loop runs from registers. Longer runs (bigger
+  // chunks) read the table twice.
+  constexpr int RR = 40;
+  CODE cc[RR];
+  const bool in_regs = run <= (size_t)RR;
+  unsigned s = 0;
+  if (in_regs) {
+#pragma unroll
+    for (int k = 0; k < RR; k++) {
+      cc[k] = lo + k < hi ? scode[ssym[lo + k]] : (CODE)0;  // (a zero entry packs nothing)
+      s += (unsigned)(cc[k] >> SH);
+    }
+  } else {
+    for (size_t i = lo; i < hi; i++) s += (unsigned)(scode[ssym[i]] >> SH);
   }
-  const unsigned long long chunk_bits = sc[kEncThreads - 1];
+  // exclusive scan of the per-thread bit counts: inside the waves with shuffles, across them
+  // through swave[] (a chunk holds fewer than 2^32 bits: the host limits the chunk size)
+  unsigned incl = s;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned v = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += v;
+  }
+  if (lane == 63) swave[wv] = incl;
+  __syncthreads();
+  unsigned wave_off = 0, total_bits = 0;
+  for (int k = 0; k < kEncThreads / 64; k++) {
+    const unsigned t = swave[k];
+    if (k < wv) wave_off += t;
+    total_bits += t;
+  }
+  sc[threadIdx.x] = wave_off + incl;  // inclusive, as below
+  const unsigned long long chunk_bits = total_bits;
   const unsigned long long my_units = (chunk_bits + kUnitBits - 1) / kUnitBits;
   if (threadIdx.x < 64) {  // wave 0: publish, look back, publish
     const int lane = threadIdx.x;
     unsigned long long excl = 0;
     if (id > 0) {
-      if (lane == 0) atomicExch(&state[3 + id], kStAggregate | my_units);
+      if (lane == 0) __hip_atomic_store(&state[3 + id], kStAggregate | my_units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       long long p = (long long)id - 1;  // first predecessor this round looks at
       while (true) {
         const long long mine = p - lane;
         unsigned long long st = kStInclusive;  // lanes before chunk 0 terminate the walk
-        if (mine >= 0) st = atomicAdd(&state[3 + mine], 0ull);
+        if (mine >= 0) st = __hip_atomic_load(&state[3 + mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long ready = __ballot((st >> 62) != 0);
         const unsigned long long incl = __ballot((st >> 62) == 2);
         // usable prefix of lanes: all ready up to (and including) the first inclusive one
@@ -439,7 +474,7 @@ k_encode_chain(const SYM *__restrict__ q, size_t n, int chunk, int dict, size_t 
       }
     }
     if (lane == 0) {
-      atomicExch(&state[3 + id], kStInclusive | (excl + my_units));
+      __hip_atomic_store(&state[3 + id], kStInclusive | (excl + my_units), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       bits[id] = chunk_bits;
       entry[id] = excl;
       if (id == nchunk - 1) state[1] = excl + my_units;
@@ -451,42 +486,67 @@ k_encode_chain(const SYM *__restrict__ q, size_t n, int chunk, int dict, size_t 
   const unsigned long long e0 = sh_entry;
   if (e0 + my_units > cap_units) return;
   unsigned long long *dst = out + e0;
-  for (size_t i = threadIdx.x; i < my_units; i += kEncThreads) dst[i] = 0;
-  __syncthreads();
-  unsigned long long pos = sc[threadIdx.x] - s;
-  if (lo >= hi || s == 0) return;
-  size_t w = pos / kUnitBits;
-  int room = kUnitBits - (int)(pos % kUnitBits);
-  unsigned long long acc = 0;
-  bool first_unit = true;
-  auto flush = [&](bool last) {
-    if (first_unit || last) atomicOr(&dst[w], acc);
-    else dst[w] = acc;
-    first_unit = false;
-  };
-  for (size_t i = lo; i < hi; i++) {
-    const uint64_t c = scode[ssym[i]];
-    const int len = (int)(c >> kMaxCodeBits);
-    const unsigned long long val = c & (((uint64_t)1 << kMaxCodeBits) - 1);
-    if (len <= room) {
-      room -= len;
-      acc |= val << room;
-      if (room == 0) {
+  const unsigned pos = sc[threadIdx.x] - s;  // first bit of this thread's run
+  const bool active = lo < hi && s != 0;
+  // pack the runs into `buf` (zeroed): whole units are stored, the first and the last unit of a
+  // run are shared with the neighbours and OR-ed in
+  auto pack = [&](unsigned long long *buf) {
+    size_t w = pos / kUnitBits;
+    int room = kUnitBits - (int)(pos % kUnitBits);
+    unsigned long long acc = 0;
+    bool first_unit = true;
+    auto flush = [&](bool last) {
+      if (first_unit || last) atomicOr(&buf[w], acc);
+      else buf[w] = acc;
+      first_unit = false;
+    };
+    auto put = [&](CODE c) {
+      const int len = (int)(c >> SH);
+      const unsigned long long val = (unsigned long long)(c & (((CODE)1 << SH) - 1));
+      if (len <= room) {
+        room -= len;
+        acc |= val << room;
+        if (room == 0) {
+          flush(false);
+          w++;
+          acc = 0;
+          room = kUnitBits;
+        }
+      } else {
+        const int rest = len - room;
+        acc |= val >> rest;
         flush(false);
         w++;
-        acc = 0;
-        room = kUnitBits;
+        room = kUnitBits - rest;
+        acc = val << room;
       }
+    };
+    if (in_regs) {
+#pragma unroll
+      for (int k = 0; k < RR; k++) put(cc[k]);
     } else {
-      const int rest = len - room;
-      acc |= val >> rest;
-      flush(false);
-      w++;
-      room = kUnitBits - rest;
-      acc = val << room;
+      for (size_t i = lo; i < hi; i++) put(scode[ssym[i]]);
     }
+    if (room != kUnitBits) flush(true);
+  };
+  // With the code entries in registers the symbol area of the LDS is free: the chunk's stream is
+  // assembled there (LDS atomics, no zeroing of global memory) and written out in whole lines --
+  // packing straight into global memory stores 8 bytes per lane from a few lanes at a time
+  // (0.48 of 0.65 ms at 512^3). Streams longer than that area (more than 16 bits per symbol on
+  // average) take the direct path.
+  const bool via_lds = in_regs && my_units * 8 <= (unsigned long long)chunk * 2;
+  if (via_lds) {
+    unsigned long long *obuf = reinterpret_cast<unsigned long long *>(ssym);
+    for (size_t i = threadIdx.x; i < my_units; i += kEncThreads) obuf[i] = 0;
+    __syncthreads();
+    if (active) pack(obuf);
+    __syncthreads();
+    for (size_t i = threadIdx.x; i < my_units; i += kEncThreads) dst[i] = obuf[i];
+  } else {
+    for (size_t i = threadIdx.x; i < my_units; i += kEncThreads) dst[i] = 0;
+    __syncthreads();
+    if (active) pack(dst);
   }
-  if (room != kUnitBits) flush(true);
 }
 
 // Canonical decoding, one lane per chunk (the chunks are the only entry points of the stream);
