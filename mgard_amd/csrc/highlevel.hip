@@ -428,7 +428,10 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
   };
   head.clear();
   if (!need(0, 24)) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
-  HL_TRY(fetch(24));
+  // (a record in device memory: one copy that covers the whole leading part for the default
+  // parameters instead of one per field -- every synchronous copy costs tens of microseconds)
+  if (on_dev) HL_TRY(fetch(std::min<size_t>(psize, 24 + 16 * ((n - 1) / 20480 + 1) + 16 + 8 * 128 + 8 * 8192 + 16)));
+  else HL_TRY(fetch(24));
   uint64_t primary = 0, huffmeta_size = 0;
   int32_t dict = 0, chunk = 0;
   std::memcpy(&primary, head.data(), 8);
@@ -451,8 +454,14 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
   const size_t o_oc = L.ddata + 8 * units;
   if (!need(o_oc, 8)) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
   uint64_t ocount = 0;
-  if (on_dev) HL_HIP(hipMemcpy(&ocount, p + o_oc, 8, hipMemcpyDeviceToHost));
-  else std::memcpy(&ocount, p + o_oc, 8);
+  if (on_dev) {
+    // the record ends with the two outlier arrays: their length follows from the record size
+    // (saves a synchronous 8-byte copy from the device)
+    if ((psize - o_oc - 8) % 16 != 0) return hl_fail(MGH_ERR_FORMAT, "Huffman record: outlier lists");
+    ocount = (psize - o_oc - 8) / 16;
+  } else {
+    std::memcpy(&ocount, p + o_oc, 8);
+  }
   if (ocount > (psize - o_oc - 8) / 16) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
   const size_t o_oidx = o_oc + 8, o_oval = o_oidx + 8 * ocount;
   // the chunk entries must stay inside the unit array (they index it in the decoder)
