@@ -254,6 +254,35 @@ def test_nonuniform_coordinates_roundtrip():
     h.close()
 
 
+@pytest.mark.parametrize("dict_size,block", [(4096, 1000), (16384, 3333), (8192, 70000), (2048, 2000)])
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_huffman_parameters_roundtrip(dict_size, block, where):
+    """Chunk sizes that are not multiples of 8 / below the parallel decoder's limit / beyond the
+    encoder's LDS budget (two-pass fallback), small and large dictionaries; the record must hold
+    exactly the low-level integers."""
+    torch, mg, hl = _mods()
+    shape = (65, 97, 130)
+    u = smooth_field(shape, np.float32)
+    x = u if where == "host" else torch.from_numpy(u).cuda()
+    cfg = hl.Config(huff_dict_size=dict_size, huff_block_size=block)
+    buf = hl.compress(x, 1e-2, np.inf, mg.REL, config=cfg)
+    raw = buf if where == "host" else buf.cpu().numpy()
+    m = hl.metadata_parse(bytes(raw[:4096]))
+    recs = pl.split_container(raw, m["metadata_size"])
+    assert len(recs) == 1 and len(recs[0]) < u.nbytes        # (not the raw fallback)
+    r = pl.parse_huffman_record(recs[0])
+    assert r["dict_size"] == dict_size and r["chunk_size"] == block
+    h = mg.Hierarchy(shape, np.float32)
+    q, oi, ov, cnt, _ = h.decompose_quantize(torch.from_numpy(u).cuda(), mg.REL, 1e-2, np.inf, dict_size=dict_size)
+    h.close()
+    assert np.array_equal(pl.decode_huffman_record(r), q.cpu().numpy().ravel())
+    assert sorted(r["outlier_idx"].tolist()) == sorted(oi.cpu().numpy().tolist())
+    v = hl.decompress(buf)
+    v = v if where == "host" else v.cpu().numpy()
+    assert np.max(np.abs(v - u)) <= 1e-2 * np.max(np.abs(u))
+    hl.release_cache()
+
+
 def test_incompressible_subdomain_is_stored_raw():
     torch, mg, hl = _mods()
     rng = np.random.default_rng(1)
