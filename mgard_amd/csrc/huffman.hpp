@@ -15,14 +15,19 @@
 // recognised by v >= first[l], its symbol is keys[entry[l] + v - first[l]], unused lengths carry
 // first = 2^64-1 (GenerateCW.hpp:77-83). The stock decoder therefore reads these payloads.
 //
-// How it is built here (not a port of the reference's kernels): histogram with LDS privatised
-// bins; code lengths on the host (8192 symbols: microseconds) with the classic two-queue
-// construction, codes assigned longest-first so that first[] has the property above; encoding
-// in two passes over the symbols -- per-chunk bit totals, a scan for the unit offsets, then
-// every workgroup writes its chunk straight into its final (condensed) position, each thread
-// packing a run of symbols in registers and touching shared units with atomicOr only at the
-// two ends of its run. Decoding is one lane per chunk, as the format dictates (chunks are the
-// only entry points into the bit stream).
+// How it is built here (not a port of the reference's kernels):
+//  * histogram with LDS-privatised bins (k_histogram);
+//  * code lengths on the host (build_codebook: two-queue Huffman over the used symbols, codes
+//    assigned longest-first so that first[] has the property above; ~0.1 ms);
+//  * encoding in ONE pass over the symbols (k_encode_chain): a workgroup per chunk stages symbols
+//    and code table in LDS, counts its bits, gets its unit offset by a decoupled look-back over
+//    one status word per chunk, assembles the chunk's stream in LDS and writes it out in whole
+//    lines at its final (condensed) position. k_chunk_bits + k_unit_offsets + k_encode are the
+//    two-pass fallback for parameters whose tables do not fit in LDS;
+//  * decoding parallel INSIDE the chunks although the format has entry points per chunk only
+//    (k_decode_ring: speculative subsequences that re-synchronise, two-level table built by
+//    build_decode_table). k_decode_par (the same without rings / second-level table) and
+//    k_decode (one lane per chunk; used below 1024 symbols per chunk) remain as cross-checks.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -291,72 +296,8 @@ k_encode(const int64_t *__restrict__ q, size_t n, int chunk, const uint64_t *__r
 
 constexpr int kEncThreads = 512;  // threads of an encoder workgroup (two workgroups per CU with 32-bit code entries)
 
-// Same as k_encode with the chunk's symbols (16 bit) and the code table staged in LDS: the
-// symbols are read from HBM once, coalesced, instead of every lane walking its own run, and the
-// per-symbol table lookups never leave the CU. Dynamic LDS: 8 * dict + 2 * chunk bytes.
-__global__ void __launch_bounds__(kEncThreads)
-k_encode_lds(const int64_t *__restrict__ q, size_t n, int chunk, int dict,
-             const uint64_t *__restrict__ code, const unsigned long long *__restrict__ entry,
-             unsigned long long *__restrict__ out) {
-  extern __shared__ unsigned long long enc_lds[];
-  unsigned long long *scode = enc_lds;
-  unsigned short *ssym = reinterpret_cast<unsigned short *>(enc_lds + dict);
-  const size_t base = (size_t)blockIdx.x * chunk;
-  const size_t cnt = min((size_t)chunk, n - base);
-  for (int i = threadIdx.x; i < dict; i += kEncThreads) scode[i] = code[i];
-  for (size_t i = threadIdx.x; i < cnt; i += kEncThreads) ssym[i] = (unsigned short)q[base + i];
-  __syncthreads();
-  const size_t run = (cnt + kEncThreads - 1) / kEncThreads;
-  const size_t lo = min(cnt, threadIdx.x * run), hi = min(cnt, lo + run);
-  unsigned long long s = 0;
-  for (size_t i = lo; i < hi; i++) s += scode[ssym[i]] >> kMaxCodeBits;
-  __shared__ unsigned long long sc[kEncThreads];
-  sc[threadIdx.x] = s;
-  __syncthreads();
-  for (int off = 1; off < kEncThreads; off <<= 1) {
-    const unsigned long long v = threadIdx.x >= (unsigned)off ? sc[threadIdx.x - off] : 0;
-    __syncthreads();
-    sc[threadIdx.x] += v;
-    __syncthreads();
-  }
-  unsigned long long pos = sc[threadIdx.x] - s;
-  if (lo >= hi || s == 0) return;
-  unsigned long long *dst = out + entry[blockIdx.x];
-  size_t w = pos / kUnitBits;
-  int room = kUnitBits - (int)(pos % kUnitBits);
-  unsigned long long acc = 0;
-  bool first_unit = true;
-  auto flush = [&](bool last) {
-    if (first_unit || last) atomicOr(&dst[w], acc);
-    else dst[w] = acc;
-    first_unit = false;
-  };
-  for (size_t i = lo; i < hi; i++) {
-    const uint64_t c = scode[ssym[i]];
-    const int len = (int)(c >> kMaxCodeBits);
-    const unsigned long long val = c & (((uint64_t)1 << kMaxCodeBits) - 1);
-    if (len <= room) {
-      room -= len;
-      acc |= val << room;
-      if (room == 0) {
-        flush(false);
-        w++;
-        acc = 0;
-        room = kUnitBits;
-      }
-    } else {
-      const int rest = len - room;
-      acc |= val >> rest;
-      flush(false);
-      w++;
-      room = kUnitBits - rest;
-      acc = val << room;
-    }
-  }
-  if (room != kUnitBits) flush(true);
-}
 
-// One pass over the symbols instead of two (k_chunk_bits + k_encode_lds): the unit offset of a
+// One pass over the symbols instead of two (k_chunk_bits + k_encode): the unit offset of a
 // chunk is the sum of the unit counts of all chunks before it, which a workgroup obtains while
 // its symbols sit in LDS by a decoupled look-back over a status word per chunk (the single-pass
 // prefix scan of Merrill & Garland): chunks are handed out in ticket order, so every
