@@ -503,7 +503,15 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
   }
   static const bool serial_decode = std::getenv("MGH_HUFF_SERIAL_DECODE") != nullptr;  // cross-check
   static const bool par_decode = std::getenv("MGH_HUFF_PAR_DECODE") != nullptr;           // cross-check
-  if (!serial_decode && !par_decode && (size_t)chunk >= 1024 && (size_t)chunk <= (1u << 24) && dict <= 65536) {
+  int book_max_len = 0;  // longest code of the decodebook (unused lengths carry first = 2^64-1)
+  {
+    const uint64_t *first = reinterpret_cast<const uint64_t *>(head.data() + L.decodebook);
+    for (int l = 1; l < 64; l++)
+      if (first[l] != ~(uint64_t)0) book_max_len = l;
+  }
+  // (the ring decoder keeps more than 32 bits in its bit buffer: codes of up to 32 bits)
+  if (!serial_decode && !par_decode && (size_t)chunk >= 1024 && (size_t)chunk <= (1u << 24) && dict <= 65536 &&
+      book_max_len <= 32) {
     // parallel decoding inside the chunks: two-level table from the decodebook (host, microseconds),
     // code units through per-lane LDS rings. 16 waves per workgroup when the table leaves room.
     const uint64_t *book = reinterpret_cast<const uint64_t *>(head.data() + L.decodebook);

@@ -975,14 +975,31 @@ k_decode_ring(const unsigned long long *__restrict__ units, const unsigned long 
       pos = rec_end;
       live = false;
     }
-    unsigned cw = pos >> 6, hi = cw;
+    // Bit buffer: `win` holds the next `avail` bits of the stream left-aligned (the rest zero);
+    // it is topped up 32 bits at a time from the ring (word w = half of unit w / 2, the high half
+    // first), so that more than 32 bits are there whenever a code is looked up -- the host sends
+    // streams with longer codes to k_decode_par. `wnext` = next word to take.
+    const unsigned cw0 = pos >> 6;
+    unsigned hi = cw0;
 #pragma unroll
     for (int r = 0; r < kRingUnits; r++)  // initial fill of the ring
-      ring[((cw + r) % kRingUnits) * 64 + lane] = src[min(cw + r, nun)];
-    hi = cw + kRingUnits;
-    unsigned long long cur = ring[(cw % kRingUnits) * 64 + lane];
-    unsigned long long nxt = ring[((cw + 1) % kRingUnits) * 64 + lane];
-    bool have_nxt = true;
+      ring[((cw0 + r) % kRingUnits) * 64 + lane] = src[min(cw0 + r, nun)];
+    hi = cw0 + kRingUnits;
+    unsigned long long win;
+    unsigned avail, wnext;
+    {
+      const unsigned long long u0 = ring[(cw0 % kRingUnits) * 64 + lane];
+      const unsigned long long u1 = ring[((cw0 + 1) % kRingUnits) * 64 + lane];
+      const int sh = (int)(pos & 63);
+      win = sh ? (u0 << sh) | (u1 >> (64 - sh)) : u0;  // 64 valid bits from pos on
+      avail = 64;
+      wnext = ((pos + 64) >> 5);                        // first word not (completely) in win ...
+      // ... pos + 64 is in the middle of that word unless pos is a multiple of 32: keep only the
+      // whole words, drop the partial one so that refills stay word-aligned
+      const unsigned part = (pos + 64) & 31;
+      avail -= part;
+      win = part ? (win >> part) << part : win;
+    }
     unsigned long long pf[kRingFetch];
     bool pending = false;
     int jrec = 0;           // MODE 1: next remembered boundary to compare with
@@ -1000,13 +1017,14 @@ k_decode_ring(const unsigned long long *__restrict__ units, const unsigned long 
           pending = true;
         }
         for (int k = 0; k < kRingStep; k++) {
-          if (live && !have_nxt && cw + 1 < hi) {
-            nxt = ring[((cw + 1) % kRingUnits) * 64 + lane];
-            have_nxt = true;
+          if (live && avail <= 32 && (wnext >> 1) < hi) {  // top up (a lane out of units pauses)
+            const unsigned long long u = ring[((wnext >> 1) % kRingUnits) * 64 + lane];
+            const unsigned wd = (wnext & 1) ? (unsigned)u : (unsigned)(u >> 32);
+            win |= (unsigned long long)wd << (32 - avail);
+            avail += 32;
+            wnext++;
           }
-          if (live && have_nxt) {
-            const int sh = (int)(pos & 63);
-            const unsigned long long win = sh ? (cur << sh) | (nxt >> (64 - sh)) : cur;
+          if (live && avail > 32) {
             unsigned e = table[win >> (64 - tb)];
             if (e & 0x80000000u) {  // second level: the next sub_bits bits
               const int sb = (int)((e >> 24) & 0x7f);
@@ -1034,15 +1052,11 @@ k_decode_ring(const unsigned long long *__restrict__ units, const unsigned long 
               if (MODE == 2) stage[lane * kRingBatch + got] = (unsigned short)sym;
               got++;
               pos += l;
+              win <<= l;
+              avail -= l;
               cnt++;
               if (MODE == 0 && cnt % kRecStride == 0 && cnt / kRecStride <= (unsigned)kRingBatch)
                 rec[cnt / kRecStride - 1] = (unsigned short)min(pos - start, 0xfffeu);
-              if ((pos >> 6) != cw) {
-                cw++;
-                cur = nxt;
-                have_nxt = cw + 1 < hi;
-                if (have_nxt) nxt = ring[((cw + 1) % kRingUnits) * 64 + lane];
-              }
               live = MODE == 2 ? (pos < lim && cnt < want) : pos < lim;
               if (MODE == 1 && live && pos >= rec_start) {
                 const unsigned rel = pos - rec_start;
@@ -1065,7 +1079,7 @@ k_decode_ring(const unsigned long long *__restrict__ units, const unsigned long 
           }
         }
         // refill point: commit the units requested before these symbols if the ring has room
-        if (pending && hi + kRingFetch <= cw + kRingUnits) {
+        if (pending && hi + kRingFetch <= (wnext >> 1) + kRingUnits) {
 #pragma unroll
           for (int j = 0; j < kRingFetch; j++) ring[((hi + j) % kRingUnits) * 64 + lane] = pf[j];
           hi += kRingFetch;
