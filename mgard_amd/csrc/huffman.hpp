@@ -625,9 +625,6 @@ k_decode(const unsigned long long *__restrict__ units, const unsigned long long 
 //   3. symbol counts are prefix-summed across the wave and every lane decodes its subsequence
 //      once more, now writing the symbols to their final positions.
 // Same tables and semantics as k_decode. Dynamic LDS as for k_decode without the unit ring.
-#ifndef MGH_DEC_ROUNDS
-#define MGH_DEC_ROUNDS 64
-#endif
 constexpr int kParWaves = 16;
 constexpr int kParBatch = 32;  // symbols a lane decodes between two write-outs
 
@@ -733,7 +730,7 @@ k_decode_par(const unsigned long long *__restrict__ units, const unsigned long l
 
   unsigned long long s = min((unsigned long long)lane * B, total), cnt = 0;
   unsigned long long e = run(s, &cnt, nullptr, 0);
-  for (int it = 0; it < MGH_DEC_ROUNDS; it++) {
+  for (int it = 0; it < 64; it++) {
     unsigned long long pe = __shfl_up(e, 1, 64);
     if (lane == 0) pe = 0;
     const bool changed = s != pe;
@@ -889,10 +886,7 @@ inline std::vector<uint32_t> build_decode_table(const uint64_t *first, const uin
 //   (write-out staging); blockDim.x = 64 * waves.
 constexpr int kRingUnits = 8;   // units per lane in the ring
 constexpr int kRingFetch = 4;   // units per lane per refill
-#ifndef MGH_RING_STEP
-#define MGH_RING_STEP 8
-#endif
-constexpr int kRingStep = MGH_RING_STEP;    // symbols between two refills
+constexpr int kRingStep = 8;    // symbols between two refills
 constexpr int kRingBatch = 16;  // symbols a lane stages between two write-outs (multiple of kRingStep)
 constexpr int kRecStride = 8;   // every kRecStride-th code boundary of the first pass is remembered
 
