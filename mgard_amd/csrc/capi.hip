@@ -1033,8 +1033,13 @@ int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> 
     A.fI = (l == L) ? ds->full_I : (size_t)b.n[1] * b.n[2];
     const dim3 blk(64, 4, 1);
     TRY(launch(h, "restore_q", st, [&] {
-      // one 64-lane wave per fine row, 4 rows per block
-      k_level_restore_q<T, QT><<<dim3(1, (b.n[1] + 3) / 4, b.n[0]), blk, 0, st>>>(A);
+      // one 64-lane wave per PAIR of fine rows, 4 pairs per block (MGH_RESTORE_ROWS=1: one row
+      // per wave, the previous kernel: cross-check)
+      static const bool single = std::getenv("MGH_RESTORE_ROWS") != nullptr;
+      if (single)
+        k_level_restore_q<T, QT><<<dim3(1, (b.n[1] + 3) / 4, b.n[0]), blk, 0, st>>>(A);
+      else
+        k_level_restore2_q<T, QT><<<dim3(1, ((b.n[1] + 1) / 2 + 3) / 4, b.n[0]), blk, 0, st>>>(A);
     }));
   }
   return MGH_SUCCESS;
