@@ -992,7 +992,39 @@ int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> 
                      hipStream_t st) {
   auto *ds = DS<T>(h);
   const int L = h->L;
-  {
+  // levels 1 .. l_head run inside ONE single-workgroup kernel (their working set fits in LDS);
+  // MGH_NO_RECOMPOSE_HEAD=1: every level with its own launches (cross-check)
+  static const bool no_head = std::getenv("MGH_NO_RECOMPOSE_HEAD") != nullptr;
+  int l_head = 0;
+  if (!no_head)
+    for (int l = 1; l <= std::min(L, kTailMaxLevels); l++)
+      if (head_lds_elems(ds->lt[l].box) * sizeof(T) <= 150 * 1024) l_head = l;
+      else break;
+  if (l_head >= 1) {
+    HeadArgs<T> HA{};
+    HA.nlevels = l_head;
+    for (int l = 1; l <= l_head; l++) {
+      HeadLevel<T> &hl = HA.lv[l - 1];
+      const LevelTables<T> &t = ds->lt[l];
+      hl.b = t.box;
+      for (int k = 0; k < 3; k++) {
+        hl.ratio[k] = t.ratio[k];
+        hl.mass[k] = t.mass[k];
+        hl.thomas[k] = t.thomas[k];
+      }
+      hl.qv = level_qv[l];
+    }
+    HA.qv0 = level_qv[0];
+    HA.in = A;
+    const Box3 &bl = ds->lt[l_head].box;
+    HA.out = (l_head == L) ? data : ds->nodal[l_head];
+    HA.oJ = (l_head == L) ? ds->full_J : bl.n[2];
+    HA.oI = (l_head == L) ? ds->full_I : (size_t)bl.n[1] * bl.n[2];
+    const size_t lds = head_lds_elems(bl) * sizeof(T);
+    static bool once = false;
+    if (!once) { TRY(allow_big_lds(k_recompose_head<T, QT>)); once = true; }
+    TRY(launch(h, "recompose_head", st, [&] { k_recompose_head<T, QT><<<1, 1024, lds, st>>>(HA); }));
+  } else {
     const Box3 &b = ds->lt[1].box;
     A.qv = level_qv[0];
     TRY(launch(h, "head_in", st, [&] {
@@ -1000,7 +1032,7 @@ int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> 
     }));
   }
   constexpr int TC = 8, TF = 32;
-  for (int l = 1; l <= L; l++) {
+  for (int l = l_head + 1; l <= L; l++) {
     const LevelTables<T> &t = ds->lt[l];
     const Box3 &b = t.box;
     for (int k = 0; k < 3; k++) {

@@ -13,6 +13,7 @@
 
 #include "kernels_fused.hpp"
 #include "kernels_ipk.hpp"
+#include "kernels_recompose.hpp"
 #include "kernels_v1.hpp"
 
 namespace mgh {
@@ -171,6 +172,133 @@ k_tail(TailArgs<T> A) {
         const bool on[1] = {live};
         emit_quantized<T, 1>(O, vv, ll, on);
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// The mirror for decompression: the small levels of the recomposition (coarsest first) in ONE
+// launch -- level-0 nodal values out of the head of the coefficient array, then per level the
+// dequantized coefficient field, the three mass/restriction sweeps, the three Thomas solves, the
+// subtraction of the correction from the coarse nodes and the node restore (kernels_v1.hpp
+// element code; k_level_loadvec_q / k_level_restore_q compute the same values). Without it
+// every one of these levels costs four dependent launches of a few microseconds each.
+// ---------------------------------------------------------------------------------------
+template <typename T> struct HeadLevel {
+  Box3 b;
+  const T *ratio[3];
+  const T *mass[3];
+  const T *thomas[3];
+  T qv;  // dequantize factor of the level
+};
+
+template <typename T> struct HeadArgs {
+  int nlevels;  // lv[0] is level 1 (the coarsest), lv[nlevels - 1] the finest handled here
+  HeadLevel<T> lv[kTailMaxLevels];
+  T qv0;        // dequantize factor of level 0
+  RecomposeArgs<T> in;  // coefficient source (q / coef / q16, strides dI dJ, half, outlier table)
+  T *out;       // nodal values of the finest level handled, strides (oI, oJ, 1)
+  size_t oI, oJ;
+};
+
+inline size_t head_lds_elems(const Box3 &b) {
+  const size_t nf = (size_t)b.n[0] * b.n[1] * b.n[2];
+  const size_t mc = (size_t)b.m[0] * b.m[1] * b.m[2];
+  return 3 * nf + (size_t)b.n[0] * b.n[1] * b.m[2] + (size_t)b.n[0] * b.m[1] * b.m[2] + mc;
+}
+
+template <typename T, typename QT>
+__global__ void __launch_bounds__(1024)
+k_recompose_head(HeadArgs<T> A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const uint32_t tid = threadIdx.x, NT = blockDim.x;
+  RecomposeArgs<T> Q = A.in;
+  T *X, *Y, *C, *T1, *T2, *T3;
+  {
+    const Box3 &b = A.lv[A.nlevels - 1].b;  // the largest level: deeper ones reuse its regions
+    const size_t nf = (size_t)b.n[0] * b.n[1] * b.n[2];
+    T *base = reinterpret_cast<T *>(smem_raw);
+    X = base;
+    Y = X + nf;
+    C = Y + nf;
+    T1 = C + nf;
+    T2 = T1 + (size_t)b.n[0] * b.n[1] * b.m[2];
+    T3 = T2 + (size_t)b.n[0] * b.m[1] * b.m[2];
+  }
+  {  // level-0 nodal values
+    const Box3 &b = A.lv[0].b;
+    const uint32_t m0 = b.m[0], m1 = b.m[1], m2 = b.m[2];
+    Q.qv = A.qv0;
+    for (uint32_t e = tid; e < m0 * m1 * m2; e += NT) {
+      const uint32_t k = e % m2, j = (e / m2) % m1, i = e / (m2 * m1);
+      const size_t lin = (size_t)i * Q.dI + (size_t)j * Q.dJ + k;
+      X[e] = qdecode(Q, qload<T>(Q, qsrc<T>(Q, QT()) + lin), lin);
+    }
+  }
+  __syncthreads();
+  for (int li = 0; li < A.nlevels; li++) {
+    const HeadLevel<T> &L = A.lv[li];
+    const Box3 b = L.b;
+    const uint32_t n0 = b.n[0], n1 = b.n[1], n2 = b.n[2];
+    const uint32_t m0 = b.m[0], m1 = b.m[1], m2 = b.m[2];
+    const uint32_t nf = n0 * n1 * n2;
+    Q.qv = L.qv;
+    // ---- dequantized coefficient field in the reordered layout of the level's box (the coarse
+    // corner is never read as a coefficient: the f-sweep takes it as zero, the restore skips it)
+    for (uint32_t e = tid; e < nf; e += NT) {
+      const uint32_t k = e % n2, j = (e / n2) % n1, i = e / (n2 * n1);
+      const bool corner = i < m0 && j < m1 && k < m2;
+      const size_t lin = (size_t)i * Q.dI + (size_t)j * Q.dJ + k;
+      C[e] = corner ? (T)0 : qdecode(Q, qload<T>(Q, qsrc<T>(Q, QT()) + lin), lin);
+    }
+    __syncthreads();
+    // ---- mass/restriction sweeps: f, c, r ----
+    for (uint32_t e = tid; e < n0 * n1 * m2; e += NT) {
+      const uint32_t k = e % m2, j = (e / m2) % n1, i = e / (m2 * n1);
+      T1[e] = lpk_elem<T, 2>(n2, m2, (const T *)C, (size_t)n1 * n2, (size_t)n2, L.mass[2], m0, m1, i, j, k);
+    }
+    __syncthreads();
+    for (uint32_t e = tid; e < n0 * m1 * m2; e += NT) {
+      const uint32_t k = e % m2, j = (e / m2) % m1, i = e / (m2 * m1);
+      T2[e] = lpk_elem<T, 1>(n1, m1, (const T *)T1, (size_t)n1 * m2, (size_t)m2, L.mass[1], 0, 0, i, j, k);
+    }
+    __syncthreads();
+    const uint32_t mtot = m0 * m1 * m2;
+    for (uint32_t e = tid; e < mtot; e += NT) {
+      const uint32_t k = e % m2, j = (e / m2) % m1, i = e / (m2 * m1);
+      T3[e] = lpk_elem<T, 0>(n0, m0, (const T *)T2, (size_t)m1 * m2, (size_t)m2, L.mass[0], 0, 0, i, j, k);
+    }
+    __syncthreads();
+    // ---- Thomas solves: f, c, r ----
+    for (uint32_t p = tid; p < m0 * m1; p += NT) thomas_lds<T, false>(T3 + (size_t)p * m2, 1, m2, L.thomas[2]);
+    __syncthreads();
+    for (uint32_t p = tid; p < m0 * m2; p += NT)
+      thomas_lds<T, false>(T3 + (size_t)(p / m2) * m1 * m2 + (p % m2), m2, m1, L.thomas[1]);
+    __syncthreads();
+    for (uint32_t p = tid; p < m1 * m2; p += NT) thomas_lds<T, false>(T3 + p, m1 * m2, m0, L.thomas[0]);
+    __syncthreads();
+    // ---- subtract the correction from the coarse nodes (SubtractND) ----
+    for (uint32_t e = tid; e < mtot; e += NT) X[e] = X[e] - T3[e];
+    __syncthreads();
+    // ---- node restore: the fine nodal values of this level = the coarse nodes of the next ----
+    for (uint32_t e = tid; e < nf; e += NT) {
+      const uint32_t k = e % n2, j = (e / n2) % n1, i = e / (n2 * n1);
+      uint32_t rp, cp, fp;
+      const T v = gpk_rev_elem(b, (const T *)X, (const T *)C, (size_t)n1 * n2, (size_t)n2, L.ratio[0],
+                               L.ratio[1], L.ratio[2], i, j, k, rp, cp, fp);
+      Y[((size_t)rp * n1 + cp) * n2 + fp] = v;
+    }
+    __syncthreads();
+    T *tmp = X;
+    X = Y;
+    Y = tmp;
+  }
+  {
+    const Box3 &b = A.lv[A.nlevels - 1].b;
+    const uint32_t n0 = b.n[0], n1 = b.n[1], n2 = b.n[2];
+    for (uint32_t e = tid; e < n0 * n1 * n2; e += NT) {
+      const uint32_t k = e % n2, j = (e / n2) % n1, i = e / (n2 * n1);
+      A.out[i * A.oI + j * A.oJ + k] = X[e];
     }
   }
 }

@@ -102,28 +102,23 @@ k_gpk_reo(Box3 b, const T *__restrict__ src, size_t sI, size_t sJ, T *__restrict
 // GpkRev3D (GridProcessingKernel3D.hpp:1231-2352): natural fine box out of
 // (coarse compact, coefficients in `coef` reordered layout). One thread per
 // fine node; odd nodes add the interpolant of their coarse neighbours.
+// value of the fine node that reordered position (i, j, k) stands for, and its natural position
 template <typename T>
-__global__ void __launch_bounds__(256)
-k_gpk_rev(Box3 b, const T *__restrict__ coarse, const T *__restrict__ coef, size_t cI, size_t cJ,
-          T *__restrict__ out, size_t oI, size_t oJ, const T *__restrict__ ratio_r,
-          const T *__restrict__ ratio_c, const T *__restrict__ ratio_f) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t j = blockIdx.y * blockDim.y + threadIdx.y;
-  const uint32_t i = blockIdx.z;
-  if (k >= b.n[2] || j >= b.n[1] || i >= b.n[0]) return;
+__device__ __forceinline__ T gpk_rev_elem(const Box3 &b, const T *__restrict__ coarse,
+                                          const T *__restrict__ coef, size_t cI, size_t cJ,
+                                          const T *__restrict__ ratio_r, const T *__restrict__ ratio_c,
+                                          const T *__restrict__ ratio_f, uint32_t i, uint32_t j,
+                                          uint32_t k, uint32_t &rp, uint32_t &cp, uint32_t &fp) {
   bool ro, co, fo;
-  const uint32_t rp = fine_pos(i, b.n[0], b.m[0], ro);
-  const uint32_t cp = fine_pos(j, b.n[1], b.m[1], co);
-  const uint32_t fp = fine_pos(k, b.n[2], b.m[2], fo);
+  rp = fine_pos(i, b.n[0], b.m[0], ro);
+  cp = fine_pos(j, b.n[1], b.m[1], co);
+  fp = fine_pos(k, b.n[2], b.m[2], fo);
   const size_t mJ = b.m[2], mI = (size_t)b.m[1] * b.m[2];
   // coarse index of the even fine position p (or of the padded last node)
   auto cidx = [](uint32_t p, uint32_t n, uint32_t m) -> uint32_t {
     return (p == n - 1) ? m - 1 : p / 2;
   };
-  if (!ro && !co && !fo) {
-    out[rp * oI + cp * oJ + fp] = coarse[i * mI + j * mJ + k];
-    return;
-  }
+  if (!ro && !co && !fo) return coarse[i * mI + j * mJ + k];
   const uint32_t r0 = cidx(ro ? rp - 1 : rp, b.n[0], b.m[0]), r1 = cidx(rp + 1, b.n[0], b.m[0]);
   const uint32_t c0 = cidx(co ? cp - 1 : cp, b.n[1], b.m[1]), c1 = cidx(cp + 1, b.n[1], b.m[1]);
   const uint32_t f0 = cidx(fo ? fp - 1 : fp, b.n[2], b.m[2]), f1 = cidx(fp + 1, b.n[2], b.m[2]);
@@ -144,6 +139,20 @@ k_gpk_rev(Box3 b, const T *__restrict__ coarse, const T *__restrict__ coef, size
   }
   T res = coef[i * cI + j * cJ + k];
   res += ro ? lerp_ref(hr[0], hr[1], ratio_r[rp - 1]) : hr[0];
+  return res;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_gpk_rev(Box3 b, const T *__restrict__ coarse, const T *__restrict__ coef, size_t cI, size_t cJ,
+          T *__restrict__ out, size_t oI, size_t oJ, const T *__restrict__ ratio_r,
+          const T *__restrict__ ratio_c, const T *__restrict__ ratio_f) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t j = blockIdx.y * blockDim.y + threadIdx.y;
+  const uint32_t i = blockIdx.z;
+  if (k >= b.n[2] || j >= b.n[1] || i >= b.n[0]) return;
+  uint32_t rp, cp, fp;
+  const T res = gpk_rev_elem(b, coarse, coef, cI, cJ, ratio_r, ratio_c, ratio_f, i, j, k, rp, cp, fp);
   out[rp * oI + cp * oJ + fp] = res;
 }
 
