@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <memory>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -190,6 +191,41 @@ namespace {
 // The single-pass encoder stages code table and symbols of a chunk in LDS.
 inline bool lossless_sym16_ok(uint64_t dict, uint64_t chunk) {
   return dict <= 65536 && dict * 8 + chunk * 2 <= 140 * 1024;
+}
+
+// Host copy of the first bytes of the device-resident stream a decompression call is reading:
+// header, record size and the leading part of the first record come out of ONE device-to-host
+// copy instead of four synchronous ones (tens of microseconds each). Valid only inside
+// mgh_decompress (HostPrefix guard).
+struct HostPrefixState {
+  const uint8_t *base = nullptr;
+  std::vector<uint8_t> bytes;
+};
+inline HostPrefixState &host_prefix() {
+  static thread_local HostPrefixState s;
+  return s;
+}
+struct HostPrefix {
+  HostPrefix(const void *dev, size_t size) {
+    HostPrefixState &s = host_prefix();
+    s.base = nullptr;
+    const size_t want = std::min<size_t>(size, 320 * 1024);
+    s.bytes.resize(want);
+    if (hipMemcpy(s.bytes.data(), dev, want, hipMemcpyDeviceToHost) == hipSuccess)
+      s.base = (const uint8_t *)dev;
+  }
+  ~HostPrefix() { host_prefix().base = nullptr; }
+};
+// device -> host copy that is served from the prefix where it can be
+inline int dev_to_host(void *dst, const void *src, size_t bytes) {
+  const HostPrefixState &s = host_prefix();
+  const uint8_t *p = (const uint8_t *)src;
+  if (s.base && p >= s.base && bytes <= s.bytes.size() && (size_t)(p - s.base) <= s.bytes.size() - bytes) {
+    std::memcpy(dst, s.bytes.data() + (p - s.base), bytes);
+    return MGH_SUCCESS;
+  }
+  HL_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return MGH_SUCCESS;
 }
 
 // Copy the record of the last lossless_compress() to dst (host or device memory, record_size()
@@ -422,7 +458,7 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
     if (head.size() >= upto) return MGH_SUCCESS;
     const size_t have = head.size();
     head.resize(upto);
-    if (on_dev) HL_HIP(hipMemcpy(head.data() + have, p + have, upto - have, hipMemcpyDeviceToHost));
+    if (on_dev) HL_TRY(dev_to_host(head.data() + have, p + have, upto - have));
     else std::memcpy(head.data() + have, p + have, upto - have);
     return MGH_SUCCESS;
   };
@@ -472,6 +508,7 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
       if (ent[k] > units || (bits[k] + 63) / 64 > units - ent[k])
         return hl_fail(MGH_ERR_FORMAT, "Huffman record: chunk outside the code stream");
   }
+  hl_debug("lossless_decompress: record head parsed");
   HL_TRY(c->bits.ensure(nchunk * 8));
   HL_TRY(c->entry.ensure(nchunk * 8));
   HL_TRY(c->tables.ensure(dbsize));
@@ -502,6 +539,7 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
     once = true;
   }
   static const bool serial_decode = std::getenv("MGH_HUFF_SERIAL_DECODE") != nullptr;  // cross-check
+  hl_debug("lossless_decompress: uploads done (units, tables, outliers)");
   static const bool par_decode = std::getenv("MGH_HUFF_PAR_DECODE") != nullptr;           // cross-check
   int book_max_len = 0;  // longest code of the decodebook (unused lengths carry first = 2^64-1)
   {
@@ -1175,7 +1213,7 @@ int decomposer_from_header(const fmt::Header &hd, const mgh_config &cfg, Decompo
 int fetch_host(const void *data, size_t size, size_t want, std::vector<uint8_t> &out) {
   want = std::min(want, size);
   out.resize(want);
-  if (is_device_pointer(data)) HL_HIP(hipMemcpy(out.data(), data, want, hipMemcpyDeviceToHost));
+  if (is_device_pointer(data)) HL_TRY(dev_to_host(out.data(), data, want));
   else std::memcpy(out.data(), data, want);
   return MGH_SUCCESS;
 }
@@ -1380,6 +1418,8 @@ int mgh_decompress(const void *compressed_data, size_t compressed_size, void **d
   int ndev = mgh_device_count();
   if (ndev <= 0) return hl_fail(MGH_ERR_NO_DEVICE, "no HIP device");
   if (hipSetDevice(config->dev_id) != hipSuccess) return hl_fail(MGH_ERR_DEVICE, "hipSetDevice");
+  std::unique_ptr<HostPrefix> prefix;
+  if (is_device_pointer(compressed_data)) prefix.reset(new HostPrefix(compressed_data, compressed_size));
   fmt::Header hd;
   size_t meta_size = 0;
   HL_TRY(read_header(compressed_data, compressed_size, hd, meta_size));
