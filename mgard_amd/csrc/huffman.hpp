@@ -1080,11 +1080,15 @@ k_decode_ring(const unsigned long long *__restrict__ units, const unsigned long 
           pending = false;
         }
       }
-      if (MODE == 2) {  // write-out: run after run, 8-byte elements side by side
-        for (int L = 0; L < 64; L++) {
+      if (MODE == 2) {  // write-out: 64 / kRingBatch runs per instruction, the elements of a run side by side
+        constexpr int RPI = 64 / kRingBatch;  // runs per store instruction
+        const unsigned my_o = out0 + cnt - got;
+#pragma unroll 4
+        for (int it = 0; it < 64 / RPI; it++) {
+          const int L = it * RPI + lane / kRingBatch, k = lane % kRingBatch;
           const int n_L = __shfl(got, L, 64);
-          const unsigned o_L = __shfl(out0 + cnt - got, L, 64);
-          if (lane < n_L && o_L + lane < cap) dst[o_L + lane] = (OUT)stage[L * kRingBatch + lane];
+          const unsigned o_L = __shfl(my_o, L, 64);
+          if (k < n_L && o_L + k < cap) dst[o_L + k] = (OUT)stage[L * kRingBatch + k];
         }
       }
     }
