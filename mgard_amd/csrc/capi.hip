@@ -996,10 +996,12 @@ int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> 
   // MGH_NO_RECOMPOSE_HEAD=1: every level with its own launches (cross-check)
   static const bool no_head = std::getenv("MGH_NO_RECOMPOSE_HEAD") != nullptr;
   int l_head = 0;
-  if (!no_head)
-    for (int l = 1; l <= std::min(L, kTailMaxLevels); l++)
-      if (head_lds_elems(ds->lt[l].box) * sizeof(T) <= 150 * 1024) l_head = l;
-      else break;
+  if (!no_head) {
+    for (int l = 1; l <= std::min(L, kTailMaxLevels); l++) {
+      if (head_lds_elems(ds->lt[l].box) * sizeof(T) > 150 * 1024) break;
+      l_head = l;
+    }
+  }
   if (l_head >= 1) {
     HeadArgs<T> HA{};
     HA.nlevels = l_head;
