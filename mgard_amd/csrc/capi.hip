@@ -832,9 +832,15 @@ template <typename T> int decompose_nd(mgh_hierarchy *h, T *v, hipStream_t st) {
       nn *= b.n[d];
       mm *= b.m[d];
     }
-    TRY(launch(h, "nd_gather", st, [&] {
-      k_nd_gather<T><<<nd_grid(nn), 256, 0, st>>>(b, v, ds->nd_w, nn, 0);
-    }));
+    if (nd_box_is_whole_array(b)) {  // the top level: the fine box IS the array -- a plain copy
+      TRY(launch(h, "nd_gather", st, [&] {
+        (void)hipMemcpyAsync(ds->nd_w, v, nn * sizeof(T), hipMemcpyDeviceToDevice, st);
+      }));
+    } else {
+      TRY(launch(h, "nd_gather", st, [&] {
+        k_nd_gather<T><<<nd_grid(nn), 256, 0, st>>>(b, v, ds->nd_w, nn, 0);
+      }));
+    }
     TRY(launch(h, "nd_coeff", st, [&] {
       k_nd_coeff<T><<<nd_grid(nn), 256, 0, st>>>(b, tb, ds->nd_w, v, nn, 0);
     }));
@@ -870,9 +876,15 @@ template <typename T> int recompose_nd(mgh_hierarchy *h, T *v, hipStream_t st) {
     TRY(launch(h, "nd_coeff", st, [&] {
       k_nd_coeff<T><<<nd_grid(nn), 256, 0, st>>>(b, tb, ds->nd_w, v, nn, 2);
     }));
-    TRY(launch(h, "nd_gather", st, [&] {
-      k_nd_gather<T><<<nd_grid(nn), 256, 0, st>>>(b, v, ds->nd_w, nn, 1);
-    }));
+    if (nd_box_is_whole_array(b)) {
+      TRY(launch(h, "nd_gather", st, [&] {
+        (void)hipMemcpyAsync(v, ds->nd_w, nn * sizeof(T), hipMemcpyDeviceToDevice, st);
+      }));
+    } else {
+      TRY(launch(h, "nd_gather", st, [&] {
+        k_nd_gather<T><<<nd_grid(nn), 256, 0, st>>>(b, v, ds->nd_w, nn, 1);
+      }));
+    }
   }
   return MGH_SUCCESS;
 }

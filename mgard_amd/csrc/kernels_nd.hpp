@@ -25,6 +25,16 @@ struct NdBox {
   uint64_t fs[kNd];  // element strides of the full (reordered) array
 };
 
+// the level's fine box covers the whole (dense) array: box-order = array-order
+inline bool nd_box_is_whole_array(const NdBox &b) {
+  uint64_t st = 1;
+  for (int d = b.D - 1; d >= 0; d--) {
+    if (b.fs[d] != st) return false;
+    st *= b.n[d];
+  }
+  return true;
+}
+
 template <typename T> struct NdTables {
   const T *ratio[kNd];
 };
@@ -113,9 +123,12 @@ k_nd_coeff(NdBox b, NdTables<T> tb, T *__restrict__ w, T *__restrict__ v, uint64
            int mode) {
   for (uint64_t lin = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; lin < total;
        lin += (uint64_t)gridDim.x * blockDim.x) {
+    // threads run over the NATURAL order of the fine box: the centre and its neighbours -- on
+    // average five reads per node -- are then contiguous across a wave; the one access to the
+    // reordered array splits into the coarse and the coefficient half of a row
     uint32_t idx[kNd], pos[kNd];
     bool odd[kNd], any = false;
-    nd_unravel(b.D, b.n, lin, idx);
+    nd_unravel(b.D, b.n, lin, pos);
     uint64_t ns[kNd];  // strides of the natural-order compact box
     {
       uint64_t sacc = 1;
@@ -124,12 +137,14 @@ k_nd_coeff(NdBox b, NdTables<T> tb, T *__restrict__ w, T *__restrict__ v, uint64
         sacc *= b.n[d];
       }
     }
-    uint64_t off = 0, wl = 0;
+    uint64_t off = 0;
+    const uint64_t wl = lin;
     for (int d = 0; d < b.D; d++) {
-      pos[d] = fine_pos(idx[d], b.n[d], b.m[d], odd[d]);
+      const uint32_t p = pos[d], n = b.n[d], m = b.m[d];
+      odd[d] = (p & 1) && !(n % 2 == 0 && p == n - 1);  // (inverse of fine_pos)
+      idx[d] = odd[d] ? m + (p - 1) / 2 : (p == n - 1 ? m - 1 : p / 2);
       any |= odd[d];
       off += idx[d] * b.fs[d];
-      wl += pos[d] * ns[d];
     }
     if (mode == 0) {
       const T centre = w[wl];

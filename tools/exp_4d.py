@@ -3,7 +3,14 @@ sys.path.insert(0, '/root/repo')
 import mgard_amd
 from tests.util import smooth_field
 shape=tuple(int(x) for x in sys.argv[1].split(',')) if len(sys.argv)>1 else (8,256,256,256)
-u=smooth_field(shape,np.float32); d=torch.from_numpy(u).cuda()
+# a slab of time steps: a 3-D field that evolves slowly along dim 0 (smooth_field oscillates along
+# every dim, which with 8 samples along dim 0 makes half the nodes outliers)
+if len(shape) == 4:
+    base = smooth_field(shape[1:], np.float32)
+    u = np.stack([base * np.float32(1.0 + 0.002 * t) + np.float32(1e-4 * t) for t in range(shape[0])])
+else:
+    u = smooth_field(shape, np.float32)
+d=torch.from_numpy(u).cuda()
 h=mgard_amd.Hierarchy(shape,np.float32)
 print("shape",shape,"l_target",h.l_target)
 cap=u.size//8
