@@ -1,0 +1,21 @@
+"""Worker of test_gpu_highlevel.py::test_alternative_kernels_give_the_same_result: compress and
+decompress a few arrays and print digests; the parent runs it with and without the developer
+switches that select the older / simpler kernels (they are read once per process)."""
+import hashlib
+import sys
+
+import numpy as np
+
+sys.path.insert(0, __file__.rsplit("/tests/", 1)[0])
+import mgard_amd as mg  # noqa: E402
+from mgard_amd import highlevel as hl  # noqa: E402
+from tests.util import smooth_field  # noqa: E402
+
+out = []
+for shape, dt, tol in [((65, 97, 130), np.float32, 1e-2), ((40, 129, 66), np.float64, 1e-3), ((300, 70), np.float32, 1e-2)]:
+    u = smooth_field(shape, dt)
+    buf = hl.compress(u, tol, np.inf, mg.REL)
+    v = hl.decompress(buf)
+    out.append(str(len(buf)))  # (the bytes themselves vary: the outlier list is in atomic order)
+    out.append(hashlib.sha256(v.tobytes()).hexdigest()[:16])
+print("DIGESTS " + " ".join(out))

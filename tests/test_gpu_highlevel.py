@@ -283,6 +283,30 @@ def test_huffman_parameters_roundtrip(dict_size, block, where):
     hl.release_cache()
 
 
+def test_alternative_kernels_give_the_same_result():
+    """The developer switches select the previous / simpler kernels (one fine row per wave in the
+    node restore, every level with its own launches, the parallel decoder without rings, 16-bit
+    symbols on the decompression side): same container size, bit-identical reconstruction."""
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(__file__), "crosscheck_worker.py")
+
+    def run(extra):
+        env = dict(os.environ)
+        env.update(extra)
+        r = subprocess.run([sys.executable, worker], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGESTS ")]
+        assert line, r.stdout[-2000:]
+        return line[-1]
+
+    ref = run({})
+    assert run({"MGH_RESTORE_ROWS": "1", "MGH_NO_RECOMPOSE_HEAD": "1", "MGH_HUFF_PAR_DECODE": "1"}) == ref
+    assert run({"MGH_SYM16_DECODE": "1", "MGH_HUFF_SERIAL_DECODE": "1"}) == ref
+    assert run({"MGH_FORCE_V1": "1"}) == ref
+
+
 def test_incompressible_subdomain_is_stored_raw():
     torch, mg, hl = _mods()
     rng = np.random.default_rng(1)
