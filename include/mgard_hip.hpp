@@ -200,6 +200,28 @@ public:
           "DequantizeRecompose");
   }
 
+  // Extension (mgh_*_sym16): the same two calls with the quantized values as 16-bit dictionary
+  // symbols in a caller-provided device buffer of hierarchy.total_num_elems() uint16_t
+  // (prep_huffman semantics; only where SupportsSym16(), i.e. on the fused 3-D path).
+  bool SupportsSym16() const { return mgh_sym16_supported(hierarchy_->handle()) != 0; }
+  void DecomposeQuantizeSym16(const T *original_data, error_bound_type ebtype, T tol, T s, T &norm,
+                              uint16_t *symbols, void *queue = nullptr) {
+    double n = ebtype == error_bound_type::REL ? 0.0 : 1.0;
+    check(mgh_decompose_quantize_sym16(hierarchy_->handle(), original_data, (int)ebtype, (double)tol,
+                                       (double)s, n, &n, config_.huff_dict_size, symbols,
+                                       outlier_count_, outlier_idx_, outliers_, outlier_cap_, queue),
+          "DecomposeQuantizeSym16");
+    norm = (T)n;
+  }
+  void DequantizeRecomposeSym16(T *decompressed_data, error_bound_type ebtype, T tol, T s, T norm,
+                                const uint16_t *symbols, SIZE outlier_count, void *queue = nullptr) {
+    check(mgh_dequantize_recompose_sym16(hierarchy_->handle(), symbols, (int)ebtype, (double)tol,
+                                         (double)s, (double)norm, config_.huff_dict_size,
+                                         outlier_idx_, outliers_, outlier_count, decompressed_data,
+                                         queue),
+          "DequantizeRecomposeSym16");
+  }
+
   QUANTIZED_INT *quantized_array() { return quantized_; }
   ATOMIC_IDX *outlier_count_device() { return outlier_count_; }
   ATOMIC_IDX *outlier_indexes() { return outlier_idx_; }

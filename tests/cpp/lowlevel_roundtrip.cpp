@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include "mgard_hip.hpp"
@@ -62,6 +63,28 @@ template <typename T> int run(std::vector<mgard_hip::SIZE> shape, double tol, T 
   compressor.DequantizeRecompose(d_data, error_bound_type::REL, (T)tol, s, norm, count);
   std::vector<T> back(n);
   (void)hipMemcpy(back.data(), d_data, n * sizeof(T), hipMemcpyDeviceToHost);
+
+  // --- the 16-bit symbol extension: same values narrowed, bit-identical reconstruction
+  if (compressor.SupportsSym16()) {
+    uint16_t *d_sym = nullptr;
+    if (hipMalloc(&d_sym, n * sizeof(uint16_t)) != hipSuccess) return 1;
+    T norm3 = 0;
+    compressor.DecomposeQuantizeSym16(d_orig, error_bound_type::REL, (T)tol, s, norm3, d_sym);
+    ATOMIC_IDX count3 = 0;
+    (void)hipMemcpy(&count3, compressor.outlier_count_device(), sizeof(count3), hipMemcpyDeviceToHost);
+    std::vector<uint16_t> sym(n);
+    (void)hipMemcpy(sym.data(), d_sym, n * sizeof(uint16_t), hipMemcpyDeviceToHost);
+    bool same = norm3 == norm && count3 == count;
+    for (SIZE i = 0; same && i < n; i++) same = (QUANTIZED_INT)sym[i] == q2[i];
+    compressor.DequantizeRecomposeSym16(d_data, error_bound_type::REL, (T)tol, s, norm, d_sym, count3);
+    std::vector<T> back16(n);
+    (void)hipMemcpy(back16.data(), d_data, n * sizeof(T), hipMemcpyDeviceToHost);
+    (void)hipFree(d_sym);
+    if (!same || std::memcmp(back16.data(), back.data(), n * sizeof(T)) != 0) {
+      std::printf("16-bit symbol path differs from the int64 path\n");
+      return 1;
+    }
+  }
   double err = 0;
   for (SIZE i = 0; i < n; i++) err = std::fmax(err, std::fabs((double)back[i] - (double)u[i]));
   std::printf("shape %llux%llux%llu %s: l_target %llu, norm %g, outliers %llu, L-inf error %.3e <= %.3e\n",
