@@ -515,9 +515,12 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
   HL_TRY(c->units.ensure((units + 1) * 8));
   HL_TRY(c->oidx.ensure(std::max<size_t>(ocount, 1) * 8));
   HL_TRY(c->oval.ensure(std::max<size_t>(ocount, 1) * 8));
-  HL_HIP(hipMemcpyAsync(c->bits.p, head.data() + L.huffmeta, nchunk * 8, hipMemcpyHostToDevice, st));
-  HL_HIP(hipMemcpyAsync(c->entry.p, head.data() + L.huffmeta + nchunk * 8, nchunk * 8, hipMemcpyHostToDevice, st));
-  HL_HIP(hipMemcpyAsync(c->tables.p, head.data() + L.decodebook, dbsize, hipMemcpyHostToDevice, st));
+  // (a record in device memory: these go device-to-device from the record itself, not back up
+  // from the pageable host copy)
+  const uint8_t *meta_src = on_dev ? p : head.data();
+  HL_HIP(hipMemcpyAsync(c->bits.p, meta_src + L.huffmeta, nchunk * 8, hipMemcpyDefault, st));
+  HL_HIP(hipMemcpyAsync(c->entry.p, meta_src + L.huffmeta + nchunk * 8, nchunk * 8, hipMemcpyDefault, st));
+  HL_HIP(hipMemcpyAsync(c->tables.p, meta_src + L.decodebook, dbsize, hipMemcpyDefault, st));
   if (units) HL_HIP(hipMemcpyAsync(c->units.p, p + L.ddata, units * 8, hipMemcpyDefault, st));
   HL_HIP(hipMemsetAsync((char *)c->units.p + units * 8, 0, 8, st));  // (the decoder peeks one unit ahead)
   if (ocount) {
