@@ -21,6 +21,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "format.hpp"
@@ -188,6 +189,8 @@ struct mgh_lossless_ctx {
 
 namespace {
 
+int copy_any(void *dst, const void *src, size_t bytes, hipStream_t st);  // (below)
+
 // The single-pass encoder stages code table and symbols of a chunk in LDS.
 inline bool lossless_sym16_ok(uint64_t dict, uint64_t chunk) {
   return dict <= 65536 && dict * 8 + chunk * 2 <= 140 * 1024;
@@ -239,7 +242,7 @@ int record_write(mgh_lossless_ctx *c, void *dst, hipStream_t st) {
   const PayloadLayout &L = c->lay;
   HL_HIP(hipMemcpyAsync(d, c->head.data(), c->head.size(), hipMemcpyDefault, st));
   if (c->n_units)
-    HL_HIP(hipMemcpyAsync(d + L.ddata, c->units.p, c->n_units * 8, hipMemcpyDefault, st));
+    HL_TRY(copy_any(d + L.ddata, c->units.p, c->n_units * 8, st));
   // (the count travels from a member that outlives the asynchronous copy)
   HL_HIP(hipMemcpyAsync(d + L.outlier_count, &c->n_outliers, 8, hipMemcpyDefault, st));
   if (c->n_outliers) {
@@ -781,6 +784,112 @@ int make_decomposer(Decomposer &dd, int D, const uint64_t *shape, size_t elem, c
   return MGH_SUCCESS;
 }
 
+// Large contiguous transfers between PAGEABLE host memory and the device go through two pinned
+// bounce buffers owned by the library, the host-side memcpy split over a few threads: the runtime
+// moves pageable memory at ~11 GB/s (one staging thread), this way the transfer runs near the
+// slower of PCIe and the host's copy bandwidth. (The reference registers the caller's buffers
+// instead -- auto_pin_host_buffers -- which this ROCm version does not survive, see
+// mgh_config_default.) Buffers are per thread, released with the cache.
+struct PinnedBounce {
+  static constexpr size_t kChunk = (size_t)32 << 20;
+  void *buf[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  int ensure() {
+    for (int i = 0; i < 2; i++) {
+      if (!buf[i]) HL_HIP(hipHostMalloc(&buf[i], kChunk, hipHostMallocDefault));
+      if (!ev[i]) HL_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    }
+    return MGH_SUCCESS;
+  }
+  void release() {
+    for (int i = 0; i < 2; i++) {
+      if (buf[i]) (void)hipHostFree(buf[i]);
+      if (ev[i]) (void)hipEventDestroy(ev[i]);
+      buf[i] = nullptr;
+      ev[i] = nullptr;
+    }
+  }
+};
+thread_local PinnedBounce *g_bounce_ptr = nullptr;  // (never destroyed automatically, like the cache)
+inline PinnedBounce &bounce() {
+  if (!g_bounce_ptr) g_bounce_ptr = new PinnedBounce();
+  return *g_bounce_ptr;
+}
+
+inline void parallel_memcpy(void *dst, const void *src, size_t bytes) {
+  constexpr int kThreads = 8;
+  if (bytes < ((size_t)4 << 20)) {
+    std::memcpy(dst, src, bytes);
+    return;
+  }
+  const size_t part = (bytes / kThreads + 4095) / 4096 * 4096;
+  std::thread th[kThreads - 1];
+  for (int t = 1; t < kThreads; t++) {
+    const size_t lo = std::min(bytes, t * part), hi = std::min(bytes, (t + 1) * part);
+    th[t - 1] = std::thread([=] { if (hi > lo) std::memcpy((char *)dst + lo, (const char *)src + lo, hi - lo); });
+  }
+  std::memcpy(dst, src, std::min(bytes, part));
+  for (auto &x : th) x.join();
+}
+
+// dst (device) <- src (pageable host). The source is consumed when the call returns; the device
+// side is complete in stream order.
+int staged_h2d(void *dst, const void *src, size_t bytes, hipStream_t st) {
+  PinnedBounce &b = bounce();
+  HL_TRY(b.ensure());
+  size_t off = 0;
+  for (int c = 0; off < bytes; c++) {
+    const int i = c & 1;
+    const size_t nb = std::min(PinnedBounce::kChunk, bytes - off);
+    HL_HIP(hipEventSynchronize(b.ev[i]));  // the previous transfer out of this buffer is done
+    parallel_memcpy(b.buf[i], (const char *)src + off, nb);
+    HL_HIP(hipMemcpyAsync((char *)dst + off, b.buf[i], nb, hipMemcpyHostToDevice, st));
+    HL_HIP(hipEventRecord(b.ev[i], st));
+    off += nb;
+  }
+  return MGH_SUCCESS;
+}
+
+// dst (pageable host) <- src (device), after everything queued on st. Complete on return.
+int staged_d2h(void *dst, const void *src, size_t bytes, hipStream_t st) {
+  PinnedBounce &b = bounce();
+  HL_TRY(b.ensure());
+  size_t off = 0, done = 0;
+  size_t len[2] = {0, 0};
+  int c = 0;
+  for (; off < bytes; c++) {
+    const int i = c & 1;
+    if (c >= 2) {  // drain the buffer we are about to reuse
+      HL_HIP(hipEventSynchronize(b.ev[i]));
+      parallel_memcpy((char *)dst + done, b.buf[i], len[i]);
+      done += len[i];
+    }
+    len[i] = std::min(PinnedBounce::kChunk, bytes - off);
+    HL_HIP(hipMemcpyAsync(b.buf[i], (const char *)src + off, len[i], hipMemcpyDeviceToHost, st));
+    HL_HIP(hipEventRecord(b.ev[i], st));
+    off += len[i];
+  }
+  for (int k = std::max(0, c - 2); k < c; k++) {
+    const int i = k & 1;
+    HL_HIP(hipEventSynchronize(b.ev[i]));
+    parallel_memcpy((char *)dst + done, b.buf[i], len[i]);
+    done += len[i];
+  }
+  return MGH_SUCCESS;
+}
+
+// contiguous copy between any two of device / pinned host / pageable host memory
+int copy_any(void *dst, const void *src, size_t bytes, hipStream_t st) {
+  constexpr size_t kStagedMin = (size_t)8 << 20;
+  if (bytes >= kStagedMin) {
+    const bool dd = is_device_pointer(dst), sd = is_device_pointer(src);
+    if (dd && !sd && !is_registered_host(src)) return staged_h2d(dst, src, bytes, st);
+    if (sd && !dd && !is_registered_host(dst)) return staged_d2h(dst, src, bytes, st);
+  }
+  HL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st));
+  return MGH_SUCCESS;
+}
+
 // copy_subdomain (DomainDecomposer.hpp:649-845): dense subdomain buffer <-> its box inside the
 // full array (host or device), as few strided copies as the box allows.
 int copy_subdomain(const Decomposer &dd, uint64_t id, size_t elem, void *sub, const void *full_c,
@@ -809,9 +918,8 @@ int copy_subdomain(const Decomposer &dd, uint64_t id, size_t elem, void *sub, co
   }
   if (k == 0) {  // one contiguous run
     const size_t fo = off[0] * fstride[0];
-    if (to_sub) HL_HIP(hipMemcpyAsync(sub, (const char *)full_c + fo * elem, width, hipMemcpyDefault, st));
-    else HL_HIP(hipMemcpyAsync((char *)full_m + fo * elem, sub, width, hipMemcpyDefault, st));
-    return MGH_SUCCESS;
+    if (to_sub) return copy_any(sub, (const char *)full_c + fo * elem, width, st);
+    return copy_any((char *)full_m + fo * elem, sub, width, st);
   }
   size_t sub_off = 0;
   const size_t sub_block = rows * width;
@@ -1465,6 +1573,7 @@ void mgh_free_device(void *p) {
 
 void mgh_release_cache(void) {
   if (g_cache_ptr) g_cache_ptr->release();
+  if (g_bounce_ptr) g_bounce_ptr->release();
 }
 
 int mgh_memcpy(void *dst, const void *src, size_t bytes) {
