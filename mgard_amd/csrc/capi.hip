@@ -21,6 +21,7 @@
 #include "kernels_v1.hpp"
 #include "kernels_ipk.hpp"
 #include "kernels_fused.hpp"
+#include "kernels_fused2.hpp"
 #include "kernels_emit.hpp"
 #include "kernels_tail.hpp"
 #include "kernels_recompose.hpp"
@@ -72,6 +73,9 @@ struct mgh_hierarchy {
   // MGH_SPLIT: 0 = never split a level (default: measured within 5% of the split schedules
   // and single-stream), 1 = split the biggest size class, 2 = also the mid-size class
   int split = 0;
+  // MGH_FUSED_V: 2 = second-generation fused level kernel (kernels_fused2.hpp, default),
+  // 1 = first generation (kernels_fused.hpp; cross-check)
+  int fused_v = 2;
   std::map<std::string, ProfileEntry> prof;
   size_t device_bytes = 0;
 };
@@ -658,21 +662,26 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
       if (l == L) TRY(after_first());
       // long marches (RCH = 16: 9% r-halo) when there are plenty of tiles, short ones
       // (RCH = 4) on the small levels where the march length is pure latency
+      // second generation: needs the dictionary test in 32 bits
+      const bool v2 = h->fused_v == 2 && (OUT != OUT_Q || (qp->dict_size >= 0 && qp->dict_size <= ((int64_t)1 << 30)));
       if (cls == 2) {
         const dim3 grid(gx, gy, (b.m[0] + 15) / 16);
         TRY(launch(h, OUT == OUT_Q ? "level_fused_q" : "level_fused", s, [&] {
-          k_level_fused<T, OUT, TC, TF, 16, false><<<grid, 256, 0, s>>>(A);
+          if (v2) k_level_fused2<T, OUT, TC, TF, 16><<<grid, 256, 0, s>>>(A);
+          else k_level_fused<T, OUT, TC, TF, 16, false><<<grid, 256, 0, s>>>(A);
         }));
       } else if (cls == 1) {
         const dim3 grid(gx, gy, (b.m[0] + 3) / 4);
         TRY(launch(h, OUT == OUT_Q ? "level_fused_q_small" : "level_fused_small", s, [&] {
-          k_level_fused<T, OUT, TC, TF, 4, false><<<grid, 256, 0, s>>>(A);
+          if (v2) k_level_fused2<T, OUT, TC, TF, 4><<<grid, 256, 0, s>>>(A);
+          else k_level_fused<T, OUT, TC, TF, 4, false><<<grid, 256, 0, s>>>(A);
         }));
       } else {
         // few tiles: the march length is the whole cost -> one coarse plane per block
         const dim3 grid(gx, gy, b.m[0]);
         TRY(launch(h, OUT == OUT_Q ? "level_fused_q_small" : "level_fused_small", s, [&] {
-          k_level_fused<T, OUT, TC, TF, 1, true><<<grid, 256, 0, s>>>(A);
+          if (v2) k_level_fused2<T, OUT, TC, TF, 1><<<grid, 256, 0, s>>>(A);
+          else k_level_fused<T, OUT, TC, TF, 1, true><<<grid, 256, 0, s>>>(A);
         }));
       }
     }
@@ -1430,6 +1439,8 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->force_nd = e2 && e2[0] == '1';
     const char *e3 = std::getenv("MGH_SPLIT");
     if (e3 && e3[0] >= '0' && e3[0] <= '2') h->split = e3[0] - '0';
+    const char *e6 = std::getenv("MGH_FUSED_V");
+    if (e6 && e6[0] >= '1' && e6[0] <= '2') h->fused_v = e6[0] - '0';
     const char *e4 = std::getenv("MGH_EMIT_BPC");
     if (e4 && std::atoi(e4) > 0) h->emit_bpc = (unsigned)std::atoi(e4);
     const char *e5 = std::getenv("MGH_EMIT_CCH");

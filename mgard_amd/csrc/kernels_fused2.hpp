@@ -1,0 +1,456 @@
+// Fused level kernel, second generation (gfx950): the same pass as kernels_fused.hpp --
+// coarse nodes + level coefficients (quantized) + load vector Lr(Lc(Lf(C))) from ONE read of
+// the level's nodal array -- rebuilt around its measured limit. rocprofv3 SQ counters on the
+// first generation (512^3 f32): 263 VALU + 181 SALU + 33 LDS instructions per wave and fine
+// plane, VALU busy 65-70 % of the kernel's time, HBM at 40 %: the kernel is bound by
+// instruction issue, and only ~70 of those VALU instructions are arithmetic the algorithm asks
+// for. What is different here:
+//   * planes are processed in (odd, even) PAIRS and the even plane comes first: its four
+//     interpolants (node, f, c, fc) are exactly the upper neighbours the odd plane's r-lerp
+//     needs, and the lower neighbours are the ones kept in registers from the pair before --
+//     8 instead of 20 lerps per cell and pair, 11 instead of 19 LDS reads, and the raw ring
+//     shrinks from three planes to two;
+//   * out-of-grid and ghost nodes are handled by DATA, not control flow: loads are
+//     unconditional from clamped addresses (no valid coefficient ever reads a clamped node),
+//     coefficient values of invalid nodes are zeroed by one select on a lane mask that is
+//     constant for the thread, and only the stores of boundary tiles are predicated;
+//   * every global access is wave-uniform base (SGPR pair) + 32-bit lane-constant offset;
+//   * quantization in 32 bits: v_cvt_i32_f32 of copysign(0.5 + |t q|, t) saturates, so one
+//     unsigned compare against the dictionary size finds the outliers (whose exact 64-bit
+//     value is recomputed on the rare path), and the upper word of an in-dictionary symbol is 0;
+//   * the r-sweep keeps tb(R+1) = td(R) (the same expression with the same operands:
+//     LPKFunctor.h:77-93, dist[2R], dist[2R+1]) and a 3-value window instead of 5;
+//   * 3 barriers per plane pair instead of 5.
+// Arithmetic per value is unchanged (same operations in the same order, no FMA contraction):
+// results are bit-identical to kernels_fused.hpp / kernels_v1.hpp.
+// Reference: DataRefactoring.hpp:80-109, GridProcessingKernel3D.hpp:21-1179,
+// LinearProcessingKernel3D.hpp:27-1048, LinearQuantization.hpp:146-245.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels_fused.hpp"
+
+namespace mgh {
+
+// (int) x with saturation -- exactly v_cvt_i32_f32 / v_cvt_i32_f64 (C's conversion is undefined
+// out of range; the instruction is not)
+__device__ __forceinline__ int32_t cvt_i32_sat(float x) {
+  int32_t r;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ int32_t cvt_i32_sat(double x) {
+  int32_t r;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+// the three restricted mass rows of one coarse node (LPKFunctor.h:77-93)
+template <typename T> __device__ __forceinline__ T mass_tb(T a, T b, T c, const T (&w)[9]) {
+  return a * w[0] + b * w[1] + c * w[2];
+}
+template <typename T> __device__ __forceinline__ T mass_tc(T b, T c, T d, const T (&w)[9]) {
+  return b * w[2] + c * w[3] + d * w[4];
+}
+template <typename T> __device__ __forceinline__ T mass_td(T c, T d, T e, const T (&w)[9]) {
+  return c * w[4] + d * w[5] + e * w[6];
+}
+
+template <typename T, int OUT, int TC, int TF, int RCH>
+__global__ void __launch_bounds__(TC * TF)
+k_level_fused2(FusedArgs<T> A) {
+  constexpr int WC = 2 * TC + 3;
+  constexpr int WF = 2 * TF + 3;
+  constexpr int HF = TF + 2;     // even-f slots of a window row (odd-f slots: TF + 1)
+  constexpr int ROW = 2 * HF;    // LDS row: [0,HF) even f, [HF, HF+TF+1) odd f (stride-1 access)
+  constexpr int PL = WC * ROW;   // one window plane
+  constexpr int NT = TC * TF;    // one owned cell / one c-sweep output per thread
+  constexpr int NH = (TC + 2) * (TF + 2) - TC * TF;  // halo cells
+  constexpr int TP = TF + 1;     // pitch of the f-swept rows
+  constexpr int BX = (WC * TF - 2 * NT);  // f-sweep items of the third round (per plane)
+  static_assert(NH <= NT, "halo cells are handled in one extra pass");
+  static_assert(BX >= 0 && BX <= NT && BX % TF == 0, "f-sweep: two full rounds + one partial");
+  __shared__ T raw[2][PL];          // [0] odd plane, [1] even plane of the pair
+  __shared__ T Cs[2][PL];           // coefficient fields of the pair
+  __shared__ T t1s[2][WC * TP];     // f-swept rows of the pair
+  __shared__ T rfs[WF];
+  __shared__ T rcs[WC];
+  __shared__ T rrs[2 * RCH + 3];    // ratio_r[p - 1] of plane p = r_lo + index
+  __shared__ __attribute__((aligned(16))) T wrs[RCH][12];  // r-sweep constants of the chunk
+#define LI(lc, lf) ((lc) * ROW + ((lf) & 1) * HF + ((lf) >> 1))
+
+  if (OUT == OUT_Q && A.qp) {
+    A.quantizer = A.qp[A.level];
+    A.volume = A.qp[A.nlev + A.level];
+  }
+  const int tid = threadIdx.x;
+  // r-chunks in reverse launch order: whatever ran before this kernel (the norm reduction,
+  // the level above) leaves the END of the level's input in the memory-side cache
+  const int F0 = blockIdx.x * TF, C0 = blockIdx.y * TC, R0 = (gridDim.z - 1 - blockIdx.z) * RCH;
+  const int nr = A.n[0], nc = A.n[1], nf = A.n[2];
+  const int mr = A.m[0], mc = A.m[1], mf = A.m[2];
+  const int c_lo = 2 * C0 - 2, f_lo = 2 * F0 - 2;
+  const int r_lo = 2 * R0 - 2;
+  const int r_hi = min(2 * R0 + 2 * RCH, 2 * mr);  // planes beyond 2mr-2 are empty anyway
+  const int Pmax_r = 2 * mr - 2, Pmax_c = 2 * mc - 2, Pmax_f = 2 * mf - 2;
+  // ghost (padded) positions of even-sized dims; -7 = none
+  const int ghost_r = (nr % 2 == 0) ? nr - 1 : -7;
+  const int ghost_c = (nc % 2 == 0) ? nc - 1 : -7;
+  const int ghost_f = (nf % 2 == 0) ? nf - 1 : -7;
+
+  // interpolation ratios of the window (index = padded position of the left node)
+  for (int e = tid; e < WF; e += NT) {
+    const int P = f_lo + e;
+    rfs[e] = (P >= 0 && P < nf) ? A.ratio[2][P] : (T)0;
+  }
+  for (int e = tid; e < WC; e += NT) {
+    const int P = c_lo + e;
+    rcs[e] = (P >= 0 && P < nc) ? A.ratio[1][P] : (T)0;
+  }
+  for (int e = tid; e < 2 * RCH + 3; e += NT) {
+    const int P = r_lo + e - 1;  // left neighbour of plane r_lo + e
+    rrs[e] = (P >= 0 && P < nr) ? A.ratio[0][P] : (T)0;
+  }
+  for (int e = tid; e < RCH * 9; e += NT) {
+    const int R = R0 + e / 9, k = e % 9;
+    wrs[e / 9][k] = R < mr ? A.mass[0][k * mr + R] : (T)0;
+  }
+  // per-thread sweep constants: f-sweep for jf = tid % TF, c-sweep for jc = tid / TF
+  const int jf = tid % TF, jc = tid / TF;
+  T wf[9], wc[9];
+  {
+    const int Jf = F0 + jf, Jc = C0 + jc;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      wf[k] = Jf < mf ? A.mass[2][k * mf + Jf] : (T)0;
+      wc[k] = Jc < mc ? A.mass[1][k * mc + Jc] : (T)0;
+    }
+  }
+
+  // ---- raw-plane streaming: window elements e = tid + k*NT, loaded from clamped positions
+  // (a node outside the grid is never read by a valid coefficient) ---------------------------
+  constexpr int NL = (WC * WF + NT - 1) / NT;
+  uint32_t lidx[NL];  // LDS index
+  uint32_t goff[NL];  // clamp(Pc) * uJ + clamp(Pf)
+#pragma unroll
+  for (int k = 0; k < NL; k++) {
+    const int e = min(tid + k * NT, WC * WF - 1);
+    const int lc = e / WF, lf = e - lc * WF;
+    const int Pc = min(max(c_lo + lc, 0), nc - 1), Pf = min(max(f_lo + lf, 0), nf - 1);
+    lidx[k] = LI(lc, lf);
+    goff[k] = (uint32_t)Pc * (uint32_t)A.uJ + (uint32_t)Pf;
+  }
+  auto fetch = [&](int p, T(&reg)[NL]) {
+    const T *base = A.u + (size_t)min(max(p, 0), nr - 1) * A.uI;
+#pragma unroll
+    for (int k = 0; k < NL; k++) reg[k] = base[goff[k]];
+  };
+  auto stash = [&](T *dst, const T(&reg)[NL]) {
+#pragma unroll
+    for (int k = 0; k < NL; k++) dst[lidx[k]] = reg[k];
+  };
+
+  // ---- cells: a cell is the 2x2 group of window nodes (lc0 + {0,1}, lf0 + {0,1}) with even
+  // lc0, lf0. The thread's OWNED cell is (jc, jf); threads < NH also take one HALO cell. ------
+  struct Cell {
+    bool c1, f1;       // odd row / odd column of the cell lies inside the window
+    bool m0, m1, m2, m3;  // node (ee, eo, oe, oo) exists in the grid and is not a ghost node
+    T rc, rf;          // interpolation ratios at the left (even) nodes
+    uint32_t i00, i01, i02, i10, i11, i20, i22;  // LDS indices (clamped inside the window)
+  };
+  auto make_cell = [&](int cj, int fj) {
+    Cell c;
+    const int lc0 = 2 * cj + 2, lf0 = 2 * fj + 2;
+    c.c1 = cj < TC;
+    c.f1 = fj < TF;
+    const int Pc0 = c_lo + lc0, Pf0 = f_lo + lf0;
+    const bool vc0 = Pc0 >= 0 && Pc0 <= Pmax_c;
+    const bool vf0 = Pf0 >= 0 && Pf0 <= Pmax_f;
+    const bool vc1 = c.c1 && Pc0 + 1 >= 0 && Pc0 + 1 <= Pmax_c && Pc0 + 1 != ghost_c;
+    const bool vf1 = c.f1 && Pf0 + 1 >= 0 && Pf0 + 1 <= Pmax_f && Pf0 + 1 != ghost_f;
+    c.m0 = vc0 && vf0;
+    c.m1 = vc0 && vf1;
+    c.m2 = vc1 && vf0;
+    c.m3 = vc1 && vf1;
+    const int dc1 = c.c1 ? 1 : 0, dc2 = c.c1 ? 2 : 0, df1 = c.f1 ? 1 : 0, df2 = c.f1 ? 2 : 0;
+    c.rc = rcs[lc0];
+    c.rf = rfs[lf0];
+    c.i00 = LI(lc0, lf0);
+    c.i01 = LI(lc0, lf0 + df1);
+    c.i02 = LI(lc0, lf0 + df2);
+    c.i10 = LI(lc0 + dc1, lf0);
+    c.i11 = LI(lc0 + dc1, lf0 + df1);
+    c.i20 = LI(lc0 + dc2, lf0);
+    c.i22 = LI(lc0 + dc2, lf0 + df2);
+    return c;
+  };
+  __syncthreads();  // rfs / rcs visible
+  const Cell own = make_cell(jc, jf);
+  int hcj = 0, hfj = 0;
+  if (tid < NH) {
+    if (tid < 2 * (TF + 2)) {
+      hcj = tid < TF + 2 ? -1 : TC;
+      hfj = tid % (TF + 2) - 1;
+    } else {
+      const int h2 = tid - 2 * (TF + 2);
+      hfj = h2 < TC ? -1 : TF;
+      hcj = h2 % TC;
+    }
+  }
+  const Cell halo = make_cell(hcj, hfj);
+  // boundary tiles predicate their stores; everywhere else every owned node exists
+  const bool all_on = __syncthreads_and(own.m0 && own.m1 && own.m2 && own.m3) != 0;
+
+  // output offsets of the owned cell relative to the output plane (reordered layout:
+  // c index C0+jc / mc+C0+jc, same in f); planes of < 2^29 elements (capi.hip: fused_ok)
+  const uint32_t oc0 = (uint32_t)(C0 + jc) * (uint32_t)A.dJ, oc1 = (uint32_t)(mc + C0 + jc) * (uint32_t)A.dJ;
+  const uint32_t of0 = (uint32_t)(F0 + jf), of1 = (uint32_t)(mf + F0 + jf);
+  const uint32_t off[4] = {oc0 + of0, oc0 + of1, oc1 + of0, oc1 + of1};
+  const uint32_t coarse_off = (uint32_t)(C0 + jc) * (uint32_t)mf + (uint32_t)(F0 + jf);
+  const T qz = A.quantizer, qv = A.volume;
+  const uint32_t dict = (uint32_t)A.dict_size, half = (uint32_t)(A.dict_size / 2);
+
+  // even plane of a cell: the four interpolants (node, f, c, fc) and its coefficients.
+  // Interpolation: f innermost, then c (GridProcessingKernel3D.hpp:614-617, 737-744).
+  auto cell_even = [&](const Cell &c, const T *rw, T *cs, bool pv, T(&E)[4], T(&cv)[4]) {
+    const T v00 = rw[c.i00], v01 = rw[c.i01], v02 = rw[c.i02], v10 = rw[c.i10], v11 = rw[c.i11],
+            v20 = rw[c.i20], v22 = rw[c.i22];
+    const T f0 = lerp_ref(v00, v02, c.rf), f2 = lerp_ref(v20, v22, c.rf);
+    E[0] = v00;
+    E[1] = f0;
+    E[2] = lerp_ref(v00, v20, c.rc);
+    E[3] = lerp_ref(f0, f2, c.rc);
+    cv[0] = (T)0;  // coarse node: no coefficient
+    cv[1] = (pv && c.m1) ? v01 - E[1] : (T)0;
+    cv[2] = (pv && c.m2) ? v10 - E[2] : (T)0;
+    cv[3] = (pv && c.m3) ? v11 - E[3] : (T)0;
+    cs[c.i00] = cv[0];
+    if (c.f1) cs[c.i01] = cv[1];
+    if (c.c1) cs[c.i10] = cv[2];
+    if (c.c1 && c.f1) cs[c.i11] = cv[3];
+  };
+  // odd plane: r-lerp of the interpolants of the planes below (G) and above (E)
+  // (GridProcessingKernel3D.hpp:854-871)
+  auto cell_odd = [&](const Cell &c, const T *rw, T *cs, bool pv, T rr, const T(&G)[4],
+                      const T(&E)[4], T(&cv)[4]) {
+    const T v00 = rw[c.i00], v01 = rw[c.i01], v10 = rw[c.i10], v11 = rw[c.i11];
+    cv[0] = (pv && c.m0) ? v00 - lerp_ref(G[0], E[0], rr) : (T)0;
+    cv[1] = (pv && c.m1) ? v01 - lerp_ref(G[1], E[1], rr) : (T)0;
+    cv[2] = (pv && c.m2) ? v10 - lerp_ref(G[2], E[2], rr) : (T)0;
+    cv[3] = (pv && c.m3) ? v11 - lerp_ref(G[3], E[3], rr) : (T)0;
+    cs[c.i00] = cv[0];
+    if (c.f1) cs[c.i01] = cv[1];
+    if (c.c1) cs[c.i10] = cv[2];
+    if (c.c1 && c.f1) cs[c.i11] = cv[3];
+  };
+
+  // coefficients of one owned plane to HBM. K0 = 1: even plane (slot 0 is the coarse node,
+  // stored by the caller); oi = index of the output plane in the reordered layout.
+  auto emit = [&](const T(&cv)[4], int oi, int K0) {
+    const size_t ob = (size_t)oi * A.dI;
+    if (OUT == OUT_T) {
+      T *o = A.coef + ob;
+      if (all_on) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (k >= K0) o[off[k]] = cv[k];
+      } else {
+        if (K0 == 0 && own.m0) o[off[0]] = cv[0];
+        if (own.m1) o[off[1]] = cv[1];
+        if (own.m2) o[off[2]] = cv[2];
+        if (own.m3) o[off[3]] = cv[3];
+      }
+      return;
+    }
+    if (OUT != OUT_Q) return;
+    const bool on[4] = {own.m0, own.m1, own.m2, own.m3};
+    int32_t qs[4];
+    bool slow = false;
+    if (A.prep_huffman) {
+      bool ol[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (k < K0) continue;
+        const T a = (T)0.5 + abs_t(cv[k] * qz * qv);
+        const uint32_t s = (uint32_t)cvt_i32_sat(copysign_t(a, cv[k])) + half;
+        ol[k] = on[k] && s >= dict;
+        qs[k] = ol[k] ? 0 : (int32_t)s;
+        slow |= ol[k];
+      }
+      if (__any(slow)) {
+        // out-of-dictionary values: exact 64-bit value into the outlier list, slots of the
+        // whole wave from ONE atomicAdd (LinearQuantization.hpp:208-241)
+        unsigned long long masks[4];
+        unsigned total = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          masks[k] = k >= K0 ? __ballot(ol[k]) : 0ull;
+          total += __popcll(masks[k]);
+        }
+        unsigned long long base = 0;
+        const int lane = tid & 63;
+        if (lane == 0) base = atomicAdd(A.outlier_count, (unsigned long long)total);
+        base = __shfl(base, 0, 64);
+        unsigned before = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (k >= K0 && ol[k]) {
+            const unsigned rank = __popcll(masks[k] & ((1ULL << lane) - 1ULL));
+            const unsigned long long o = base + before + rank;
+            if (o < A.outlier_cap) {
+              A.outlier_idx[o] = ob + off[k];
+              A.outlier_val[o] = quantize_fast(cv[k], qz, qv) + A.dict_size / 2;
+            }
+          }
+          before += __popcll(masks[k]);
+        }
+      }
+      if (A.q16) {
+        uint16_t *o = A.q16 + ob;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (k >= K0 && (all_on || on[k])) o[off[k]] = (uint16_t)qs[k];
+      } else {
+        int64_t *o = A.q + ob;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (k >= K0 && (all_on || on[k])) o[off[k]] = (int64_t)(uint32_t)qs[k];
+      }
+    } else {
+      // no dictionary: plain integers; |value| >= 2^31 (the conversion saturated) goes through
+      // the 64-bit conversion
+      int64_t *o = A.q + ob;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (k < K0) continue;
+        const T a = (T)0.5 + abs_t(cv[k] * qz * qv);
+        qs[k] = cvt_i32_sat(copysign_t(a, cv[k]));
+        slow |= qs[k] == INT32_MAX || qs[k] == INT32_MIN;
+      }
+      if (__any(slow)) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (k >= K0 && (all_on || on[k])) o[off[k]] = quantize_fast(cv[k], qz, qv);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (k >= K0 && (all_on || on[k])) o[off[k]] = (int64_t)qs[k];
+      }
+    }
+  };
+
+  // Phase B: f-sweep of the window rows of one plane at coarse column jf: rows jc, jc + TC,
+  // and (threads of the last BX / TF values of jc) the remaining BX / TF rows
+  auto f_sweep_row = [&](const T *cs, T *t1, int lc) {
+    const T *row = cs + lc * ROW;
+    const T a = row[jf], b = row[HF + jf], c = row[jf + 1], d = row[HF + jf + 1], e = row[jf + 2];
+    const T tb = mass_tb(a, b, c, wf);
+    T tc = mass_tc(b, c, d, wf);
+    const T td = mass_td(c, d, e, wf);
+    tc += tb * wf[7] + td * wf[8];
+    t1[lc * TP + jf] = tc;
+  };
+  auto phase_b = [&](const T *cs, T *t1) {
+    f_sweep_row(cs, t1, jc);
+    f_sweep_row(cs, t1, jc + TC);
+    if (BX > 0 && jc >= TC - BX / TF) f_sweep_row(cs, t1, jc + 2 * TC - (TC - BX / TF));
+  };
+  // Phase C: c-sweep, one value per thread and plane
+  auto c_sweep = [&](const T *t1) {
+    const T *col = t1 + (2 * jc) * TP + jf;
+    const T a = col[0], b = col[TP], c = col[2 * TP], d = col[3 * TP], e = col[4 * TP];
+    const T tb = mass_tb(a, b, c, wc);
+    T tc = mass_tc(b, c, d, wc);
+    const T td = mass_td(c, d, e, wc);
+    tc += tb * wc[7] + td * wc[8];
+    return tc;
+  };
+
+  // ---- march ------------------------------------------------------------------------------
+  T Go[4], Gh[4];  // interpolants of the previous even plane: owned cell, halo cell
+  T e_prev;        // c-swept value of the previous even plane
+  T td_prev = 0;   // r-sweep: td of the previous coarse plane = tb of the next one
+  T pre_o[NL], pre_e[NL];
+  fetch(r_lo, pre_e);
+  stash(raw[1], pre_e);
+  fetch(r_lo + 1, pre_o);
+  fetch(r_lo + 2, pre_e);
+  __syncthreads();
+  {
+    const bool pv = r_lo >= 0 && r_lo <= Pmax_r && r_lo != ghost_r;
+    T cv[4];
+    cell_even(own, raw[1], Cs[1], pv, Go, cv);
+    if (tid < NH) cell_even(halo, raw[1], Cs[1], pv, Gh, cv);
+  }
+  __syncthreads();
+  phase_b(Cs[1], t1s[1]);
+  __syncthreads();
+  e_prev = c_sweep(t1s[1]);
+  T o_first = 0;  // c-swept value of the first odd plane (for the first tb)
+  for (int p = r_lo + 1; p < r_hi; p += 2) {
+    // the ring slots are free: their last readers (phase A of the previous pair) are behind
+    // two barriers
+    stash(raw[0], pre_o);
+    stash(raw[1], pre_e);
+    __syncthreads();
+    if (p + 2 < r_hi) {
+      fetch(p + 2, pre_o);
+      fetch(p + 3, pre_e);
+    }
+    // ---- phase A: coefficient fields of both planes, owned coefficients to HBM ----
+    {
+      const bool pv_o = p >= 0 && p <= Pmax_r && p != ghost_r;
+      const bool pv_e = p + 1 >= 0 && p + 1 <= Pmax_r && p + 1 != ghost_r;
+      const T rr = rrs[p - r_lo];
+      T E[4], cve[4], cvo[4];
+      cell_even(own, raw[1], Cs[1], pv_e, E, cve);
+      cell_odd(own, raw[0], Cs[0], pv_o, rr, Go, E, cvo);
+#pragma unroll
+      for (int k = 0; k < 4; k++) Go[k] = E[k];
+      if (pv_o && p >= 2 * R0) emit(cvo, mr + (p - 1) / 2, 0);
+      if (pv_e && p + 1 < 2 * R0 + 2 * RCH) {
+        if (all_on || own.m0) A.coarse[(size_t)((p + 1) / 2) * mc * mf + coarse_off] = E[0];
+        emit(cve, (p + 1) / 2, 1);
+      }
+      if (tid < NH) {
+        T Eh[4], ch[4];
+        cell_even(halo, raw[1], Cs[1], pv_e, Eh, ch);
+        cell_odd(halo, raw[0], Cs[0], pv_o, rr, Gh, Eh, ch);
+#pragma unroll
+        for (int k = 0; k < 4; k++) Gh[k] = Eh[k];
+      }
+    }
+    __syncthreads();
+    phase_b(Cs[0], t1s[0]);
+    phase_b(Cs[1], t1s[1]);
+    __syncthreads();
+    // ---- phases C, D: c-sweep of both planes, r-sweep of coarse plane R = (p - 1) / 2 ----
+    const T vo = c_sweep(t1s[0]);
+    const T ve = c_sweep(t1s[1]);
+    if (p + 1 == 2 * R0) {
+      // first pair of the chunk: planes 2R0-2, 2R0-1, 2R0 give tb of coarse plane R0
+      T wr[9];
+#pragma unroll
+      for (int k = 0; k < 3; k++) wr[k] = wrs[0][k];
+      td_prev = e_prev * wr[0] + vo * wr[1] + ve * wr[2];
+    } else {
+      const int R = (p - 1) / 2;
+      if (R < mr) {
+        T wr[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) wr[k] = wrs[R - R0][k];
+        T tc = mass_tc(o_first, e_prev, vo, wr);
+        const T td = mass_td(e_prev, vo, ve, wr);
+        tc += td_prev * wr[7] + td * wr[8];
+        td_prev = td;
+        if (all_on || own.m0) A.load[(size_t)R * mc * mf + coarse_off] = tc;
+      }
+    }
+    o_first = vo;
+    e_prev = ve;
+  }
+#undef LI
+}
+
+} // namespace mgh

@@ -1,0 +1,239 @@
+// Streaming Thomas solves (IPK) for gfx950: every wave is a solver.
+//
+// A one-wave workgroup owns W <= 64 pencils, one per lane, and there are no
+// separate stream-in / stream-out phases and no barriers: the lane loads the
+// elements of ITS pencil straight from global memory a batch ahead of the
+// dependent chain (strided pencils: a row of W neighbouring pencils is one
+// coalesced segment; contiguous pencils: 16-byte pieces of the lane's own row,
+// a whole 128-byte line per batch), runs the forward substitution, parks the
+// forward results, then runs the backward substitution and stores each batch
+// (optionally accumulated +/- into the coarse nodal array: AddND / SubtractND
+// fused) as soon as its chain is done.
+//
+// Where the forward results are parked decides how many pencils a CU can work
+// on at once (the chain is pure dependent-operation latency, so residency is
+// the throughput): the remainder and the last full batch stay in registers,
+// the leading `n_glob` elements go back to global memory in place (they are
+// re-read a batch ahead of the backward chain; L2-resident) and only the rest
+// occupies LDS at sm[(i - n_glob) * W + lane] (conflict-free). The host picks
+// W and n_glob so that all tiles of a level are resident in ONE round.
+//
+// Arithmetic and order are those of tridiag_forward2 / tridiag_backward2
+// (reference include/mgard-x/DataRefactoring/MultiDimension/Correction/IPKFunctor.h:127,147)
+// with the am/bm indexing of IterativeProcessingKernel3D.hpp:108-124,223-262;
+// results are bit-identical to kernels_v1.hpp:k_ipk.
+//
+// FD = true: the quotient of the backward step is formed from a tabulated
+// correctly rounded reciprocal y = RN(1/b) with Markstein's FMA sequence
+//   q0 = RN(a y); r0 = fma(-b, q0, a); q1 = fma(r0, y, q0); r1 = fma(-b, q1, a); q = fma(r1, y, q1)
+// which equals the IEEE quotient RN(a / b) whenever no intermediate under- or
+// overflows (5 dependent operations instead of the 10 of the IEEE expansion).
+// Every numerator is checked against a safe window (or +0); a batch with any
+// numerator outside it is redone with the IEEE division, so the result is
+// bit-identical in all cases (tools/micro/fastdiv_check.hip: exhaustive check).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels_ipk.hpp"
+
+namespace mgh {
+
+template <typename T> __device__ __forceinline__ T fma_t(T a, T b, T c);
+template <> __device__ __forceinline__ float fma_t<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+template <> __device__ __forceinline__ double fma_t<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+template <typename T> __device__ __forceinline__ T div_markstein(T a, T b, T y) {
+  T q = a * y;
+  T r = fma_t<T>(-b, q, a);
+  q = fma_t<T>(r, y, q);
+  r = fma_t<T>(-b, q, a);
+  return fma_t<T>(r, y, q);
+}
+
+// numerator outside the window in which div_markstein is proven equal to a / b
+// (+0 is fine as well: every step of the sequence reproduces it)
+__device__ __forceinline__ bool fd_unsafe(float a) {
+  const float m = __builtin_fabsf(a);
+  return !(m >= 0x1p-80f && m <= 0x1p80f) && __float_as_uint(a) != 0u;
+}
+__device__ __forceinline__ bool fd_unsafe(double a) {
+  const double m = __builtin_fabs(a);
+  return !(m >= 0x1p-900 && m <= 0x1p900) && __double_as_longlong(a) != 0ll;
+}
+
+// Access to the lane's pencil. STRIDED: element i at p[i * stride]. Contiguous: p[i], moved in
+// 16-byte pieces (the rows start at arbitrary elements: 4/8-byte alignment only).
+template <typename T, int U, bool CONTIG> struct PencilIO {
+  using VU = typename VecU<T>::type;
+  using VA = typename VecU<T>::aligned_type;
+  static constexpr int VN = VecU<T>::N;
+  static __device__ __forceinline__ void load(const T *p, size_t stride, uint32_t i, T (&v)[U]) {
+    if constexpr (CONTIG) {
+      static_assert(U % VN == 0, "batch must be whole vectors");
+#pragma unroll
+      for (int q = 0; q < U / VN; q++) {
+        const VA t = *reinterpret_cast<const VU *>(p + i + q * VN);
+#pragma unroll
+        for (int k = 0; k < VN; k++) v[q * VN + k] = t[k];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; u++) v[u] = p[(size_t)(i + u) * stride];
+    }
+  }
+  static __device__ __forceinline__ void store(T *p, size_t stride, uint32_t i, const T (&v)[U]) {
+    if constexpr (CONTIG) {
+#pragma unroll
+      for (int q = 0; q < U / VN; q++) {
+        VA t;
+#pragma unroll
+        for (int k = 0; k < VN; k++) t[k] = v[q * VN + k];
+        *reinterpret_cast<VU *>(p + i + q * VN) = t;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; u++) p[(size_t)(i + u) * stride] = v[u];
+    }
+  }
+};
+
+// tt: [0,n) forward multiplier am[i]/bm[i]; [n,2n) am[i+1]; [2n,3n) bm[i+1]; FD: [3n,4n) RN(1/bm[i+1]).
+// Pencil id p in [0, npencil): base = (p / n_inner) * outer_stride + (p % n_inner) * inner_stride,
+// consecutive elements `stride` apart (CONTIG: stride == 1).
+template <typename T, int U, bool CONTIG, bool FD>
+__global__ void __launch_bounds__(64)
+k_ipk_stream(uint32_t npencil, uint32_t n_inner, size_t outer_stride, size_t inner_stride,
+             size_t stride, uint32_t n, uint32_t W, uint32_t n_glob, T *__restrict__ x,
+             const T *__restrict__ tt, T *__restrict__ add_to, int sign) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T *sm = reinterpret_cast<T *>(smem_raw);
+  using IO = PencilIO<T, U, CONTIG>;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t ls = min(lane, W - 1);  // lanes beyond the tile shadow its last pencil
+  // workgroups go round-robin to the 8 XCDs (own L2 each): give every XCD a contiguous range of
+  // tiles, so that the cache lines neighbouring tiles share are fetched by one L2
+  const uint32_t per = (gridDim.x + 7) / 8;
+  const uint32_t tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+  if ((uint64_t)tile * W >= npencil) return;  // grid is padded to a multiple of 8
+  const uint32_t pid = tile * W + ls;
+  const bool live = lane < W && pid < npencil;
+  const uint32_t p = min(pid, npencil - 1);
+  const size_t base = (size_t)(p / n_inner) * outer_stride + (size_t)(p % n_inner) * inner_stride;
+  T *px = x + base;
+  T *po = add_to ? add_to + base : px;
+  T *sl = sm + ls;
+  const uint32_t nb = n / U, rem = n - nb * U;
+  const T *am = tt + n, *bm = tt + 2 * n, *ym = tt + 3 * n;
+
+  // ---- forward: x[i] -= x[i-1] * w[i] -------------------------------------------------------
+  T prev = 0;
+  T v[U], R[U];  // v: current batch (after the loop: the last full batch), R: remainder
+  if (nb) IO::load(px, stride, 0, v);
+#pragma unroll
+  for (int u = 0; u < U - 1; u++)
+    R[u] = (uint32_t)u < rem ? px[(size_t)(nb * U + u) * stride] : (T)0;
+  for (uint32_t b = 0; b < nb; b++) {
+    const uint32_t i = b * U;
+    T nx[U];
+    if (b + 1 < nb) IO::load(px, stride, i + U, nx);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      v[u] = v[u] - prev * tt[i + u];
+      prev = v[u];
+    }
+    if (b + 1 < nb) {
+      if (i < n_glob) {
+        if (live) IO::store(px, stride, i, v);
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; u++) sl[(i - n_glob + u) * W] = v[u];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) v[u] = nx[u];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U - 1; u++)
+    if ((uint32_t)u < rem) {
+      R[u] = R[u] - prev * tt[nb * U + u];
+      prev = R[u];
+    }
+
+  // ---- backward: x[i] = (x[i] - am[i+1] x[i+1]) / bm[i+1] ----------------------------------
+  prev = 0;
+  {
+    T o[U];
+    if (add_to) {
+#pragma unroll
+      for (int u = 0; u < U - 1; u++)
+        o[u] = (uint32_t)u < rem ? po[(size_t)(nb * U + u) * stride] : (T)0;
+    }
+#pragma unroll
+    for (int u = U - 2; u >= 0; u--)
+      if ((uint32_t)u < rem) {
+        const uint32_t k = nb * U + u;
+        R[u] = (R[u] - am[k] * prev) / bm[k];
+        prev = R[u];
+      }
+#pragma unroll
+    for (int u = 0; u < U - 1; u++)
+      if ((uint32_t)u < rem && live) {
+        const T r = add_to ? (sign > 0 ? o[u] + R[u] : o[u] - R[u]) : R[u];
+        po[(size_t)(nb * U + u) * stride] = r;
+      }
+  }
+  for (uint32_t b = nb; b-- > 0;) {
+    const uint32_t i = b * U;
+    T nx[U], o[U];
+    if (b > 0) {  // forward results of the batch below: LDS or global, in flight during this chain
+      const uint32_t j = i - U;
+      if (j < n_glob) {
+        IO::load(px, stride, j, nx);
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; u++) nx[u] = sl[(j - n_glob + u) * W];
+      }
+    }
+    if (add_to) IO::load(po, stride, i, o);
+    bool redo = !FD;
+    if constexpr (FD) {
+      T a[U];
+      T pv = prev;
+      bool bad = false;
+#pragma unroll
+      for (int u = U - 1; u >= 0; u--) {
+        const T num = v[u] - am[i + u] * pv;
+        bad |= fd_unsafe(num);
+        a[u] = div_markstein<T>(num, bm[i + u], ym[i + u]);
+        pv = a[u];
+      }
+      redo = __any(bad);
+      if (!redo) {
+        prev = pv;
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = a[u];
+      }
+    }
+    if (redo) {
+#pragma unroll
+      for (int u = U - 1; u >= 0; u--) {
+        v[u] = (v[u] - am[i + u] * prev) / bm[i + u];
+        prev = v[u];
+      }
+    }
+    if (add_to) {
+#pragma unroll
+      for (int u = 0; u < U; u++) o[u] = sign > 0 ? o[u] + v[u] : o[u] - v[u];
+      if (live) IO::store(po, stride, i, o);
+    } else {
+      if (live) IO::store(po, stride, i, v);
+    }
+    if (b > 0) {
+#pragma unroll
+      for (int u = 0; u < U; u++) v[u] = nx[u];
+    }
+  }
+}
+
+} // namespace mgh
