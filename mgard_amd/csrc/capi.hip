@@ -20,6 +20,7 @@
 #include "hierarchy.hpp"
 #include "kernels_v1.hpp"
 #include "kernels_ipk.hpp"
+#include "kernels_ipk_stream.hpp"
 #include "kernels_fused.hpp"
 #include "kernels_fused2.hpp"
 #include "kernels_emit.hpp"
@@ -76,6 +77,9 @@ struct mgh_hierarchy {
   // MGH_FUSED_V: 2 = second-generation fused level kernel (kernels_fused2.hpp, default),
   // 1 = first generation (kernels_fused.hpp; cross-check)
   int fused_v = 2;
+  // MGH_IPK_STREAM: 1 = streaming Thomas solves (kernels_ipk_stream.hpp) on the levels whose
+  // LDS-staged solve needs more than one round of resident workgroups (default), 0 = never
+  int ipk_stream = 1;
   std::map<std::string, ProfileEntry> prof;
   size_t device_bytes = 0;
 };
@@ -376,6 +380,55 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
     if (rounds < best_rounds) {
       best_rounds = rounds;
       best_w = w;
+    }
+  }
+  // Streaming solves (float): when the LDS-staged tiles need more than one round, park half of
+  // every pencil in registers and only the rest in LDS, so that ALL tiles are resident at once
+  if constexpr (sizeof(T) == 4) {
+    constexpr uint32_t U = 16, KR = 8;
+    const uint32_t nb = n / U;
+    const size_t box_bytes = (size_t)m[0] * m[1] * m[2] * sizeof(T);
+    // (strided pencils only: measured inside the step at 512^3, ipk_c 59 -> 52 us, ipk_r of
+    // all levels 128 -> 103 us, but the contiguous solve 60 -> 65 us)
+    if (h->ipk_stream && axis != 2 && best_w && best_rounds >= 2 && nb >= KR &&
+        box_bytes < ((size_t)1 << 32)) {
+      const uint32_t parked = (nb - KR) * U;  // elements per pencil outside the registers
+      uint32_t W = 0, n_glob = 0;
+      for (uint32_t ng = 0; ng <= parked && !W; ng += U) {
+        for (uint32_t w : {64u, 60u, 56u, 48u, 40u, 32u}) {
+          const size_t lds = (size_t)w * (parked - ng) * sizeof(T);
+          // 230-odd VGPRs: two waves per SIMD
+          // (five 32 KB allocations do not fit one CU although 5 * 32 KB = 160 KB: leave a margin)
+          const size_t per_cu = lds ? std::min<size_t>((kLdsPerCU - 4096) / lds, 8) : 8;
+          if (per_cu && ((size_t)npencil + w - 1) / w <= per_cu * 256) {
+            W = w;
+            n_glob = ng;
+            break;
+          }
+        }
+      }
+      if (W) {
+        const size_t lds = (size_t)W * (parked - n_glob) * sizeof(T);
+        const unsigned blocks = ((npencil + W - 1) / W + 7) / 8 * 8;
+        uint32_t n_inner;
+        size_t outer_stride, inner_stride, stride;
+        if (axis == 2) { n_inner = npencil; outer_stride = 0; inner_stride = n; stride = 1; }
+        else if (axis == 1) { n_inner = m[2]; outer_stride = (size_t)m[1] * m[2]; inner_stride = 1; stride = m[2]; }
+        else { n_inner = npencil; outer_stride = 0; inner_stride = 1; stride = (size_t)m[1] * m[2]; }
+#define MGH_STREAM(CONTIG)                                                                    \
+  {                                                                                           \
+    static bool once = false;                                                                 \
+    if (!once) { TRY(allow_big_lds(k_ipk_stream<T, U, KR, 1, CONTIG, false>)); once = true; } \
+    return launch(h, name, s, [&] {                                                           \
+      k_ipk_stream<T, U, KR, 1, CONTIG, false><<<blocks, 64, lds, s>>>(                       \
+          npencil, n_inner, outer_stride, inner_stride, stride, n, W, n_glob, x, tt, add_to,  \
+          sign);                                                                              \
+    });                                                                                       \
+  }
+        if (axis == 2) MGH_STREAM(true)
+        MGH_STREAM(false)
+#undef MGH_STREAM
+      }
     }
   }
   if (axis == 2 && best_w) {
@@ -1441,6 +1494,8 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     if (e3 && e3[0] >= '0' && e3[0] <= '2') h->split = e3[0] - '0';
     const char *e6 = std::getenv("MGH_FUSED_V");
     if (e6 && e6[0] >= '1' && e6[0] <= '2') h->fused_v = e6[0] - '0';
+    const char *e7 = std::getenv("MGH_IPK_STREAM");
+    if (e7 && e7[0] >= '0' && e7[0] <= '1') h->ipk_stream = e7[0] - '0';
     const char *e4 = std::getenv("MGH_EMIT_BPC");
     if (e4 && std::atoi(e4) > 0) h->emit_bpc = (unsigned)std::atoi(e4);
     const char *e5 = std::getenv("MGH_EMIT_CCH");

@@ -62,38 +62,51 @@ __device__ __forceinline__ bool fd_unsafe(double a) {
   return !(m >= 0x1p-900 && m <= 0x1p900) && __double_as_longlong(a) != 0ll;
 }
 
-// Access to the lane's pencil. STRIDED: element i at p[i * stride]. Contiguous: p[i], moved in
-// 16-byte pieces (the rows start at arbitrary elements: 4/8-byte alignment only).
+// Access to the lane's pencil: wave-uniform array pointer + 32-bit lane offset `lo` (BYTES), so
+// that every access is `global_load/store v, v_off, s[base:base+1]` and the uniform part of the
+// address is scalar arithmetic (arrays of < 2^32 bytes; the host checks). STRIDED: element i at
+// x[lo + i * stride]. Contiguous: x[lo + i], moved in 16-byte pieces (the rows start at arbitrary
+// elements: 4/8-byte alignment only).
 template <typename T, int U, bool CONTIG> struct PencilIO {
   using VU = typename VecU<T>::type;
   using VA = typename VecU<T>::aligned_type;
   static constexpr int VN = VecU<T>::N;
-  static __device__ __forceinline__ void load(const T *p, size_t stride, uint32_t i, T (&v)[U]) {
+  static __device__ __forceinline__ void load(const T *x, uint32_t lo, size_t stride, uint32_t i, T (&v)[U]) {
     if constexpr (CONTIG) {
       static_assert(U % VN == 0, "batch must be whole vectors");
+      const T *r = x + i;
 #pragma unroll
       for (int q = 0; q < U / VN; q++) {
-        const VA t = *reinterpret_cast<const VU *>(p + i + q * VN);
+        const VA t = *reinterpret_cast<const VU *>(reinterpret_cast<const char *>(r + q * VN) + lo);
 #pragma unroll
         for (int k = 0; k < VN; k++) v[q * VN + k] = t[k];
       }
     } else {
+      const T *r = x + (size_t)i * stride;
 #pragma unroll
-      for (int u = 0; u < U; u++) v[u] = p[(size_t)(i + u) * stride];
+      for (int u = 0; u < U; u++) {
+        v[u] = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(r) + lo);
+        r += stride;
+      }
     }
   }
-  static __device__ __forceinline__ void store(T *p, size_t stride, uint32_t i, const T (&v)[U]) {
+  static __device__ __forceinline__ void store(T *x, uint32_t lo, size_t stride, uint32_t i, const T (&v)[U]) {
     if constexpr (CONTIG) {
+      T *r = x + i;
 #pragma unroll
       for (int q = 0; q < U / VN; q++) {
         VA t;
 #pragma unroll
         for (int k = 0; k < VN; k++) t[k] = v[q * VN + k];
-        *reinterpret_cast<VU *>(p + i + q * VN) = t;
+        *reinterpret_cast<VU *>(reinterpret_cast<char *>(r + q * VN) + lo) = t;
       }
     } else {
+      T *r = x + (size_t)i * stride;
 #pragma unroll
-      for (int u = 0; u < U; u++) p[(size_t)(i + u) * stride] = v[u];
+      for (int u = 0; u < U; u++) {
+        *reinterpret_cast<T *>(reinterpret_cast<char *>(r) + lo) = v[u];
+        r += stride;
+      }
     }
   }
 };
@@ -101,11 +114,19 @@ template <typename T, int U, bool CONTIG> struct PencilIO {
 // tt: [0,n) forward multiplier am[i]/bm[i]; [n,2n) am[i+1]; [2n,3n) bm[i+1]; FD: [3n,4n) RN(1/bm[i+1]).
 // Pencil id p in [0, npencil): base = (p / n_inner) * outer_stride + (p % n_inner) * inner_stride,
 // consecutive elements `stride` apart (CONTIG: stride == 1).
-template <typename T, int U, bool CONTIG, bool FD>
+// KR = number of trailing full batches whose forward results stay in registers (the host
+// guarantees n / U >= KR); the batches before them are parked in LDS, the first n_glob / U of
+// them in global memory. PD = depth of the load pipeline in batches (PD divides KR): the loads of
+// the register-resident batches and of the first PD others are ALL issued before the first chain
+// starts, and a pipeline slot is refilled as soon as its chain is done, so the forward sweep pays
+// the memory latency a couple of times instead of once per batch; the values to accumulate into
+// (add_to) run through the same slots PD batches ahead of the backward sweep.
+template <typename T, int U, int KR, int PD, bool CONTIG, bool FD>
 __global__ void __launch_bounds__(64)
 k_ipk_stream(uint32_t npencil, uint32_t n_inner, size_t outer_stride, size_t inner_stride,
              size_t stride, uint32_t n, uint32_t W, uint32_t n_glob, T *__restrict__ x,
              const T *__restrict__ tt, T *__restrict__ add_to, int sign) {
+  static_assert(KR % PD == 0, "pipeline depth must divide the register-resident batches");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T *sm = reinterpret_cast<T *>(smem_raw);
   using IO = PencilIO<T, U, CONTIG>;
@@ -119,83 +140,22 @@ k_ipk_stream(uint32_t npencil, uint32_t n_inner, size_t outer_stride, size_t inn
   const uint32_t pid = tile * W + ls;
   const bool live = lane < W && pid < npencil;
   const uint32_t p = min(pid, npencil - 1);
-  const size_t base = (size_t)(p / n_inner) * outer_stride + (size_t)(p % n_inner) * inner_stride;
-  T *px = x + base;
-  T *po = add_to ? add_to + base : px;
+  const uint32_t lo = (uint32_t)(((size_t)(p / n_inner) * outer_stride + (size_t)(p % n_inner) * inner_stride) * sizeof(T));
+  T *xo = add_to ? add_to : x;
   T *sl = sm + ls;
   const uint32_t nb = n / U, rem = n - nb * U;
+  const uint32_t nbl = nb - KR;  // batches parked in LDS / global memory
   const T *am = tt + n, *bm = tt + 2 * n, *ym = tt + 3 * n;
 
-  // ---- forward: x[i] -= x[i-1] * w[i] -------------------------------------------------------
-  T prev = 0;
-  T v[U], R[U];  // v: current batch (after the loop: the last full batch), R: remainder
-  if (nb) IO::load(px, stride, 0, v);
-#pragma unroll
-  for (int u = 0; u < U - 1; u++)
-    R[u] = (uint32_t)u < rem ? px[(size_t)(nb * U + u) * stride] : (T)0;
-  for (uint32_t b = 0; b < nb; b++) {
-    const uint32_t i = b * U;
-    T nx[U];
-    if (b + 1 < nb) IO::load(px, stride, i + U, nx);
+  auto fwd_chain = [&](uint32_t i, T(&v)[U], T &prev) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
       v[u] = v[u] - prev * tt[i + u];
       prev = v[u];
     }
-    if (b + 1 < nb) {
-      if (i < n_glob) {
-        if (live) IO::store(px, stride, i, v);
-      } else {
-#pragma unroll
-        for (int u = 0; u < U; u++) sl[(i - n_glob + u) * W] = v[u];
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) v[u] = nx[u];
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < U - 1; u++)
-    if ((uint32_t)u < rem) {
-      R[u] = R[u] - prev * tt[nb * U + u];
-      prev = R[u];
-    }
-
-  // ---- backward: x[i] = (x[i] - am[i+1] x[i+1]) / bm[i+1] ----------------------------------
-  prev = 0;
-  {
-    T o[U];
-    if (add_to) {
-#pragma unroll
-      for (int u = 0; u < U - 1; u++)
-        o[u] = (uint32_t)u < rem ? po[(size_t)(nb * U + u) * stride] : (T)0;
-    }
-#pragma unroll
-    for (int u = U - 2; u >= 0; u--)
-      if ((uint32_t)u < rem) {
-        const uint32_t k = nb * U + u;
-        R[u] = (R[u] - am[k] * prev) / bm[k];
-        prev = R[u];
-      }
-#pragma unroll
-    for (int u = 0; u < U - 1; u++)
-      if ((uint32_t)u < rem && live) {
-        const T r = add_to ? (sign > 0 ? o[u] + R[u] : o[u] - R[u]) : R[u];
-        po[(size_t)(nb * U + u) * stride] = r;
-      }
-  }
-  for (uint32_t b = nb; b-- > 0;) {
-    const uint32_t i = b * U;
-    T nx[U], o[U];
-    if (b > 0) {  // forward results of the batch below: LDS or global, in flight during this chain
-      const uint32_t j = i - U;
-      if (j < n_glob) {
-        IO::load(px, stride, j, nx);
-      } else {
-#pragma unroll
-        for (int u = 0; u < U; u++) nx[u] = sl[(j - n_glob + u) * W];
-      }
-    }
-    if (add_to) IO::load(po, stride, i, o);
+  };
+  // backward chain of the batch at i (values in v; o = what to accumulate into), then its store
+  auto bwd_batch = [&](uint32_t i, T(&v)[U], const T(&o)[U], T &prev) {
     bool redo = !FD;
     if constexpr (FD) {
       T a[U];
@@ -223,15 +183,114 @@ k_ipk_stream(uint32_t npencil, uint32_t n_inner, size_t outer_stride, size_t inn
       }
     }
     if (add_to) {
+      T r[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) o[u] = sign > 0 ? o[u] + v[u] : o[u] - v[u];
-      if (live) IO::store(po, stride, i, o);
+      for (int u = 0; u < U; u++) r[u] = sign > 0 ? o[u] + v[u] : o[u] - v[u];
+      if (live) IO::store(xo, lo, stride, i, r);
     } else {
-      if (live) IO::store(po, stride, i, v);
+      if (live) IO::store(xo, lo, stride, i, v);
     }
-    if (b > 0) {
+  };
+
+  // ---- forward: x[i] -= x[i-1] * w[i] -------------------------------------------------------
+  T prev = 0;
+  T R[U];         // remainder
+  T buf[PD][U];   // pipeline slots
+  T park[KR][U];  // the last KR full batches
 #pragma unroll
-      for (int u = 0; u < U; u++) v[u] = nx[u];
+  for (int j = 0; j < PD; j++)
+    if ((uint32_t)j < nbl) IO::load(x, lo, stride, j * U, buf[j]);
+#pragma unroll
+  for (int j = 0; j < KR; j++) IO::load(x, lo, stride, (nbl + j) * U, park[j]);
+#pragma unroll
+  for (int u = 0; u < U - 1; u++)
+    R[u] = (uint32_t)u < rem ? *reinterpret_cast<const T *>(reinterpret_cast<const char *>(x + (size_t)(nb * U + u) * stride) + lo) : (T)0;
+  for (uint32_t g = 0; g < nbl; g += PD) {
+#pragma unroll
+    for (int j = 0; j < PD; j++) {
+      const uint32_t b = g + j;
+      if (b < nbl) {
+        const uint32_t i = b * U;
+        fwd_chain(i, buf[j], prev);
+        if (i < n_glob) {
+          if (live) IO::store(x, lo, stride, i, buf[j]);
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; u++) sl[(i - n_glob + u) * W] = buf[j][u];
+        }
+        if (b + PD < nbl) IO::load(x, lo, stride, i + PD * U, buf[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < KR; j++) fwd_chain((nbl + j) * U, park[j], prev);
+#pragma unroll
+  for (int u = 0; u < U - 1; u++)
+    if ((uint32_t)u < rem) {
+      R[u] = R[u] - prev * tt[nb * U + u];
+      prev = R[u];
+    }
+
+  // ---- backward: x[i] = (x[i] - am[i+1] x[i+1]) / bm[i+1] ----------------------------------
+  // backward order t = 0 .. nb-1 is batch nb-1-t; its add_to values sit in slot t % PD
+  if (add_to) {
+#pragma unroll
+    for (int t = 0; t < PD; t++) IO::load(xo, lo, stride, (nb - 1 - t) * U, buf[t]);  // nb >= KR >= PD
+  }
+  prev = 0;
+  {
+    T o[U];
+    if (add_to) {
+#pragma unroll
+      for (int u = 0; u < U - 1; u++)
+        o[u] = (uint32_t)u < rem ? *reinterpret_cast<const T *>(reinterpret_cast<const char *>(xo + (size_t)(nb * U + u) * stride) + lo) : (T)0;
+    }
+#pragma unroll
+    for (int u = U - 2; u >= 0; u--)
+      if ((uint32_t)u < rem) {
+        const uint32_t k = nb * U + u;
+        R[u] = (R[u] - am[k] * prev) / bm[k];
+        prev = R[u];
+      }
+#pragma unroll
+    for (int u = 0; u < U - 1; u++)
+      if ((uint32_t)u < rem && live) {
+        const T r = add_to ? (sign > 0 ? o[u] + R[u] : o[u] - R[u]) : R[u];
+        *reinterpret_cast<T *>(reinterpret_cast<char *>(xo + (size_t)(nb * U + u) * stride) + lo) = r;
+      }
+  }
+  auto load_parked = [&](uint32_t j, T(&dst)[U]) {
+    if (j < n_glob) {
+      IO::load(x, lo, stride, j, dst);
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; u++) dst[u] = sl[(j - n_glob + u) * W];
+    }
+  };
+  T v[U];
+  // the first parked batch is in flight while the register-resident ones are solved
+  if (nbl > 0) load_parked((nbl - 1) * U, v);
+#pragma unroll
+  for (int t = 0; t < KR; t++) {
+    const uint32_t b = nb - 1 - t;
+    bwd_batch(b * U, park[KR - 1 - t], buf[t % PD], prev);
+    if (add_to && (uint32_t)(t + PD) < nb) IO::load(xo, lo, stride, (b - PD) * U, buf[t % PD]);
+  }
+  for (uint32_t g = 0; g < nbl; g += PD) {
+#pragma unroll
+    for (int j = 0; j < PD; j++) {
+      const uint32_t t = KR + g + j;  // slot t % PD == j
+      if (t < nb) {
+        const uint32_t b = nb - 1 - t;
+        T nx[U];
+        if (b > 0) load_parked((b - 1) * U, nx);
+        bwd_batch(b * U, v, buf[j], prev);
+        if (add_to && t + PD < nb) IO::load(xo, lo, stride, (b - PD) * U, buf[j]);
+        if (b > 0) {
+#pragma unroll
+          for (int u = 0; u < U; u++) v[u] = nx[u];
+        }
+      }
     }
   }
 }

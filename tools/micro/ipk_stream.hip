@@ -29,6 +29,19 @@ __global__ void __launch_bounds__(64) k_chain(int steps, float a0, float w, floa
   if (prev == 12345.f) out[0] = prev;
 }
 
+// streaming baselines: in-place scale of N floats, 16 bytes per lane / 4 bytes per lane
+__global__ void __launch_bounds__(256) k_scale4(float4 *x, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 v = x[i]; v.x *= 2; v.y *= 2; v.z *= 2; v.w *= 2; x[i] = v;
+  }
+}
+__global__ void __launch_bounds__(256) k_scale1(float *x, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] *= 2;
+}
+__global__ void __launch_bounds__(256) k_scale_add(float *x, float *a, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a[i] += x[i];
+}
+
 int main(int argc, char **argv) {
   const uint32_t n = argc > 1 ? atoi(argv[1]) : 257;
   const size_t N = (size_t)n * n * n;
@@ -110,9 +123,10 @@ int main(int argc, char **argv) {
   auto set_ref = [&](bool with_add) { CK(hipMemcpy(hr.data(), with_add ? add : x, N * 4, hipMemcpyDeviceToHost)); };
 
   // one variant of the streaming kernel; dir: 2 = f (contiguous), 1 = c, 0 = r (+ add)
-  auto stream = [&](int dir, uint32_t W, uint32_t lds_batches_max, auto kern, int U, const char *tag) {
+  auto stream = [&](int dir, uint32_t W, uint32_t lds_batches_max, auto kern, int U, int KR, const char *tag) {
     const uint32_t nb = n / U;
-    const uint32_t parked = nb ? nb - 1 : 0;  // batches parked between the sweeps
+    if ((int)nb < KR) return;
+    const uint32_t parked = nb - KR;  // batches parked outside the registers
     const uint32_t lb = std::min(parked, lds_batches_max);
     const uint32_t n_glob = (parked - lb) * U;
     const size_t lds = (size_t)W * lb * U * 4;
@@ -120,7 +134,7 @@ int main(int argc, char **argv) {
     CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const unsigned blocks = ((np + W - 1) / W + 7) / 8 * 8;
     char name[128];
-    snprintf(name, sizeof name, "stream %s dir=%d W=%u U=%d lds=%zuK n_glob=%u", tag, dir, W, U, lds / 1024, n_glob);
+    snprintf(name, sizeof name, "stream %s dir=%d W=%u U=%d KR=%d lds=%zuK n_glob=%u", tag, dir, W, U, KR, lds / 1024, n_glob);
     timeit(name, dir == 0, [&] {
       if (dir == 2) kern<<<blocks, 64, lds>>>(np, np, 0, n, 1, n, W, n_glob, x, tt, nullptr, 1);
       if (dir == 1) kern<<<blocks, 64, lds>>>(np, n, (size_t)n * n, 1, n, n, W, n_glob, x, tt, nullptr, 1);
@@ -128,6 +142,15 @@ int main(int argc, char **argv) {
     }, true);
   };
 
+  for (int blocks : {1024, 2048, 4096, 16384}) {
+    char nm[64];
+    snprintf(nm, sizeof nm, "baseline scale float4 blocks=%d", blocks);
+    timeit(nm, false, [&] { k_scale4<<<blocks, 256>>>((float4 *)x, N / 4); }, false);
+    snprintf(nm, sizeof nm, "baseline scale float blocks=%d", blocks);
+    timeit(nm, false, [&] { k_scale1<<<blocks, 256>>>(x, N); }, false);
+    snprintf(nm, sizeof nm, "baseline add float blocks=%d", blocks);
+    timeit(nm, true, [&] { k_scale_add<<<blocks, 256>>>(x, add, N); }, false);
+  }
   for (int dir : {2, 1, 0}) {
     // reference: the LDS-staged kernels
     if (dir == 2)
@@ -137,26 +160,21 @@ int main(int argc, char **argv) {
     if (dir == 0)
       timeit("lds strided<48> r add", true, [&] { k_ipk_lds_strided<float, 48><<<((np + 47) / 48 + 7) / 8 * 8, 256, 48 * n * 4>>>(1, n * n, (size_t)n * n, (size_t)n * n, n, x, tt, add, 1); }, false);
     set_ref(dir == 0);
-    for (uint32_t W : {64u, 48u, 32u}) {
-      for (uint32_t lbm : {1000u, 4u, 2u, 0u}) {
-        if (dir == 2) {
-          stream(dir, W, lbm, k_ipk_stream<float, 32, true, false>, 32, "ieee");
-          stream(dir, W, lbm, k_ipk_stream<float, 32, true, true>, 32, "fma ");
-        } else {
-          stream(dir, W, lbm, k_ipk_stream<float, 32, false, false>, 32, "ieee");
-          stream(dir, W, lbm, k_ipk_stream<float, 32, false, true>, 32, "fma ");
-        }
+#define VARIANTS(U, KR, PD)                                                                     \
+    for (uint32_t W : {60u, 48u})                                                               \
+      for (uint32_t lbm : {1000u, 4u}) {                                                         \
+        if (dir == 2) {                                                                         \
+          stream(dir, W, lbm, k_ipk_stream<float, U, KR, PD, true, false>, U, KR, "ieee pd" #PD);          \
+          stream(dir, W, lbm, k_ipk_stream<float, U, KR, PD, true, true>, U, KR, "fma  pd" #PD);           \
+        } else {                                                                                \
+          stream(dir, W, lbm, k_ipk_stream<float, U, KR, PD, false, false>, U, KR, "ieee pd" #PD);         \
+          stream(dir, W, lbm, k_ipk_stream<float, U, KR, PD, false, true>, U, KR, "fma  pd" #PD);          \
+        }                                                                                       \
       }
-      for (uint32_t lbm : {1000u, 8u, 0u}) {
-        if (dir == 2) {
-          stream(dir, W, lbm, k_ipk_stream<float, 16, true, false>, 16, "ieee");
-          stream(dir, W, lbm, k_ipk_stream<float, 16, true, true>, 16, "fma ");
-        } else {
-          stream(dir, W, lbm, k_ipk_stream<float, 16, false, false>, 16, "ieee");
-          stream(dir, W, lbm, k_ipk_stream<float, 16, false, true>, 16, "fma ");
-        }
-      }
-    }
+    VARIANTS(16, 8, 4)
+    VARIANTS(16, 8, 2)
+    VARIANTS(16, 8, 1)
+    VARIANTS(16, 4, 4)
   }
   CK(hipDeviceSynchronize());
   return 0;
