@@ -80,6 +80,9 @@ struct mgh_hierarchy {
   // MGH_IPK_STREAM: 1 = streaming Thomas solves (kernels_ipk_stream.hpp) on the levels whose
   // LDS-staged solve needs more than one round of resident workgroups (default), 0 = never
   int ipk_stream = 1;
+  // MGH_FUSED_FACES: 1 = face tiles for the remainder columns / rows of a level (default), 0 = off
+  int fused_faces = 1;
+  int fused_xcd = 1;  // MGH_FUSED_XCD: tiles of a level in contiguous ranges per XCD (default 1)
   std::map<std::string, ProfileEntry> prof;
   size_t device_bytes = 0;
 };
@@ -717,24 +720,56 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
       // (RCH = 4) on the small levels where the march length is pure latency
       // second generation: needs the dictionary test in 32 bits
       const bool v2 = h->fused_v == 2 && (OUT != OUT_Q || (qp->dict_size >= 0 && qp->dict_size <= ((int64_t)1 << 30)));
-      if (cls == 2) {
+      if (v2) {
+        // tiles of the launch (kernels_fused2.hpp: Fused2Grid): a remainder of up to 4 coarse
+        // columns / rows beyond the full tiles goes to face tiles, the last r-chunk owns what is
+        // left of the planes (one more than the others for sizes 2^k + 1)
+        const int rchs[3] = {1, 4, 16};
+        const int RCHv = rchs[cls];
+        Fused2Grid G{};
+        const int mfi = (int)b.m[2], mci = (int)b.m[1], mri = (int)b.m[0];
+        const int nfull_f = (mfi - 1) / TF, rem_f = mfi - nfull_f * TF;
+        const int nfull_c = (mci - 1) / TC, rem_c = mci - nfull_c * TC;
+        const bool face_f = h->fused_faces && nfull_f >= 1 && rem_f <= 4;
+        const bool face_c = h->fused_faces && nfull_c >= 1 && rem_c <= 4;
+        G.gxm = face_f ? nfull_f : (mfi + TF - 1) / TF;
+        const int gym = face_c ? nfull_c : (mci + TC - 1) / TC;
+        G.n_main = G.gxm * gym;
+        G.ff_F0 = nfull_f * TF;
+        G.n_ff = face_f ? (mci + 63) / 64 : 0;
+        G.cf_C0 = nfull_c * TC;
+        G.n_cf = face_c ? ((face_f ? G.ff_F0 : mfi) + 63) / 64 : 0;
+        G.nchunk = std::max(1, (mri - 1 + RCHv - 1) / RCHv);
+        G.xcd_ranges = h->fused_xcd;
+        const unsigned ntile = (unsigned)(G.n_main + G.n_ff + G.n_cf);
+        const dim3 grid(G.xcd_ranges ? (ntile + 7) / 8 * 8 : ntile, (unsigned)G.nchunk, 1);
+        const bool faces = G.n_ff || G.n_cf;
+        const char *nm = cls == 2 ? (OUT == OUT_Q ? "level_fused_q" : "level_fused")
+                                  : (OUT == OUT_Q ? "level_fused_q_small" : "level_fused_small");
+#define MGH_F2(RCH)                                                                          \
+  TRY(launch(h, nm, s, [&] {                                                                  \
+    if (faces) k_level_fused2<T, OUT, TC, TF, RCH, true><<<grid, 256, 0, s>>>(A, G);          \
+    else k_level_fused2<T, OUT, TC, TF, RCH, false><<<grid, 256, 0, s>>>(A, G);               \
+  }));
+        if (cls == 2) MGH_F2(16)
+        else if (cls == 1) MGH_F2(4)
+        else MGH_F2(1)
+#undef MGH_F2
+      } else if (cls == 2) {
         const dim3 grid(gx, gy, (b.m[0] + 15) / 16);
         TRY(launch(h, OUT == OUT_Q ? "level_fused_q" : "level_fused", s, [&] {
-          if (v2) k_level_fused2<T, OUT, TC, TF, 16><<<grid, 256, 0, s>>>(A);
-          else k_level_fused<T, OUT, TC, TF, 16, false><<<grid, 256, 0, s>>>(A);
+          k_level_fused<T, OUT, TC, TF, 16, false><<<grid, 256, 0, s>>>(A);
         }));
       } else if (cls == 1) {
         const dim3 grid(gx, gy, (b.m[0] + 3) / 4);
         TRY(launch(h, OUT == OUT_Q ? "level_fused_q_small" : "level_fused_small", s, [&] {
-          if (v2) k_level_fused2<T, OUT, TC, TF, 4><<<grid, 256, 0, s>>>(A);
-          else k_level_fused<T, OUT, TC, TF, 4, false><<<grid, 256, 0, s>>>(A);
+          k_level_fused<T, OUT, TC, TF, 4, false><<<grid, 256, 0, s>>>(A);
         }));
       } else {
         // few tiles: the march length is the whole cost -> one coarse plane per block
         const dim3 grid(gx, gy, b.m[0]);
         TRY(launch(h, OUT == OUT_Q ? "level_fused_q_small" : "level_fused_small", s, [&] {
-          if (v2) k_level_fused2<T, OUT, TC, TF, 1><<<grid, 256, 0, s>>>(A);
-          else k_level_fused<T, OUT, TC, TF, 1, true><<<grid, 256, 0, s>>>(A);
+          k_level_fused<T, OUT, TC, TF, 1, true><<<grid, 256, 0, s>>>(A);
         }));
       }
     }
@@ -1496,6 +1531,10 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     if (e6 && e6[0] >= '1' && e6[0] <= '2') h->fused_v = e6[0] - '0';
     const char *e7 = std::getenv("MGH_IPK_STREAM");
     if (e7 && e7[0] >= '0' && e7[0] <= '1') h->ipk_stream = e7[0] - '0';
+    const char *e8 = std::getenv("MGH_FUSED_FACES");
+    if (e8 && e8[0] >= '0' && e8[0] <= '1') h->fused_faces = e8[0] - '0';
+    const char *e9 = std::getenv("MGH_FUSED_XCD");
+    if (e9 && e9[0] >= '0' && e9[0] <= '1') h->fused_xcd = e9[0] - '0';
     const char *e4 = std::getenv("MGH_EMIT_BPC");
     if (e4 && std::atoi(e4) > 0) h->emit_bpc = (unsigned)std::atoi(e4);
     const char *e5 = std::getenv("MGH_EMIT_CCH");

@@ -20,7 +20,8 @@
 //     value is recomputed on the rare path), and the upper word of an in-dictionary symbol is 0;
 //   * the r-sweep keeps tb(R+1) = td(R) (the same expression with the same operands:
 //     LPKFunctor.h:77-93, dist[2R], dist[2R+1]) and a 3-value window instead of 5;
-//   * 3 barriers per plane pair instead of 5.
+//   * 2 barriers per plane pair instead of 5: the next pair's raw planes are written into the
+//     ring beside the f-sweep.
 // Arithmetic per value is unchanged (same operations in the same order, no FMA contraction):
 // results are bit-identical to kernels_fused.hpp / kernels_v1.hpp.
 // Reference: DataRefactoring.hpp:80-109, GridProcessingKernel3D.hpp:21-1179,
@@ -57,42 +58,50 @@ template <typename T> __device__ __forceinline__ T mass_td(T c, T d, T e, const 
   return c * w[4] + d * w[5] + e * w[6];
 }
 
+// LDS of one tile (elements of T): raw ring 2 planes, coefficient fields 2 planes, f-swept rows,
+// ratios, r-sweep constants (RCH + 1 coarse planes: the last chunk of a level owns one more)
+template <int TC, int TF, int RCH> struct Fused2Geom {
+  static constexpr int WC = 2 * TC + 3, WF = 2 * TF + 3, HF = TF + 2, ROW = 2 * HF, PL = WC * ROW;
+  static constexpr int TP = TF + 1;
+  static constexpr int o_cs = 2 * PL, o_t1 = 4 * PL, o_rf = o_t1 + 2 * WC * TP, o_rc = o_rf + WF,
+                       o_rr = o_rc + WC, o_wr = (o_rr + 2 * RCH + 5 + 3) / 4 * 4,
+                       elems = o_wr + (RCH + 1) * 12;
+};
+
+// One tile: TC x TF coarse nodes at (C0, F0), marching over the coarse planes [R0, R0 + rch).
+// c_end / f_end: coarse indices from which on the nodes belong to another tile of the launch
+// (face tiles, below); lds: Fused2Geom<TC, TF, RCH>::elems elements, 16-byte aligned.
 template <typename T, int OUT, int TC, int TF, int RCH>
-__global__ void __launch_bounds__(TC * TF)
-k_level_fused2(FusedArgs<T> A) {
-  constexpr int WC = 2 * TC + 3;
-  constexpr int WF = 2 * TF + 3;
-  constexpr int HF = TF + 2;     // even-f slots of a window row (odd-f slots: TF + 1)
-  constexpr int ROW = 2 * HF;    // LDS row: [0,HF) even f, [HF, HF+TF+1) odd f (stride-1 access)
-  constexpr int PL = WC * ROW;   // one window plane
+__device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const int C0,
+                                            const int R0, const int rch, const int c_end,
+                                            const int f_end, T *lds) {
+  using GM = Fused2Geom<TC, TF, RCH>;
+  constexpr int WC = GM::WC;
+  constexpr int WF = GM::WF;
+  constexpr int HF = GM::HF;     // even-f slots of a window row (odd-f slots: TF + 1)
+  constexpr int ROW = GM::ROW;   // LDS row: [0,HF) even f, [HF, HF+TF+1) odd f (stride-1 access)
+  constexpr int PL = GM::PL;     // one window plane
   constexpr int NT = TC * TF;    // one owned cell / one c-sweep output per thread
   constexpr int NH = (TC + 2) * (TF + 2) - TC * TF;  // halo cells
-  constexpr int TP = TF + 1;     // pitch of the f-swept rows
+  constexpr int TP = GM::TP;     // pitch of the f-swept rows
   constexpr int BX = (WC * TF - 2 * NT);  // f-sweep items of the third round (per plane)
   static_assert(NH <= NT, "halo cells are handled in one extra pass");
   static_assert(BX >= 0 && BX <= NT && BX % TF == 0, "f-sweep: two full rounds + one partial");
-  __shared__ T raw[2][PL];          // [0] odd plane, [1] even plane of the pair
-  __shared__ T Cs[2][PL];           // coefficient fields of the pair
-  __shared__ T t1s[2][WC * TP];     // f-swept rows of the pair
-  __shared__ T rfs[WF];
-  __shared__ T rcs[WC];
-  __shared__ T rrs[2 * RCH + 3];    // ratio_r[p - 1] of plane p = r_lo + index
-  __shared__ __attribute__((aligned(16))) T wrs[RCH][12];  // r-sweep constants of the chunk
+  T *const raw0 = lds, *const raw1 = lds + PL;             // odd / even plane of the pair
+  T *const Cs0 = lds + GM::o_cs, *const Cs1 = Cs0 + PL;    // coefficient fields of the pair
+  T *const t1s0 = lds + GM::o_t1, *const t1s1 = t1s0 + WC * TP;  // f-swept rows of the pair
+  T *const rfs = lds + GM::o_rf;
+  T *const rcs = lds + GM::o_rc;
+  T *const rrs = lds + GM::o_rr;  // ratio_r[p - 1] of plane p = r_lo + index
+  T *const wrs = lds + GM::o_wr;  // r-sweep constants of the chunk, [rch][12]
 #define LI(lc, lf) ((lc) * ROW + ((lf) & 1) * HF + ((lf) >> 1))
 
-  if (OUT == OUT_Q && A.qp) {
-    A.quantizer = A.qp[A.level];
-    A.volume = A.qp[A.nlev + A.level];
-  }
   const int tid = threadIdx.x;
-  // r-chunks in reverse launch order: whatever ran before this kernel (the norm reduction,
-  // the level above) leaves the END of the level's input in the memory-side cache
-  const int F0 = blockIdx.x * TF, C0 = blockIdx.y * TC, R0 = (gridDim.z - 1 - blockIdx.z) * RCH;
   const int nr = A.n[0], nc = A.n[1], nf = A.n[2];
   const int mr = A.m[0], mc = A.m[1], mf = A.m[2];
   const int c_lo = 2 * C0 - 2, f_lo = 2 * F0 - 2;
   const int r_lo = 2 * R0 - 2;
-  const int r_hi = min(2 * R0 + 2 * RCH, 2 * mr);  // planes beyond 2mr-2 are empty anyway
+  const int r_hi = min(2 * R0 + 2 * rch, 2 * mr);  // planes beyond 2mr-2 are empty anyway
   const int Pmax_r = 2 * mr - 2, Pmax_c = 2 * mc - 2, Pmax_f = 2 * mf - 2;
   // ghost (padded) positions of even-sized dims; -7 = none
   const int ghost_r = (nr % 2 == 0) ? nr - 1 : -7;
@@ -108,13 +117,13 @@ k_level_fused2(FusedArgs<T> A) {
     const int P = c_lo + e;
     rcs[e] = (P >= 0 && P < nc) ? A.ratio[1][P] : (T)0;
   }
-  for (int e = tid; e < 2 * RCH + 3; e += NT) {
+  for (int e = tid; e < 2 * rch + 3; e += NT) {
     const int P = r_lo + e - 1;  // left neighbour of plane r_lo + e
     rrs[e] = (P >= 0 && P < nr) ? A.ratio[0][P] : (T)0;
   }
-  for (int e = tid; e < RCH * 9; e += NT) {
+  for (int e = tid; e < rch * 9; e += NT) {
     const int R = R0 + e / 9, k = e % 9;
-    wrs[e / 9][k] = R < mr ? A.mass[0][k * mr + R] : (T)0;
+    wrs[(e / 9) * 12 + k] = R < mr ? A.mass[0][k * mr + R] : (T)0;
   }
   // per-thread sweep constants: f-sweep for jf = tid % TF, c-sweep for jc = tid / TF
   const int jf = tid % TF, jc = tid / TF;
@@ -156,6 +165,7 @@ k_level_fused2(FusedArgs<T> A) {
   struct Cell {
     bool c1, f1;       // odd row / odd column of the cell lies inside the window
     bool m0, m1, m2, m3;  // node (ee, eo, oe, oo) exists in the grid and is not a ghost node
+    bool s0, s1, s2, s3;  // ... and belongs to this tile (store predicate)
     T rc, rf;          // interpolation ratios at the left (even) nodes
     uint32_t i00, i01, i02, i10, i11, i20, i22;  // LDS indices (clamped inside the window)
   };
@@ -173,6 +183,11 @@ k_level_fused2(FusedArgs<T> A) {
     c.m1 = vc0 && vf1;
     c.m2 = vc1 && vf0;
     c.m3 = vc1 && vf1;
+    const bool mine = C0 + cj < c_end && F0 + fj < f_end;
+    c.s0 = c.m0 && mine;
+    c.s1 = c.m1 && mine;
+    c.s2 = c.m2 && mine;
+    c.s3 = c.m3 && mine;
     const int dc1 = c.c1 ? 1 : 0, dc2 = c.c1 ? 2 : 0, df1 = c.f1 ? 1 : 0, df2 = c.f1 ? 2 : 0;
     c.rc = rcs[lc0];
     c.rf = rfs[lf0];
@@ -200,7 +215,7 @@ k_level_fused2(FusedArgs<T> A) {
   }
   const Cell halo = make_cell(hcj, hfj);
   // boundary tiles predicate their stores; everywhere else every owned node exists
-  const bool all_on = __syncthreads_and(own.m0 && own.m1 && own.m2 && own.m3) != 0;
+  const bool all_on = __syncthreads_and(own.s0 && own.s1 && own.s2 && own.s3) != 0;
 
   // output offsets of the owned cell relative to the output plane (reordered layout:
   // c index C0+jc / mc+C0+jc, same in f); planes of < 2^29 elements (capi.hip: fused_ok)
@@ -256,15 +271,15 @@ k_level_fused2(FusedArgs<T> A) {
         for (int k = 0; k < 4; k++)
           if (k >= K0) o[off[k]] = cv[k];
       } else {
-        if (K0 == 0 && own.m0) o[off[0]] = cv[0];
-        if (own.m1) o[off[1]] = cv[1];
-        if (own.m2) o[off[2]] = cv[2];
-        if (own.m3) o[off[3]] = cv[3];
+        if (K0 == 0 && own.s0) o[off[0]] = cv[0];
+        if (own.s1) o[off[1]] = cv[1];
+        if (own.s2) o[off[2]] = cv[2];
+        if (own.s3) o[off[3]] = cv[3];
       }
       return;
     }
     if (OUT != OUT_Q) return;
-    const bool on[4] = {own.m0, own.m1, own.m2, own.m3};
+    const bool on[4] = {own.s0, own.s1, own.s2, own.s3};
     int32_t qs[4];
     bool slow = false;
     if (A.prep_huffman) {
@@ -373,84 +388,145 @@ k_level_fused2(FusedArgs<T> A) {
   T td_prev = 0;   // r-sweep: td of the previous coarse plane = tb of the next one
   T pre_o[NL], pre_e[NL];
   fetch(r_lo, pre_e);
-  stash(raw[1], pre_e);
+  stash(raw1, pre_e);
   fetch(r_lo + 1, pre_o);
   fetch(r_lo + 2, pre_e);
   __syncthreads();
   {
     const bool pv = r_lo >= 0 && r_lo <= Pmax_r && r_lo != ghost_r;
     T cv[4];
-    cell_even(own, raw[1], Cs[1], pv, Go, cv);
-    if (tid < NH) cell_even(halo, raw[1], Cs[1], pv, Gh, cv);
+    cell_even(own, raw1, Cs1, pv, Go, cv);
+    if (tid < NH) cell_even(halo, raw1, Cs1, pv, Gh, cv);
   }
   __syncthreads();
-  phase_b(Cs[1], t1s[1]);
+  // (the first pair's raw planes go into the ring next to the f-sweep of the first plane,
+  // exactly like every later pair's)
+  stash(raw0, pre_o);
+  stash(raw1, pre_e);
+  if (r_lo + 3 < r_hi) {
+    fetch(r_lo + 3, pre_o);
+    fetch(r_lo + 4, pre_e);
+  }
+  phase_b(Cs1, t1s1);
   __syncthreads();
-  e_prev = c_sweep(t1s[1]);
-  T o_first = 0;  // c-swept value of the first odd plane (for the first tb)
+  e_prev = c_sweep(t1s1);
+  T o_prev = 0;  // c-swept value of the previous odd plane
+  // Two barriers per pair. Per pair and thread: A (reads the raw ring, writes Cs) | barrier |
+  // stash of the NEXT pair's raw planes + f-sweep (reads Cs, writes t1s) | barrier | c- and
+  // r-sweep (read t1s) -- and straight on into A of the next pair: the ring was refilled before
+  // the last barrier, Cs was last read before it, and t1s is rewritten only behind the next one.
   for (int p = r_lo + 1; p < r_hi; p += 2) {
-    // the ring slots are free: their last readers (phase A of the previous pair) are behind
-    // two barriers
-    stash(raw[0], pre_o);
-    stash(raw[1], pre_e);
-    __syncthreads();
-    if (p + 2 < r_hi) {
-      fetch(p + 2, pre_o);
-      fetch(p + 3, pre_e);
-    }
     // ---- phase A: coefficient fields of both planes, owned coefficients to HBM ----
     {
       const bool pv_o = p >= 0 && p <= Pmax_r && p != ghost_r;
       const bool pv_e = p + 1 >= 0 && p + 1 <= Pmax_r && p + 1 != ghost_r;
       const T rr = rrs[p - r_lo];
       T E[4], cve[4], cvo[4];
-      cell_even(own, raw[1], Cs[1], pv_e, E, cve);
-      cell_odd(own, raw[0], Cs[0], pv_o, rr, Go, E, cvo);
+      cell_even(own, raw1, Cs1, pv_e, E, cve);
+      cell_odd(own, raw0, Cs0, pv_o, rr, Go, E, cvo);
 #pragma unroll
       for (int k = 0; k < 4; k++) Go[k] = E[k];
       if (pv_o && p >= 2 * R0) emit(cvo, mr + (p - 1) / 2, 0);
-      if (pv_e && p + 1 < 2 * R0 + 2 * RCH) {
-        if (all_on || own.m0) A.coarse[(size_t)((p + 1) / 2) * mc * mf + coarse_off] = E[0];
+      if (pv_e && p + 1 < 2 * R0 + 2 * rch) {
+        if (all_on || own.s0) A.coarse[(size_t)((p + 1) / 2) * mc * mf + coarse_off] = E[0];
         emit(cve, (p + 1) / 2, 1);
       }
       if (tid < NH) {
         T Eh[4], ch[4];
-        cell_even(halo, raw[1], Cs[1], pv_e, Eh, ch);
-        cell_odd(halo, raw[0], Cs[0], pv_o, rr, Gh, Eh, ch);
+        cell_even(halo, raw1, Cs1, pv_e, Eh, ch);
+        cell_odd(halo, raw0, Cs0, pv_o, rr, Gh, Eh, ch);
 #pragma unroll
         for (int k = 0; k < 4; k++) Gh[k] = Eh[k];
       }
     }
     __syncthreads();
-    phase_b(Cs[0], t1s[0]);
-    phase_b(Cs[1], t1s[1]);
+    if (p + 2 < r_hi) {
+      stash(raw0, pre_o);
+      stash(raw1, pre_e);
+      if (p + 4 < r_hi) {
+        fetch(p + 4, pre_o);
+        fetch(p + 5, pre_e);
+      }
+    }
+    phase_b(Cs0, t1s0);
+    phase_b(Cs1, t1s1);
     __syncthreads();
     // ---- phases C, D: c-sweep of both planes, r-sweep of coarse plane R = (p - 1) / 2 ----
-    const T vo = c_sweep(t1s[0]);
-    const T ve = c_sweep(t1s[1]);
+    const T vo = c_sweep(t1s0);
+    const T ve = c_sweep(t1s1);
     if (p + 1 == 2 * R0) {
       // first pair of the chunk: planes 2R0-2, 2R0-1, 2R0 give tb of coarse plane R0
       T wr[9];
 #pragma unroll
-      for (int k = 0; k < 3; k++) wr[k] = wrs[0][k];
+      for (int k = 0; k < 3; k++) wr[k] = wrs[k];
       td_prev = e_prev * wr[0] + vo * wr[1] + ve * wr[2];
     } else {
       const int R = (p - 1) / 2;
       if (R < mr) {
         T wr[9];
 #pragma unroll
-        for (int k = 0; k < 9; k++) wr[k] = wrs[R - R0][k];
-        T tc = mass_tc(o_first, e_prev, vo, wr);
+        for (int k = 0; k < 9; k++) wr[k] = wrs[(R - R0) * 12 + k];
+        T tc = mass_tc(o_prev, e_prev, vo, wr);
         const T td = mass_td(e_prev, vo, ve, wr);
         tc += td_prev * wr[7] + td * wr[8];
         td_prev = td;
-        if (all_on || own.m0) A.load[(size_t)R * mc * mf + coarse_off] = tc;
+        if (all_on || own.s0) A.load[(size_t)R * mc * mf + coarse_off] = tc;
       }
     }
-    o_first = vo;
+    o_prev = vo;
     e_prev = ve;
   }
 #undef LI
+}
+
+// Tiles of one launch. Sizes 2^k + 1 leave one coarse column / row / plane beyond the last full
+// tile, and a whole tile for it costs almost as much as a full one (the instruction stream is the
+// same): the remainder of f and c (up to 4 coarse nodes) goes to FACE tiles instead -- the same
+// tile code instantiated 64 x 4 and 4 x 64 -- and the last r-chunk owns one plane more.
+struct Fused2Grid {
+  int gxm, n_main;    // main tiles TC x TF: gxm along f, n_main in all
+  int ff_F0, n_ff;    // f-face: tiles of 64 x 4 at F0 = ff_F0, C0 = k * 64 (n_ff = 0: none)
+  int cf_C0, n_cf;    // c-face: tiles of 4 x 64 at C0 = cf_C0, F0 = k * 64 (n_cf = 0: none)
+  int nchunk;         // r-chunks of RCH coarse planes; the last one takes what is left (<= RCH + 1)
+  int xcd_ranges;     // tiles handed to the XCDs in contiguous ranges (grid.x padded to 8)
+};
+
+template <typename T, int OUT, int TC, int TF, int RCH, bool FACES>
+__global__ void __launch_bounds__(TC * TF)
+k_level_fused2(FusedArgs<T> A, Fused2Grid G) {
+  static_assert(TC * TF == 256, "face tiles are 64 x 4 and 4 x 64");
+  constexpr int e0 = Fused2Geom<TC, TF, RCH>::elems, e1 = Fused2Geom<64, 4, RCH>::elems,
+                e2 = Fused2Geom<4, 64, RCH>::elems;
+  constexpr int elems = FACES ? (e0 > e1 ? (e0 > e2 ? e0 : e2) : (e1 > e2 ? e1 : e2)) : e0;
+  __shared__ __attribute__((aligned(16))) T lds[elems];
+  if (OUT == OUT_Q && A.qp) {
+    A.quantizer = A.qp[A.level];
+    A.volume = A.qp[A.nlev + A.level];
+  }
+  // r-chunks in reverse launch order: whatever ran before this kernel (the norm reduction,
+  // the level above) leaves the END of the level's input in the memory-side cache
+  const int chunk = G.nchunk - 1 - (int)blockIdx.y;
+  const int R0 = chunk * RCH;
+  const int rch = chunk == G.nchunk - 1 ? A.m[0] - R0 : RCH;
+  // workgroups go round-robin to the 8 XCDs (own L2 each): every XCD gets a contiguous range of
+  // the launch's tiles, so that the partial cache lines neighbouring tiles write (the output rows
+  // start at odd multiples of 8 bytes) meet in one L2. The grid is padded to a multiple of 8.
+  int b = blockIdx.x;
+  if (G.xcd_ranges) {
+    const int per = gridDim.x / 8;
+    b = (b % 8) * per + b / 8;
+    if (b >= G.n_main + G.n_ff + G.n_cf) return;
+  }
+  const int f_main_end = G.n_ff ? G.ff_F0 : A.m[2], c_main_end = G.n_cf ? G.cf_C0 : A.m[1];
+  if (!FACES || b < G.n_main) {
+    level_tile2<T, OUT, TC, TF, RCH>(A, (b % G.gxm) * TF, (b / G.gxm) * TC, R0, rch, c_main_end,
+                                     f_main_end, lds);
+  } else if (b < G.n_main + G.n_ff) {
+    level_tile2<T, OUT, 64, 4, RCH>(A, G.ff_F0, (b - G.n_main) * 64, R0, rch, A.m[1], A.m[2], lds);
+  } else {
+    level_tile2<T, OUT, 4, 64, RCH>(A, (b - G.n_main - G.n_ff) * 64, G.cf_C0, R0, rch, A.m[1],
+                                    f_main_end, lds);
+  }
 }
 
 } // namespace mgh
