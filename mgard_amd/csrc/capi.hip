@@ -646,7 +646,9 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
   constexpr size_t kTailLdsMax = 150 * 1024;
   int l_tail = 0;  // levels l_tail .. 1 go to the tail (0 = none)
   for (int l = std::min(L, kTailMaxLevels); l >= 1; l--) {
-    if (tail_lds_elems(ds->lt[l].box) * sizeof(T) <= kTailLdsMax) {
+    size_t tab = 0;
+    for (int k = l; k >= 1; k--) tab += tail_table_elems(ds->lt[k].box);
+    if ((tail_lds_elems(ds->lt[l].box) + tab) * sizeof(T) + tail_header_bytes<T>() <= kTailLdsMax) {
       l_tail = l;
       break;
     }
@@ -806,7 +808,9 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
       TA.head_volume = qp->vol[0];
     }
     TA.out = A;
-    const size_t lds = tail_lds_elems(ds->lt[l_tail].box) * sizeof(T);
+    size_t tab = 0;
+    for (int k = l_tail; k >= 1; k--) tab += tail_table_elems(ds->lt[k].box);
+    const size_t lds = (tail_lds_elems(ds->lt[l_tail].box) + tab) * sizeof(T) + tail_header_bytes<T>();
     static bool once = false;
     if (!once) { TRY(allow_big_lds(k_tail<T, OUT>)); once = true; }
     TRY(launch(h, "tail", s, [&] { k_tail<T, OUT><<<1, 1024, lds, s>>>(TA); }));

@@ -45,25 +45,63 @@ inline size_t tail_lds_elems(const Box3 &b) {
   return 2 * nf + (size_t)b.n[0] * b.n[1] * b.m[2] + (size_t)b.n[0] * b.m[1] * b.m[2] + 2 * mc;
 }
 
+constexpr int kTailQpMax = 40;  // = kMaxLevels (kernels_fused.hpp)
+// bytes of the LDS header of k_tail: table offsets + quantizer table
+template <typename T> constexpr size_t tail_header_bytes() {
+  return (kTailMaxLevels * 9 * sizeof(uint32_t) + 2 * kTailQpMax * sizeof(T) + 15) / 16 * 16;
+}
+// LDS elements of the tables (ratios, mass constants, Thomas coefficients) of one tail level
+inline size_t tail_table_elems(const Box3 &b) {
+  return (size_t)b.n[0] + b.n[1] + b.n[2] + 12 * ((size_t)b.m[0] + b.m[1] + b.m[2]);
+}
+
 template <typename T, int OUT>
 __global__ void __launch_bounds__(1024)
 k_tail(TailArgs<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const uint32_t tid = threadIdx.x, NT = blockDim.x;
   FusedArgs<T> O = A.out;
+  // Every phase below reads its tables per element; out of global memory each phase would start
+  // with a dependent round trip of a microsecond or two (12 us per level measured). All tables of
+  // the tail levels are a few KB: they go to LDS once, behind the data regions.
+  // (header of the dynamic LDS: a static __shared__ array would count against the 160 KB)
+  uint32_t(*toff)[9] = reinterpret_cast<uint32_t(*)[9]>(smem_raw);  // ratio[3], mass[3], thomas[3]
+  T *qps = reinterpret_cast<T *>(smem_raw + kTailMaxLevels * 9 * sizeof(uint32_t));
+  T *tab;
   // carve LDS for the first (largest) level; deeper levels reuse the same regions
   T *X, *Y, *C, *T1, *T2, *T3;
   {
     const Box3 &b = A.lv[0].b;
     const size_t nf = (size_t)b.n[0] * b.n[1] * b.n[2];
     const size_t mc = (size_t)b.m[0] * b.m[1] * b.m[2];
-    T *base = reinterpret_cast<T *>(smem_raw);
+    T *base = reinterpret_cast<T *>(smem_raw + tail_header_bytes<T>());
     X = base;
     C = X + nf;
     T1 = C + nf;
     T2 = T1 + (size_t)b.n[0] * b.n[1] * b.m[2];
     T3 = T2 + (size_t)b.n[0] * b.m[1] * b.m[2];
     Y = T3 + mc;
+    tab = Y + mc;
+    if (tid == 0) {
+      uint32_t o = 0;
+      for (int li = 0; li < A.nlevels; li++) {
+        const Box3 &bl = A.lv[li].b;
+        for (int d = 0; d < 3; d++) { toff[li][d] = o; o += bl.n[d]; }
+        for (int d = 0; d < 3; d++) { toff[li][3 + d] = o; o += 9 * bl.m[d]; }
+        for (int d = 0; d < 3; d++) { toff[li][6 + d] = o; o += 3 * bl.m[d]; }
+      }
+    }
+    if (O.qp)
+      for (uint32_t e = tid; e < 2u * (uint32_t)O.nlev && e < 2u * kMaxLevels; e += NT) qps[e] = O.qp[e];
+    __syncthreads();
+    for (int li = 0; li < A.nlevels; li++) {
+      const TailLevel<T> &L = A.lv[li];
+      for (int d = 0; d < 3; d++) {
+        for (uint32_t e = tid; e < L.b.n[d]; e += NT) tab[toff[li][d] + e] = L.ratio[d][e];
+        for (uint32_t e = tid; e < 9 * L.b.m[d]; e += NT) tab[toff[li][3 + d] + e] = L.mass[d][e];
+        for (uint32_t e = tid; e < 3 * L.b.m[d]; e += NT) tab[toff[li][6 + d] + e] = L.thomas[d][e];
+      }
+    }
     // bring the nodal values of the first tail level into LDS
     const uint32_t n1 = b.n[1], n2 = b.n[2];
     for (uint32_t e = tid; e < nf; e += NT) {
@@ -77,8 +115,12 @@ k_tail(TailArgs<T> A) {
     const Box3 b = L.b;
     const uint32_t n0 = b.n[0], n1 = b.n[1], n2 = b.n[2];
     const uint32_t m0 = b.m[0], m1 = b.m[1], m2 = b.m[2];
-    O.quantizer = O.qp ? O.qp[L.level] : L.quantizer;
-    O.volume = O.qp ? O.qp[O.nlev + L.level] : L.volume;
+    const bool qp_lds = O.qp && O.nlev <= kMaxLevels;
+    O.quantizer = qp_lds ? qps[L.level] : (O.qp ? O.qp[L.level] : L.quantizer);
+    O.volume = qp_lds ? qps[O.nlev + L.level] : (O.qp ? O.qp[O.nlev + L.level] : L.volume);
+    const T *ratio0 = tab + toff[li][0], *ratio1 = tab + toff[li][1], *ratio2 = tab + toff[li][2];
+    const T *mass0 = tab + toff[li][3], *mass1 = tab + toff[li][4], *mass2 = tab + toff[li][5];
+    const T *thom0 = tab + toff[li][6], *thom1 = tab + toff[li][7], *thom2 = tab + toff[li][8];
     // ---- coefficients (+ output) and coarse nodes ----
     {
       const uint32_t total = n0 * n1 * n2;
@@ -88,8 +130,8 @@ k_tail(TailArgs<T> A) {
         const uint32_t ee = live ? e : 0;
         const uint32_t k = ee % n2, j = (ee / n2) % n1, i = ee / (n2 * n1);
         bool is_coarse;
-        const T v = gpk_reo_elem(b, (const T *)X, (size_t)n1 * n2, (size_t)n2, L.ratio[0],
-                                 L.ratio[1], L.ratio[2], i, j, k, is_coarse);
+        const T v = gpk_reo_elem(b, (const T *)X, (size_t)n1 * n2, (size_t)n2, ratio0, ratio1,
+                                 ratio2, i, j, k, is_coarse);
         const size_t lin = (size_t)i * O.dI + (size_t)j * O.dJ + k;
         if (live) {
           if (is_coarse)
@@ -114,8 +156,8 @@ k_tail(TailArgs<T> A) {
       const uint32_t total = n0 * n1 * m2;
       for (uint32_t e = tid; e < total; e += NT) {
         const uint32_t k = e % m2, j = (e / m2) % n1, i = e / (m2 * n1);
-        T1[e] = lpk_elem<T, 2>(n2, m2, (const T *)C, (size_t)n1 * n2, (size_t)n2, L.mass[2], m0,
-                               m1, i, j, k);
+        T1[e] = lpk_elem<T, 2>(n2, m2, (const T *)C, (size_t)n1 * n2, (size_t)n2, mass2, m0, m1, i,
+                               j, k);
       }
     }
     __syncthreads();
@@ -123,25 +165,24 @@ k_tail(TailArgs<T> A) {
       const uint32_t total = n0 * m1 * m2;
       for (uint32_t e = tid; e < total; e += NT) {
         const uint32_t k = e % m2, j = (e / m2) % m1, i = e / (m2 * m1);
-        T2[e] = lpk_elem<T, 1>(n1, m1, (const T *)T1, (size_t)n1 * m2, (size_t)m2, L.mass[1], 0, 0,
-                               i, j, k);
+        T2[e] = lpk_elem<T, 1>(n1, m1, (const T *)T1, (size_t)n1 * m2, (size_t)m2, mass1, 0, 0, i, j,
+                               k);
       }
     }
     __syncthreads();
     const uint32_t mtot = m0 * m1 * m2;
     for (uint32_t e = tid; e < mtot; e += NT) {
       const uint32_t k = e % m2, j = (e / m2) % m1, i = e / (m2 * m1);
-      T3[e] = lpk_elem<T, 0>(n0, m0, (const T *)T2, (size_t)m1 * m2, (size_t)m2, L.mass[0], 0, 0,
-                             i, j, k);
+      T3[e] = lpk_elem<T, 0>(n0, m0, (const T *)T2, (size_t)m1 * m2, (size_t)m2, mass0, 0, 0, i, j, k);
     }
     __syncthreads();
     // ---- Thomas solves in LDS: f, c, r ----
-    for (uint32_t p = tid; p < m0 * m1; p += NT) thomas_lds<T, false>(T3 + (size_t)p * m2, 1, m2, L.thomas[2]);
+    for (uint32_t p = tid; p < m0 * m1; p += NT) thomas_lds<T, false>(T3 + (size_t)p * m2, 1, m2, thom2);
     __syncthreads();
     for (uint32_t p = tid; p < m0 * m2; p += NT)
-      thomas_lds<T, false>(T3 + (size_t)(p / m2) * m1 * m2 + (p % m2), m2, m1, L.thomas[1]);
+      thomas_lds<T, false>(T3 + (size_t)(p / m2) * m1 * m2 + (p % m2), m2, m1, thom1);
     __syncthreads();
-    for (uint32_t p = tid; p < m1 * m2; p += NT) thomas_lds<T, false>(T3 + p, m1 * m2, m0, L.thomas[0]);
+    for (uint32_t p = tid; p < m1 * m2; p += NT) thomas_lds<T, false>(T3 + p, m1 * m2, m0, thom0);
     __syncthreads();
     // ---- apply the correction (AddND); the corrected coarse nodes are the next level ----
     for (uint32_t e = tid; e < mtot; e += NT) Y[e] += T3[e];
@@ -155,8 +196,9 @@ k_tail(TailArgs<T> A) {
     const TailLevel<T> &L = A.lv[A.nlevels - 1];
     const uint32_t m0 = L.b.m[0], m1 = L.b.m[1], m2 = L.b.m[2];
     const uint32_t total = m0 * m1 * m2;
-    O.quantizer = O.qp ? O.qp[0] : A.head_quantizer;
-    O.volume = O.qp ? O.qp[O.nlev] : A.head_volume;
+    const bool qp_lds = O.qp && O.nlev <= kMaxLevels;
+    O.quantizer = qp_lds ? qps[0] : (O.qp ? O.qp[0] : A.head_quantizer);
+    O.volume = qp_lds ? qps[O.nlev] : (O.qp ? O.qp[O.nlev] : A.head_volume);
     for (uint32_t e0 = 0; e0 < total; e0 += NT) {
       const uint32_t e = e0 + tid;
       const bool live = e < total;
