@@ -92,6 +92,13 @@ int mgh_infer_shape(const void *compressed_data, size_t compressed_size, int *D_
                     uint64_t *shape_out /* [MGH_MAX_DIM] */);
 int mgh_infer_data_type(const void *compressed_data, size_t compressed_size, int *dtype_out);
 
+/* Stream contract of mgh_compress / mgh_decompress: the calls return when the result is
+ * complete (they synchronise their own pipeline streams before returning). The pipeline streams
+ * are created with default (blocking) flags like the reference's queues
+ * (include/mgard-x/RuntimeX/DeviceAdapters/DeviceAdapterHip.h:514), i.e. they are ordered against
+ * the NULL stream: a device-resident input that earlier work on the NULL stream is still
+ * producing is complete before the first stage reads it. Work the caller has in flight on other
+ * NON-BLOCKING streams is not waited for -- synchronise those before the call. */
 void mgh_free_device(void *p);
 /* release_cache (compress_x.hpp:159): drops this thread's cached hierarchies and buffers. */
 void mgh_release_cache(void);

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -360,6 +361,17 @@ template <typename K> int allow_big_lds(K kernel) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCU));
   return MGH_SUCCESS;
 }
+// ... once per DEVICE (the attribute belongs to the function on the current device) and safe
+// from several host threads: `done` holds one bit per device ordinal.
+template <typename K> int allow_big_lds_once(K kernel, std::atomic<uint64_t> &done) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  const uint64_t bit = (uint64_t)1 << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return MGH_SUCCESS;
+  TRY(allow_big_lds(kernel));
+  done.fetch_or(bit, std::memory_order_release);
+  return MGH_SUCCESS;
+}
 
 // Thomas solve along `axis` of the compact (m[0], m[1], m[2]) box.
 template <typename T>
@@ -420,8 +432,8 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
         else { n_inner = npencil; outer_stride = 0; inner_stride = 1; stride = (size_t)m[1] * m[2]; }
 #define MGH_STREAM(CONTIG)                                                                    \
   {                                                                                           \
-    static bool once = false;                                                                 \
-    if (!once) { TRY(allow_big_lds(k_ipk_stream<T, U, KR, 1, CONTIG, false>)); once = true; } \
+    static std::atomic<uint64_t> once{0};                                                                 \
+    TRY(allow_big_lds_once(k_ipk_stream<T, U, KR, 1, CONTIG, false>, once)); \
     return launch(h, name, s, [&] {                                                           \
       k_ipk_stream<T, U, KR, 1, CONTIG, false><<<blocks, 64, lds, s>>>(                       \
           npencil, n_inner, outer_stride, inner_stride, stride, n, W, n_glob, x, tt, add_to,  \
@@ -437,8 +449,8 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
   if (axis == 2 && best_w) {
     const uint32_t pad = (n % 2 == 0) ? 1u : 0u;
     const uint32_t magic = (uint32_t)((((uint64_t)1 << 32) + n - 1) / n);  // e/n for e < 2^17
-    static bool once = false;
-    if (!once) { TRY(allow_big_lds(k_ipk_lds_contig<T>)); once = true; }
+    static std::atomic<uint64_t> once{0};
+    TRY(allow_big_lds_once(k_ipk_lds_contig<T>, once));
     const uint32_t P = (uint32_t)best_w;
     return launch(h, name, s, [&] {
       k_ipk_lds_contig<T><<<(npencil + P - 1) / P, 256, P * pencil_bytes, s>>>(
@@ -454,8 +466,8 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
     const unsigned blocks = ((npencil + best_w - 1) / best_w + 7) / 8 * 8;  // XCD-contiguous tile ranges
 #define MGH_STRIDED(W)                                                                        \
   {                                                                                           \
-    static bool once = false;                                                                 \
-    if (!once) { TRY(allow_big_lds(k_ipk_lds_strided<T, W>)); once = true; }                  \
+    static std::atomic<uint64_t> once{0};                                                                 \
+    TRY(allow_big_lds_once(k_ipk_lds_strided<T, W>, once));                  \
     return launch(h, name, s, [&] {                                                           \
       k_ipk_lds_strided<T, W><<<blocks, 256, lds, s>>>(n_outer, n_inner, outer_stride,        \
                                                        stride, n, x, tt, add_to, sign);       \
@@ -493,8 +505,8 @@ int ipk_fc_launch(mgh_hierarchy *h, const uint32_t *m, T *x, const T *tt_f, cons
                   hipStream_t s) {
   const uint32_t pitch = m[2] | 1u;
   if ((size_t)m[1] * pitch * sizeof(T) <= 150 * 1024 && m[1] <= 1024 && m[2] <= 1024) {
-    static bool once = false;
-    if (!once) { TRY(allow_big_lds(k_ipk_plane_fc<T>)); once = true; }
+    static std::atomic<uint64_t> once{0};
+    TRY(allow_big_lds_once(k_ipk_plane_fc<T>, once));
     const uint32_t magic = (uint32_t)((((uint64_t)1 << 32) + m[2] - 1) / m[2]);  // e / m2, e < 2^32 / m2
     return launch(h, "ipk_fc", s, [&] {
       k_ipk_plane_fc<T><<<m[0], 256, (size_t)m[1] * pitch * sizeof(T), s>>>(m[1], m[2], pitch, magic,
@@ -811,8 +823,8 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
     size_t tab = 0;
     for (int k = l_tail; k >= 1; k--) tab += tail_table_elems(ds->lt[k].box);
     const size_t lds = (tail_lds_elems(ds->lt[l_tail].box) + tab) * sizeof(T) + tail_header_bytes<T>();
-    static bool once = false;
-    if (!once) { TRY(allow_big_lds(k_tail<T, OUT>)); once = true; }
+    static std::atomic<uint64_t> once{0};
+    TRY(allow_big_lds_once(k_tail<T, OUT>, once));
     TRY(launch(h, "tail", s, [&] { k_tail<T, OUT><<<1, 1024, lds, s>>>(TA); }));
   } else {
     const Box3 &b = ds->lt[1].box;
@@ -1136,8 +1148,8 @@ int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> 
     HA.oJ = (l_head == L) ? ds->full_J : bl.n[2];
     HA.oI = (l_head == L) ? ds->full_I : (size_t)bl.n[1] * bl.n[2];
     const size_t lds = head_lds_elems(bl) * sizeof(T);
-    static bool once = false;
-    if (!once) { TRY(allow_big_lds(k_recompose_head<T, QT>)); once = true; }
+    static std::atomic<uint64_t> once{0};
+    TRY(allow_big_lds_once(k_recompose_head<T, QT>, once));
     TRY(launch(h, "recompose_head", st, [&] { k_recompose_head<T, QT><<<1, 1024, lds, st>>>(HA); }));
   } else {
     const Box3 &b = ds->lt[1].box;

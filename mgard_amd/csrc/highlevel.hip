@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <memory>
 #include <chrono>
@@ -30,6 +31,15 @@
 extern "C" void mgh_set_last_error_(const char *msg);  // capi.hip
 
 namespace {
+// true exactly once per device ordinal for the given flag word (kernel attributes such as the
+// dynamic-LDS limit belong to the function on the current device); safe from several threads
+inline bool hl_once_per_device(std::atomic<uint64_t> &done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return true;
+  const uint64_t bit = (uint64_t)1 << (dev & 63);
+  return !(done.fetch_or(bit, std::memory_order_acq_rel) & bit);
+}
+
 
 using namespace mgh;
 
@@ -275,6 +285,10 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
   HL_TRY(c->entry.ensure(nchunk * 8));
   HL_TRY(c->total.ensure(8));
   hl_debug("lossless_compress: begin");
+  // the frequency counts are 32-bit (a subdomain of 2^32 symbols is 32 GB of int64: the domain
+  // decomposer never produces one, but the stand-alone entry point could be handed one)
+  if (n >= ((uint64_t)1 << 32))
+    return hl_fail(MGH_ERR_INVALID_ARGUMENT, "lossless stage: more than 2^32 - 1 symbols in one record");
   HL_HIP(hipMemsetAsync(c->freq.p, 0, dict * 4, st));
   const unsigned hblocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
   if (sym16)
@@ -332,8 +346,8 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
     HL_TRY(c->units.ensure(std::max<size_t>(cap, 1) * 8 + 8));
     HL_TRY(c->state.ensure((3 + nchunk) * 8));
     HL_HIP(hipMemsetAsync(c->state.p, 0, (3 + nchunk) * 8, st));
-    static bool once = false;
-    if (!once) {
+    static std::atomic<uint64_t> once{0};
+    if (hl_once_per_device(once)) {
       const int lim = 144 * 1024;
       HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_encode_chain<int64_t, uint64_t>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -343,7 +357,6 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lim));
       HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_encode_chain<uint16_t, uint32_t>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-      once = true;
     }
     auto enc = [&](auto sym_tag, auto code_tag) {
       using SYM = decltype(sym_tag);
@@ -538,11 +551,10 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
   while (tb > 8 && ((size_t)4 << tb) + lds_keys_ring > 154 * 1024) tb--;
   if (const char *e = std::getenv("MGH_HUFF_TB")) tb = std::max(8, std::min(tb, atoi(e)));  // developer switch
   const size_t lds = ((size_t)4 << tb) + lds_keys_ring;
-  static bool once = false;
-  if (!once) {
+  static std::atomic<uint64_t> once{0};
+  if (hl_once_per_device(once)) {
     HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_decode),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    once = true;
   }
   static const bool serial_decode = std::getenv("MGH_HUFF_SERIAL_DECODE") != nullptr;  // cross-check
   hl_debug("lossless_decompress: uploads done (units, tables, outliers)");
@@ -568,13 +580,12 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
     const int waves = huff::decode_ring_lds(dt.size(), 16) <= lds_cap ? 16 : 8;
     HL_TRY(c->dtable.ensure(dt.size() * 4));
     HL_HIP(hipMemcpyAsync(c->dtable.p, dt.data(), dt.size() * 4, hipMemcpyHostToDevice, st));
-    static bool once3 = false;
-    if (!once3) {
+    static std::atomic<uint64_t> once3{0};
+    if (hl_once_per_device(once3)) {
       HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_decode_ring<int64_t>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
       HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_decode_ring<uint16_t>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-      once3 = true;
     }
     if (sym16 && *sym16)
       huff::k_decode_ring<uint16_t><<<(unsigned)((nchunk + waves - 1) / waves), 64 * waves,
@@ -593,11 +604,10 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
   } else if (!serial_decode && (size_t)chunk >= 1024) {
     if (sym16) *sym16 = false;
     // parallel decoding inside the chunks (one wave per chunk)
-    static bool once2 = false;
-    if (!once2) {
+    static std::atomic<uint64_t> once2{0};
+    if (hl_once_per_device(once2)) {
       HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_decode_par),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-      once2 = true;
     }
     // 14-bit prefix table at most, so that the write-out staging (4 KiB per wave) fits beside it
     while (tb > 8 && ((size_t)4 << tb) + ((size_t)dict + 3) / 4 * 8 + huff::kParWaves * 64 * huff::kParBatch * 2 >
@@ -794,7 +804,14 @@ struct PinnedBounce {
   static constexpr size_t kChunk = (size_t)32 << 20;
   void *buf[2] = {nullptr, nullptr};
   hipEvent_t ev[2] = {nullptr, nullptr};
+  int dev = -1;  // device the events belong to
   int ensure() {
+    int cur = 0;
+    HL_HIP(hipGetDevice(&cur));
+    if (cur != dev) {  // events recorded into another device's stream fail: recreate them
+      release();
+      dev = cur;
+    }
     for (int i = 0; i < 2; i++) {
       if (!buf[i]) HL_HIP(hipHostMalloc(&buf[i], kChunk, hipHostMallocDefault));
       if (!ev[i]) HL_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
@@ -810,10 +827,12 @@ struct PinnedBounce {
     }
   }
 };
-thread_local PinnedBounce *g_bounce_ptr = nullptr;  // (never destroyed automatically, like the cache)
-inline PinnedBounce &bounce() {
-  if (!g_bounce_ptr) g_bounce_ptr = new PinnedBounce();
-  return *g_bounce_ptr;
+// One set per direction: the host->device prefetch of subdomain id+1 and the device->host copy of
+// record id run on different streams of the same thread and must not share buffers.
+thread_local PinnedBounce *g_bounce_ptr[2] = {nullptr, nullptr};  // (never destroyed automatically, like the cache)
+inline PinnedBounce &bounce(int dir) {
+  if (!g_bounce_ptr[dir]) g_bounce_ptr[dir] = new PinnedBounce();
+  return *g_bounce_ptr[dir];
 }
 
 inline void parallel_memcpy(void *dst, const void *src, size_t bytes) {
@@ -835,7 +854,7 @@ inline void parallel_memcpy(void *dst, const void *src, size_t bytes) {
 // dst (device) <- src (pageable host). The source is consumed when the call returns; the device
 // side is complete in stream order.
 int staged_h2d(void *dst, const void *src, size_t bytes, hipStream_t st) {
-  PinnedBounce &b = bounce();
+  PinnedBounce &b = bounce(0);
   HL_TRY(b.ensure());
   size_t off = 0;
   for (int c = 0; off < bytes; c++) {
@@ -852,7 +871,7 @@ int staged_h2d(void *dst, const void *src, size_t bytes, hipStream_t st) {
 
 // dst (pageable host) <- src (device), after everything queued on st. Complete on return.
 int staged_d2h(void *dst, const void *src, size_t bytes, hipStream_t st) {
-  PinnedBounce &b = bounce();
+  PinnedBounce &b = bounce(1);
   HL_TRY(b.ensure());
   size_t off = 0, done = 0;
   size_t len[2] = {0, 0};
@@ -863,6 +882,8 @@ int staged_d2h(void *dst, const void *src, size_t bytes, hipStream_t st) {
       HL_HIP(hipEventSynchronize(b.ev[i]));
       parallel_memcpy((char *)dst + done, b.buf[i], len[i]);
       done += len[i];
+    } else {
+      HL_HIP(hipEventSynchronize(b.ev[i]));  // a transfer of an earlier call may still use it
     }
     len[i] = std::min(PinnedBounce::kChunk, bytes - off);
     HL_HIP(hipMemcpyAsync(b.buf[i], (const char *)src + off, len[i], hipMemcpyDeviceToHost, st));
@@ -988,7 +1009,13 @@ int cache_prepare(int dev) {
   if (g_cache.dev != dev) {
     g_cache.release();
     HL_HIP(hipSetDevice(dev));
-    for (auto &s : g_cache.streams) HL_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    // Default (blocking) flags like the reference's queues (DeviceAdapterHip.h:514): the pipeline
+    // streams are ordered against the NULL stream, so a device-resident input that an earlier
+    // kernel / copy on the NULL stream (torch's default stream) is still producing is complete
+    // before the first pipeline stage reads it, and work the caller queues on the NULL stream
+    // afterwards waits for the pipeline. Inputs produced on OTHER non-blocking streams must be
+    // synchronised by the caller (include/mgard_hip_compress.h).
+    for (auto &s : g_cache.streams) HL_HIP(hipStreamCreate(&s));
     HL_TRY(mgh_lossless_create(&g_cache.ll, dev));
     g_cache.dev = dev;
   }
@@ -1573,7 +1600,8 @@ void mgh_free_device(void *p) {
 
 void mgh_release_cache(void) {
   if (g_cache_ptr) g_cache_ptr->release();
-  if (g_bounce_ptr) g_bounce_ptr->release();
+  for (auto *b : g_bounce_ptr)
+    if (b) b->release();
 }
 
 int mgh_memcpy(void *dst, const void *src, size_t bytes) {

@@ -63,7 +63,9 @@ def scatter_slabs(full, shape, src=0, group=None, device=None, dtype=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return full
+    # `src` and the loop index are ranks INSIDE `group`; isend / recv address peers by GLOBAL rank
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    g = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
     lo, hi = split_slowest(shape, world, rank)
     if rank == src:
         reqs = []
@@ -71,13 +73,13 @@ def scatter_slabs(full, shape, src=0, group=None, device=None, dtype=None):
             if r == src:
                 continue
             a, b = split_slowest(shape, world, r)
-            reqs.append(dist.isend(full[a:b].contiguous(), dst=r, group=group))
+            reqs.append(dist.isend(full[a:b].contiguous(), dst=g(r), group=group))
         mine = full[lo:hi].clone()
         for q in reqs:
             q.wait()
         return mine
     mine = torch.empty((hi - lo,) + tuple(shape[1:]), dtype=dtype, device=device)
-    dist.recv(mine, src=src, group=group)
+    dist.recv(mine, src=g(src), group=group)
     return mine
 
 
@@ -92,11 +94,12 @@ def gather_payloads(payload, dst=0, group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return [payload]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    g = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
     n = torch.tensor([payload.numel()], dtype=torch.int64, device=payload.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
     if rank != dst:
-        dist.send(payload.contiguous(), dst=dst, group=group)
+        dist.send(payload.contiguous(), dst=g(dst), group=group)
         return None
     out = []
     for r in range(world):
@@ -104,7 +107,7 @@ def gather_payloads(payload, dst=0, group=None):
             out.append(payload)
         else:
             buf = torch.empty(int(sizes[r].item()), dtype=payload.dtype, device=payload.device)
-            dist.recv(buf, src=r, group=group)
+            dist.recv(buf, src=g(r), group=group)
             out.append(buf)
     return out
 

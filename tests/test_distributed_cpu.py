@@ -118,3 +118,47 @@ def test_two_rank_slab_scatter_and_payload_gather():
         assert p.exitcode == 0
     assert res[0][1] and res[1][1]
     assert res[0][2] == struct.pack("<Q", 5) + b"\x01" * 5 + struct.pack("<Q", 8) + b"\x02" * 8
+
+
+def _subgroup_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    from mgard_amd import distributed as mdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    grp = dist.new_group(ranks=[1, 2])     # group rank 0 = global rank 1, group rank 1 = global rank 2
+    ok, framed = True, b""
+    if rank in (1, 2):
+        shape = (9, 4, 5)
+        ref = torch.arange(9 * 4 * 5, dtype=torch.float32).reshape(shape)
+        full = ref if rank == 1 else None
+        slab = mdist.scatter_slabs(full, shape, src=0, group=grp, dtype=torch.float32)
+        gr = dist.get_rank(grp)
+        lo, hi = mdist.split_slowest(shape, 2, gr)
+        ok = torch.equal(slab, ref[lo:hi])
+        payload = torch.full((4 + 2 * gr,), gr + 7, dtype=torch.uint8)
+        got = mdist.gather_payloads(payload, dst=0, group=grp)
+        if gr == 0:
+            framed = mdist.frame_payloads([g.numpy().tobytes() for g in got])
+    out.put((rank, ok, framed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scatter_gather_inside_a_subgroup():
+    """src / dst are ranks inside the group; the point-to-point calls need global ranks."""
+    import struct
+    world = 3
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict((r[0], r) for r in (out.get(timeout=120) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(res[r][1] for r in range(world))
+    assert res[1][2] == struct.pack("<Q", 4) + b"\x07" * 4 + struct.pack("<Q", 6) + b"\x08" * 6

@@ -159,6 +159,43 @@ def test_compress_decompress_roundtrip(shape, s, mode, lossless, dt, where):
     assert _err(u, v, s, shape) <= bound * (1 + 1e-6)
 
 
+def test_device_input_still_being_produced_on_the_default_stream():
+    """The pipeline streams are ordered against the NULL stream (reference queues:
+    DeviceAdapterHip.h:514): an input that earlier kernels on torch's default stream are still
+    producing -- no torch.cuda.synchronize() in between -- must be compressed as it will be, and a
+    reconstruction must be complete for work queued behind it."""
+    torch, mg, hl = _mods()
+    shape = (257, 260, 300)
+    u = smooth_field(shape, np.float32)
+    base = torch.from_numpy(u).cuda()
+    # (the records themselves may differ from run to run: the outlier list is in atomic order)
+    ref = hl.decompress(hl.compress(base * 3.0 + 1.0, 1e-3, np.inf, mg.REL)).cpu().numpy()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        d = base.clone()
+        for _k in range(40):       # a queue of kernels that keeps the default stream busy
+            d = d * 1.0
+        d = d * 3.0 + 1.0          # the value to compress exists only after all of them
+        buf = hl.compress(d, 1e-3, np.inf, mg.REL)
+        v = hl.decompress(buf)
+        w = (v - d).abs().max()    # queued on the default stream right behind the pipeline
+        assert np.array_equal(v.cpu().numpy(), ref)
+        assert float(w) <= 1e-3 * float(d.abs().max()) * (1 + 1e-6)
+
+
+@pytest.mark.parametrize("mode", ["REL", "ABS"])
+def test_all_zero_input(mode):
+    """norm == 0: the reference replaces it by epsilon (NormCalculator.hpp:61-66); the header
+    must keep the size it was reserved with and the round trip must give zeros back."""
+    torch, mg, hl = _mods()
+    u = np.zeros((40, 33, 70), np.float32)
+    for src in (u, torch.from_numpy(u).cuda()):
+        buf = hl.compress(src, 1e-3, np.inf, mg.REL if mode == "REL" else mg.ABS)
+        v = hl.decompress(buf)
+        v = v if isinstance(v, np.ndarray) else v.cpu().numpy()
+        assert v.shape == u.shape and not v.any()
+
+
 def test_container_records_hold_the_quantized_coefficients():
     """The single record of a non-decomposed stream decodes (independent reader) to exactly the
     integers the low-level path produces, outliers included."""
