@@ -72,22 +72,75 @@ def algorithmic_bytes_per_step(h, esz):
     return out
 
 
-def cpu_baseline(u, tol):
-    """The CPU oracle (a port of the reference algorithm, OpenMP over pencils, all host cores)
-    timed on ONE step of the same workload. Reported baseline only."""
+def _oracle_step(o, oracle, u, tol, s):
+    import numpy as np
+    t0 = time.perf_counter()
+    nrm = oracle.norm(u, u.dtype.type(s))
+    c = o.decompose(u)
+    q, oi, ov, n = o.quantize(c, oracle.REL, u.dtype.type(tol), u.dtype.type(s), u.dtype.type(nrm))
+    return time.perf_counter() - t0, q
+
+
+def cpu_baseline(u, tol, s, coords=None):
+    """The CPU oracle (a port of the reference algorithm, OpenMP over pencils) timed on the host
+    of the GPU box, beside the GPU numbers of the same run. Reported baseline only.
+    (i) all host cores on the whole workload: one untimed warm-up, then the MEDIAN of 5 steps;
+    (ii) one thread (continuity with the reference's SERIAL backend) on a bounded sample --
+    the leading 128 planes of the same volume -- median of 3."""
     import numpy as np
     import oracle
     cores = oracle.num_threads()
-    o = oracle.Hierarchy(u.shape, u.dtype)
-    t0 = time.perf_counter()
-    nrm = oracle.norm(u, u.dtype.type(np.inf))
-    c = o.decompose(u)
-    q, oi, ov, n = o.quantize(c, oracle.REL, u.dtype.type(tol), u.dtype.type(np.inf),
-                              u.dtype.type(nrm))
-    dt = time.perf_counter() - t0
-    return {"value": u.nbytes / dt / 1e9, "unit": "GB/s", "cores": cores, "kind": "port",
-            "sample": "1 step of the same 512^3 f32 workload (norm+decompose+quantize), %.1f s"
-                      % dt}, q
+    o = oracle.Hierarchy(u.shape, u.dtype, coords=coords)
+    _oracle_step(o, oracle, u, tol, s)
+    ts = []
+    q = None
+    for _ in range(5):
+        dt, q = _oracle_step(o, oracle, u, tol, s)
+        ts.append(dt)
+    med = sorted(ts)[len(ts) // 2]
+    out = {"value": u.nbytes / med / 1e9, "unit": "GB/s", "cores": cores, "kind": "port",
+           "nproc": os.cpu_count(),
+           "sample": "the same %s %s workload (norm+decompose+quantize): 1 warm-up, median of 5 "
+                     "steps = %.2f s (min %.2f, max %.2f)"
+                     % ("x".join(map(str, u.shape)), u.dtype.name, med, min(ts), max(ts))}
+    try:
+        sub = np.ascontiguousarray(u[:min(128, u.shape[0])])
+        sc = None if coords is None else [coords[0][:sub.shape[0]]] + list(coords[1:])
+        oracle.set_num_threads(1)
+        o1 = oracle.Hierarchy(sub.shape, sub.dtype, coords=sc)
+        _oracle_step(o1, oracle, sub, tol, s)
+        t1 = sorted(_oracle_step(o1, oracle, sub, tol, s)[0] for _ in range(3))[1]
+        out["serial"] = {"value": sub.nbytes / t1 / 1e9, "unit": "GB/s", "cores": 1,
+                         "sample": "leading %s block of the volume, 1 warm-up, median of 3 = %.2f s"
+                                   % ("x".join(map(str, sub.shape)), t1)}
+    finally:
+        oracle.set_num_threads(cores)
+    return out, q
+
+
+def source_hash():
+    """Hash of the kernel sources: PMC traffic files are only valid for the code they were taken
+    on (tools/make_traffic.py stores the hash of that code)."""
+    import hashlib
+    hsh = hashlib.sha256()
+    d = os.path.join(ROOT, "mgard_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            hsh.update(open(os.path.join(d, f), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
+CONFIGS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "512f32": dict(shape=(512, 512, 512), dtype="float32", s=float("inf"), nonuniform=False,
+                   what="3D 512x512x512 float32 uniform grid, REL L-inf tol 1e-3, s=inf"),
+    # configs[2]: non-uniform spacing, s = 0 (mass-matrix + tridiagonal path, L2 norm)
+    "512f64nu": dict(shape=(512, 512, 512), dtype="float64", s=0.0, nonuniform=True,
+                     what="3D 512x512x512 float64 NON-uniform spacing, REL tol 1e-3, s=0"),
+    # configs[4]: 1024^3 round trip, error against the tolerance, end-to-end GB/s
+    "1024f32": dict(shape=(1024, 1024, 1024), dtype="float32", s=float("inf"), nonuniform=False,
+                    what="3D 1024x1024x1024 float32 uniform grid, REL L-inf tol 1e-3, s=inf"),
+}
 
 
 def main():
@@ -97,6 +150,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shape", type=str, default=None, help="override, e.g. 256,256,256")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="512f32",
+                    help="BASELINE.json configuration: 512f32 = configs[1] (the metric's, default), "
+                         "512f64nu = configs[2], 1024f32 = configs[4]")
     ap.add_argument("--force-dist-path", action="store_true",
                     help="exercise the N>1 code path (process group + norm all-reduce) with any "
                          "world size, e.g. 1 (developer check)")
@@ -106,7 +162,7 @@ def main():
     import torch
     import mgard_amd
     from mgard_amd import distributed as mdist
-    from tests.util import smooth_field
+    from tests.util import smooth_field, nonuniform_coords
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -125,12 +181,17 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    shape = tuple(int(x) for x in args.shape.split(",")) if args.shape else SHAPE
+    cfg = CONFIGS[args.config]
+    shape = tuple(int(x) for x in args.shape.split(",")) if args.shape else cfg["shape"]
+    np_dt = np.dtype(cfg["dtype"])
+    esz = np_dt.itemsize
+    S = cfg["s"]
+    coords = nonuniform_coords(shape, np_dt) if cfg["nonuniform"] else None
 
     # synthetic subdomain of this rank (seeded)
-    u = smooth_field(shape, np.float32, seed=20260101 + rank)
+    u = smooth_field(shape, np_dt.type, seed=20260101 + rank)
     d_u = torch.from_numpy(u).to(dev)
-    h = mgard_amd.Hierarchy(shape, np.float32, device=local_rank)
+    h = mgard_amd.Hierarchy(shape, np_dt, coords=coords, device=local_rank)
     N = h.total
     cap = N // 16  # outlier capacity; checked below
     q = torch.empty(shape, dtype=torch.int64, device=dev)
@@ -138,18 +199,18 @@ def main():
     oidx = torch.empty(cap, dtype=torch.int64, device=dev)
     oval = torch.empty(cap, dtype=torch.int64, device=dev)
     bufs = (q, cnt, oidx, oval)
-    nrm_t = torch.zeros(1, dtype=torch.float32, device=dev)
+    nrm_t = torch.zeros(1, dtype=h.torch_dtype, device=dev)
 
     def step():
         if dist is None:
             # REL bound: norm computed inside the call, on the device (no host round trip)
-            return h.decompose_quantize(d_u, mgard_amd.REL, TOL, float("inf"), 0.0, bufs=bufs,
+            return h.decompose_quantize(d_u, mgard_amd.REL, TOL, S, 0.0, bufs=bufs,
                                         want_norm=False)[4]
         # decomposed domain: global norm = MAX of subdomain norms (one scalar all-reduce over
         # RCCL), then an ABS bound per subdomain (mgard_amd/distributed.py)
-        h.norm_device(d_u, float("inf"), out=nrm_t)
+        h.norm_device(d_u, S, out=nrm_t)
         dist.all_reduce(nrm_t, op=dist.ReduceOp.MAX)
-        h.decompose_quantize_dn(d_u, mgard_amd.REL, TOL, float("inf"), nrm_t, world, bufs)
+        h.decompose_quantize_dn(d_u, mgard_amd.REL, TOL, S, nrm_t, world, bufs)
         return None
 
     def barrier():
@@ -189,35 +250,46 @@ def main():
         elapsed = float(t.item())
 
     # HBM traffic of the dominant kernel from the committed PMC passes (same workload only)
+    # (a file taken on other kernel sources than the ones this run loads is refused)
     traffic = None
+    traffic_note = "no PMC traffic file for this configuration"
     tpath = os.path.join(ROOT, "profiles", "traffic_512cube_f32.json")
-    if shape == SHAPE and os.path.exists(tpath):
-        t = json.load(open(tpath)).get(dominant)
-        if t:
+    if args.config == "512f32" and shape == SHAPE and os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        t = tj.get(dominant)
+        if tj.get("source_hash") != source_hash():
+            traffic_note = "profiles/traffic_512cube_f32.json was taken on other kernel sources (hash %s, now %s): refused" % (
+                tj.get("source_hash"), source_hash())
+        elif t:
             traffic = int((t["fetch_kib"] * t["read_correction"] + t["write_kib"]) * 1024)
-    in_bytes = N * 4
+            traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on these kernel sources, per launch"
+    in_bytes = N * esz
     value = in_bytes * args.steps * world / elapsed / 1e9
-    alg = algorithmic_bytes_per_step(h, 4)
+    alg = algorithmic_bytes_per_step(h, esz)
     dom_ms, dom_launches = dom
     dom_bytes = alg.get(dominant, 0) * args.steps
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     result = {
         "metric": "compress GB/s (input) at rel-Linf 1e-3, 3D 512^3 f32, decompose+quantize on "
-                  "device-resident data",
+                  "device-resident data" if args.config == "512f32" else
+                  "compress GB/s (input), %s, decompose+quantize on device-resident data" % args.config,
         "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if esz == 4 else "f64",
         "data": "synthetic (seeded smooth field + 1e-3 uniform noise), HBM-resident",
-        "config": {"workload": "3D %s float32 uniform grid, REL L-inf tol 1e-3, s=inf; "
-                               "[norm+]decompose+quantize (int64 out)" % "x".join(map(str, shape)),
+        "config": {"workload": "%s; [norm+]decompose+quantize (int64 out)" % (
+                       cfg["what"] if not args.shape else "3D %s %s" % ("x".join(map(str, shape)), np_dt.name)),
+                   "name": args.config,
                    "per_gpu_shape": list(shape), "l_target": h.l_target, "dict_size": 8192,
                    "outliers_per_step": n_out,
                    "parallelism": "1 subdomain per GPU%s" % (
                        "" if dist is None else ", scalar norm all-reduce over RCCL")},
-        "hbm_frac_whole_step": round(12.0 * N / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+        "hbm_frac_whole_step": round((esz + 8.0) * N / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
         "roofline": {"bound": "hbm", "kernel": dominant,
                      "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_source": traffic_note,
                      "avg_launch_ms": round(dom_ms / max(dom_launches, 1), 5),
                      "launches": dom_launches,
                      "algorithmic_bytes_per_step": alg.get(dominant, 0),
@@ -228,30 +300,37 @@ def main():
         # decompression side (BASELINE.json configs[4] asks for the round trip): dequantize +
         # recompose of the same volume, error against the requested tolerance
         n_keep = int(cnt.item())
-        nrm_host = float(h.norm(d_u, float("inf")))
+        nrm_host = float(h.norm(d_u, S))
         back = torch.empty_like(d_u)
         q_work = q.clone()
         for _ in range(2):
-            h.dequantize_recompose(q_work, mgard_amd.REL, TOL, float("inf"), nrm_host,
+            h.dequantize_recompose(q_work, mgard_amd.REL, TOL, S, nrm_host,
                                    outlier_idx=oidx[:n_keep], outlier_val=oval[:n_keep], out=back)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         ND = 10
         for _ in range(ND):
-            h.dequantize_recompose(q_work, mgard_amd.REL, TOL, float("inf"), nrm_host,
+            h.dequantize_recompose(q_work, mgard_amd.REL, TOL, S, nrm_host,
                                    outlier_idx=oidx[:n_keep], outlier_val=oval[:n_keep], out=back)
         torch.cuda.synchronize()
         d_ms = (time.perf_counter() - t1) / ND * 1e3
-        err = float((back - d_u).abs().max().item())
+        if S == float("inf"):
+            err = float((back - d_u).abs().max().item())
+            ename = "roundtrip_linf_error"
+        else:  # s = 0: the bound is on the L2 norm (root mean square with normalised coordinates)
+            err = float(((back - d_u).double() ** 2).mean().sqrt().item())
+            ename = "roundtrip_l2_error"
         result["decompress"] = {"ms_per_step": round(d_ms, 4),
                                 "value": round(in_bytes / d_ms / 1e6, 3), "unit": "GB/s (output)",
-                                "roundtrip_linf_error": err, "tolerance_abs": TOL * nrm_host,
+                                ename: err, "tolerance_abs": TOL * nrm_host,
                                 "within_tolerance": bool(err <= TOL * nrm_host)}
         del back, q_work
         # the same step with the quantized values delivered as 16-bit dictionary symbols (what
         # mgh_compress feeds its Huffman stage with; an extension, never `value`: the metric
         # is defined on the reference's int64 output)
         try:
+            if args.config != "512f32":
+                raise mgard_amd.MgardHipError("not measured for this configuration")
             sym_out = h.decompose_quantize_sym16(d_u, mgard_amd.REL, TOL, float("inf"))
             torch.cuda.synchronize()
             t16 = time.perf_counter()
@@ -276,12 +355,13 @@ def main():
         # decompose, quantize, Huffman, serialisation into the MGARD-X container and back
         from mgard_amd import highlevel
         try:
-            stream = highlevel.compress(d_u, TOL, float("inf"), mgard_amd.REL)
+            hl_coords = None if coords is None else [np.asarray(c, np.float64) for c in coords]
+            stream = highlevel.compress(d_u, TOL, S, mgard_amd.REL, coords=hl_coords)
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             NE = 3
             for _ in range(NE):
-                stream = highlevel.compress(d_u, TOL, float("inf"), mgard_amd.REL)
+                stream = highlevel.compress(d_u, TOL, S, mgard_amd.REL, coords=hl_coords)
             torch.cuda.synchronize()
             c_ms = (time.perf_counter() - t2) / NE * 1e3
             out = highlevel.decompress(stream)
@@ -291,7 +371,8 @@ def main():
                 out = highlevel.decompress(stream)
             torch.cuda.synchronize()
             x_ms = (time.perf_counter() - t3) / NE * 1e3
-            e2e_err = float((out - d_u).abs().max().item())
+            e2e_err = float((out - d_u).abs().max().item()) if S == float("inf") else \
+                float(((out - d_u).double() ** 2).mean().sqrt().item())
             result["end_to_end"] = {
                 "what": "mgh_compress / mgh_decompress: device-resident in, MGARD-X container "
                         "(Huffman) out, and back",
@@ -303,11 +384,14 @@ def main():
             highlevel.release_cache()
         except mgard_amd.MgardHipError as e:  # the headline metric does not depend on this path
             result["end_to_end"] = {"error": str(e)}
-    if rank == 0 and dist is None and not args.no_cpu_baseline:
-        base, rq = cpu_baseline(u, TOL)
+    if rank == 0 and dist is None and not args.no_cpu_baseline and args.config != "1024f32":
+        base, rq = cpu_baseline(u, TOL, S, coords)
         result["cpu_baseline"] = base
         # parity spot check on the bench workload itself: quantized integers are bit-exact
-        result["parity_vs_cpu"] = bool(np.array_equal(q.cpu().numpy(), rq))
+        # (s = inf only: with an L2 norm the two norms differ in the last bits by nature --
+        # sequential vs tree sum -- and so may the integers; tests inject the norm instead)
+        if S == float("inf"):
+            result["parity_vs_cpu"] = bool(np.array_equal(q.cpu().numpy(), rq))
     else:
         result["cpu_baseline"] = None
     if dist is not None:

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""profiles/traffic_512cube_f32.json from two rocprofv3 PMC passes of the bench workload
+(FETCH_SIZE and WRITE_SIZE must be collected in separate runs, kernel-trace only):
+
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d out/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline
+  python tools/make_traffic.py out/fetch/*/*.db out/write/*/*.db [raw_out.json]
+
+The file records the hash of the kernel sources it was taken on; bench.py refuses it for any
+other sources. Units: KiB per launch (averages over the dispatches of the biggest grid of each
+kernel). read_correction: /opt/skills/guides/MI355X_MICROARCH.md, HBM section -- on gfx950
+FETCH_SIZE reports half of the bytes of 16-byte-per-lane streaming loads (absmax: float4 loads);
+the fused level kernel reads 4 bytes per lane, which count 1:1 (calibration in profiles/README.md).
+"""
+import json
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def per_kernel(db, counter):
+    c = sqlite3.connect(db)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    T = lambda p: [t for t in tabs if t.startswith(p)][0]
+    kd, ks, pe, pi = T("rocpd_kernel_dispatch"), T("rocpd_info_kernel_symbol"), T("rocpd_pmc_event"), T("rocpd_info_pmc")
+    q = f"""select s.kernel_name, d.grid_size_x * d.grid_size_y * d.grid_size_z, d.dispatch_id, sum(e.value)
+            from {pe} e join {kd} d on e.event_id = d.event_id join {ks} s on d.kernel_id = s.id
+            join {pi} p on e.pmc_id = p.id where p.name = ? group by 1, 2, 3"""
+    out = {}
+    for name, grid, _disp, val in c.execute(q, (counter,)):
+        out.setdefault((name.split("(")[0], grid), []).append(val)
+    return out
+
+
+def biggest(stats, needle):
+    keys = [k for k in stats if needle in k[0]]
+    if not keys:
+        return None, 0
+    k = max(keys, key=lambda kk: kk[1])
+    v = stats[k]
+    v = v[1:] if len(v) > 1 else v  # first dispatch: warm-up
+    return sum(v) / len(v), len(v)
+
+
+def main():
+    from bench import source_hash
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {"_about": __doc__.strip(), "source_hash": source_hash()}
+    for label, needle, corr in (("level_fused_q", "k_level_fused2", 1.0), ("absmax", "k_absmax", 2.0)):
+        f, nf = biggest(fetch, needle)
+        w, nw = biggest(write, needle)
+        if f is None or w is None:
+            continue
+        out[label] = {"fetch_kib": round(f, 1), "write_kib": round(w, 1), "read_correction": corr,
+                      "dispatches": [nf, nw]}
+    json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_512cube_f32.json"), "w"), indent=1)
+    if len(sys.argv) > 3:
+        raw = {"fetch": [{"kernel": k[0][:90], "grid_threads": k[1], "avg_kib": sum(v) / len(v), "n": len(v)}
+                         for k, v in sorted(fetch.items()) if "mgh" in k[0]],
+               "write": [{"kernel": k[0][:90], "grid_threads": k[1], "avg_kib": sum(v) / len(v), "n": len(v)}
+                         for k, v in sorted(write.items()) if "mgh" in k[0]],
+               "source_hash": out["source_hash"]}
+        json.dump(raw, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k != "_about"}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
