@@ -48,6 +48,20 @@ def algorithmic_bytes_per_step(h, esz):
     N = vol(h.shape)
     add("absmax", N * esz)
     add("quantize", N * (esz + 8))
+    if len(h.shape) == 4:
+        # D = 4 (decompose_fused4): per level the even t-slices run the 3-D pass of the slice, the
+        # odd ones read their own slice once (the neighbours' even planes are re-reads), write a
+        # coefficient for every node and the slice's load vector
+        for l in range(L, 0, -1):
+            n, m = h.level_shape(l), h.level_shape(l - 1)
+            n3, m3 = vol(n[1:]), vol(m[1:])
+            add("level4_even", m[0] * (n3 * esz + (n3 - m3) * 8 + 2 * m3 * esz))
+            add("level4_odd", (n[0] - m[0]) * (n3 * esz + n3 * 8 + m3 * esz))
+            add("tsweep", ((2 * m[0] - 1) + m[0]) * m3 * esz)
+            add("ipk_f", 2 * vol(m) * esz)
+            add("ipk_c", 2 * vol(m) * esz)
+            add("ipk_r", 2 * vol(m) * esz + 4 * vol(m) * esz)  # r solves + the t solve with the add
+        return out
     for l in range(L, 0, -1):
         n = h.level_shape(l)
         m = h.level_shape(l - 1)
@@ -137,6 +151,10 @@ CONFIGS = {
     # configs[2]: non-uniform spacing, s = 0 (mass-matrix + tridiagonal path, L2 norm)
     "512f64nu": dict(shape=(512, 512, 512), dtype="float64", s=0.0, nonuniform=True,
                      what="3D 512x512x512 float64 NON-uniform spacing, REL tol 1e-3, s=0"),
+    # configs[3]: one rank's 4-D slab of the 64 x 512^3 volume (weak scaling: 8 x 512^3 per GPU)
+    "4d": dict(shape=(8, 512, 512, 512), dtype="float32", s=float("inf"), nonuniform=False,
+               what="4D 8x512x512x512 float32 slab (one of the 8 slabs of 64x512^3, split on dim 0), "
+                    "REL L-inf tol 1e-3, s=inf"),
     # configs[4]: 1024^3 round trip, error against the tolerance, end-to-end GB/s
     "1024f32": dict(shape=(1024, 1024, 1024), dtype="float32", s=float("inf"), nonuniform=False,
                     what="3D 1024x1024x1024 float32 uniform grid, REL L-inf tol 1e-3, s=inf"),
@@ -189,11 +207,17 @@ def main():
     coords = nonuniform_coords(shape, np_dt) if cfg["nonuniform"] else None
 
     # synthetic subdomain of this rank (seeded)
-    u = smooth_field(shape, np_dt.type, seed=20260101 + rank)
+    if len(shape) == 4:
+        # a slab of time steps: a 3-D field that drifts slowly along dim 0
+        base = smooth_field(shape[1:], np_dt.type, seed=20260101 + rank)
+        u = np.stack([base * np_dt.type(1.0 + 0.002 * t) + np_dt.type(1e-4 * t) for t in range(shape[0])])
+        del base
+    else:
+        u = smooth_field(shape, np_dt.type, seed=20260101 + rank)
     d_u = torch.from_numpy(u).to(dev)
     h = mgard_amd.Hierarchy(shape, np_dt, coords=coords, device=local_rank)
     N = h.total
-    cap = N // 16  # outlier capacity; checked below
+    cap = N // (16 if len(shape) == 3 else 8)  # outlier capacity; checked below
     q = torch.empty(shape, dtype=torch.int64, device=dev)
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
     oidx = torch.empty(cap, dtype=torch.int64, device=dev)
@@ -384,7 +408,7 @@ def main():
             highlevel.release_cache()
         except mgard_amd.MgardHipError as e:  # the headline metric does not depend on this path
             result["end_to_end"] = {"error": str(e)}
-    if rank == 0 and dist is None and not args.no_cpu_baseline and args.config != "1024f32":
+    if rank == 0 and dist is None and not args.no_cpu_baseline and args.config not in ("1024f32", "4d"):
         base, rq = cpu_baseline(u, TOL, S, coords)
         result["cpu_baseline"] = base
         # parity spot check on the bench workload itself: quantized integers are bit-exact

@@ -84,6 +84,7 @@ struct mgh_hierarchy {
   // MGH_FUSED_FACES: 1 = face tiles for the remainder columns / rows of a level (default), 0 = off
   int fused_faces = 1;
   int fused_xcd = 1;  // MGH_FUSED_XCD: tiles of a level in contiguous ranges per XCD (default 1)
+  int fused4 = 1;     // MGH_FUSED4: D = 4 through the 3-D tile code, slice by slice (default 1)
   std::map<std::string, ProfileEntry> prof;
   size_t device_bytes = 0;
 };
@@ -116,6 +117,10 @@ template <typename T> struct DeviceState {
   };
   std::vector<NdLevel> nd;         // [l], l >= 1 (all D dims; used by the D > 3 path)
   T *nd_w = nullptr, *nd_a = nullptr, *nd_b = nullptr;  // N-D scratch (lazily allocated)
+  // fused D = 4 path (lazily allocated): compact coarse arrays per level, per-slice load vectors
+  // of the biggest level (padded slice positions), t-swept load vector / correction
+  std::vector<T *> nodal4;
+  T *load4 = nullptr, *corr4 = nullptr;
   std::vector<T *> nodal;          // [l] compact nodal buffers, l = 0..L-1
   T *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;
   T *scratch_full = nullptr;       // lazily allocated full-size copy
@@ -336,6 +341,9 @@ template <typename T> void destroy_state(mgh_hierarchy *h) {
     (void)hipFree(ds->nd_w);
     (void)hipFree(ds->nd_a);
     (void)hipFree(ds->nd_b);
+    for (T *p : ds->nodal4) (void)hipFree(p);
+    (void)hipFree(ds->load4);
+    (void)hipFree(ds->corr4);
     (void)hipFree(ds->qz);
     (void)hipFree(ds->scalar);
     (void)hipFree(ds->fscal);
@@ -630,8 +638,13 @@ inline int ensure_side_stream(mgh_hierarchy *h) {
 // end. `norm_in_first`: the top-level pass also reduces abs-max(input) into ds->scalar, and
 // `after_first` (the quantizer set-up that consumes it) is issued right behind it.
 template <typename T, int OUT, typename AfterFirst>
+int decompose_fused4(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams<T> *qp,
+                     hipStream_t s, AfterFirst &&after_first);
+
+template <typename T, int OUT, typename AfterFirst>
 int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams<T> *qp,
                     hipStream_t s, bool norm_in_first, AfterFirst &&after_first) {
+  if (h->D == 4) return decompose_fused4<T, OUT>(h, data, coeff, qp, s, after_first);
   auto *ds = DS<T>(h);
   const int L = h->L;
   const size_t fI = ds->full_I, fJ = ds->full_J;
@@ -762,8 +775,8 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
                                   : (OUT == OUT_Q ? "level_fused_q_small" : "level_fused_small");
 #define MGH_F2(RCH)                                                                          \
   TRY(launch(h, nm, s, [&] {                                                                  \
-    if (faces) k_level_fused2<T, OUT, TC, TF, RCH, true><<<grid, 256, 0, s>>>(A, G);          \
-    else k_level_fused2<T, OUT, TC, TF, RCH, false><<<grid, 256, 0, s>>>(A, G);               \
+    if (faces) k_level_fused2<T, OUT, TC, TF, RCH, true><<<grid, 256, 0, s>>>(A, G, Fused4<T>{});          \
+    else k_level_fused2<T, OUT, TC, TF, RCH, false><<<grid, 256, 0, s>>>(A, G, Fused4<T>{});               \
   }));
         if (cls == 2) MGH_F2(16)
         else if (cls == 1) MGH_F2(4)
@@ -843,6 +856,158 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
   return MGH_SUCCESS;
 }
 
+// D = 4 on the 3-D tile code (kernels_fused2.hpp: TMODE 1 / 2, k_tsweep): per level the even
+// slices of the slowest dimension t run the 3-D pass of the slice, the odd slices the TODD
+// variant that interpolates across t as well; the fourth mass/restriction sweep and the four
+// Thomas solves (f, c, r, t; the last one adds the correction into the coarse array) follow on
+// the N/16-sized arrays. Order of every operation as in CalcCoefficientsND.hpp:25-236 and
+// CalcCorrectionND.hpp:25-267 (dims D-1 .. 0): bit-identical to the generic N-D kernels.
+template <typename T, int OUT, typename AfterFirst>
+int decompose_fused4(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams<T> *qp,
+                     hipStream_t s, AfterFirst &&after_first) {
+  auto *ds = DS<T>(h);
+  auto *hh = HH<T>(h);
+  const int L = h->L;
+  constexpr int TC = 8, TF = 32;
+  const auto &sh = hh->level_shape;  // [l][d]
+  const size_t full[4] = {(size_t)sh[L][1] * sh[L][2] * sh[L][3], (size_t)sh[L][2] * sh[L][3],
+                          (size_t)sh[L][3], 1};
+  if (ds->nodal4.empty()) {
+    ds->nodal4.assign(L + 1, nullptr);
+    for (int l = 0; l < L; l++)
+      TRY(dev_alloc(h, &ds->nodal4[l], (size_t)sh[l][0] * sh[l][1] * sh[l][2] * sh[l][3]));
+    const size_t M = (size_t)sh[L - 1][1] * sh[L - 1][2] * sh[L - 1][3];
+    TRY(dev_alloc(h, &ds->load4, (2 * (size_t)sh[L - 1][0] - 1) * M));
+    TRY(dev_alloc(h, &ds->corr4, (size_t)sh[L - 1][0] * M));
+  }
+  FusedArgs<T> A{};
+  A.coef = coeff;
+  A.dI = full[1];
+  A.dJ = full[2];
+  if (OUT == OUT_Q) {
+    A.q = qp->q;
+    A.q16 = qp->q16;
+    A.dict_size = qp->dict_size;
+    A.prep_huffman = qp->prep_huffman;
+    A.outlier_count = qp->ocount;
+    A.outlier_idx = qp->oidx;
+    A.outlier_val = qp->oval;
+    A.outlier_cap = qp->ocap;
+    A.qp = qp->d_qp;
+    A.nlev = L + 1;
+  }
+  TRY(after_first());
+  const T *src = data;
+  size_t sT = full[0], sI = full[1], sJ = full[2];
+  for (int l = L; l >= 1; l--) {
+    const auto &N = sh[l], &Mc = sh[l - 1];
+    Box3 b;
+    for (int k = 0; k < 3; k++) {
+      b.n[k] = (uint32_t)N[1 + k];
+      b.m[k] = (uint32_t)Mc[1 + k];
+      A.n[k] = (int)N[1 + k];
+      A.m[k] = (int)Mc[1 + k];
+      A.ratio[k] = ds->nd[l].ratio[1 + k];
+      A.mass[k] = ds->nd[l].mass[1 + k];
+    }
+    const size_t M = (size_t)Mc[1] * Mc[2] * Mc[3];
+    const int n_t = (int)N[0], m_t = (int)Mc[0];
+    A.u = src;
+    A.uI = sI;
+    A.uJ = sJ;
+    A.coarse = ds->nodal4[l - 1];
+    A.load = ds->load4;
+    A.level = l;
+    if (OUT == OUT_Q && !qp->d_qp) {
+      A.quantizer = qp->qz[l];
+      A.volume = qp->vol[l];
+    }
+    Fused4<T> Q{};
+    Q.ratio_t = ds->nd[l].ratio[0];
+    Q.uT = sT;
+    Q.dT = full[0];
+    Q.cT = M;
+    Q.n_t = n_t;
+    Q.m_t = m_t;
+    // an even n_t has a ghost slice (padded position n_t - 1): its load vector is zero
+    if (n_t % 2 == 0)
+      HIP_TRY(hipMemsetAsync(ds->load4 + (size_t)(n_t - 1) * M, 0, M * sizeof(T), s));
+    const int cls = level_class(b);
+    const int rchs[3] = {1, 4, 16};
+    const int RCHv = rchs[cls];
+    Fused2Grid G{};
+    const int mfi = (int)b.m[2], mci = (int)b.m[1], mri = (int)b.m[0];
+    const int nfull_f = (mfi - 1) / TF, rem_f = mfi - nfull_f * TF;
+    const int nfull_c = (mci - 1) / TC, rem_c = mci - nfull_c * TC;
+    const bool face_f = h->fused_faces && nfull_f >= 1 && rem_f <= 4;
+    const bool face_c = h->fused_faces && nfull_c >= 1 && rem_c <= 4;
+    G.gxm = face_f ? nfull_f : (mfi + TF - 1) / TF;
+    const int gym = face_c ? nfull_c : (mci + TC - 1) / TC;
+    G.n_main = G.gxm * gym;
+    G.ff_F0 = nfull_f * TF;
+    G.n_ff = face_f ? (mci + 63) / 64 : 0;
+    G.cf_C0 = nfull_c * TC;
+    G.n_cf = face_c ? ((face_f ? G.ff_F0 : mfi) + 63) / 64 : 0;
+    G.nchunk = std::max(1, (mri - 1 + RCHv - 1) / RCHv);
+    G.xcd_ranges = h->fused_xcd;
+    const unsigned ntile = (unsigned)(G.n_main + G.n_ff + G.n_cf);
+    const unsigned gx = G.xcd_ranges ? (ntile + 7) / 8 * 8 : ntile;
+    const bool faces = G.n_ff || G.n_cf;
+    const unsigned n_even = (unsigned)m_t, n_odd = (unsigned)(n_t - m_t);
+#define MGH_F4(RCH, TMODE, NZ, NAME)                                                          \
+  if ((NZ) > 0) {                                                                             \
+    const dim3 grid(gx, (unsigned)G.nchunk, (NZ));                                            \
+    TRY(launch(h, NAME, s, [&] {                                                              \
+      if (faces) k_level_fused2<T, OUT, TC, TF, RCH, true, TMODE><<<grid, 256, 0, s>>>(A, G, Q);  \
+      else k_level_fused2<T, OUT, TC, TF, RCH, false, TMODE><<<grid, 256, 0, s>>>(A, G, Q);   \
+    }));                                                                                      \
+  }
+    if (cls == 2) {
+      MGH_F4(16, 1, n_even, "level4_even")
+      MGH_F4(16, 2, n_odd, "level4_odd")
+    } else if (cls == 1) {
+      MGH_F4(4, 1, n_even, "level4_even")
+      MGH_F4(4, 2, n_odd, "level4_odd")
+    } else {
+      MGH_F4(1, 1, n_even, "level4_even")
+      MGH_F4(1, 2, n_odd, "level4_odd")
+    }
+#undef MGH_F4
+    // t-sweep, then the Thomas solves f, c, r, t on the coarse box (m_t, m_r, m_c, m_f)
+    {
+      const dim3 grid((unsigned)std::min<size_t>((M + 255) / 256, 4096), (unsigned)m_t, 1);
+      TRY(launch(h, "tsweep", s, [&] {
+        k_tsweep<T><<<grid, 256, 0, s>>>(ds->load4, ds->corr4, M, m_t, ds->nd[l].mass[0]);
+      }));
+    }
+    const uint32_t m3a[3] = {(uint32_t)(m_t * Mc[1]), (uint32_t)Mc[2], (uint32_t)Mc[3]};
+    TRY(ipk_launch<T>(h, 2, m3a, ds->corr4, ds->nd[l].thomas[3], nullptr, +1, s));
+    TRY(ipk_launch<T>(h, 1, m3a, ds->corr4, ds->nd[l].thomas[2], nullptr, +1, s));
+    for (int t = 0; t < m_t; t++)
+      TRY(ipk_launch<T>(h, 0, b.m, ds->corr4 + (size_t)t * M, ds->nd[l].thomas[1], nullptr, +1, s));
+    const uint32_t m3t[3] = {(uint32_t)m_t, (uint32_t)(Mc[1] * Mc[2]), (uint32_t)Mc[3]};
+    TRY(ipk_launch<T>(h, 0, m3t, ds->corr4, ds->nd[l].thomas[0], ds->nodal4[l - 1], +1, s));
+    src = ds->nodal4[l - 1];
+    sT = M;
+    sI = (size_t)Mc[2] * Mc[3];
+    sJ = Mc[3];
+  }
+  // head: the level-0 nodal values
+  {
+    if (OUT == OUT_Q && !qp->d_qp) {
+      A.quantizer = qp->qz[0];
+      A.volume = qp->vol[0];
+    }
+    const auto &M0 = sh[0];
+    const size_t tot = (size_t)M0[0] * M0[1] * M0[2] * M0[3];
+    TRY(launch(h, "head_out", s, [&] {
+      k_head_out4<T, OUT><<<(unsigned)std::min<size_t>((tot + 255) / 256, 1024), 256, 0, s>>>(
+          (int)M0[0], (int)M0[1], (int)M0[2], (int)M0[3], ds->nodal4[0], A, full[0]);
+    }));
+  }
+  return MGH_SUCCESS;
+}
+
 template <typename T, int OUT>
 int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams<T> *qp,
                     hipStream_t s) {
@@ -854,6 +1019,11 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
 inline bool fused_ok(const mgh_hierarchy *h) {
   return h->D == 3 && h->L >= 1 && h->plane_elems < ((uint64_t)1 << 29);
 }
+// compression side: also D = 4 (decompose_fused4); arrays of < 2^32 elements per t-slice
+inline bool fused4_ok(const mgh_hierarchy *h) {
+  return h->D == 4 && h->fused4 && !h->force_nd && h->L >= 1 && h->plane_elems < ((uint64_t)1 << 29);
+}
+inline bool fusedc_ok(const mgh_hierarchy *h) { return fused_ok(h) || fused4_ok(h); }
 
 
 // ---- N-D path (D = 4, 5): in place on `v` (full array, reordered as levels proceed) -------
@@ -1005,6 +1175,15 @@ template <typename T> int recompose_nd(mgh_hierarchy *h, T *v, hipStream_t st) {
 template <typename T>
 int decompose_impl(mgh_hierarchy *h, const T *data, T *coeff, hipStream_t s) {
   auto *ds = DS<T>(h);
+  if (fused4_ok(h) && !h->force_v1) {
+    const T *src4 = data;
+    if ((const void *)data == (const void *)coeff) {
+      TRY(ensure_scratch<T>(h));
+      HIP_TRY(hipMemcpyAsync(ds->scratch_full, data, h->total * sizeof(T), hipMemcpyDeviceToDevice, s));
+      src4 = ds->scratch_full;
+    }
+    return decompose_fused<T, OUT_T>(h, src4, coeff, nullptr, s);
+  }
   if (h->D > 3 || h->force_nd) {
     if ((const void *)data != (const void *)coeff)
       HIP_TRY(hipMemcpyAsync(coeff, data, h->total * sizeof(T), hipMemcpyDeviceToDevice, s));
@@ -1461,7 +1640,7 @@ int fused_q_entry_device(mgh_hierarchy *h, const T *data, int ebtype, double tol
   // load-vector pass (it reads every input element anyway) -- no separate norm pass
   const bool need_norm = !d_norm && ebtype == MGH_REL;
   const bool norm_in_first = need_norm && (T)s == std::numeric_limits<T>::infinity() &&
-                             h->L >= 1 && level_is_split<T>(h, h->L);
+                             h->D == 3 && h->L >= 1 && level_is_split<T>(h, h->L);
   // The norm scalar has two slots used alternately: this call reduces into scalar[slot] (zero on
   // entry) and k_make_qparams zeroes the other one for the next call, together with the outlier
   // counter -- two memset launches less per step.
@@ -1551,6 +1730,8 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     if (e8 && e8[0] >= '0' && e8[0] <= '1') h->fused_faces = e8[0] - '0';
     const char *e9 = std::getenv("MGH_FUSED_XCD");
     if (e9 && e9[0] >= '0' && e9[0] <= '1') h->fused_xcd = e9[0] - '0';
+    const char *e10 = std::getenv("MGH_FUSED4");
+    if (e10 && e10[0] >= '0' && e10[0] <= '1') h->fused4 = e10[0] - '0';
     const char *e4 = std::getenv("MGH_EMIT_BPC");
     if (e4 && std::atoi(e4) > 0) h->emit_bpc = (unsigned)std::atoi(e4);
     const char *e5 = std::getenv("MGH_EMIT_CCH");
@@ -1754,7 +1935,7 @@ int mgh_decompose_quantize(mgh_hierarchy *h, const void *d_data, int error_bound
                            uint64_t outlier_capacity, void *d_coeff_opt, void *stream) {
   if (!h || !d_data || !d_quantized) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
   HIP_TRY(hipSetDevice(h->device));
-  const bool fused = !d_coeff_opt && fused_ok(h) && !h->force_v1;
+  const bool fused = !d_coeff_opt && fusedc_ok(h) && !h->force_v1;
   if (fused && error_bound_type == MGH_REL && !(norm > 0)) {
     // the norm and the quantizers stay on the device: no host round trip inside the call
     if (prep_huffman && (!d_outlier_count || (outlier_capacity && (!d_outlier_idx || !d_outlier_val))))
@@ -1774,7 +1955,7 @@ int mgh_decompose_quantize(mgh_hierarchy *h, const void *d_data, int error_bound
     if (rc != MGH_SUCCESS) return rc;
   }
   if (h_norm_out) *h_norm_out = norm;
-  if (!d_coeff_opt && fused_ok(h) && !h->force_v1) {
+  if (!d_coeff_opt && fusedc_ok(h) && !h->force_v1) {
     if (prep_huffman && (!d_outlier_count || (outlier_capacity && (!d_outlier_idx || !d_outlier_val))))
       return fail(MGH_ERR_INVALID_ARGUMENT, "outlier buffers required with prep_huffman");
     if (d_outlier_count) HIP_TRY(hipMemsetAsync(d_outlier_count, 0, sizeof(uint64_t), (hipStream_t)stream));
@@ -1827,8 +2008,8 @@ int mgh_decompose_quantize_dn(mgh_hierarchy *h, const void *d_data, int error_bo
                               uint64_t *d_outlier_count, uint64_t *d_outlier_idx,
                               int64_t *d_outlier_val, uint64_t outlier_capacity, void *stream) {
   if (!h || !d_data || !d_quantized || !d_norm) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
-  if (!fused_ok(h) || h->force_v1)
-    return fail(MGH_ERR_UNSUPPORTED_DIMENSION, "device-norm entry point needs the fused 3-D path");
+  if (!fusedc_ok(h) || h->force_v1)
+    return fail(MGH_ERR_UNSUPPORTED_DIMENSION, "device-norm entry point needs the fused 3-D / 4-D path");
   if (prep_huffman && (!d_outlier_count || (outlier_capacity && (!d_outlier_idx || !d_outlier_val))))
     return fail(MGH_ERR_INVALID_ARGUMENT, "outlier buffers required with prep_huffman");
   HIP_TRY(hipSetDevice(h->device));

@@ -60,22 +60,34 @@ template <typename T> __device__ __forceinline__ T mass_td(T c, T d, T e, const 
 
 // LDS of one tile (elements of T): raw ring 2 planes, coefficient fields 2 planes, f-swept rows,
 // ratios, r-sweep constants (RCH + 1 coarse planes: the last chunk of a level owns one more)
-template <int TC, int TF, int RCH> struct Fused2Geom {
+template <int TC, int TF, int RCH, bool TODD = false> struct Fused2Geom {
   static constexpr int WC = 2 * TC + 3, WF = 2 * TF + 3, HF = TF + 2, ROW = 2 * HF, PL = WC * ROW;
   static constexpr int TP = TF + 1;
-  static constexpr int o_cs = 2 * PL, o_t1 = 4 * PL, o_rf = o_t1 + 2 * WC * TP, o_rc = o_rf + WF,
+  static constexpr int NRAW = TODD ? 4 : 2;  // odd t-slices (D = 4) also hold the even planes of
+                                             // the two neighbouring slices
+  static constexpr int o_cs = NRAW * PL, o_t1 = (NRAW + 2) * PL, o_rf = o_t1 + 2 * WC * TP, o_rc = o_rf + WF,
                        o_rr = o_rc + WC, o_wr = (o_rr + 2 * RCH + 5 + 3) / 4 * 4,
                        elems = o_wr + (RCH + 1) * 12;
 };
 
 // One tile: TC x TF coarse nodes at (C0, F0), marching over the coarse planes [R0, R0 + rch).
 // c_end / f_end: coarse indices from which on the nodes belong to another tile of the launch
-// (face tiles, below); lds: Fused2Geom<TC, TF, RCH>::elems elements, 16-byte aligned.
-template <typename T, int OUT, int TC, int TF, int RCH>
+// (face tiles, below); lds: Fused2Geom<TC, TF, RCH, TODD>::elems elements, 16-byte aligned.
+//
+// TODD (D = 4, kernels below): the volume A.u is an ODD slice of the slowest dimension t. Its
+// nodes are all coefficients, interpolated f, c, r and then t (CalcCoefficientsND.hpp:25-236:
+// nested lerps, fastest dim innermost): value - lerp_t(X(t-1), X(t+1)) where X(s) are the
+// interpolants of the even slice s completed through r -- the four cell interpolants of its even
+// planes (`ua`, `ub`: the same planes of the neighbouring slices), r-lerped on odd planes. The odd
+// planes of the neighbours are never read. `rt` = ratio_t at the left neighbour; out_base =
+// element offset of the slice inside the output array (outlier indices are global).
+template <typename T, int OUT, int TC, int TF, int RCH, bool TODD = false>
 __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const int C0,
                                             const int R0, const int rch, const int c_end,
-                                            const int f_end, T *lds) {
-  using GM = Fused2Geom<TC, TF, RCH>;
+                                            const int f_end, T *lds, const T *ua = nullptr,
+                                            const T *ub = nullptr, const T rt = 0,
+                                            const size_t out_base = 0) {
+  using GM = Fused2Geom<TC, TF, RCH, TODD>;
   constexpr int WC = GM::WC;
   constexpr int WF = GM::WF;
   constexpr int HF = GM::HF;     // even-f slots of a window row (odd-f slots: TF + 1)
@@ -88,6 +100,7 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
   static_assert(NH <= NT, "halo cells are handled in one extra pass");
   static_assert(BX >= 0 && BX <= NT && BX % TF == 0, "f-sweep: two full rounds + one partial");
   T *const raw0 = lds, *const raw1 = lds + PL;             // odd / even plane of the pair
+  T *const rawa = lds + 2 * PL, *const rawb = lds + 3 * PL;  // TODD: even plane of slices t-1, t+1
   T *const Cs0 = lds + GM::o_cs, *const Cs1 = Cs0 + PL;    // coefficient fields of the pair
   T *const t1s0 = lds + GM::o_t1, *const t1s1 = t1s0 + WC * TP;  // f-swept rows of the pair
   T *const rfs = lds + GM::o_rf;
@@ -150,11 +163,12 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
     lidx[k] = LI(lc, lf);
     goff[k] = (uint32_t)Pc * (uint32_t)A.uJ + (uint32_t)Pf;
   }
-  auto fetch = [&](int p, T(&reg)[NL]) {
-    const T *base = A.u + (size_t)min(max(p, 0), nr - 1) * A.uI;
+  auto fetch_from = [&](const T *vol, int p, T(&reg)[NL]) {
+    const T *base = vol + (size_t)min(max(p, 0), nr - 1) * A.uI;
 #pragma unroll
     for (int k = 0; k < NL; k++) reg[k] = base[goff[k]];
   };
+  auto fetch = [&](int p, T(&reg)[NL]) { fetch_from(A.u, p, reg); };
   auto stash = [&](T *dst, const T(&reg)[NL]) {
 #pragma unroll
     for (int k = 0; k < NL; k++) dst[lidx[k]] = reg[k];
@@ -260,10 +274,49 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
     if (c.c1 && c.f1) cs[c.i11] = cv[3];
   };
 
+  // TODD: the four interpolants of an even plane of a neighbouring slice
+  auto interp2 = [&](const Cell &c, const T *rw, T(&E)[4]) {
+    const T v00 = rw[c.i00], v02 = rw[c.i02], v20 = rw[c.i20], v22 = rw[c.i22];
+    const T f0 = lerp_ref(v00, v02, c.rf), f2 = lerp_ref(v20, v22, c.rf);
+    E[0] = v00;
+    E[1] = f0;
+    E[2] = lerp_ref(v00, v20, c.rc);
+    E[3] = lerp_ref(f0, f2, c.rc);
+  };
+  // TODD: coefficients of one plane of the odd slice from the interpolants of its neighbours
+  auto cell_todd = [&](const Cell &c, const T *rw, T *cs, bool pv, const T(&Xa)[4],
+                       const T(&Xb)[4], T(&cv)[4]) {
+    const T v00 = rw[c.i00], v01 = rw[c.i01], v10 = rw[c.i10], v11 = rw[c.i11];
+    cv[0] = (pv && c.m0) ? v00 - lerp_ref(Xa[0], Xb[0], rt) : (T)0;
+    cv[1] = (pv && c.m1) ? v01 - lerp_ref(Xa[1], Xb[1], rt) : (T)0;
+    cv[2] = (pv && c.m2) ? v10 - lerp_ref(Xa[2], Xb[2], rt) : (T)0;
+    cv[3] = (pv && c.m3) ? v11 - lerp_ref(Xa[3], Xb[3], rt) : (T)0;
+    cs[c.i00] = cv[0];
+    if (c.f1) cs[c.i01] = cv[1];
+    if (c.c1) cs[c.i10] = cv[2];
+    if (c.c1 && c.f1) cs[c.i11] = cv[3];
+  };
+  // TODD, one cell and plane pair: Ga / Gb = interpolants of the neighbours' previous even plane
+  auto pair_todd = [&](const Cell &c, bool pv_o, bool pv_e, T rr, T(&Ga)[4], T(&Gb)[4],
+                       T(&cvo)[4], T(&cve)[4]) {
+    T Ea[4], Eb[4], Xa[4], Xb[4];
+    interp2(c, rawa, Ea);
+    interp2(c, rawb, Eb);
+    cell_todd(c, raw1, Cs1, pv_e, Ea, Eb, cve);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      Xa[k] = lerp_ref(Ga[k], Ea[k], rr);
+      Xb[k] = lerp_ref(Gb[k], Eb[k], rr);
+      Ga[k] = Ea[k];
+      Gb[k] = Eb[k];
+    }
+    cell_todd(c, raw0, Cs0, pv_o, Xa, Xb, cvo);
+  };
+
   // coefficients of one owned plane to HBM. K0 = 1: even plane (slot 0 is the coarse node,
   // stored by the caller); oi = index of the output plane in the reordered layout.
   auto emit = [&](const T(&cv)[4], int oi, int K0) {
-    const size_t ob = (size_t)oi * A.dI;
+    const size_t ob = out_base + (size_t)oi * A.dI;
     if (OUT == OUT_T) {
       T *o = A.coef + ob;
       if (all_on) {
@@ -386,26 +439,56 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
   T Go[4], Gh[4];  // interpolants of the previous even plane: owned cell, halo cell
   T e_prev;        // c-swept value of the previous even plane
   T td_prev = 0;   // r-sweep: td of the previous coarse plane = tb of the next one
-  T pre_o[NL], pre_e[NL];
+  T Ga2[TODD ? 4 : 1], Gb2[TODD ? 4 : 1], Gha[TODD ? 4 : 1], Ghb[TODD ? 4 : 1];  // TODD
+  T pre_o[NL], pre_e[NL], pre_a[TODD ? NL : 1], pre_b[TODD ? NL : 1];
   fetch(r_lo, pre_e);
   stash(raw1, pre_e);
+  if constexpr (TODD) {
+    fetch_from(ua, r_lo, pre_a);
+    fetch_from(ub, r_lo, pre_b);
+    stash(rawa, pre_a);
+    stash(rawb, pre_b);
+  }
   fetch(r_lo + 1, pre_o);
   fetch(r_lo + 2, pre_e);
+  if constexpr (TODD) {
+    fetch_from(ua, r_lo + 2, pre_a);
+    fetch_from(ub, r_lo + 2, pre_b);
+  }
   __syncthreads();
   {
     const bool pv = r_lo >= 0 && r_lo <= Pmax_r && r_lo != ghost_r;
     T cv[4];
-    cell_even(own, raw1, Cs1, pv, Go, cv);
-    if (tid < NH) cell_even(halo, raw1, Cs1, pv, Gh, cv);
+    if constexpr (TODD) {
+      interp2(own, rawa, Ga2);
+      interp2(own, rawb, Gb2);
+      cell_todd(own, raw1, Cs1, pv, Ga2, Gb2, cv);
+      if (tid < NH) {
+        interp2(halo, rawa, Gha);
+        interp2(halo, rawb, Ghb);
+        cell_todd(halo, raw1, Cs1, pv, Gha, Ghb, cv);
+      }
+    } else {
+      cell_even(own, raw1, Cs1, pv, Go, cv);
+      if (tid < NH) cell_even(halo, raw1, Cs1, pv, Gh, cv);
+    }
   }
   __syncthreads();
   // (the first pair's raw planes go into the ring next to the f-sweep of the first plane,
   // exactly like every later pair's)
   stash(raw0, pre_o);
   stash(raw1, pre_e);
+  if constexpr (TODD) {
+    stash(rawa, pre_a);
+    stash(rawb, pre_b);
+  }
   if (r_lo + 3 < r_hi) {
     fetch(r_lo + 3, pre_o);
     fetch(r_lo + 4, pre_e);
+    if constexpr (TODD) {
+      fetch_from(ua, r_lo + 4, pre_a);
+      fetch_from(ub, r_lo + 4, pre_b);
+    }
   }
   phase_b(Cs1, t1s1);
   __syncthreads();
@@ -422,30 +505,48 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
       const bool pv_e = p + 1 >= 0 && p + 1 <= Pmax_r && p + 1 != ghost_r;
       const T rr = rrs[p - r_lo];
       T E[4], cve[4], cvo[4];
-      cell_even(own, raw1, Cs1, pv_e, E, cve);
-      cell_odd(own, raw0, Cs0, pv_o, rr, Go, E, cvo);
+      if constexpr (TODD) {
+        pair_todd(own, pv_o, pv_e, rr, Ga2, Gb2, cvo, cve);
+        if (pv_o && p >= 2 * R0) emit(cvo, mr + (p - 1) / 2, 0);
+        if (pv_e && p + 1 < 2 * R0 + 2 * rch) emit(cve, (p + 1) / 2, 0);
+        if (tid < NH) {
+          T ho[4], he[4];
+          pair_todd(halo, pv_o, pv_e, rr, Gha, Ghb, ho, he);
+        }
+      } else {
+        cell_even(own, raw1, Cs1, pv_e, E, cve);
+        cell_odd(own, raw0, Cs0, pv_o, rr, Go, E, cvo);
 #pragma unroll
-      for (int k = 0; k < 4; k++) Go[k] = E[k];
-      if (pv_o && p >= 2 * R0) emit(cvo, mr + (p - 1) / 2, 0);
-      if (pv_e && p + 1 < 2 * R0 + 2 * rch) {
-        if (all_on || own.s0) A.coarse[(size_t)((p + 1) / 2) * mc * mf + coarse_off] = E[0];
-        emit(cve, (p + 1) / 2, 1);
-      }
-      if (tid < NH) {
-        T Eh[4], ch[4];
-        cell_even(halo, raw1, Cs1, pv_e, Eh, ch);
-        cell_odd(halo, raw0, Cs0, pv_o, rr, Gh, Eh, ch);
+        for (int k = 0; k < 4; k++) Go[k] = E[k];
+        if (pv_o && p >= 2 * R0) emit(cvo, mr + (p - 1) / 2, 0);
+        if (pv_e && p + 1 < 2 * R0 + 2 * rch) {
+          if (all_on || own.s0) A.coarse[(size_t)((p + 1) / 2) * mc * mf + coarse_off] = E[0];
+          emit(cve, (p + 1) / 2, 1);
+        }
+        if (tid < NH) {
+          T Eh[4], ch[4];
+          cell_even(halo, raw1, Cs1, pv_e, Eh, ch);
+          cell_odd(halo, raw0, Cs0, pv_o, rr, Gh, Eh, ch);
 #pragma unroll
-        for (int k = 0; k < 4; k++) Gh[k] = Eh[k];
+          for (int k = 0; k < 4; k++) Gh[k] = Eh[k];
+        }
       }
     }
     __syncthreads();
     if (p + 2 < r_hi) {
       stash(raw0, pre_o);
       stash(raw1, pre_e);
+      if constexpr (TODD) {
+        stash(rawa, pre_a);
+        stash(rawb, pre_b);
+      }
       if (p + 4 < r_hi) {
         fetch(p + 4, pre_o);
         fetch(p + 5, pre_e);
+        if constexpr (TODD) {
+          fetch_from(ua, p + 5, pre_a);
+          fetch_from(ub, p + 5, pre_b);
+        }
       }
     }
     phase_b(Cs0, t1s0);
@@ -491,17 +592,52 @@ struct Fused2Grid {
   int xcd_ranges;     // tiles handed to the XCDs in contiguous ranges (grid.x padded to 8)
 };
 
-template <typename T, int OUT, int TC, int TF, int RCH, bool FACES>
+// D = 4: the level is processed slice by slice of the slowest dimension t with the 3-D tile code
+// (the reference treats D > 3 "three dimensions at a time" as well: CalcCoefficientsND.hpp:25-236,
+// CalcCorrectionND.hpp:131-155,199-213). blockIdx.z = slice index zi.
+//   TMODE 1, even slices (padded position P = 2 zi, coarse index zi): exactly the 3-D pass of the
+//     slice; coarse nodes -> slice zi of the 4-D coarse array, load vector -> slice P of the
+//     per-slice load vectors (the t-sweep and the four solves follow in k_tsweep / ipk).
+//   TMODE 2, odd slices (P = 2 zi + 1, coefficient index m_t + zi): TODD tiles.
+template <typename T> struct Fused4 {
+  const T *ratio_t;  // fine-level interpolation ratios of dim t
+  size_t uT;         // element stride of t in the level's input
+  size_t dT;         // element stride of t in the output array
+  size_t cT;         // m_r * m_c * m_f
+  int n_t, m_t;
+};
+
+template <typename T, int OUT, int TC, int TF, int RCH, bool FACES, int TMODE = 0>
 __global__ void __launch_bounds__(TC * TF)
-k_level_fused2(FusedArgs<T> A, Fused2Grid G) {
+k_level_fused2(FusedArgs<T> A, Fused2Grid G, Fused4<T> Q) {
   static_assert(TC * TF == 256, "face tiles are 64 x 4 and 4 x 64");
-  constexpr int e0 = Fused2Geom<TC, TF, RCH>::elems, e1 = Fused2Geom<64, 4, RCH>::elems,
-                e2 = Fused2Geom<4, 64, RCH>::elems;
+  constexpr bool TODD = TMODE == 2;
+  constexpr int e0 = Fused2Geom<TC, TF, RCH, TODD>::elems, e1 = Fused2Geom<64, 4, RCH, TODD>::elems,
+                e2 = Fused2Geom<4, 64, RCH, TODD>::elems;
   constexpr int elems = FACES ? (e0 > e1 ? (e0 > e2 ? e0 : e2) : (e1 > e2 ? e1 : e2)) : e0;
   __shared__ __attribute__((aligned(16))) T lds[elems];
   if (OUT == OUT_Q && A.qp) {
     A.quantizer = A.qp[A.level];
     A.volume = A.qp[A.nlev + A.level];
+  }
+  const T *ua = nullptr, *ub = nullptr;
+  T rt = 0;
+  size_t out_base = 0;
+  if (TMODE != 0) {
+    const int zi = blockIdx.z;
+    const int P = 2 * zi + (TODD ? 1 : 0);            // padded position of the slice
+    const T *vol = A.u;
+    A.u = vol + (size_t)min(P, Q.n_t - 1) * Q.uT;     // (even n_t: the last node sits at P = n_t)
+    A.load = A.load + (size_t)P * Q.cT;
+    if (TODD) {
+      ua = vol + (size_t)(P - 1) * Q.uT;
+      ub = vol + (size_t)min(P + 1, Q.n_t - 1) * Q.uT;
+      rt = Q.ratio_t[P - 1];
+      out_base = (size_t)(Q.m_t + zi) * Q.dT;
+    } else {
+      A.coarse = A.coarse + (size_t)zi * Q.cT;
+      out_base = (size_t)zi * Q.dT;
+    }
   }
   // r-chunks in reverse launch order: whatever ran before this kernel (the norm reduction,
   // the level above) leaves the END of the level's input in the memory-side cache
@@ -519,13 +655,71 @@ k_level_fused2(FusedArgs<T> A, Fused2Grid G) {
   }
   const int f_main_end = G.n_ff ? G.ff_F0 : A.m[2], c_main_end = G.n_cf ? G.cf_C0 : A.m[1];
   if (!FACES || b < G.n_main) {
-    level_tile2<T, OUT, TC, TF, RCH>(A, (b % G.gxm) * TF, (b / G.gxm) * TC, R0, rch, c_main_end,
-                                     f_main_end, lds);
+    level_tile2<T, OUT, TC, TF, RCH, TODD>(A, (b % G.gxm) * TF, (b / G.gxm) * TC, R0, rch,
+                                           c_main_end, f_main_end, lds, ua, ub, rt, out_base);
   } else if (b < G.n_main + G.n_ff) {
-    level_tile2<T, OUT, 64, 4, RCH>(A, G.ff_F0, (b - G.n_main) * 64, R0, rch, A.m[1], A.m[2], lds);
+    level_tile2<T, OUT, 64, 4, RCH, TODD>(A, G.ff_F0, (b - G.n_main) * 64, R0, rch, A.m[1], A.m[2],
+                                          lds, ua, ub, rt, out_base);
   } else {
-    level_tile2<T, OUT, 4, 64, RCH>(A, (b - G.n_main - G.n_ff) * 64, G.cf_C0, R0, rch, A.m[1],
-                                    f_main_end, lds);
+    level_tile2<T, OUT, 4, 64, RCH, TODD>(A, (b - G.n_main - G.n_ff) * 64, G.cf_C0, R0, rch, A.m[1],
+                                          f_main_end, lds, ua, ub, rt, out_base);
+  }
+}
+
+// D = 4: quantize (or copy) the level-0 nodal values (compact (m0, m1, m2, m3)) into the head of
+// the output; dT = element stride of t in the output array.
+template <typename T, int OUT>
+__global__ void __launch_bounds__(256)
+k_head_out4(int m0, int m1, int m2, int m3, const T *__restrict__ nodal, FusedArgs<T> A, size_t dT) {
+  if (OUT == OUT_Q && A.qp) {
+    A.quantizer = A.qp[0];
+    A.volume = A.qp[A.nlev];
+  }
+  const int total = m0 * m1 * m2 * m3;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int k = e % m3, j = (e / m3) % m2, i = (e / (m3 * m2)) % m1, t = e / (m3 * m2 * m1);
+    const size_t lin = (size_t)t * dT + (size_t)i * A.dI + (size_t)j * A.dJ + k;
+    const T v = nodal[e];
+    if (OUT == OUT_T) {
+      A.coef[lin] = v;
+    } else {
+      int64_t qd = quantize_one(v, A.quantizer, A.volume);
+      if (A.prep_huffman) {
+        qd += A.dict_size / 2;
+        if (!(qd >= 0 && qd < A.dict_size)) {
+          const unsigned long long o = atomicAdd(A.outlier_count, 1ULL);
+          if (o < A.outlier_cap) {
+            A.outlier_idx[o] = lin;
+            A.outlier_val[o] = qd;
+          }
+          qd = 0;
+        }
+      }
+      if (A.q16) A.q16[lin] = (uint16_t)qd;
+      else A.q[lin] = qd;
+    }
+  }
+}
+
+// D = 4: the last mass/restriction sweep, along t, on the per-slice load vectors:
+// L[P][j], P in [0, 2 m_t - 2] padded positions (a ghost slice is all zero), j < M = m_r m_c m_f
+// -> out[T][j] (LPKFunctor.h:77-93; operands out of range are zero).
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_tsweep(const T *__restrict__ L, T *__restrict__ out, size_t M, int m_t, const T *__restrict__ mass) {
+  const int Tt = blockIdx.y;
+  T w[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) w[k] = mass[k * m_t + Tt];
+  const int np = 2 * m_t - 1;
+  for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < M; j += (size_t)gridDim.x * 256) {
+    T v[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const int P = 2 * Tt - 2 + k;
+      v[k] = (P >= 0 && P < np) ? L[(size_t)P * M + j] : (T)0;
+    }
+    out[(size_t)Tt * M + j] = mass_apply(v[0], v[1], v[2], v[3], v[4], w);
   }
 }
 

@@ -530,6 +530,71 @@ def test_config3_4d_slab(shape):
     h.close()
 
 
+def _slab4d(shape, dt=np.float32):
+    """A slab of time steps: a 3-D field that drifts slowly along dim 0 (tools/exp_4d.py)."""
+    base = smooth_field(shape[1:], dt)
+    return np.stack([base * dt(1.0 + 0.002 * t) + dt(1e-4 * t) for t in range(shape[0])])
+
+
+@pytest.mark.parametrize("shape,dt", [((8, 66, 70, 129), np.float32), ((7, 33, 130, 65), np.float64),
+                                      ((5, 40, 36, 72), np.float32), ((16, 65, 65, 65), np.float32)])
+def test_fused_4d_path_equals_generic_nd(shape, dt, monkeypatch):
+    """D = 4 runs slice by slice on the 3-D tile code (decompose_fused4: even slices of the
+    slowest dim as 3-D passes, odd slices interpolating across t as well, then the t-sweep and
+    four Thomas solves). MGH_FUSED4=0 keeps the generic one-thread-per-element N-D kernels:
+    same coefficients, integers and outliers, bit for bit -- and both equal the oracle."""
+    torch, mg = _gpu()
+    u = smooth_field(shape, dt, noise=1e-2)
+    ud = torch.from_numpy(u).cuda()
+    o = oracle.Hierarchy(shape, dt)
+    ref = o.decompose(u)
+    h = mg.Hierarchy(shape, dt)
+    c = h.decompose(ud)
+    assert_bit_equal(c.cpu().numpy(), ref, "fused 4-D decompose %r" % (shape,))
+    q, oi, ov, cnt, nrm = h.decompose_quantize(ud, mg.REL, 1e-3, np.inf, outlier_cap=u.size)
+    h.close()
+    monkeypatch.setenv("MGH_FUSED4", "0")
+    g = mg.Hierarchy(shape, dt)
+    q2, oi2, ov2, cnt2, nrm2 = g.decompose_quantize(ud, mg.REL, 1e-3, np.inf, outlier_cap=u.size)
+    assert cnt == cnt2 and nrm == nrm2 and torch.equal(q, q2)
+    a, b = _outlier_set(oi.cpu().numpy(), ov.cpu().numpy()), _outlier_set(oi2.cpu().numpy(), ov2.cpu().numpy())
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    g.close()
+
+
+def test_config3_full_size_slab():
+    """BASELINE.json configs[3] at FULL per-rank size, 8 x 512^3 float32 (the oracle would need
+    minutes): the fused 4-D path against the generic N-D kernels bit for bit, and the round trip
+    through the (generic) recomposition within the tolerance."""
+    torch, mg = _gpu()
+    shape = (8, 512, 512, 512)
+    if _host_mem_gb() < 24 or torch.cuda.mem_get_info()[0] < (40 << 30):
+        pytest.skip("not enough memory for the full-size slab")
+    u = _slab4d(shape)
+    ud = torch.from_numpy(u).cuda()
+    nrm = float(np.max(np.abs(u)))
+    del u
+    cap = ud.numel() // 8
+    h = mg.Hierarchy(shape, np.float32)
+    assert h.l_target == 3
+    q, oi, ov, cnt, n1 = h.decompose_quantize(ud, mg.REL, 1e-3, np.inf, outlier_cap=cap)
+    assert n1 == nrm and cnt <= cap
+    os.environ["MGH_FUSED4"] = "0"
+    try:
+        g = mg.Hierarchy(shape, np.float32)
+    finally:
+        del os.environ["MGH_FUSED4"]
+    q2, oi2, ov2, cnt2, n2 = g.decompose_quantize(ud, mg.REL, 1e-3, np.inf, outlier_cap=cap)
+    assert cnt == cnt2 and torch.equal(q, q2)
+    a, b = _outlier_set(oi.cpu().numpy(), ov.cpu().numpy()), _outlier_set(oi2.cpu().numpy(), ov2.cpu().numpy())
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    del q2, oi2, ov2
+    g.close()
+    back = h.dequantize_recompose(q, mg.REL, 1e-3, np.inf, nrm, outlier_idx=oi, outlier_val=ov)
+    assert float((back - ud).abs().max().item()) <= 1e-3 * nrm
+    h.close()
+
+
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 @pytest.mark.parametrize("split", ["1", "2"])
 @pytest.mark.parametrize("shape,mode,s", [((257, 300, 258), "REL", np.inf), ((200, 130, 513), "ABS", 0.0),
