@@ -150,8 +150,9 @@ int mgh_decompose_quantize_sym16(mgh_hierarchy *h, const void *d_data, int error
 /* Inverse of mgh_decompose_quantize_sym16: dequantize + recompose from 16-bit symbols and the
  * outlier list (found by index through a hash table: symbol 0 at an outlier's position).
  * Same result as mgh_dequantize_recompose on the widened values. mgh_sym16_supported tells
- * whether this hierarchy runs the two *_sym16 calls (1) or returns
- * MGH_ERR_UNSUPPORTED_DIMENSION (0). */
+ * whether this hierarchy runs BOTH *_sym16 calls (1: the fused 3-D path) or not (0); the
+ * compression-side call alone also runs on the fused 4-D path and returns
+ * MGH_ERR_UNSUPPORTED_DIMENSION elsewhere. */
 int mgh_dequantize_recompose_sym16(mgh_hierarchy *h, const uint16_t *d_symbols, int error_bound_type,
                                    double tol, double s, double norm, uint64_t dict_size,
                                    const uint64_t *d_outlier_idx, const int64_t *d_outlier_val,

@@ -1871,8 +1871,8 @@ int mgh_decompose_quantize_sym16(mgh_hierarchy *h, const void *d_data, int error
     return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
   if (dict_size == 0 || dict_size > 65536) return fail(MGH_ERR_INVALID_ARGUMENT, "dict_size must be in 1..65536");
   HIP_TRY(hipSetDevice(h->device));
-  if (!mgh_sym16_supported(h))
-    return fail(MGH_ERR_UNSUPPORTED_DIMENSION, "16-bit symbols: only on the fused 3-D path");
+  if (!(fusedc_ok(h) && !h->force_v1 && !h->split))
+    return fail(MGH_ERR_UNSUPPORTED_DIMENSION, "16-bit symbols: only on the fused 3-D / 4-D path");
   // (the norm and the quantizers stay on the device; a given norm is uploaded first)
   const void *d_norm = nullptr;
   if (!(error_bound_type == MGH_REL && !(norm > 0)) && error_bound_type == MGH_REL) {
