@@ -87,6 +87,25 @@ int mgh_decompress(const void *compressed_data, size_t compressed_size,
                    void **decompressed_data, const mgh_config *config,
                    int output_pre_allocated);
 
+/* One process, several devices (the reference's MGARD_ENABLE_MULTI_DEVICE switch is dead code,
+ * include/mgard-x/RuntimeX/RuntimeX.h:53; its multi-GPU example runs one rank per GPU:
+ * examples/mgard-x/CompressXgcData/TestXGCAbsoluteError.cpp:36-252). HOST buffers only. The domain
+ * is cut into slabs of the slowest dimension, slab id runs on device dev_ids[id % num_dev] (one
+ * host thread, stream set and cache per device; an id may be listed more than once); a REL
+ * bound uses the norm of the WHOLE domain (slab norms combined on the host,
+ * ErrorToleranceCalculator.hpp:69-89) and every slab the ABS bound of :134-155. The result is an
+ * ordinary MGARD-X container with a MaxDim decomposition of dimension 0: mgh_decompress,
+ * mgh_decompress_multi and stock MGARD-X read it; mgh_decompress_multi shares the subdomains of
+ * any container decomposed that way out over the devices and hands everything else to
+ * mgh_decompress on dev_ids[0]. config->dev_id is ignored. */
+int mgh_compress_multi(int num_dev, const int *dev_ids, int D, int dtype, const uint64_t *shape,
+                       double tol, double s, int error_bound_type, const void *original_data,
+                       void **compressed_data, size_t *compressed_size, const void *const *coords,
+                       const mgh_config *config, int output_pre_allocated);
+int mgh_decompress_multi(int num_dev, const int *dev_ids, const void *compressed_data,
+                         size_t compressed_size, void **decompressed_data,
+                         const mgh_config *config, int output_pre_allocated);
+
 /* infer_shape / infer_data_type (Metadata.hpp:244-247). compressed_data: host or device. */
 int mgh_infer_shape(const void *compressed_data, size_t compressed_size, int *D_out,
                     uint64_t *shape_out /* [MGH_MAX_DIM] */);

@@ -14,6 +14,7 @@
 #include <atomic>
 #include <cmath>
 #include <memory>
+#include <mutex>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -1573,6 +1574,358 @@ int mgh_decompress(const void *compressed_data, size_t compressed_size, void **d
     return hl_fail(MGH_ERR_DEVICE, e.what());
   }
 }
+
+}  // extern "C"
+
+// ---- one process, several devices ------------------------------------------------------------
+// The domain is cut into slabs along the slowest dimension (recorded in the header as a
+// MaxDim decomposition of dimension 0, so any MGARD-X reader finds the subdomains where it
+// expects them); slab id runs on device dev_ids[id % num_dev], every device on its own host
+// thread with its own streams and caches. Subdomains are independent (own hierarchy, no halo:
+// DomainDecomposer.hpp:260-303); the only coupling is the error budget of a REL bound: the slab
+// norms are combined on the host (ErrorToleranceCalculator.hpp:69-89) and every slab then runs
+// with the ABS bound calc_local_abs_tol (:134-155) -- exactly what mgh_compress does for a
+// decomposed domain, so the container is the one mgh_compress would write with this decomposition
+// (up to the order of the outlier lists) and mgh_decompress / mgh_decompress_multi both read it.
+// Payloads are framed `[u64 size][payload]` in id order (GPUPipelines.hpp:189-193).
+namespace {
+
+struct MultiErr {
+  std::mutex m;
+  int rc = MGH_SUCCESS;
+  std::string msg;
+  void set(int code) {
+    std::lock_guard<std::mutex> g(m);
+    if (rc == MGH_SUCCESS) {
+      rc = code;
+      msg = mgh_last_error();
+    }
+  }
+};
+
+inline uint64_t multi_slab_size(uint64_t n0, int ndev) {
+  // ceil(n0 / ndev), grown until the last slab has at least 3 planes (a hierarchy needs them)
+  uint64_t size = (n0 + ndev - 1) / ndev;
+  size = std::max<uint64_t>(size, 3);
+  while (size < n0 && n0 % size != 0 && n0 % size < 3) size++;
+  return size;
+}
+
+template <typename T>
+int compress_multi_impl(int ndev, const int *devs, int D, int dtype, const uint64_t *shape,
+                        double tol_d, double s_d, int ebtype, const void *original,
+                        void **compressed, size_t *compressed_size, const void *const *coords_in,
+                        const mgh_config &cfg0, bool prealloc) {
+  const size_t elem = sizeof(T);
+  Decomposer dd;
+  dd.D = D;
+  dd.shape.assign(shape, shape + D);
+  dd.method = MGH_DD_MAXDIM;
+  dd.dim = 0;
+  dd.size = multi_slab_size(shape[0], ndev);
+  dd.num = (shape[0] - 1) / dd.size + 1;
+  dd.decomposed = dd.num > 1;
+  if (!dd.decomposed) {  // nothing to share out
+    mgh_config c = cfg0;
+    c.dev_id = devs[0];
+    return mgh_compress(D, dtype, shape, tol_d, s_d, ebtype, original, compressed, compressed_size,
+                        coords_in, &c, prealloc);
+  }
+  size_t total = 1, inner = 1;
+  for (int d = 0; d < D; d++) total *= shape[d];
+  for (int d = 1; d < D; d++) inner *= shape[d];
+  const T tol = (T)tol_d, s = (T)s_d;
+  std::vector<std::vector<double>> coords;
+  if (coords_in) {
+    coords.resize(D);
+    for (int d = 0; d < D; d++) {
+      const T *c = static_cast<const T *>(coords_in[d]);
+      coords[d].assign(c, c + shape[d]);
+    }
+  }
+  const uint64_t num = dd.num;
+  const int nthr = (int)std::min<uint64_t>(num, (uint64_t)ndev);
+  auto slab_ptr = [&](uint64_t id) { return (const char *)original + dd.linear_offset(id) * elem; };
+  auto slab_coords = [&](uint64_t id, std::vector<const void *> &out) {
+    out.assign(D, nullptr);
+    if (!coords_in) return (const void *const *)nullptr;
+    for (int d = 0; d < D; d++)
+      out[d] = (const void *)(static_cast<const T *>(coords_in[d]) + (d == 0 ? dd.subdomain_offset(id)[0] : 0));
+    return (const void *const *)out.data();
+  };
+  MultiErr err;
+  // ---- phase 1 (REL): slab norms on their devices, combined on the host --------------------
+  T norm = 1;
+  if (ebtype == MGH_REL) {
+    std::vector<double> ln(num, 0.0);
+    std::vector<std::thread> th;
+    for (int k = 0; k < nthr; k++)
+      th.emplace_back([&, k] {
+        mgh_config c = cfg0;
+        c.dev_id = devs[k];
+        if (hipSetDevice(c.dev_id) != hipSuccess || cache_prepare(c.dev_id) != MGH_SUCCESS) {
+          err.set(hl_fail(MGH_ERR_DEVICE, "device of a worker thread"));
+          return;
+        }
+        for (uint64_t id = k; id < num && err.rc == MGH_SUCCESS; id += nthr) {
+          const auto sshape = dd.subdomain_shape(id);
+          uint64_t cnt = 1;
+          for (uint64_t e : sshape) cnt *= e;
+          mgh_hierarchy *h = nullptr;
+          bool owned = false;
+          int rc = get_hierarchy(&h, &owned, dtype, sshape, nullptr, dd.subdomain_offset(id), c);
+          if (rc == MGH_SUCCESS) rc = g_cache.in[0].ensure(cnt * elem);
+          if (rc == MGH_SUCCESS) rc = copy_any(g_cache.in[0].p, slab_ptr(id), cnt * elem, g_cache.streams[0]);
+          if (rc == MGH_SUCCESS) rc = mgh_norm(h, g_cache.in[0].p, s_d, &ln[id], g_cache.streams[0]);
+          if (owned) mgh_hierarchy_destroy(h);
+          if (rc != MGH_SUCCESS) err.set(rc);
+        }
+        mgh_release_cache();
+      });
+    for (auto &t : th) t.join();
+    if (err.rc != MGH_SUCCESS) {
+      mgh_set_last_error_(err.msg.c_str());
+      return err.rc;
+    }
+    double acc = 0;
+    for (uint64_t id = 0; id < num; id++) {
+      uint64_t cnt = inner * dd.subdomain_shape(id)[0];
+      if (s == std::numeric_limits<T>::infinity()) acc = std::max(acc, ln[id]);
+      else acc += ln[id] * ln[id] * (cfg0.normalize_coordinates ? (double)cnt : 1.0);
+    }
+    if (s == std::numeric_limits<T>::infinity()) norm = (T)acc;
+    else norm = (T)(cfg0.normalize_coordinates ? std::sqrt(acc / (double)total) : std::sqrt(acc));
+  }
+  const T local_tol = local_abs_tol<T>(ebtype, norm, tol, s, num);
+  // ---- phase 2: every slab as a stand-alone ABS compression on its device -------------------
+  std::vector<void *> part(num, nullptr);
+  std::vector<size_t> part_size(num, 0);
+  {
+    std::vector<std::thread> th;
+    for (int k = 0; k < nthr; k++)
+      th.emplace_back([&, k] {
+        mgh_config c = cfg0;
+        c.dev_id = devs[k];
+        c.domain_decomposition = MGH_DD_MAXDIM;  // (a slab that does not fit is split further)
+        for (uint64_t id = k; id < num && err.rc == MGH_SUCCESS; id += nthr) {
+          const auto sshape = dd.subdomain_shape(id);
+          std::vector<const void *> cs;
+          const void *const *cp = slab_coords(id, cs);
+          size_t sz = 0;
+          const int rc = mgh_compress(D, dtype, sshape.data(), (double)local_tol, s_d, MGH_ABS,
+                                      slab_ptr(id), &part[id], &sz, cp, &c, 0);
+          part_size[id] = sz;
+          if (rc != MGH_SUCCESS) err.set(rc);
+        }
+        mgh_release_cache();
+      });
+    for (auto &t : th) t.join();
+  }
+  auto free_parts = [&] {
+    for (void *p : part) std::free(p);
+  };
+  if (err.rc != MGH_SUCCESS) {
+    free_parts();
+    mgh_set_last_error_(err.msg.c_str());
+    return err.rc;
+  }
+  // ---- assembly: one header, the records in id order -------------------------------------------
+  fmt::Header hdr;
+  header_from(dd, dtype, ebtype, tol_d, s_d, ebtype == MGH_REL ? (double)norm : 0.0,
+              coords_in ? &coords : nullptr, cfg0, hdr);
+  const std::vector<uint8_t> meta = fmt::serialize_metadata(hdr);
+  std::vector<size_t> body_off(num), body_len(num);
+  size_t need = meta.size();
+  for (uint64_t id = 0; id < num; id++) {
+    fmt::Header sh;
+    size_t ms = 0;
+    int rc = read_header(part[id], part_size[id], sh, ms);
+    if (rc == MGH_SUCCESS && sh.dd_method != fmt::DD_NOOP)
+      rc = hl_fail(MGH_ERR_OUT_OF_MEMORY, "a slab does not fit its device in one piece: use more, smaller slabs");
+    if (rc != MGH_SUCCESS) {
+      free_parts();
+      return rc;
+    }
+    body_off[id] = ms;
+    body_len[id] = part_size[id] - ms;
+    need += body_len[id];
+  }
+  if (!prealloc) {
+    if (!(*compressed = std::malloc(need))) {
+      free_parts();
+      return hl_fail(MGH_ERR_OUT_OF_MEMORY, "malloc");
+    }
+  } else if (*compressed_size < need) {
+    free_parts();
+    return hl_fail(MGH_ERR_OUTPUT_TOO_LARGE, "output buffer too small");
+  }
+  char *o = (char *)*compressed;
+  std::memcpy(o, meta.data(), meta.size());
+  size_t at = meta.size();
+  for (uint64_t id = 0; id < num; id++) {
+    std::memcpy(o + at, (const char *)part[id] + body_off[id], body_len[id]);
+    at += body_len[id];
+  }
+  *compressed_size = at;
+  free_parts();
+  return MGH_SUCCESS;
+}
+
+template <typename T>
+int decompress_multi_impl(int ndev, const int *devs, const fmt::Header &hd, size_t meta_size,
+                          const void *compressed, size_t compressed_size, void **out,
+                          const mgh_config &cfg0, bool prealloc) {
+  const size_t elem = sizeof(T);
+  Decomposer dd;
+  HL_TRY(decomposer_from_header(hd, cfg0, dd));
+  size_t total = 1;
+  for (uint64_t e : hd.shape) total *= e;
+  if (!prealloc && !(*out = std::malloc(total * elem))) return hl_fail(MGH_ERR_OUT_OF_MEMORY, "malloc");
+  auto bail = [&](int rc) {
+    if (!prealloc) {
+      std::free(*out);
+      *out = nullptr;
+    }
+    return rc;
+  };
+  // record offsets (the sizes are in the stream)
+  const uint64_t num = dd.num;
+  std::vector<size_t> off(num), len(num);
+  size_t at = meta_size;
+  for (uint64_t id = 0; id < num; id++) {
+    if (at + 8 > compressed_size) return bail(hl_fail(MGH_ERR_FORMAT, "truncated stream"));
+    uint64_t cs = 0;
+    std::memcpy(&cs, (const char *)compressed + at, 8);
+    if (cs > compressed_size - at - 8) return bail(hl_fail(MGH_ERR_FORMAT, "truncated record"));
+    off[id] = at;
+    len[id] = 8 + (size_t)cs;
+    at += len[id];
+  }
+  const T norm = (T)hd.norm, tol = (T)hd.tol, s = (T)hd.s;
+  const T local_tol = local_abs_tol<T>(hd.rel ? MGH_REL : MGH_ABS, norm, tol, s, num);
+  const int nthr = (int)std::min<uint64_t>(num, (uint64_t)ndev);
+  MultiErr err;
+  std::vector<std::thread> th;
+  for (int k = 0; k < nthr; k++)
+    th.emplace_back([&, k] {
+      mgh_config c = cfg0;
+      c.dev_id = devs[k];
+      for (uint64_t id = k; id < num && err.rc == MGH_SUCCESS; id += nthr) {
+        // the record as a container of its own: header of the slab (ABS bound) + the record
+        Decomposer one;
+        one.D = dd.D;
+        one.shape = dd.subdomain_shape(id);
+        one.decomposed = false;
+        one.num = 1;
+        std::vector<std::vector<double>> sc;
+        if (!hd.uniform) {
+          sc = hd.coords;
+          const uint64_t o0 = dd.subdomain_offset(id)[0];
+          sc[0].assign(hd.coords[0].begin() + o0, hd.coords[0].begin() + o0 + one.shape[0]);
+        }
+        fmt::Header sh;
+        header_from(one, hd.is_double ? MGH_DOUBLE : MGH_FLOAT, MGH_ABS, (double)local_tol, hd.s, 0.0,
+                    hd.uniform ? nullptr : &sc, c, sh);
+        sh.compressor = hd.compressor;
+        sh.huff_dict_size = hd.huff_dict_size;
+        sh.huff_block_size = hd.huff_block_size;
+        const std::vector<uint8_t> meta = fmt::serialize_metadata(sh);
+        std::vector<uint8_t> mini(meta.size() + len[id]);
+        std::memcpy(mini.data(), meta.data(), meta.size());
+        std::memcpy(mini.data() + meta.size(), (const char *)compressed + off[id], len[id]);
+        void *dst = (char *)*out + dd.linear_offset(id) * elem;
+        const int rc = mgh_decompress(mini.data(), mini.size(), &dst, &c, 1);
+        if (rc != MGH_SUCCESS) err.set(rc);
+      }
+      mgh_release_cache();
+    });
+  for (auto &t : th) t.join();
+  if (err.rc != MGH_SUCCESS) {
+    mgh_set_last_error_(err.msg.c_str());
+    return bail(err.rc);
+  }
+  return MGH_SUCCESS;
+}
+
+int check_devs(int num_dev, const int *dev_ids) {
+  if (num_dev < 1 || !dev_ids) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "device list");
+  const int have = mgh_device_count();
+  if (have <= 0) return hl_fail(MGH_ERR_NO_DEVICE, "no HIP device");
+  for (int k = 0; k < num_dev; k++)
+    if (dev_ids[k] < 0 || dev_ids[k] >= have) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "device id out of range");
+  return MGH_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mgh_compress_multi(int num_dev, const int *dev_ids, int D, int dtype, const uint64_t *shape,
+                       double tol, double s, int ebtype, const void *original_data,
+                       void **compressed_data, size_t *compressed_size, const void *const *coords,
+                       const mgh_config *config, int output_pre_allocated) {
+  if (!shape || !original_data || !compressed_data || !compressed_size)
+    return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (D < 1 || D > MGH_MAX_DIM) return hl_fail(MGH_ERR_UNSUPPORTED_DIMENSION, "D must be 1..5");
+  if (dtype != MGH_FLOAT && dtype != MGH_DOUBLE) return hl_fail(MGH_ERR_UNSUPPORTED_DTYPE, "dtype");
+  if (ebtype != MGH_REL && ebtype != MGH_ABS) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "error_bound_type");
+  if (output_pre_allocated && !*compressed_data) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "pre-allocated output is NULL");
+  HL_TRY(check_devs(num_dev, dev_ids));
+  HL_TRY(check_config(config));
+  if (is_device_pointer(original_data) || (output_pre_allocated && is_device_pointer(*compressed_data)))
+    return hl_fail(MGH_ERR_INVALID_ARGUMENT, "mgh_compress_multi: host buffers only (the slabs travel to their devices inside)");
+  try {
+    if (dtype == MGH_FLOAT)
+      return compress_multi_impl<float>(num_dev, dev_ids, D, dtype, shape, tol, s, ebtype, original_data,
+                                        compressed_data, compressed_size, coords, *config,
+                                        output_pre_allocated != 0);
+    return compress_multi_impl<double>(num_dev, dev_ids, D, dtype, shape, tol, s, ebtype, original_data,
+                                       compressed_data, compressed_size, coords, *config,
+                                       output_pre_allocated != 0);
+  } catch (const std::exception &e) {
+    return hl_fail(MGH_ERR_DEVICE, e.what());
+  }
+}
+
+int mgh_decompress_multi(int num_dev, const int *dev_ids, const void *compressed_data,
+                         size_t compressed_size, void **decompressed_data, const mgh_config *config,
+                         int output_pre_allocated) {
+  if (!compressed_data || !decompressed_data) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (output_pre_allocated && !*decompressed_data) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "pre-allocated output is NULL");
+  HL_TRY(check_devs(num_dev, dev_ids));
+  mgh_config def;
+  if (!config) {
+    mgh_config_default(&def);
+    config = &def;
+  }
+  if (is_device_pointer(compressed_data) || (output_pre_allocated && is_device_pointer(*decompressed_data)))
+    return hl_fail(MGH_ERR_INVALID_ARGUMENT, "mgh_decompress_multi: host buffers only");
+  fmt::Header hd;
+  size_t meta_size = 0;
+  HL_TRY(read_header(compressed_data, compressed_size, hd, meta_size));
+  if (hd.shape.empty() || hd.shape.size() > MGH_MAX_DIM) return hl_fail(MGH_ERR_UNSUPPORTED_DIMENSION, "header: dimension");
+  if (!hd.quantized) return hl_fail(MGH_ERR_FORMAT, "not a compressed (quantized) stream");
+  // slabs of the slowest dimension only; anything else goes through the single-device path
+  const bool slabs = hd.dd_method == fmt::DD_MAX_DIMENSION && hd.dd_dim == 0;
+  if (!slabs) {
+    mgh_config c = *config;
+    c.dev_id = dev_ids[0];
+    return mgh_decompress(compressed_data, compressed_size, decompressed_data, &c, output_pre_allocated);
+  }
+  try {
+    if (hd.is_double)
+      return decompress_multi_impl<double>(num_dev, dev_ids, hd, meta_size, compressed_data, compressed_size,
+                                           decompressed_data, *config, output_pre_allocated != 0);
+    return decompress_multi_impl<float>(num_dev, dev_ids, hd, meta_size, compressed_data, compressed_size,
+                                        decompressed_data, *config, output_pre_allocated != 0);
+  } catch (const std::exception &e) {
+    return hl_fail(MGH_ERR_DEVICE, e.what());
+  }
+}
+
+}  // extern "C"
+
+extern "C" {
 
 int mgh_infer_shape(const void *data, size_t size, int *D_out, uint64_t *shape_out) {
   if (!data || !D_out || !shape_out) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");

@@ -21,6 +21,7 @@ HL_SYMBOLS = [
     "mgh_infer_data_type", "mgh_free_device", "mgh_release_cache", "mgh_metadata_serialize",
     "mgh_metadata_parse", "mgh_lossless_create", "mgh_lossless_destroy", "mgh_lossless_compress",
     "mgh_lossless_decompress", "mgh_memcpy", "mgh_huffman_codebook",
+    "mgh_compress_multi", "mgh_decompress_multi",
 ]
 
 
@@ -97,6 +98,11 @@ def _hl():
                                C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp),
                                C.POINTER(Config), C.c_int]
     L.mgh_decompress.argtypes = [vp, C.c_size_t, C.POINTER(vp), C.POINTER(Config), C.c_int]
+    L.mgh_compress_multi.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(u64), C.c_double,
+                                     C.c_double, C.c_int, vp, C.POINTER(vp), C.POINTER(C.c_size_t),
+                                     C.POINTER(vp), C.POINTER(Config), C.c_int]
+    L.mgh_decompress_multi.argtypes = [C.c_int, C.POINTER(C.c_int), vp, C.c_size_t, C.POINTER(vp),
+                                       C.POINTER(Config), C.c_int]
     L.mgh_infer_shape.argtypes = [vp, C.c_size_t, C.POINTER(C.c_int), C.POINTER(u64)]
     L.mgh_infer_data_type.argtypes = [vp, C.c_size_t, C.POINTER(C.c_int)]
     L.mgh_free_device.argtypes = [vp]
@@ -269,6 +275,48 @@ def decompress(buf, config=None):
         out = np.empty(shape, dtype=np.float32 if dt == FLOAT else np.float64)
         p, n, optr = C.c_void_p(buf.ctypes.data), buf.size, C.c_void_p(out.ctypes.data)
     _check(L.mgh_decompress(p, n, C.byref(optr), C.byref(cfg), 1))
+    return out
+
+
+def compress_multi(data, tol, s=INF, mode=REL, devices=(0,), coords=None, config=None):
+    """mgh_compress_multi: host numpy array in, host stream out; slab id of the slowest dimension
+    runs on devices[id % len(devices)] (one host thread per device)."""
+    L = _hl()
+    cfg = config if config is not None else Config()
+    data = np.ascontiguousarray(data)
+    dt = {np.dtype(np.float32): FLOAT, np.dtype(np.float64): DOUBLE}[data.dtype]
+    D = data.ndim
+    shp = (C.c_uint64 * D)(*data.shape)
+    cptr, ckeep = None, []
+    if coords is not None:
+        arr = (C.c_void_p * D)()
+        for d in range(D):
+            c = np.ascontiguousarray(coords[d], dtype=data.dtype)
+            ckeep.append(c)
+            arr[d] = c.ctypes.data
+        cptr = arr
+    devs = (C.c_int * len(devices))(*devices)
+    cap = data.nbytes + 1000000
+    out = np.empty(cap, dtype=np.uint8)
+    optr = C.c_void_p(out.ctypes.data)
+    size = C.c_size_t(cap)
+    _check(L.mgh_compress_multi(len(devices), devs, D, dt, shp, float(tol), float(s), int(mode),
+                                C.c_void_p(data.ctypes.data), C.byref(optr), C.byref(size), cptr,
+                                C.byref(cfg), 1))
+    return out[:size.value]
+
+
+def decompress_multi(buf, devices=(0,), config=None):
+    """mgh_decompress_multi: host stream in, host numpy array out."""
+    L = _hl()
+    cfg = config if config is not None else Config()
+    shape, dt = infer(buf)
+    buf = np.ascontiguousarray(buf)
+    out = np.empty(shape, dtype=np.float32 if dt == FLOAT else np.float64)
+    optr = C.c_void_p(out.ctypes.data)
+    devs = (C.c_int * len(devices))(*devices)
+    _check(L.mgh_decompress_multi(len(devices), devs, C.c_void_p(buf.ctypes.data), buf.size,
+                                  C.byref(optr), C.byref(cfg), 1))
     return out
 
 

@@ -422,3 +422,33 @@ def test_decompress_survives_random_damage():
             outcomes["error"] += 1
     assert outcomes["error"] > 0 and outcomes["array"] > 0
     hl.release_cache()
+
+
+@pytest.mark.parametrize("shape,dt,s,mode,ndev", [
+    ((40, 65, 70), np.float32, np.inf, "REL", 2), ((37, 33, 50), np.float64, 0.0, "REL", 3),
+    ((64, 20, 33), np.float32, np.inf, "ABS", 4), ((24, 9, 17, 33), np.float32, np.inf, "REL", 2),
+    ((5, 40, 40), np.float32, np.inf, "REL", 4)])
+def test_multi_device_api_on_one_gpu(shape, dt, s, mode, ndev):
+    """mgh_compress_multi / mgh_decompress_multi (one process, one host thread per device): with
+    device 0 listed several times the whole control flow -- slabs of the slowest dimension, norm
+    of the whole domain, per-slab ABS bound, records framed in id order behind one header -- runs
+    on a single GPU. The container must be the one mgh_compress writes for the same MaxDim
+    decomposition: both decoders must read both containers, with identical reconstructions."""
+    torch, mg, hl = _mods()
+    u = smooth_field(shape, dt)
+    m = mg.REL if mode == "REL" else mg.ABS
+    devs = (0,) * ndev
+    buf = hl.compress_multi(u, 1e-3, s, m, devices=devs)
+    meta = hl.metadata_parse(bytes(buf[:4096]) if buf.size > 4096 else bytes(buf))
+    assert meta["shape"] == list(shape)
+    if shape[0] >= 6:
+        assert meta["domain_decomposed"] is True
+    if mode == "REL":
+        assert abs(meta["norm"] - _norm(u, s)) <= 1e-5 * _norm(u, s)
+    v1 = hl.decompress_multi(buf, devices=devs)
+    v2 = hl.decompress(buf)                      # the single-device reader on the same stream
+    assert np.array_equal(v1, v2)
+    bound = 1e-3 * (_norm(u, s) if mode == "REL" else 1.0)
+    assert _err(u, v1, s, shape) <= bound * (1 + 1e-6)
+    v3 = hl.decompress_multi(hl.compress(u, 1e-3, s, m), devices=devs)   # not decomposed: falls back
+    assert _err(u, v3, s, shape) <= bound * (1 + 1e-6)
