@@ -118,6 +118,11 @@ int mgh_infer_data_type(const void *compressed_data, size_t compressed_size, int
  * the NULL stream: a device-resident input that earlier work on the NULL stream is still
  * producing is complete before the first stage reads it. Work the caller has in flight on other
  * NON-BLOCKING streams is not waited for -- synchronise those before the call. */
+/* pin_memory / check_memory_pinned / unpin_memory (compress_x.hpp:166-178): page-lock a host
+ * buffer so that the pipeline's transfers out of / into it are asynchronous DMA. */
+int mgh_pin_memory(void *ptr, size_t num_bytes);
+int mgh_check_memory_pinned(const void *ptr); /* 1 = pinned, 0 = not */
+int mgh_unpin_memory(void *ptr);
 void mgh_free_device(void *p);
 /* release_cache (compress_x.hpp:159): drops this thread's cached hierarchies and buffers. */
 void mgh_release_cache(void);

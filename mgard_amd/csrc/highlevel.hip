@@ -1947,6 +1947,23 @@ int mgh_infer_data_type(const void *data, size_t size, int *dtype_out) {
   return MGH_SUCCESS;
 }
 
+// pin_memory / check_memory_pinned / unpin_memory (compress_x.hpp:166-178; HIP backend:
+// MemoryManager<HIP>::HostRegister / CheckHostRegister / HostUnregister, DeviceAdapterHip.h)
+int mgh_pin_memory(void *ptr, size_t num_bytes) {
+  if (!ptr || !num_bytes) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (is_registered_host(ptr)) return MGH_SUCCESS;  // already pinned
+  HL_HIP(hipHostRegister(ptr, num_bytes, hipHostRegisterPortable));
+  return MGH_SUCCESS;
+}
+
+int mgh_check_memory_pinned(const void *ptr) { return ptr && is_registered_host(ptr) ? 1 : 0; }
+
+int mgh_unpin_memory(void *ptr) {
+  if (!ptr) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");
+  HL_HIP(hipHostUnregister(ptr));
+  return MGH_SUCCESS;
+}
+
 void mgh_free_device(void *p) {
   if (p) (void)hipFree(p);
 }

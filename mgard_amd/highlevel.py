@@ -21,7 +21,8 @@ HL_SYMBOLS = [
     "mgh_infer_data_type", "mgh_free_device", "mgh_release_cache", "mgh_metadata_serialize",
     "mgh_metadata_parse", "mgh_lossless_create", "mgh_lossless_destroy", "mgh_lossless_compress",
     "mgh_lossless_decompress", "mgh_memcpy", "mgh_huffman_codebook",
-    "mgh_compress_multi", "mgh_decompress_multi",
+    "mgh_compress_multi", "mgh_decompress_multi", "mgh_pin_memory", "mgh_check_memory_pinned",
+    "mgh_unpin_memory",
 ]
 
 
@@ -98,6 +99,9 @@ def _hl():
                                C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp),
                                C.POINTER(Config), C.c_int]
     L.mgh_decompress.argtypes = [vp, C.c_size_t, C.POINTER(vp), C.POINTER(Config), C.c_int]
+    L.mgh_pin_memory.argtypes = [vp, C.c_size_t]
+    L.mgh_check_memory_pinned.argtypes = [vp]
+    L.mgh_unpin_memory.argtypes = [vp]
     L.mgh_compress_multi.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(u64), C.c_double,
                                      C.c_double, C.c_int, vp, C.POINTER(vp), C.POINTER(C.c_size_t),
                                      C.POINTER(vp), C.POINTER(Config), C.c_int]

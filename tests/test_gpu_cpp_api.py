@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prog", ["lowlevel_roundtrip", "highlevel_roundtrip"])
+@pytest.mark.parametrize("prog", ["lowlevel_roundtrip", "highlevel_roundtrip", "highlevel_api_example"])
 def test_cpp_roundtrip(tmp_path, prog):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     exe = str(tmp_path / prog)
@@ -30,6 +30,17 @@ def test_cpp_header_compiles_on_host():
     """No GPU needed: the header-only mirror must compile as plain C++17 against the C ABI."""
     src = ('#include "mgard_hip.hpp"\n#include "compress_hip.hpp"\n'
            'int main() { mgard_hip::HighLevelConfig c; return c.dev_id; }\n')
+    p = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+                        "-x", "c++", "-"], input=src, text=True, capture_output=True)
+    assert p.returncode == 0, p.stderr
+
+
+def test_mgard_x_namespace_header_compiles_on_host():
+    """include/compress_x_hip.hpp: the reference's names in namespace mgard_x, plain C++17."""
+    src = ('#include "compress_x_hip.hpp"\n'
+           'int main() { mgard_x::Config c; c.lossless = mgard_x::lossless_type::Huffman_Zstd;\n'
+           '  c.dev_type = mgard_x::device_type::HIP; c.domain_decomposition_sizes = {4, 4};\n'
+           '  std::vector<mgard_x::SIZE> shape{8, 8, 8}; return (int)shape.size() + c.dev_id - 3; }\n')
     p = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
                         "-x", "c++", "-"], input=src, text=True, capture_output=True)
     assert p.returncode == 0, p.stderr
