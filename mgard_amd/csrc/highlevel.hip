@@ -32,6 +32,8 @@
 extern "C" void mgh_set_last_error_(const char *msg);  // capi.hip
 
 namespace {
+constexpr int kOutlierOverflow = -1000;  // internal: more outliers than the buffers hold
+
 // true exactly once per device ordinal for the given flag word (kernel attributes such as the
 // dynamic-LDS limit belong to the function on the current device); safe from several threads
 inline bool hl_once_per_device(std::atomic<uint64_t> &done) {
@@ -192,6 +194,7 @@ struct mgh_lossless_ctx {
   std::vector<uint8_t> head;
   PayloadLayout lay;
   uint64_t n_units = 0, n_outliers = 0;
+  uint64_t outliers_needed = 0;  // set when lossless_compress returns kOutlierOverflow
   const uint64_t *d_oidx = nullptr;
   const int64_t *d_oval = nullptr;
   bool on_host = false;  // Huffman_Zstd: the whole record is in `host`
@@ -400,7 +403,12 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
     c->overflow = false;
   }
   hl_debug("lossless_compress: encode launched");
-  if (ocount > ocap) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "more outliers than estimate_outlier_ratio allows");
+  if (ocount > ocap) {
+    // the caller re-runs the quantizer with buffers of this size (the reference re-allocates and
+    // re-launches the same way: LinearQuantization.hpp:621-676)
+    c->outliers_needed = ocount;
+    return kOutlierOverflow;
+  }
   c->on_host = false;
   if (c->overflow) return MGH_SUCCESS;  // record_size() says "larger than anything"
   L.compute(nchunk, dict, units, ocount);
@@ -1158,6 +1166,7 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
   };
   const uint64_t max_elems = dd.max_subdomain_elems();
   const uint64_t ocap = std::max<uint64_t>(1, (uint64_t)(cfg.estimate_outlier_ratio * (double)max_elems));
+  uint64_t ocap_cur = ocap;  // grows when a subdomain has more outliers than estimated
   // device-resident input whose subdomains are contiguous slabs: compress them where they are
   const bool zero_copy = in_dev && dd.all_contiguous();
   auto sub_in = [&](uint64_t id, int buf) -> const void * {
@@ -1245,31 +1254,44 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
       return cleanup(rc);
     hl_debug("compress: subdomain ready");
     double norm_out = (double)norm;
-    rc = hipMemsetAsync(g_cache.ocount.p, 0, 8, st) == hipSuccess ? MGH_SUCCESS : hl_fail(MGH_ERR_DEVICE, "memset");
-    // 16-bit symbols straight from the quantizer where the fused kernels run (a quarter of the
-    // bytes written by the quantizer and read twice by the lossless stage); int64 otherwise
-    bool sym16 = false;
-    if (rc == MGH_SUCCESS && lossless_sym16_ok(cfg.huff_dict_size, cfg.huff_block_size)) {
-      const int r16 = mgh_decompose_quantize_sym16(
-          h, sub_in(id, buf), local_eb, (double)local_tol, s_d, local_eb == MGH_REL ? 0.0 : (double)norm,
-          local_eb == MGH_REL ? &norm_out : nullptr, cfg.huff_dict_size, (uint16_t *)g_cache.q.p,
-          (uint64_t *)g_cache.ocount.p, (uint64_t *)g_cache.oidx.p, (int64_t *)g_cache.oval.p, ocap, st);
-      if (r16 == MGH_SUCCESS) sym16 = true;
-      else if (r16 != MGH_ERR_UNSUPPORTED_DIMENSION) rc = r16;
+    uint64_t ocap_now = ocap_cur;
+    for (int attempt = 0; attempt < 2; attempt++) {
+      rc = hipMemsetAsync(g_cache.ocount.p, 0, 8, st) == hipSuccess ? MGH_SUCCESS : hl_fail(MGH_ERR_DEVICE, "memset");
+      // 16-bit symbols straight from the quantizer where the fused kernels run (a quarter of the
+      // bytes written by the quantizer and read twice by the lossless stage); int64 otherwise
+      bool sym16 = false;
+      if (rc == MGH_SUCCESS && lossless_sym16_ok(cfg.huff_dict_size, cfg.huff_block_size)) {
+        const int r16 = mgh_decompose_quantize_sym16(
+            h, sub_in(id, buf), local_eb, (double)local_tol, s_d, local_eb == MGH_REL ? 0.0 : (double)norm,
+            local_eb == MGH_REL ? &norm_out : nullptr, cfg.huff_dict_size, (uint16_t *)g_cache.q.p,
+            (uint64_t *)g_cache.ocount.p, (uint64_t *)g_cache.oidx.p, (int64_t *)g_cache.oval.p, ocap_now, st);
+        if (r16 == MGH_SUCCESS) sym16 = true;
+        else if (r16 != MGH_ERR_UNSUPPORTED_DIMENSION) rc = r16;
+      }
+      if (rc == MGH_SUCCESS && !sym16)
+        rc = mgh_decompose_quantize(h, sub_in(id, buf), local_eb, (double)local_tol, s_d,
+                                    local_eb == MGH_REL ? 0.0 : (double)norm,
+                                    local_eb == MGH_REL ? &norm_out : nullptr, cfg.huff_dict_size, 1,
+                                    (int64_t *)g_cache.q.p, (uint64_t *)g_cache.ocount.p,
+                                    (uint64_t *)g_cache.oidx.p, (int64_t *)g_cache.oval.p, ocap_now, nullptr, st);
+      hl_debug("compress: decompose + quantize done");
+      if (rc == MGH_SUCCESS && local_eb == MGH_REL) norm = (T)norm_out;
+      if (rc == MGH_SUCCESS)  // (the outlier count is read back together with the encoder's results)
+        rc = lossless_compress(g_cache.ll, (const int64_t *)g_cache.q.p, n, cfg.huff_dict_size,
+                               cfg.huff_block_size, cfg.lossless, cfg.zstd_compress_level,
+                               (const uint64_t *)g_cache.oidx.p, (const int64_t *)g_cache.oval.p, 0, st,
+                               (const uint64_t *)g_cache.ocount.p, ocap_now, n * elem / 8 + 1, sym16);
+      if (rc != kOutlierOverflow) break;
+      // estimate_outlier_ratio was too optimistic: grow the lists to what this subdomain needs
+      // and quantize again
+      ocap_now = g_cache.ll->outliers_needed;
+      rc = g_cache.oidx.ensure(ocap_now * 8);
+      if (rc == MGH_SUCCESS) rc = g_cache.oval.ensure(ocap_now * 8);
+      if (rc != MGH_SUCCESS) break;
+      ocap_cur = ocap_now;
+      rc = kOutlierOverflow;
     }
-    if (rc == MGH_SUCCESS && !sym16)
-      rc = mgh_decompose_quantize(h, sub_in(id, buf), local_eb, (double)local_tol, s_d,
-                                  local_eb == MGH_REL ? 0.0 : (double)norm,
-                                  local_eb == MGH_REL ? &norm_out : nullptr, cfg.huff_dict_size, 1,
-                                  (int64_t *)g_cache.q.p, (uint64_t *)g_cache.ocount.p,
-                                  (uint64_t *)g_cache.oidx.p, (int64_t *)g_cache.oval.p, ocap, nullptr, st);
-    hl_debug("compress: decompose + quantize done");
-    if (rc == MGH_SUCCESS && local_eb == MGH_REL) norm = (T)norm_out;
-    if (rc == MGH_SUCCESS)  // (the outlier count is read back together with the encoder's results)
-      rc = lossless_compress(g_cache.ll, (const int64_t *)g_cache.q.p, n, cfg.huff_dict_size,
-                             cfg.huff_block_size, cfg.lossless, cfg.zstd_compress_level,
-                             (const uint64_t *)g_cache.oidx.p, (const int64_t *)g_cache.oval.p, 0, st,
-                             (const uint64_t *)g_cache.ocount.p, ocap, n * elem / 8 + 1, sym16);
+    if (rc == kOutlierOverflow) rc = hl_fail(MGH_ERR_DEVICE, "outlier lists overflowed twice");
     hl_debug("compress: lossless stage done");
     if (owned) mgh_hierarchy_destroy(h);
     if (rc != MGH_SUCCESS) return cleanup(rc);

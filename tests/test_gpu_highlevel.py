@@ -196,6 +196,25 @@ def test_all_zero_input(mode):
         assert v.shape == u.shape and not v.any()
 
 
+def test_outlier_estimate_too_small_is_retried():
+    """estimate_outlier_ratio sizes the outlier lists; when a subdomain has more outliers than
+    that, the reference re-allocates and re-launches the quantizer (LinearQuantization.hpp:
+    621-676). Same here: the call succeeds and the stream equals the generously sized one."""
+    torch, mg, hl = _mods()
+    rng = np.random.default_rng(5)
+    u = (smooth_field((64, 65, 66), np.float32) + rng.normal(0, 30.0, (64, 65, 66)).astype(np.float32) *
+         (rng.random((64, 65, 66)) < 0.02))          # 2 % spikes: far outside a 64-entry dictionary
+    small = hl.Config(estimate_outlier_ratio=1e-5, huff_dict_size=64)
+    big = hl.Config(estimate_outlier_ratio=1.0, huff_dict_size=64)
+    for src in (u, torch.from_numpy(u).cuda()):
+        a = hl.decompress(hl.compress(src, 1e-4, np.inf, mg.REL, config=small))
+        b = hl.decompress(hl.compress(src, 1e-4, np.inf, mg.REL, config=big))
+        a = a if isinstance(a, np.ndarray) else a.cpu().numpy()
+        b = b if isinstance(b, np.ndarray) else b.cpu().numpy()
+        assert np.array_equal(a, b)
+        assert float(np.max(np.abs(a - u))) <= 1e-4 * float(np.max(np.abs(u))) * (1 + 1e-6)
+
+
 def test_container_records_hold_the_quantized_coefficients():
     """The single record of a non-decomposed stream decodes (independent reader) to exactly the
     integers the low-level path produces, outliers included."""
