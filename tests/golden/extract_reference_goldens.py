@@ -81,6 +81,23 @@ def main():
     expected = _parse_list(_braces(sec, sec.index("expected = {{") + len("expected = {")))
     out["cases"].append({"kind": "decomposition", "name": "1D, dyadic, nonuniform", "ndim": 1,
                          "dtype": "float", "coordinates": [coords], "u": u, "expected": expected})
+    # known answers of the scalar quantizer (tests/src/test_LinearQuantizer.cpp:94-121):
+    # quantize = round(x / quantum) to nearest, dequantize = quantum * n
+    qtext = open(os.path.join(ref, "tests", "src", "test_LinearQuantizer.cpp")).read()
+    qsec = qtext[qtext.index('TEST_CASE("quantization of a range"'):]
+    s1 = qsec[qsec.index('SECTION("basic quantization iteration")'):qsec.index('SECTION("basic dequantization iteration")')]
+    s2 = qsec[qsec.index('SECTION("basic dequantization iteration")'):qsec.index('SECTION("quantization inverts dequantization")')]
+    quantum1 = float(re.search(r"quantizer\(([0-9.]+)\)", s1).group(1))
+    xs1 = _parse_list(_braces(s1, s1.index("xs = {") + len("xs = ")))
+    ns1 = _parse_list(_braces(s1, s1.index("std::vector<int>({") + len("std::vector<int>(")))
+    quantum2 = float(re.search(r"dequantizer\(([0-9.]+)\)", s2).group(1))
+    ns2 = _parse_list(_braces(s2, s2.index("ns = {") + len("ns = ")))
+    xs2 = _parse_list(_braces(s2, s2.index("std::vector<float>({") + len("std::vector<float>(")))
+    out["quantizer"] = {
+        "source": "tests/src/test_LinearQuantizer.cpp:94-111 (CODARcode/MGARD v1.6.0)",
+        "quantize": {"quantum": quantum1, "dtype": "double", "x": xs1, "n": ns1},
+        "dequantize": {"quantum": quantum2, "dtype": "float", "n": ns2, "x": xs2},
+    }
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_goldens.json")
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)

@@ -665,3 +665,37 @@ def test_sym16_output_equals_the_int64_output(shape, dt, mode, tol, s, dict_size
     with pytest.raises(mg.MgardHipError):
         h2.decompose_quantize_sym16(torch.zeros((300, 40), device="cuda"), mg.ABS, 1e-3, np.inf)
     h2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_even_size_ghost_node_against_reference_number_gpu(dt):
+    """The even-size (ghost node) case tied to the reference's own golden through the even = odd
+    embedding (derivation: tests/test_oracle_goldens.py) -- through the HIP path."""
+    from tests.test_oracle_goldens import _even4_expected, approx
+    torch, mg = _gpu()
+    x_even, expected = _even4_expected()
+    h = mg.Hierarchy((4,), dt, coords=[np.array([0, 1, 2, 4], dtype=dt)])
+    got = h.decompose(torch.from_numpy(x_even.astype(dt)).cuda()).cpu().numpy()
+    assert approx(got, expected), (got, expected)
+    back = h.recompose(torch.from_numpy(expected.astype(dt)).cuda()).cpu().numpy()
+    assert approx(back, x_even)
+    h.close()
+
+
+@pytest.mark.gpu
+def test_quantizer_known_answers_gpu():
+    """tests/src/test_LinearQuantizer.cpp:94-111 through mgh_quantize / mgh_dequantize."""
+    torch, mg = _gpu()
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_goldens.json")))["quantizer"]
+    qz, dq = G["quantize"], G["dequantize"]
+    h = mg.Hierarchy((5,), np.float64)
+    x = torch.tensor(qz["x"], dtype=torch.float64, device="cuda")
+    q, oi, ov, n = h.quantize(x, mg.ABS, 6 * qz["quantum"], np.inf, 1.0, prep_huffman=False)
+    assert n == 0 and q.cpu().tolist() == qz["n"]
+    h.close()
+    h = mg.Hierarchy((5,), np.float32)
+    ns = torch.tensor(dq["n"] + [0], dtype=torch.int64, device="cuda")
+    back = h.dequantize(ns, mg.ABS, 6 * dq["quantum"], np.inf, 1.0, prep_huffman=False)
+    assert back.cpu().tolist() == dq["x"] + [0.0]
+    h.close()
