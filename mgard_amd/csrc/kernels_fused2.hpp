@@ -383,7 +383,13 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
         int64_t *o = A.q + ob;
 #pragma unroll
         for (int k = 0; k < 4; k++)
-          if (k >= K0 && (all_on || on[k])) o[off[k]] = (int64_t)(uint32_t)qs[k];
+          if (k >= K0 && (all_on || on[k])) {
+            // streaming store: the gigabyte of integers is not read again by this pass, and lines
+            // left dirty in the memory-side cache are written back at the expense of whatever
+            // streams next (measured: the norm pass of the following step 162 -> 110 us, this
+            // kernel 412 -> 449 us, the step 1.014 -> 0.994 ms)
+            __builtin_nontemporal_store((int64_t)(uint32_t)qs[k], &o[off[k]]);
+          }
       }
     } else {
       // no dictionary: plain integers; |value| >= 2^31 (the conversion saturated) goes through
