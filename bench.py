@@ -167,6 +167,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only-step", action="store_true",
+                    help="time the step only: no decompression / 16-bit / end-to-end legs, no CPU "
+                         "baseline (profiling runs: every launch of the trace belongs to the metric)")
     ap.add_argument("--shape", type=str, default=None, help="override, e.g. 256,256,256")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="512f32",
                     help="BASELINE.json configuration: 512f32 = configs[1] (the metric's, default), "
@@ -320,7 +323,9 @@ def main():
                      "kernel_ms_per_step_all": {k: round(v[0] / NPROF, 4)
                                                 for k, v in sorted(prof.items())}},
     }
-    if dist is None:
+    if args.only_step:
+        args.no_cpu_baseline = True
+    if dist is None and not args.only_step:
         # decompression side (BASELINE.json configs[4] asks for the round trip): dequantize +
         # recompose of the same volume, error against the requested tolerance
         n_keep = int(cnt.item())

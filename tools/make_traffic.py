@@ -3,15 +3,17 @@
 (FETCH_SIZE and WRITE_SIZE must be collected in separate runs, kernel-trace only):
 
   cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d out/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out/fetch -- python3 bench.py --steps 3 --warmup 1 --only-step
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d out/write -- python3 bench.py --steps 3 --warmup 1 --only-step
   python tools/make_traffic.py out/fetch/*/*.db out/write/*/*.db [raw_out.json]
 
 The file records the hash of the kernel sources it was taken on; bench.py refuses it for any
 other sources. Units: KiB per launch (averages over the dispatches of the biggest grid of each
 kernel). read_correction: /opt/skills/guides/MI355X_MICROARCH.md, HBM section -- on gfx950
-FETCH_SIZE reports half of the bytes of 16-byte-per-lane streaming loads (absmax: float4 loads);
-the fused level kernel reads 4 bytes per lane, which count 1:1 (calibration in profiles/README.md).
+FETCH_SIZE reports half of the bytes of coalesced streaming loads. Calibrated here on known byte
+counts (tools/micro/pmc_calib.hip, tools/pmc_calib_summary.py): 512 MiB read with 4-byte-per-lane
+AND with 16-byte-per-lane contiguous loads both count 262 154 KiB (x 2), 1024 MiB written with
+8-byte stores, plain or nontemporal, count 1 048 576 ... 1 048 850 KiB (x 1).
 """
 import json
 import os
@@ -51,7 +53,7 @@ def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {"_about": __doc__.strip(), "source_hash": source_hash()}
-    for label, needle, corr in (("level_fused_q", "k_level_fused2", 1.0), ("absmax", "k_absmax", 2.0)):
+    for label, needle, corr in (("level_fused_q", "k_level_fused2", 2.0), ("absmax", "k_absmax", 2.0)):
         f, nf = biggest(fetch, needle)
         w, nw = biggest(write, needle)
         if f is None or w is None:
