@@ -438,18 +438,20 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
         if (axis == 2) { n_inner = npencil; outer_stride = 0; inner_stride = n; stride = 1; }
         else if (axis == 1) { n_inner = m[2]; outer_stride = (size_t)m[1] * m[2]; inner_stride = 1; stride = m[2]; }
         else { n_inner = npencil; outer_stride = 0; inner_stride = 1; stride = (size_t)m[1] * m[2]; }
-#define MGH_STREAM(CONTIG)                                                                    \
+#define MGH_STREAM(CONTIG, PD)                                                                \
   {                                                                                           \
-    static std::atomic<uint64_t> once{0};                                                                 \
-    TRY(allow_big_lds_once(k_ipk_stream<T, U, KR, 1, CONTIG, false>, once)); \
+    static std::atomic<uint64_t> once{0};                                                     \
+    TRY(allow_big_lds_once(k_ipk_stream<T, U, KR, PD, CONTIG, false>, once));                 \
     return launch(h, name, s, [&] {                                                           \
-      k_ipk_stream<T, U, KR, 1, CONTIG, false><<<blocks, 64, lds, s>>>(                       \
+      k_ipk_stream<T, U, KR, PD, CONTIG, false><<<blocks, 64, lds, s>>>(                      \
           npencil, n_inner, outer_stride, inner_stride, stride, n, W, n_glob, x, tt, add_to,  \
           sign);                                                                              \
     });                                                                                       \
   }
-        if (axis == 2) MGH_STREAM(true)
-        MGH_STREAM(false)
+        static const int pd = std::getenv("MGH_IPK_PD") ? std::atoi(std::getenv("MGH_IPK_PD")) : 1;
+        if (pd == 4) MGH_STREAM(false, 4)
+        if (pd == 2) MGH_STREAM(false, 2)
+        MGH_STREAM(false, 1)
 #undef MGH_STREAM
       }
     }
@@ -603,8 +605,10 @@ QuantParams<T> make_quant_params(mgh_hierarchy *h, int ebtype, double tol, doubl
 inline int level_class(const Box3 &b) {
   constexpr int TC = 8, TF = 32;
   const size_t gx = (b.m[2] + TF - 1) / TF, gy = (b.m[1] + TC - 1) / TC;
-  if (gx * gy * ((b.m[0] + 15) / 16) >= 2048) return 2;
-  if (gx * gy * ((b.m[0] + 3) / 4) >= 256) return 1;
+  static const size_t t2 = std::getenv("MGH_CLS2") ? (size_t)std::atoi(std::getenv("MGH_CLS2")) : 2048;
+  static const size_t t1 = std::getenv("MGH_CLS1") ? (size_t)std::atoi(std::getenv("MGH_CLS1")) : 256;
+  if (gx * gy * ((b.m[0] + 15) / 16) >= t2) return 2;
+  if (gx * gy * ((b.m[0] + 3) / 4) >= t1) return 1;
   return 0;
 }
 
