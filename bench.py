@@ -323,6 +323,43 @@ def main():
                      "kernel_ms_per_step_all": {k: round(v[0] / NPROF, 4)
                                                 for k, v in sorted(prof.items())}},
     }
+    if dist is None and not args.only_step and args.config == "512f32":
+        # Informational, never `value`: two volumes in flight on two streams (two hierarchies, two
+        # sets of buffers) -- what a pipeline over many subdomains / time steps does. The chain
+        # below the top level is latency-bound and leaves the chip idle; the other stream's norm
+        # and top-level passes fill it.
+        try:
+            h2 = mgard_amd.Hierarchy(shape, np_dt, coords=coords, device=local_rank)
+            bufs2 = (torch.empty(shape, dtype=torch.int64, device=dev),
+                     torch.zeros(1, dtype=torch.int64, device=dev),
+                     torch.empty(cap, dtype=torch.int64, device=dev),
+                     torch.empty(cap, dtype=torch.int64, device=dev))
+            d_u2 = d_u.clone()
+            sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+
+            def two(n):
+                for i in range(n):
+                    with torch.cuda.stream(sa if i % 2 == 0 else sb):
+                        if i % 2 == 0:
+                            h.decompose_quantize(d_u, mgard_amd.REL, TOL, S, 0.0, bufs=bufs, want_norm=False)
+                        else:
+                            h2.decompose_quantize(d_u2, mgard_amd.REL, TOL, S, 0.0, bufs=bufs2, want_norm=False)
+            two(4)
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            NP2 = 2 * max(args.steps // 2, 2)
+            two(NP2)
+            torch.cuda.synchronize()
+            p_ms = (time.perf_counter() - tp) / NP2 * 1e3
+            same2 = bool(torch.equal(bufs2[0], q))
+            result["two_streams"] = {"what": "two volumes in flight on two streams (informational: a pipeline "
+                                             "over many volumes; `value` is the single-stream step)",
+                                     "ms_per_step": round(p_ms, 4), "value": round(in_bytes / p_ms / 1e6, 3),
+                                     "unit": "GB/s (input)", "equals_single_stream_output": same2}
+            del bufs2, d_u2
+            h2.close()
+        except mgard_amd.MgardHipError as e:
+            result["two_streams"] = {"error": str(e)}
     if args.only_step:
         args.no_cpu_baseline = True
     if dist is None and not args.only_step:

@@ -641,6 +641,45 @@ inline int ensure_side_stream(mgh_hierarchy *h) {
 // nodal input (and the quantizers) exist; the caller's stream joins the side stream at the
 // end. `norm_in_first`: the top-level pass also reduces abs-max(input) into ds->scalar, and
 // `after_first` (the quantizer set-up that consumes it) is issued right behind it.
+// One level on the second-generation fused kernel (kernels_fused2.hpp). Tiles of the launch
+// (Fused2Grid): a remainder of up to 4 coarse columns / rows beyond the full tiles goes to face
+// tiles, the last r-chunk owns what is left of the planes (one more than the others for sizes
+// 2^k + 1).
+template <typename T, int OUTK>
+int launch_fused2(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int cls, const char *nm,
+                  hipStream_t s) {
+  constexpr int TC = 8, TF = 32;
+  const int rchs[3] = {1, 4, 16};
+  const int RCHv = rchs[cls];
+  Fused2Grid G{};
+  const int mfi = (int)b.m[2], mci = (int)b.m[1], mri = (int)b.m[0];
+  const int nfull_f = (mfi - 1) / TF, rem_f = mfi - nfull_f * TF;
+  const int nfull_c = (mci - 1) / TC, rem_c = mci - nfull_c * TC;
+  const bool face_f = h->fused_faces && nfull_f >= 1 && rem_f <= 4;
+  const bool face_c = h->fused_faces && nfull_c >= 1 && rem_c <= 4;
+  G.gxm = face_f ? nfull_f : (mfi + TF - 1) / TF;
+  const int gym = face_c ? nfull_c : (mci + TC - 1) / TC;
+  G.n_main = G.gxm * gym;
+  G.ff_F0 = nfull_f * TF;
+  G.n_ff = face_f ? (mci + 63) / 64 : 0;
+  G.cf_C0 = nfull_c * TC;
+  G.n_cf = face_c ? ((face_f ? G.ff_F0 : mfi) + 63) / 64 : 0;
+  G.nchunk = std::max(1, (mri - 1 + RCHv - 1) / RCHv);
+  G.xcd_ranges = h->fused_xcd;
+  const unsigned ntile = (unsigned)(G.n_main + G.n_ff + G.n_cf);
+  const dim3 grid(G.xcd_ranges ? (ntile + 7) / 8 * 8 : ntile, (unsigned)G.nchunk, 1);
+  const bool faces = G.n_ff || G.n_cf;
+#define MGH_F2(RCH)                                                                           \
+  return launch(h, nm, s, [&] {                                                               \
+    if (faces) k_level_fused2<T, OUTK, TC, TF, RCH, true><<<grid, 256, 0, s>>>(A, G, Fused4<T>{});  \
+    else k_level_fused2<T, OUTK, TC, TF, RCH, false><<<grid, 256, 0, s>>>(A, G, Fused4<T>{}); \
+  });
+  if (cls == 2) MGH_F2(16)
+  if (cls == 1) MGH_F2(4)
+  MGH_F2(1)
+#undef MGH_F2
+}
+
 template <typename T, int OUT, typename AfterFirst>
 int decompose_fused4(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams<T> *qp,
                      hipStream_t s, AfterFirst &&after_first);
@@ -708,7 +747,9 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
     if (split) {
       TRY(ensure_side_stream(h));
       A.absmax_bits = (l == L && norm_in_first) ? ds->fscal + ds->scalar_slot : nullptr;
-      if (cls == 2) {
+      if (h->fused_v == 2) {
+        TRY((launch_fused2<T, OUT_NONE>(h, A, b, cls, cls == 2 ? "level_load" : "level_load_small", s)));
+      } else if (cls == 2) {
         const dim3 grid(gx, gy, (b.m[0] + 15) / 16);
         TRY(launch(h, "level_load", s, [&] {
           k_level_fused<T, OUT_NONE, TC, TF, 16, false><<<grid, 256, 0, s>>>(A);
@@ -752,40 +793,9 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
       // second generation: needs the dictionary test in 32 bits
       const bool v2 = h->fused_v == 2 && (OUT != OUT_Q || (qp->dict_size >= 0 && qp->dict_size <= ((int64_t)1 << 30)));
       if (v2) {
-        // tiles of the launch (kernels_fused2.hpp: Fused2Grid): a remainder of up to 4 coarse
-        // columns / rows beyond the full tiles goes to face tiles, the last r-chunk owns what is
-        // left of the planes (one more than the others for sizes 2^k + 1)
-        const int rchs[3] = {1, 4, 16};
-        const int RCHv = rchs[cls];
-        Fused2Grid G{};
-        const int mfi = (int)b.m[2], mci = (int)b.m[1], mri = (int)b.m[0];
-        const int nfull_f = (mfi - 1) / TF, rem_f = mfi - nfull_f * TF;
-        const int nfull_c = (mci - 1) / TC, rem_c = mci - nfull_c * TC;
-        const bool face_f = h->fused_faces && nfull_f >= 1 && rem_f <= 4;
-        const bool face_c = h->fused_faces && nfull_c >= 1 && rem_c <= 4;
-        G.gxm = face_f ? nfull_f : (mfi + TF - 1) / TF;
-        const int gym = face_c ? nfull_c : (mci + TC - 1) / TC;
-        G.n_main = G.gxm * gym;
-        G.ff_F0 = nfull_f * TF;
-        G.n_ff = face_f ? (mci + 63) / 64 : 0;
-        G.cf_C0 = nfull_c * TC;
-        G.n_cf = face_c ? ((face_f ? G.ff_F0 : mfi) + 63) / 64 : 0;
-        G.nchunk = std::max(1, (mri - 1 + RCHv - 1) / RCHv);
-        G.xcd_ranges = h->fused_xcd;
-        const unsigned ntile = (unsigned)(G.n_main + G.n_ff + G.n_cf);
-        const dim3 grid(G.xcd_ranges ? (ntile + 7) / 8 * 8 : ntile, (unsigned)G.nchunk, 1);
-        const bool faces = G.n_ff || G.n_cf;
         const char *nm = cls == 2 ? (OUT == OUT_Q ? "level_fused_q" : "level_fused")
                                   : (OUT == OUT_Q ? "level_fused_q_small" : "level_fused_small");
-#define MGH_F2(RCH)                                                                          \
-  TRY(launch(h, nm, s, [&] {                                                                  \
-    if (faces) k_level_fused2<T, OUT, TC, TF, RCH, true><<<grid, 256, 0, s>>>(A, G, Fused4<T>{});          \
-    else k_level_fused2<T, OUT, TC, TF, RCH, false><<<grid, 256, 0, s>>>(A, G, Fused4<T>{});               \
-  }));
-        if (cls == 2) MGH_F2(16)
-        else if (cls == 1) MGH_F2(4)
-        else MGH_F2(1)
-#undef MGH_F2
+        TRY((launch_fused2<T, OUT>(h, A, b, cls, nm, s)));
       } else if (cls == 2) {
         const dim3 grid(gx, gy, (b.m[0] + 15) / 16);
         TRY(launch(h, OUT == OUT_Q ? "level_fused_q" : "level_fused", s, [&] {
@@ -2052,6 +2062,17 @@ int mgh_dequantize_recompose(mgh_hierarchy *h, int64_t *d_quantized, int ebtype,
   if (rc != MGH_SUCCESS) return rc;
   return mgh_recompose(h, d_data, d_data, stream);
 }
+
+#ifdef MGH_PHASE_TIMING
+int mgh_debug_phase_read(unsigned long long *out16, int reset) {
+  HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(mgh::g_phase), sizeof(unsigned long long) * 16));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(mgh::g_phase), z, sizeof z));
+  }
+  return MGH_SUCCESS;
+}
+#endif
 
 int mgh_profile_enable(mgh_hierarchy *h, int enable) {
   if (!h) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");

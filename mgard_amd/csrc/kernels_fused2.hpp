@@ -34,6 +34,18 @@
 
 namespace mgh {
 
+// Developer build -DMGH_PHASE_TIMING: shader-clock time of the phases of a pair step, summed over
+// the pairs of a few tiles (wave 0 carries the halo cells, wave 3 does not), read back with
+// mgh_debug_phase_read (capi.hip).
+#ifdef MGH_PHASE_TIMING
+__device__ unsigned long long g_phase[2][8];
+#define MGH_PT_DECL unsigned long long pt_t = clock64(); const bool pt_on = (blockIdx.x % 97 == 5) && (threadIdx.x == 0 || threadIdx.x == 192); const int pt_w = threadIdx.x == 0 ? 0 : 1;
+#define MGH_PT(k) do { const unsigned long long pt_n = clock64(); if (pt_on) atomicAdd(&g_phase[pt_w][k], pt_n - pt_t); pt_t = pt_n; } while (0)
+#else
+#define MGH_PT_DECL
+#define MGH_PT(k)
+#endif
+
 // (int) x with saturation -- exactly v_cvt_i32_f32 / v_cvt_i32_f64 (C's conversion is undefined
 // out of range; the instruction is not)
 __device__ __forceinline__ int32_t cvt_i32_sat(float x) {
@@ -169,9 +181,17 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
     for (int k = 0; k < NL; k++) reg[k] = base[goff[k]];
   };
   auto fetch = [&](int p, T(&reg)[NL]) { fetch_from(A.u, p, reg); };
+  T amax = 0;  // OUT_NONE: abs-max over everything this thread reads (clamped loads repeat grid
+               // values, and max is idempotent)
   auto stash = [&](T *dst, const T(&reg)[NL]) {
 #pragma unroll
-    for (int k = 0; k < NL; k++) dst[lidx[k]] = reg[k];
+    for (int k = 0; k < NL; k++) {
+      dst[lidx[k]] = reg[k];
+      if (OUT == OUT_NONE) {
+        const T a = abs_t(reg[k]);
+        amax = a > amax ? a : amax;
+      }
+    }
   };
 
   // ---- cells: a cell is the 2x2 group of window nodes (lc0 + {0,1}, lf0 + {0,1}) with even
@@ -446,21 +466,38 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
   T e_prev;        // c-swept value of the previous even plane
   T td_prev = 0;   // r-sweep: td of the previous coarse plane = tb of the next one
   T Ga2[TODD ? 4 : 1], Gb2[TODD ? 4 : 1], Gha[TODD ? 4 : 1], Ghb[TODD ? 4 : 1];  // TODD
-  T pre_o[NL], pre_e[NL], pre_a[TODD ? NL : 1], pre_b[TODD ? NL : 1];
-  fetch(r_lo, pre_e);
-  stash(raw1, pre_e);
+  // Raw planes travel global -> registers -> LDS ring, requested one pair ahead. (Two pairs
+  // ahead -- two register sets, loop unrolled by two -- measured the same: 454 vs 459 us at
+  // 172 VGPRs / 2 waves per SIMD; the pair step is not waiting for these loads.)
+  struct Pre {
+    T o[NL], e[NL], a[TODD ? NL : 1], b[TODD ? NL : 1];
+  };
+  Pre P0;
+  auto fetch_pair = [&](int p, Pre &Q) {  // planes (p, p + 1) of the pair starting at odd p
+    fetch(p, Q.o);
+    fetch(p + 1, Q.e);
+    if constexpr (TODD) {
+      fetch_from(ua, p + 1, Q.a);
+      fetch_from(ub, p + 1, Q.b);
+    }
+  };
+  auto stash_pair = [&](const Pre &Q) {
+    stash(raw0, Q.o);
+    stash(raw1, Q.e);
+    if constexpr (TODD) {
+      stash(rawa, Q.a);
+      stash(rawb, Q.b);
+    }
+  };
+  fetch(r_lo, P0.e);
+  stash(raw1, P0.e);
   if constexpr (TODD) {
-    fetch_from(ua, r_lo, pre_a);
-    fetch_from(ub, r_lo, pre_b);
-    stash(rawa, pre_a);
-    stash(rawb, pre_b);
+    fetch_from(ua, r_lo, P0.a);
+    fetch_from(ub, r_lo, P0.b);
+    stash(rawa, P0.a);
+    stash(rawb, P0.b);
   }
-  fetch(r_lo + 1, pre_o);
-  fetch(r_lo + 2, pre_e);
-  if constexpr (TODD) {
-    fetch_from(ua, r_lo + 2, pre_a);
-    fetch_from(ub, r_lo + 2, pre_b);
-  }
+  fetch_pair(r_lo + 1, P0);
   __syncthreads();
   {
     const bool pv = r_lo >= 0 && r_lo <= Pmax_r && r_lo != ghost_r;
@@ -482,20 +519,8 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
   __syncthreads();
   // (the first pair's raw planes go into the ring next to the f-sweep of the first plane,
   // exactly like every later pair's)
-  stash(raw0, pre_o);
-  stash(raw1, pre_e);
-  if constexpr (TODD) {
-    stash(rawa, pre_a);
-    stash(rawb, pre_b);
-  }
-  if (r_lo + 3 < r_hi) {
-    fetch(r_lo + 3, pre_o);
-    fetch(r_lo + 4, pre_e);
-    if constexpr (TODD) {
-      fetch_from(ua, r_lo + 4, pre_a);
-      fetch_from(ub, r_lo + 4, pre_b);
-    }
-  }
+  stash_pair(P0);
+  if (r_lo + 3 < r_hi) fetch_pair(r_lo + 3, P0);
   phase_b(Cs1, t1s1);
   __syncthreads();
   e_prev = c_sweep(t1s1);
@@ -504,7 +529,9 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
   // stash of the NEXT pair's raw planes + f-sweep (reads Cs, writes t1s) | barrier | c- and
   // r-sweep (read t1s) -- and straight on into A of the next pair: the ring was refilled before
   // the last barrier, Cs was last read before it, and t1s is rewritten only behind the next one.
-  for (int p = r_lo + 1; p < r_hi; p += 2) {
+  // Q holds the planes of the pair at p + 2 and is refilled with those of the pair at p + 4.
+  auto pair_step = [&](const int p, Pre &Q) {
+    MGH_PT_DECL
     // ---- phase A: coefficient fields of both planes, owned coefficients to HBM ----
     {
       const bool pv_o = p >= 0 && p <= Pmax_r && p != ghost_r;
@@ -524,11 +551,13 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
         cell_odd(own, raw0, Cs0, pv_o, rr, Go, E, cvo);
 #pragma unroll
         for (int k = 0; k < 4; k++) Go[k] = E[k];
+        MGH_PT(6);
         if (pv_o && p >= 2 * R0) emit(cvo, mr + (p - 1) / 2, 0);
         if (pv_e && p + 1 < 2 * R0 + 2 * rch) {
           if (all_on || own.s0) A.coarse[(size_t)((p + 1) / 2) * mc * mf + coarse_off] = E[0];
           emit(cve, (p + 1) / 2, 1);
         }
+        MGH_PT(7);
         if (tid < NH) {
           T Eh[4], ch[4];
           cell_even(halo, raw1, Cs1, pv_e, Eh, ch);
@@ -538,26 +567,19 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
         }
       }
     }
+    MGH_PT(0);
     __syncthreads();
+    MGH_PT(1);
     if (p + 2 < r_hi) {
-      stash(raw0, pre_o);
-      stash(raw1, pre_e);
-      if constexpr (TODD) {
-        stash(rawa, pre_a);
-        stash(rawb, pre_b);
-      }
-      if (p + 4 < r_hi) {
-        fetch(p + 4, pre_o);
-        fetch(p + 5, pre_e);
-        if constexpr (TODD) {
-          fetch_from(ua, p + 5, pre_a);
-          fetch_from(ub, p + 5, pre_b);
-        }
-      }
+      stash_pair(Q);
+      if (p + 4 < r_hi) fetch_pair(p + 4, Q);
     }
+    MGH_PT(2);
     phase_b(Cs0, t1s0);
     phase_b(Cs1, t1s1);
+    MGH_PT(3);
     __syncthreads();
+    MGH_PT(4);
     // ---- phases C, D: c-sweep of both planes, r-sweep of coarse plane R = (p - 1) / 2 ----
     const T vo = c_sweep(t1s0);
     const T ve = c_sweep(t1s1);
@@ -582,6 +604,21 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
     }
     o_prev = vo;
     e_prev = ve;
+    MGH_PT(5);
+  };
+  for (int p = r_lo + 1; p < r_hi; p += 2) pair_step(p, P0);
+  if (OUT == OUT_NONE && A.absmax_bits) {
+    for (int off = 32; off > 0; off >>= 1) {
+      const T o = __shfl_down(amax, off, 64);
+      amax = o > amax ? o : amax;
+    }
+    if ((tid & 63) == 0) {
+      // non-negative IEEE values order like their bit patterns; the plain load keeps the
+      // tens of thousands of waves from queueing on one atomic once the maximum has settled
+      unsigned long long bits;
+      if (sizeof(T) == 4) bits = __float_as_uint((float)amax); else bits = __double_as_longlong((double)amax);
+      if (bits > __atomic_load_n(A.absmax_bits, __ATOMIC_RELAXED)) atomicMax(A.absmax_bits, bits);
+    }
   }
 #undef LI
 }
