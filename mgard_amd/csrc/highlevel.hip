@@ -721,18 +721,53 @@ struct Decomposer {
   }
 };
 
-// device bytes one subdomain of this shape needs in this implementation (two input buffers
-// for the prefetch, hierarchy workspace, quantized output, outlier lists, code stream)
-size_t estimate_footprint(const std::vector<uint64_t> &shape, size_t elem, double outlier_ratio,
+// Device bytes the REFERENCE plans for one subdomain of this shape -- its formula, so that the
+// MaxDim / Block auto-splits land on the reference's subdomain sizes
+// (DomainDecomposer::EstimateMemoryFootprint, DomainDecomposer.hpp:24-69, with
+// Hierarchy.hpp:420-, Compressor.hpp:84-116, DataRefactor.hpp:50-70, LinearQuantization.hpp:547-552,
+// Lossless.hpp:58-71, HuffmanWorkspace.hpp:58-92):
+//   [input N T + output N 8 + ratio 8 + hierarchy tables]  (x 2 with prefetch)
+//   + refactoring workspace prod(n_d + 2) T (twice for D > 3) + quantizers + Huffman workspace
+//     (outlier lists 16 N ratio, codes 8 N, chunk tables 24 nchunk, code-book scratch ~ 80 dict)
+//     + the int64 array 8 N when T is narrower than 8 bytes.
+// Left out, because they depend on the reference's runtime and are a few KB: the allocation pitch
+// of the fastest dimension (hipMallocPitch), the radix sort's temporary storage for `dict`
+// keys, 2 (warps-per-block x CUs + 1) status words. This implementation itself needs less
+// (no (n+2)^D workspace, 16-bit symbols), so following the reference only means splitting earlier.
+size_t estimate_footprint(const std::vector<uint64_t> &shape, size_t elem, const mgh_config &cfg,
                           bool prefetch) {
-  double n = 1;
-  for (uint64_t e : shape) n *= (double)e;
-  double b = n * elem * (prefetch ? 2 : 1);  // input buffer(s)
-  b += n * elem * 0.45;                      // level buffers + load vector (+ tables)
-  b += n * 8;                                // quantized integers
-  b += n * 16 * outlier_ratio;               // outlier idx + values
-  b += n * 2;                                // code stream (typical) + chunk tables
-  return (size_t)b + (64u << 20);
+  const int D = (int)shape.size();
+  double n = 1, ws = 1;
+  for (uint64_t e : shape) {
+    n *= (double)e;
+    ws *= (double)(e + 2);
+  }
+  const double ratio = cfg.estimate_outlier_ratio;
+  // levels: every dim is halved until the smallest reaches 2 (Hierarchy.hpp:428-446)
+  int L = 64;
+  for (uint64_t e : shape) {
+    int k = 0;
+    for (uint64_t m = e; m > 2; m = m / 2 + 1) k++;
+    L = std::min(L, k);
+  }
+  double hier = 0;  // per level and dim: shape words, ranges, coordinates, dist, ratio, am, bm, volumes
+  for (int l = 0; l <= L; l++) {
+    for (uint64_t e : shape) {
+      uint64_t m = e;
+      for (int k = 0; k < L - l; k++) m = m / 2 + 1;
+      hier += 6.0 * (double)(m + 1) * elem;
+    }
+    hier += (double)D * 8 * 2;
+  }
+  double b = n * elem + n * 8 + ratio * 8 + hier;
+  if (prefetch) b *= 2;
+  const double dict = (double)cfg.huff_dict_size;
+  const double nchunk = std::floor((n - 1) / (double)cfg.huff_block_size) + 1;
+  double lossless = 8 + n * ratio * 16 + dict * 4 + dict * 8 + (8 * 128 + 8 * dict) + n * 8 + 3 * nchunk * 8 +
+                    4 + dict * 4 + dict * 8 + 4 * dict * 4 + 6 * dict * 4 + 8 * dict + 64;
+  double comp = ws * elem * (D > 3 ? 2 : 1) + elem + (L + 1) * (double)elem + lossless + elem;
+  if (8 > elem) comp += 8 * n;
+  return (size_t)(b + comp);
 }
 
 int make_decomposer(Decomposer &dd, int D, const uint64_t *shape, size_t elem, const mgh_config &cfg) {
@@ -742,7 +777,7 @@ int make_decomposer(Decomposer &dd, int D, const uint64_t *shape, size_t elem, c
   HL_HIP(hipMemGetInfo(&free_b, &total_b));
   const size_t avail = std::min<size_t>(free_b, cfg.max_memory_footprint);
   auto need = [&](const std::vector<uint64_t> &s, bool prefetch) {
-    return estimate_footprint(s, elem, cfg.estimate_outlier_ratio, prefetch) >= avail;
+    return estimate_footprint(s, elem, cfg, prefetch) >= avail;
   };
   dd.method = cfg.domain_decomposition;
   if (!need(dd.shape, false) && dd.method != MGH_DD_BLOCK && dd.method != MGH_DD_VARIABLE) {

@@ -215,6 +215,59 @@ def test_outlier_estimate_too_small_is_retried():
         assert float(np.max(np.abs(a - u))) <= 1e-4 * float(np.max(np.abs(u))) * (1 + 1e-6)
 
 
+def _reference_footprint(shape, elem, ratio=1.0, dict_size=8192, block=20480, prefetch=False):
+    """DomainDecomposer::EstimateMemoryFootprint (DomainDecomposer.hpp:24-69 and the estimators it
+    calls), runtime-independent terms -- restated here independently of highlevel.hip."""
+    D = len(shape)
+    n = float(np.prod(shape, dtype=np.float64))
+    ws = float(np.prod([e + 2 for e in shape], dtype=np.float64))
+    def levels(e):
+        k = 0
+        while e > 2:
+            e = e // 2 + 1
+            k += 1
+        return k
+    L = min(levels(e) for e in shape)
+    hier = 0.0
+    for l in range(L + 1):
+        for e in shape:
+            m = e
+            for _ in range(L - l):
+                m = m // 2 + 1
+            hier += 6.0 * (m + 1) * elem
+        hier += D * 8 * 2
+    b = n * elem + n * 8 + ratio * 8 + hier
+    if prefetch:
+        b *= 2
+    nchunk = np.floor((n - 1) / block) + 1
+    lossless = (8 + n * ratio * 16 + dict_size * 4 + dict_size * 8 + (8 * 128 + 8 * dict_size) + n * 8 +
+                3 * nchunk * 8 + 4 + dict_size * 4 + dict_size * 8 + 16 * dict_size + 24 * dict_size +
+                8 * dict_size + 64)
+    comp = ws * elem * (2 if D > 3 else 1) + elem + (L + 1) * elem + lossless + elem
+    if 8 > elem:
+        comp += 8 * n
+    return int(b + comp)
+
+
+def test_maxdim_split_follows_the_reference_footprint():
+    """The auto-split happens exactly where the reference's estimate reaches the budget
+    (need = estimate >= available, DomainDecomposer.hpp:72-88), and halves the largest dimension
+    (rounding up) until the estimate with prefetch fits (:199-228)."""
+    torch, mg, hl = _mods()
+    shape = (66, 300, 80)
+    u = smooth_field(shape, np.float32)
+    est = _reference_footprint(shape, 4)
+    assert 45 * u.size < est < 52 * u.size          # ~48 bytes per element for float32 (no prefetch)
+    m = hl.metadata_parse(bytes(hl.compress(u, 1e-2, np.inf, mg.REL, config=hl.Config(max_memory_footprint=est + 1))))
+    assert not m["domain_decomposed"]
+    m = hl.metadata_parse(bytes(hl.compress(u, 1e-2, np.inf, mg.REL, config=hl.Config(max_memory_footprint=est))))
+    assert m["domain_decomposed"] and m["dd_method"] == hl.DD_MAXDIM and m["dd_dim"] == 1 and m["dd_size"] == 150
+    # a budget the halves (with prefetch) do not fit: quarters
+    half = _reference_footprint((66, 150, 80), 4, prefetch=True)
+    m = hl.metadata_parse(bytes(hl.compress(u, 1e-2, np.inf, mg.REL, config=hl.Config(max_memory_footprint=half))))
+    assert m["dd_size"] == 75
+
+
 def test_container_records_hold_the_quantized_coefficients():
     """The single record of a non-decomposed stream decodes (independent reader) to exactly the
     integers the low-level path produces, outliers included."""
@@ -249,7 +302,8 @@ def test_domain_decomposition(kind, s):
     tol = 1e-2
     if kind == "maxdim_auto":
         # a memory budget that only fits a fraction of the array forces a MaxDim split
-        cfg = hl.Config(max_memory_footprint=(64 << 20) + 30 * u.nbytes // 8)
+        # (the reference plans ~48 bytes per float32 element, test_maxdim_split_follows_...)
+        cfg = hl.Config(max_memory_footprint=40 * u.size)
     elif kind == "block":
         cfg = hl.Config(domain_decomposition=hl.DD_BLOCK, block_size=50)
     else:
