@@ -265,14 +265,16 @@ def infer(buf):
     return tuple(int(shp[d]) for d in range(D.value)), dt.value
 
 
-def decompress(buf, config=None):
-    """mgard_x::decompress. Returns a numpy array (host stream) or a cuda tensor (device stream)."""
+def decompress(buf, config=None, out=None):
+    """mgard_x::decompress. Returns a numpy array (host stream) or a cuda tensor (device stream).
+    `out`: optional pre-allocated cuda tensor of the right shape and type (device streams)."""
     import torch
     L = _hl()
     cfg = config if config is not None else Config()
     shape, dt = infer(buf)
     if isinstance(buf, torch.Tensor) and buf.is_cuda:
-        out = torch.empty(shape, dtype=torch.float32 if dt == FLOAT else torch.float64, device=buf.device)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32 if dt == FLOAT else torch.float64, device=buf.device)
         p, n, optr = C.c_void_p(buf.data_ptr()), buf.numel(), C.c_void_p(out.data_ptr())
     else:
         buf = np.ascontiguousarray(buf)
