@@ -21,7 +21,7 @@ REL, ABS = 0, 1  # mgard_x::error_bound_type (Utilities/Types.h:32)
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("mgx_oracle.c", "mgx_oracle_impl.h")]
+    src = [os.path.join(_HERE, f) for f in ("mgx_oracle.c", "mgx_oracle_impl.h", "mgcpu_1d.c")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
         return _LIB_PATH
@@ -248,3 +248,57 @@ def _dyadic_maps(shape):
     ncoarse = np.where(level > 0, (1 << np.maximum(level - 1, 0)) + 1, 0)
     reo = np.where(level == 0, pl, np.where(pl % 2 == 0, pl // 2, ncoarse + (pl - 1) // 2))
     return tuple(reo)
+
+
+# ---- MGARD-CPU (mgard::compress, BASELINE.json configs[0]) restated for one dimension -------
+class MgardCpu1D:
+    """oracle/mgcpu_1d.c: hierarchy, decompose / recompose (natural node order) and the s = inf
+    quantizer of the serial CPU code path, float64."""
+
+    def __init__(self, n, coords=None):
+        self.n = int(n)
+        self.x = (np.arange(self.n, dtype=np.float64) / (self.n - 1) if coords is None
+                  else np.ascontiguousarray(coords, dtype=np.float64))
+        L = lib()
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int64)
+        L.mgcpu1d_levels.argtypes = [C.c_uint64]
+        L.mgcpu1d_level_size.argtypes = [C.c_uint64, C.c_int]
+        L.mgcpu1d_level_size.restype = C.c_uint64
+        L.mgcpu1d_decompose.argtypes = [C.c_uint64, dp, dp]
+        L.mgcpu1d_recompose.argtypes = [C.c_uint64, dp, dp]
+        L.mgcpu1d_quantum.argtypes = [C.c_uint64, C.c_double]
+        L.mgcpu1d_quantum.restype = C.c_double
+        L.mgcpu1d_quantize.argtypes = [C.c_uint64, dp, C.c_double, ip]
+        L.mgcpu1d_dequantize.argtypes = [C.c_uint64, ip, C.c_double, dp]
+        self.L = L.mgcpu1d_levels(self.n)
+
+    def _dp(self, a):
+        return a.ctypes.data_as(C.POINTER(C.c_double))
+
+    def level_size(self, l):
+        return int(lib().mgcpu1d_level_size(self.n, l))
+
+    def decompose(self, u):
+        v = np.array(u, dtype=np.float64, order="C", copy=True)
+        lib().mgcpu1d_decompose(self.n, self._dp(self.x), self._dp(v))
+        return v
+
+    def recompose(self, c):
+        v = np.array(c, dtype=np.float64, order="C", copy=True)
+        lib().mgcpu1d_recompose(self.n, self._dp(self.x), self._dp(v))
+        return v
+
+    def quantum(self, tol):
+        return float(lib().mgcpu1d_quantum(self.n, float(tol)))
+
+    def quantize(self, v, quantum):
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        q = np.empty(self.n, dtype=np.int64)
+        lib().mgcpu1d_quantize(self.n, self._dp(v), float(quantum), q.ctypes.data_as(C.POINTER(C.c_int64)))
+        return q
+
+    def dequantize(self, q, quantum):
+        q = np.ascontiguousarray(q, dtype=np.int64)
+        v = np.empty(self.n, dtype=np.float64)
+        lib().mgcpu1d_dequantize(self.n, q.ctypes.data_as(C.POINTER(C.c_int64)), float(quantum), self._dp(v))
+        return v
