@@ -15,11 +15,14 @@
  * committed as tests/golden/reference_goldens.json by
  * tests/golden/extract_reference_goldens.py) on dyadic (2^k+1) grids, where
  * MGARD-CPU and MGARD-X agree up to the level permutation and float rounding.
+ * Also pinned (tests/test_oracle_goldens.py): one EVEN-size case (the ghost-node
+ * rule) derived from the 1-D golden through the even = odd embedding, and the
+ * scalar quantizer's known answers (tests/src/test_LinearQuantizer.cpp:94-111).
  * The MGARD-X SERIAL backend itself cannot be built under this repo's rules
  * (it needs the cmake-generated MGARDXConfig.h and zstd headers that are not on
- * the system include path), so for NON-dyadic shapes (the even-size ghost-node
- * rule) and for the quantizer, parity is "unpinned": it rests on the code
- * reading cited in mgx_oracle_impl.h plus structural property tests
+ * the system include path), so for general NON-dyadic 2-D / 3-D shapes and for
+ * the level-dependent quantizers (s != infinity) parity is "unpinned": it rests
+ * on the code reading cited in mgx_oracle_impl.h plus structural property tests
  * (tests/test_oracle_properties.py).
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
