@@ -84,6 +84,7 @@ struct mgh_hierarchy {
   // MGH_FUSED_FACES: 1 = face tiles for the remainder columns / rows of a level (default), 0 = off
   int fused_faces = 1;
   int fused_xcd = 1;  // MGH_FUSED_XCD: tiles of a level in contiguous ranges per XCD (default 1)
+  int fused_wide = 1; // MGH_FUSED_WIDE: 4 x 64 tiles for 0 = no level, 1 = long marches, 2 = all
   int fused4 = 1;     // MGH_FUSED4: D = 4 through the 3-D tile code, slice by slice (default 1)
   std::map<std::string, ProfileEntry> prof;
   size_t device_bytes = 0;
@@ -645,10 +646,9 @@ inline int ensure_side_stream(mgh_hierarchy *h) {
 // (Fused2Grid): a remainder of up to 4 coarse columns / rows beyond the full tiles goes to face
 // tiles, the last r-chunk owns what is left of the planes (one more than the others for sizes
 // 2^k + 1).
-template <typename T, int OUTK>
-int launch_fused2(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int cls, const char *nm,
-                  hipStream_t s) {
-  constexpr int TC = 8, TF = 32;
+template <typename T, int OUTK, int TC, int TF>
+int launch_fused2_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int cls, const char *nm,
+                    hipStream_t s) {
   const int rchs[3] = {1, 4, 16};
   const int RCHv = rchs[cls];
   Fused2Grid G{};
@@ -678,6 +678,18 @@ int launch_fused2(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int cl
   if (cls == 1) MGH_F2(4)
   MGH_F2(1)
 #undef MGH_F2
+}
+
+// Tile shape: long marches (class 2) run 4 x 64 coarse nodes per tile -- every row a wave reads or
+// writes is 512 contiguous bytes instead of 256, which the memory system rewards more than the
+// larger halo (1.41 x instead of 1.24 x re-read) costs: top level of 512^3 f32 435 -> 383 us, same
+// box, alternating runs. The short marches of the lower levels are a few us faster on 8 x 32.
+template <typename T, int OUTK>
+int launch_fused2(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int cls, const char *nm,
+                  hipStream_t s) {
+  if (h->fused_wide >= 2 || (h->fused_wide == 1 && cls == 2))
+    return launch_fused2_t<T, OUTK, 4, 64>(h, A, b, cls, nm, s);
+  return launch_fused2_t<T, OUTK, 8, 32>(h, A, b, cls, nm, s);
 }
 
 template <typename T, int OUT, typename AfterFirst>
@@ -876,13 +888,59 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
 // Thomas solves (f, c, r, t; the last one adds the correction into the coarse array) follow on
 // the N/16-sized arrays. Order of every operation as in CalcCoefficientsND.hpp:25-236 and
 // CalcCorrectionND.hpp:25-267 (dims D-1 .. 0): bit-identical to the generic N-D kernels.
+// D = 4: the even and the odd slices of one level (kernels_fused2.hpp, TMODE 1 / 2)
+template <typename T, int OUT, int TC, int TF>
+int launch_fused4_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Fused4<T> &Q, const Box3 &b, int cls,
+                    int n_t, int m_t, hipStream_t s) {
+    const int rchs[3] = {1, 4, 16};
+    const int RCHv = rchs[cls];
+    Fused2Grid G{};
+    const int mfi = (int)b.m[2], mci = (int)b.m[1], mri = (int)b.m[0];
+    const int nfull_f = (mfi - 1) / TF, rem_f = mfi - nfull_f * TF;
+    const int nfull_c = (mci - 1) / TC, rem_c = mci - nfull_c * TC;
+    const bool face_f = h->fused_faces && nfull_f >= 1 && rem_f <= 4;
+    const bool face_c = h->fused_faces && nfull_c >= 1 && rem_c <= 4;
+    G.gxm = face_f ? nfull_f : (mfi + TF - 1) / TF;
+    const int gym = face_c ? nfull_c : (mci + TC - 1) / TC;
+    G.n_main = G.gxm * gym;
+    G.ff_F0 = nfull_f * TF;
+    G.n_ff = face_f ? (mci + 63) / 64 : 0;
+    G.cf_C0 = nfull_c * TC;
+    G.n_cf = face_c ? ((face_f ? G.ff_F0 : mfi) + 63) / 64 : 0;
+    G.nchunk = std::max(1, (mri - 1 + RCHv - 1) / RCHv);
+    G.xcd_ranges = h->fused_xcd;
+    const unsigned ntile = (unsigned)(G.n_main + G.n_ff + G.n_cf);
+    const unsigned gx = G.xcd_ranges ? (ntile + 7) / 8 * 8 : ntile;
+    const bool faces = G.n_ff || G.n_cf;
+    const unsigned n_even = (unsigned)m_t, n_odd = (unsigned)(n_t - m_t);
+#define MGH_F4(RCH, TMODE, NZ, NAME)                                                          \
+  if ((NZ) > 0) {                                                                             \
+    const dim3 grid(gx, (unsigned)G.nchunk, (NZ));                                            \
+    TRY(launch(h, NAME, s, [&] {                                                              \
+      if (faces) k_level_fused2<T, OUT, TC, TF, RCH, true, TMODE><<<grid, 256, 0, s>>>(A, G, Q);  \
+      else k_level_fused2<T, OUT, TC, TF, RCH, false, TMODE><<<grid, 256, 0, s>>>(A, G, Q);   \
+    }));                                                                                      \
+  }
+    if (cls == 2) {
+      MGH_F4(16, 1, n_even, "level4_even")
+      MGH_F4(16, 2, n_odd, "level4_odd")
+    } else if (cls == 1) {
+      MGH_F4(4, 1, n_even, "level4_even")
+      MGH_F4(4, 2, n_odd, "level4_odd")
+    } else {
+      MGH_F4(1, 1, n_even, "level4_even")
+      MGH_F4(1, 2, n_odd, "level4_odd")
+    }
+#undef MGH_F4
+    return MGH_SUCCESS;
+}
+
 template <typename T, int OUT, typename AfterFirst>
 int decompose_fused4(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams<T> *qp,
                      hipStream_t s, AfterFirst &&after_first) {
   auto *ds = DS<T>(h);
   auto *hh = HH<T>(h);
   const int L = h->L;
-  constexpr int TC = 8, TF = 32;
   const auto &sh = hh->level_shape;  // [l][d]
   const size_t full[4] = {(size_t)sh[L][1] * sh[L][2] * sh[L][3], (size_t)sh[L][2] * sh[L][3],
                           (size_t)sh[L][3], 1};
@@ -947,46 +1005,10 @@ int decompose_fused4(mgh_hierarchy *h, const T *data, T *coeff, const QuantParam
     if (n_t % 2 == 0)
       HIP_TRY(hipMemsetAsync(ds->load4 + (size_t)(n_t - 1) * M, 0, M * sizeof(T), s));
     const int cls = level_class(b);
-    const int rchs[3] = {1, 4, 16};
-    const int RCHv = rchs[cls];
-    Fused2Grid G{};
-    const int mfi = (int)b.m[2], mci = (int)b.m[1], mri = (int)b.m[0];
-    const int nfull_f = (mfi - 1) / TF, rem_f = mfi - nfull_f * TF;
-    const int nfull_c = (mci - 1) / TC, rem_c = mci - nfull_c * TC;
-    const bool face_f = h->fused_faces && nfull_f >= 1 && rem_f <= 4;
-    const bool face_c = h->fused_faces && nfull_c >= 1 && rem_c <= 4;
-    G.gxm = face_f ? nfull_f : (mfi + TF - 1) / TF;
-    const int gym = face_c ? nfull_c : (mci + TC - 1) / TC;
-    G.n_main = G.gxm * gym;
-    G.ff_F0 = nfull_f * TF;
-    G.n_ff = face_f ? (mci + 63) / 64 : 0;
-    G.cf_C0 = nfull_c * TC;
-    G.n_cf = face_c ? ((face_f ? G.ff_F0 : mfi) + 63) / 64 : 0;
-    G.nchunk = std::max(1, (mri - 1 + RCHv - 1) / RCHv);
-    G.xcd_ranges = h->fused_xcd;
-    const unsigned ntile = (unsigned)(G.n_main + G.n_ff + G.n_cf);
-    const unsigned gx = G.xcd_ranges ? (ntile + 7) / 8 * 8 : ntile;
-    const bool faces = G.n_ff || G.n_cf;
-    const unsigned n_even = (unsigned)m_t, n_odd = (unsigned)(n_t - m_t);
-#define MGH_F4(RCH, TMODE, NZ, NAME)                                                          \
-  if ((NZ) > 0) {                                                                             \
-    const dim3 grid(gx, (unsigned)G.nchunk, (NZ));                                            \
-    TRY(launch(h, NAME, s, [&] {                                                              \
-      if (faces) k_level_fused2<T, OUT, TC, TF, RCH, true, TMODE><<<grid, 256, 0, s>>>(A, G, Q);  \
-      else k_level_fused2<T, OUT, TC, TF, RCH, false, TMODE><<<grid, 256, 0, s>>>(A, G, Q);   \
-    }));                                                                                      \
-  }
-    if (cls == 2) {
-      MGH_F4(16, 1, n_even, "level4_even")
-      MGH_F4(16, 2, n_odd, "level4_odd")
-    } else if (cls == 1) {
-      MGH_F4(4, 1, n_even, "level4_even")
-      MGH_F4(4, 2, n_odd, "level4_odd")
-    } else {
-      MGH_F4(1, 1, n_even, "level4_even")
-      MGH_F4(1, 2, n_odd, "level4_odd")
-    }
-#undef MGH_F4
+    if (h->fused_wide >= 2 || (h->fused_wide == 1 && cls == 2))
+      TRY((launch_fused4_t<T, OUT, 4, 64>(h, A, Q, b, cls, n_t, m_t, s)));
+    else
+      TRY((launch_fused4_t<T, OUT, 8, 32>(h, A, Q, b, cls, n_t, m_t, s)));
     // t-sweep, then the Thomas solves f, c, r, t on the coarse box (m_t, m_r, m_c, m_f)
     {
       const dim3 grid((unsigned)std::min<size_t>((M + 255) / 256, 4096), (unsigned)m_t, 1);
@@ -1744,6 +1766,8 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     if (e8 && e8[0] >= '0' && e8[0] <= '1') h->fused_faces = e8[0] - '0';
     const char *e9 = std::getenv("MGH_FUSED_XCD");
     if (e9 && e9[0] >= '0' && e9[0] <= '1') h->fused_xcd = e9[0] - '0';
+    const char *e11 = std::getenv("MGH_FUSED_WIDE");
+    if (e11 && e11[0] >= '0' && e11[0] <= '2') h->fused_wide = e11[0] - '0';
     const char *e10 = std::getenv("MGH_FUSED4");
     if (e10 && e10[0] >= '0' && e10[0] <= '1') h->fused4 = e10[0] - '0';
     const char *e4 = std::getenv("MGH_EMIT_BPC");

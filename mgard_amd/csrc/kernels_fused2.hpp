@@ -79,7 +79,7 @@ template <int TC, int TF, int RCH, bool TODD = false> struct Fused2Geom {
                                              // the two neighbouring slices
   static constexpr int o_cs = NRAW * PL, o_t1 = (NRAW + 2) * PL, o_rf = o_t1 + 2 * WC * TP, o_rc = o_rf + WF,
                        o_rr = o_rc + WC, o_wr = (o_rr + 2 * RCH + 5 + 3) / 4 * 4,
-                       elems = o_wr + (RCH + 1) * 12;
+                       o_wf = o_wr + (RCH + 1) * 12, o_wc = o_wf + 9 * TF, elems = o_wc + 9 * TC;
 };
 
 // One tile: TC x TF coarse nodes at (C0, F0), marching over the coarse planes [R0, R0 + rch).
@@ -119,6 +119,8 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
   T *const rcs = lds + GM::o_rc;
   T *const rrs = lds + GM::o_rr;  // ratio_r[p - 1] of plane p = r_lo + index
   T *const wrs = lds + GM::o_wr;  // r-sweep constants of the chunk, [rch][12]
+  T *const wfs = lds + GM::o_wf;  // f-sweep constants of the tile's coarse columns, [9][TF]
+  T *const wcs = lds + GM::o_wc;  // c-sweep constants of the tile's coarse rows, [9][TC]
 #define LI(lc, lf) ((lc) * ROW + ((lf) & 1) * HF + ((lf) >> 1))
 
   const int tid = threadIdx.x;
@@ -150,16 +152,18 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
     const int R = R0 + e / 9, k = e % 9;
     wrs[(e / 9) * 12 + k] = R < mr ? A.mass[0][k * mr + R] : (T)0;
   }
-  // per-thread sweep constants: f-sweep for jf = tid % TF, c-sweep for jc = tid / TF
+  // sweep constants of the tile (f-sweep at jf = tid % TF, c-sweep at jc = tid / TF). They are
+  // read from LDS where they are used: 125 instead of 152 VGPRs (f32), a fourth workgroup per CU.
+  // (Measured neutral on the top level, which runs at the rate of a pure stream with its
+  // read/write mix -- tools/micro/rw_mix.hip -- whatever the occupancy.)
   const int jf = tid % TF, jc = tid / TF;
-  T wf[9], wc[9];
-  {
-    const int Jf = F0 + jf, Jc = C0 + jc;
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-      wf[k] = Jf < mf ? A.mass[2][k * mf + Jf] : (T)0;
-      wc[k] = Jc < mc ? A.mass[1][k * mc + Jc] : (T)0;
-    }
+  for (int e = tid; e < 9 * TF; e += NT) {
+    const int k = e / TF, J = F0 + e % TF;
+    wfs[e] = J < mf ? A.mass[2][k * mf + J] : (T)0;
+  }
+  for (int e = tid; e < 9 * TC; e += NT) {
+    const int k = e / TC, J = C0 + e % TC;
+    wcs[e] = J < mc ? A.mass[1][k * mc + J] : (T)0;
   }
 
   // ---- raw-plane streaming: window elements e = tid + k*NT, loaded from clamped positions
@@ -439,6 +443,9 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
   auto f_sweep_row = [&](const T *cs, T *t1, int lc) {
     const T *row = cs + lc * ROW;
     const T a = row[jf], b = row[HF + jf], c = row[jf + 1], d = row[HF + jf + 1], e = row[jf + 2];
+    T wf[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) wf[k] = wfs[k * TF + jf];
     const T tb = mass_tb(a, b, c, wf);
     T tc = mass_tc(b, c, d, wf);
     const T td = mass_td(c, d, e, wf);
@@ -454,6 +461,9 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
   auto c_sweep = [&](const T *t1) {
     const T *col = t1 + (2 * jc) * TP + jf;
     const T a = col[0], b = col[TP], c = col[2 * TP], d = col[3 * TP], e = col[4 * TP];
+    T wc[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) wc[k] = wcs[k * TC + jc];
     const T tb = mass_tb(a, b, c, wc);
     T tc = mass_tc(b, c, d, wc);
     const T td = mass_td(c, d, e, wc);
