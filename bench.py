@@ -323,6 +323,29 @@ def main():
                      "kernel_ms_per_step_all": {k: round(v[0] / NPROF, 4)
                                                 for k, v in sorted(prof.items())}},
     }
+    if dist is None and not args.only_step and len(shape) == 3:
+        # How fast does THIS device move the dominant pass's bytes when nothing else is going on?
+        # A pure stream with the same read/write mix (N elements read, N int64 written with
+        # streaming stores, N/4 elements of side output), no halo, no arithmetic. `frac` above stays
+        # priced against the 8 TB/s pin rate; this says how much of the distance to it is the
+        # memory system's and how much the kernel's (tools/micro/rw_mix.hip has more variants).
+        import ctypes as C
+        L = mgard_amd.load_library()
+        side = torch.empty(N // 4 + 8, dtype=d_u.dtype, device=dev)
+        qcal = torch.empty(N, dtype=torch.int64, device=dev)
+        ms = C.c_double(0)
+        rc = L.mgh_stream_calibrate(0 if esz == 4 else 1, d_u.data_ptr(), qcal.data_ptr(), side.data_ptr(), N,
+                                    10, C.byref(ms), torch.cuda.current_stream().cuda_stream)
+        if rc == 0 and ms.value > 0:
+            sbytes = N * esz + N * 8 + (N // 4) * esz
+            srate = sbytes / (ms.value * 1e-3) / 1e9
+            result["roofline"]["stream_calibration"] = {
+                "what": "pure stream with the pass's read/write mix (mgh_stream_calibrate): %d B read + %d B "
+                        "int64 streaming stores + 2 side arrays per element, no halo, no arithmetic" % (esz, 8),
+                "ms": round(ms.value, 4), "GB/s": round(srate, 1),
+                "frac_of_peak": round(srate / HBM_PEAK_GBS, 4),
+                "kernel_vs_stream_time": round((dom_ms / max(dom_launches, 1)) / ms.value, 3)}
+        del side, qcal
     if dist is None and not args.only_step and args.config == "512f32":
         # Informational, never `value`: two volumes in flight on two streams (two hierarchies, two
         # sets of buffers) -- what a pipeline over many subdomains / time steps does. The chain

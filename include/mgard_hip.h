@@ -202,6 +202,16 @@ int mgh_profile_filter(mgh_hierarchy *h, const char *kernel_name_or_null);
 int mgh_profile_read(mgh_hierarchy *h, const char **names, double *total_ms, uint64_t *launches,
                      int cap, int reset);
 
+/* Measurement aid for the roofline line (no reference counterpart): a PURE stream with the
+ * read/write mix of the top-level pass of the hot path -- n elements of `dtype` read once,
+ * n int64 written once with streaming stores, two side arrays of n/8 elements written -- and
+ * nothing else, timed with HIP events on `stream` over `reps` launches after 2 warm-up
+ * launches. *ms_out = average launch time. It tells how fast this device moves the pass's
+ * bytes when no arithmetic, halo or tiling is involved (about 4.0 ... 4.9 TB/s, not the 8 TB/s
+ * pin rate). d_in: n elements; d_out: n int64; d_side: n/4 elements of `dtype`. */
+int mgh_stream_calibrate(int dtype, const void *d_in, int64_t *d_out, void *d_side, uint64_t n,
+                         int reps, double *ms_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,7 @@ SYMBOLS = [
     "mgh_dequantize", "mgh_decompose_quantize", "mgh_dequantize_recompose",
     "mgh_norm_device", "mgh_decompose_quantize_dn", "mgh_decompose_quantize_sym16",
     "mgh_dequantize_recompose_sym16", "mgh_sym16_supported",
-    "mgh_profile_enable", "mgh_profile_filter", "mgh_profile_read",
+    "mgh_profile_enable", "mgh_profile_filter", "mgh_profile_read", "mgh_stream_calibrate",
 ]
 
 
@@ -86,6 +86,7 @@ def load_library():
     L.mgh_profile_filter.argtypes = [vp, C.c_char_p]
     L.mgh_profile_read.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), u64p,
                                    C.c_int, C.c_int]
+    L.mgh_stream_calibrate.argtypes = [C.c_int, vp, vp, vp, u64, C.c_int, C.POINTER(C.c_double), vp]
     _lib = L
     return L
 

@@ -2141,4 +2141,35 @@ int mgh_profile_read(mgh_hierarchy *h, const char **names, double *total_ms, uin
   return n;
 }
 
+int mgh_stream_calibrate(int dtype, const void *d_in, int64_t *d_out, void *d_side, uint64_t n,
+                         int reps, double *ms_out, void *stream) {
+  if (!d_in || !d_out || !d_side || !ms_out || n < 8 || reps < 1 || (dtype != MGH_FLOAT && dtype != MGH_DOUBLE)) {
+    return fail(MGH_ERR_INVALID_ARGUMENT, "mgh_stream_calibrate: bad argument");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t a, b;
+  HIP_TRY(hipEventCreate(&a));
+  HIP_TRY(hipEventCreate(&b));
+  auto go = [&] {
+    if (dtype == MGH_FLOAT)
+      mgh::k_stream_mix<float><<<32768, 256, 0, st>>>((const float *)d_in, d_out, (float *)d_side,
+                                                      (float *)d_side + n / 8, (size_t)n);
+    else
+      mgh::k_stream_mix<double><<<32768, 256, 0, st>>>((const double *)d_in, d_out, (double *)d_side,
+                                                       (double *)d_side + n / 8, (size_t)n);
+  };
+  for (int i = 0; i < 2; i++) go();
+  HIP_TRY(hipEventRecord(a, st));
+  for (int i = 0; i < reps; i++) go();
+  HIP_TRY(hipEventRecord(b, st));
+  HIP_TRY(hipEventSynchronize(b));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, a, b));
+  HIP_TRY(hipEventDestroy(a));
+  HIP_TRY(hipEventDestroy(b));
+  HIP_TRY(hipGetLastError());
+  *ms_out = (double)ms / reps;
+  return MGH_SUCCESS;
+}
+
 } // extern "C"

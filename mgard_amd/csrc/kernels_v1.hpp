@@ -473,6 +473,20 @@ k_absmax(const T *__restrict__ v, size_t n, unsigned long long *out_bits) {
   }
 }
 
+// Pure stream with the read/write mix of the top-level pass (mgh_stream_calibrate).
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_stream_mix(const T *__restrict__ in, int64_t *__restrict__ out, T *__restrict__ s1, T *__restrict__ s2, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const T x = in[i];
+    __builtin_nontemporal_store((int64_t)(int)x, &out[i]);
+    if ((i & 7) == 0) {
+      s1[i >> 3] = x;
+      s2[i >> 3] = x + (T)1;
+    }
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_sqsum(const T *__restrict__ v, size_t n, double *out) {
