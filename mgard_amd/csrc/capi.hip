@@ -418,8 +418,10 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
         box_bytes < ((size_t)1 << 32)) {
       const uint32_t parked = (nb - KR) * U;  // elements per pencil outside the registers
       uint32_t W = 0, n_glob = 0;
+      static const uint32_t w_max = std::getenv("MGH_IPK_W") ? (uint32_t)std::atoi(std::getenv("MGH_IPK_W")) : 64u;
       for (uint32_t ng = 0; ng <= parked && !W; ng += U) {
-        for (uint32_t w : {64u, 60u, 56u, 48u, 40u, 32u}) {
+        for (uint32_t w : {64u, 60u, 56u, 48u, 40u, 32u, 24u, 16u}) {
+          if (w > w_max) continue;
           const size_t lds = (size_t)w * (parked - ng) * sizeof(T);
           // 230-odd VGPRs: two waves per SIMD
           // (five 32 KB allocations do not fit one CU although 5 * 32 KB = 160 KB: leave a margin)
@@ -613,6 +615,20 @@ inline int level_class(const Box3 &b) {
   return 0;
 }
 
+// Coarse planes per workgroup of the fused level kernel (the kernel is compiled for up to 16).
+inline int fused_rch(const mgh_hierarchy *h, int cls) {
+  static const char *e = std::getenv("MGH_RCH");  // "a,b,c": classes 0, 1, 2
+  static int v[3] = {1, 4, 16};
+  static bool parsed = false;
+  if (!parsed) {
+    parsed = true;
+    if (e) std::sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]);
+    for (int &x : v) x = std::min(16, std::max(1, x));
+  }
+  (void)h;
+  return v[cls];
+}
+
 // Does level l run split (load-vector pass on the caller's stream, coefficient/quantize pass on
 // the side stream)? Only the quantizing path splits.
 template <typename T> bool level_is_split(const mgh_hierarchy *h, int l) {
@@ -649,9 +665,9 @@ inline int ensure_side_stream(mgh_hierarchy *h) {
 template <typename T, int OUTK, int TC, int TF>
 int launch_fused2_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int cls, const char *nm,
                     hipStream_t s) {
-  const int rchs[3] = {1, 4, 16};
-  const int RCHv = rchs[cls];
+  const int RCHv = fused_rch(h, cls);
   Fused2Grid G{};
+  G.rch = RCHv;
   const int mfi = (int)b.m[2], mci = (int)b.m[1], mri = (int)b.m[0];
   const int nfull_f = (mfi - 1) / TF, rem_f = mfi - nfull_f * TF;
   const int nfull_c = (mci - 1) / TC, rem_c = mci - nfull_c * TC;
@@ -674,9 +690,7 @@ int launch_fused2_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int 
     if (faces) k_level_fused2<T, OUTK, TC, TF, RCH, true><<<grid, 256, 0, s>>>(A, G, Fused4<T>{});  \
     else k_level_fused2<T, OUTK, TC, TF, RCH, false><<<grid, 256, 0, s>>>(A, G, Fused4<T>{}); \
   });
-  if (cls == 2) MGH_F2(16)
-  if (cls == 1) MGH_F2(4)
-  MGH_F2(1)
+  MGH_F2(16)
 #undef MGH_F2
 }
 
@@ -892,9 +906,9 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
 template <typename T, int OUT, int TC, int TF>
 int launch_fused4_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Fused4<T> &Q, const Box3 &b, int cls,
                     int n_t, int m_t, hipStream_t s) {
-    const int rchs[3] = {1, 4, 16};
-    const int RCHv = rchs[cls];
+    const int RCHv = fused_rch(h, cls);
     Fused2Grid G{};
+    G.rch = RCHv;
     const int mfi = (int)b.m[2], mci = (int)b.m[1], mri = (int)b.m[0];
     const int nfull_f = (mfi - 1) / TF, rem_f = mfi - nfull_f * TF;
     const int nfull_c = (mci - 1) / TC, rem_c = mci - nfull_c * TC;
@@ -921,16 +935,8 @@ int launch_fused4_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Fused4<T> &Q,
       else k_level_fused2<T, OUT, TC, TF, RCH, false, TMODE><<<grid, 256, 0, s>>>(A, G, Q);   \
     }));                                                                                      \
   }
-    if (cls == 2) {
-      MGH_F4(16, 1, n_even, "level4_even")
-      MGH_F4(16, 2, n_odd, "level4_odd")
-    } else if (cls == 1) {
-      MGH_F4(4, 1, n_even, "level4_even")
-      MGH_F4(4, 2, n_odd, "level4_odd")
-    } else {
-      MGH_F4(1, 1, n_even, "level4_even")
-      MGH_F4(1, 2, n_odd, "level4_odd")
-    }
+    MGH_F4(16, 1, n_even, "level4_even")
+    MGH_F4(16, 2, n_odd, "level4_odd")
 #undef MGH_F4
     return MGH_SUCCESS;
 }

@@ -641,7 +641,7 @@ struct Fused2Grid {
   int gxm, n_main;    // main tiles TC x TF: gxm along f, n_main in all
   int ff_F0, n_ff;    // f-face: tiles of 64 x 4 at F0 = ff_F0, C0 = k * 64 (n_ff = 0: none)
   int cf_C0, n_cf;    // c-face: tiles of 4 x 64 at C0 = cf_C0, F0 = k * 64 (n_cf = 0: none)
-  int nchunk;         // r-chunks of RCH coarse planes; the last one takes what is left (<= RCH + 1)
+  int rch, nchunk;    // r-chunks of rch <= RCH coarse planes; the last one takes what is left (<= rch + 1)
   int xcd_ranges;     // tiles handed to the XCDs in contiguous ranges (grid.x padded to 8)
 };
 
@@ -695,8 +695,8 @@ k_level_fused2(FusedArgs<T> A, Fused2Grid G, Fused4<T> Q) {
   // r-chunks in reverse launch order: whatever ran before this kernel (the norm reduction,
   // the level above) leaves the END of the level's input in the memory-side cache
   const int chunk = G.nchunk - 1 - (int)blockIdx.y;
-  const int R0 = chunk * RCH;
-  const int rch = chunk == G.nchunk - 1 ? A.m[0] - R0 : RCH;
+  const int R0 = chunk * G.rch;
+  const int rch = chunk == G.nchunk - 1 ? A.m[0] - R0 : G.rch;
   // workgroups go round-robin to the 8 XCDs (own L2 each): every XCD gets a contiguous range of
   // the launch's tiles, so that the partial cache lines neighbouring tiles write (the output rows
   // start at odd multiples of 8 bytes) meet in one L2. The grid is padded to a multiple of 8.
