@@ -67,14 +67,15 @@ inline void build_codebook(const unsigned *freq, int dict, Codebook &cb) {
   cb.first.assign(kUnitBits, ~(uint64_t)0);
   cb.entry.assign(kUnitBits, 0);
   cb.keys.resize(dict);
-  // symbols by decreasing frequency (ties: increasing symbol): one integer key per used symbol,
-  // (2^32-1 - frequency) above the symbol -> plain sort
+  // symbols by decreasing frequency, ties by DECREASING symbol -- the order the reference arrives
+  // at (GetCodebook.hpp:44-57,125-128: stable ascending sort by frequency, then the arrays are
+  // reversed): one integer key per used symbol, (2^32-1 - frequency) above (2^32-1 - symbol)
   key.clear();
   key.reserve(dict);
-  for (int i = 0; i < dict; i++)
-    if (freq[i]) key.push_back(((uint64_t)(0xffffffffu - freq[i]) << 32) | (uint32_t)i);
+  for (int i = dict - 1; i >= 0; i--)
+    if (freq[i]) key.push_back(((uint64_t)(0xffffffffu - freq[i]) << 32) | (uint32_t)(0xffffffffu - (uint32_t)i));
   const int nz = (int)key.size();
-  {  // LSD radix sort on the upper 32 bits (stable: ties stay in symbol order)
+  {  // LSD radix sort on the upper 32 bits (stable: ties stay in decreasing-symbol order)
     static thread_local std::vector<uint64_t> tmp;
     tmp.resize(nz);
     uint64_t *a = key.data(), *b = tmp.data();
@@ -87,11 +88,12 @@ inline void build_codebook(const unsigned *freq, int dict, Codebook &cb) {
     }  // (4 passes: the sorted keys are back in `key`)
   }
   order.resize(nz);
-  for (int k = 0; k < nz; k++) order[k] = (int)(key[k] & 0xffffffffu);
-  // keys[]: the used symbols in code order (filled below), then the unused ones (any order)
+  for (int k = 0; k < nz; k++) order[k] = (int)(0xffffffffu - (uint32_t)(key[k] & 0xffffffffu));
+  // keys[]: the used symbols in code order (filled below), then the unused ones (decreasing
+  // symbol, as the reversed stable sort leaves them)
   {
     int k = nz;
-    for (int i = 0; i < dict; i++)
+    for (int i = dict - 1; i >= 0; i--)
       if (!freq[i]) cb.keys[k++] = (uint64_t)i;
   }
   if (nz == 0) return;
@@ -139,6 +141,9 @@ inline void build_codebook(const unsigned *freq, int dict, Codebook &cb) {
   first.assign(kUnitBits + 2, 0);
   first[cb.max_len] = 0;
   for (int l = cb.max_len - 1; l >= 1; l--) first[l] = (first[l + 1] + count[l + 1] + 1) / 2;
+  // a lone symbol: the reference's canonical code counts up from 0 and is then complemented
+  // (GenerateCW.hpp:54-71,209-222), which leaves the one-bit code "1"
+  if (nz == 1) first[1] = 1;
   uint64_t e = 0;
   for (int l = 1; l < kUnitBits; l++) {
     cb.entry[l] = e;

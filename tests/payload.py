@@ -41,30 +41,22 @@ def parse_huffman_record(b):
 
 
 def decode_huffman_record(rec, max_chunks=None):
-    """Bit-serial canonical decoding exactly as Decode.hpp:52-106 states it (slow: for small
-    inputs). Returns the symbols as int64."""
+    """Every chunk through the decoder restated from Decode.hpp:52-106 (oracle/huffman_ref.py;
+    bit-serial, slow: for small inputs). Returns the symbols as int64."""
+    from oracle import huffman_ref
     first = [int(x) for x in rec["first"]]
     entry = [int(x) for x in rec["entry_tab"]]
-    keys = rec["keys"]
+    keys = [int(x) for x in rec["keys"]]
     n, chunk = rec["primary_count"], rec["chunk_size"]
     out = np.zeros(n, dtype=np.int64)
     nchunk = len(rec["bits"]) if max_chunks is None else min(max_chunks, len(rec["bits"]))
     for c in range(nchunk):
         total = int(rec["bits"][c])
-        base = int(rec["entry"][c])
-        nun = (total + 63) // 64
-        bits = np.unpackbits(rec["units"][base:base + nun].astype(">u8").view(np.uint8))
-        i, k = 0, c * chunk
-        while i < total:
-            v, l = int(bits[i]), 1
-            i += 1
-            while v < first[l]:
-                v = (v << 1) | int(bits[i])
-                i += 1
-                l += 1
-            out[k] = keys[entry[l] + v - first[l]]
-            k += 1
-        assert k == min(n, (c + 1) * chunk), (c, k)
+        base = int(rec["entry"][c])          # dH_meta[n_chunk + chunk_id]: first code unit of the chunk
+        want = min(n, (c + 1) * chunk) - c * chunk
+        sym = huffman_ref.decode(rec["units"][base:base + (total + 63) // 64], total, first, entry, keys)
+        assert len(sym) == want, (c, len(sym), want)
+        out[c * chunk:c * chunk + want] = sym
     return out
 
 

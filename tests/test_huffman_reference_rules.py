@@ -1,0 +1,105 @@
+"""f4 pin: the codebook this library writes into a Huffman payload equals, entry by entry, what the
+reference's GetCodebook / GenerateCW rules (restated in oracle/huffman_ref.py with line citations)
+produce from the same code lengths -- including the tie cases (equal frequencies, one and two
+symbols, equal lengths across different frequencies) -- and a payload decodes with the restated
+Decode.hpp loop. CPU only: mgh_huffman_codebook is a host function."""
+import heapq
+
+import numpy as np
+import pytest
+
+from oracle import huffman_ref as ref
+
+H_MAX = (1 << 64) - 1
+
+
+def _cases():
+    rng = np.random.default_rng(11)
+    n = 64
+    c = {}
+    c["one"] = np.zeros(n, np.uint32); c["one"][17] = 5
+    c["two_equal"] = np.zeros(n, np.uint32); c["two_equal"][[3, 40]] = 7
+    c["two"] = np.zeros(n, np.uint32); c["two"][[3, 40]] = [7, 2]
+    c["three_equal"] = np.zeros(n, np.uint32); c["three_equal"][[1, 2, 60]] = 4
+    c["all_equal"] = np.full(n, 9, np.uint32)
+    c["all_equal_odd"] = np.zeros(n, np.uint32); c["all_equal_odd"][:37] = 3
+    c["1122"] = np.zeros(n, np.uint32); c["1122"][[5, 6, 7, 8]] = [1, 1, 2, 2]
+    c["powers"] = np.zeros(n, np.uint32); c["powers"][:20] = [2 ** k for k in range(20)]
+    c["fib"] = np.zeros(n, np.uint32); c["fib"][10:30] = [1, 1, 2, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233, 377,
+                                                         610, 987, 1597, 2584, 4181, 6765]
+    c["plateaus"] = np.zeros(n, np.uint32); c["plateaus"][:48] = np.repeat([100, 50, 50, 10, 10, 10], 8)
+    c["geometric"] = np.zeros(n, np.uint32)
+    c["geometric"][:] = (1e6 * 0.7 ** np.abs(np.arange(-32, 32))).astype(np.uint32)
+    c["random_ties"] = rng.integers(0, 6, n).astype(np.uint32)
+    big = np.zeros(8192, np.uint32)
+    big[4096 - 60:4096 + 60] = (1e7 * 0.85 ** np.abs(np.arange(-60, 60))).astype(np.uint32) + 1
+    c["dict8192"] = big
+    r = np.zeros(8192, np.uint32)
+    r[rng.choice(8192, 700, replace=False)] = rng.integers(1, 50, 700)
+    c["dict8192_random_ties"] = r
+    return c
+
+
+CASES = _cases()
+
+
+def _optimal_cost(freq):
+    h = [int(f) for f in freq if f]
+    if len(h) == 1:
+        return h[0]
+    heapq.heapify(h)
+    cost = 0
+    while len(h) > 1:
+        a, b = heapq.heappop(h), heapq.heappop(h)
+        cost += a + b
+        heapq.heappush(h, a + b)
+    return cost
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_codebook_equals_reference_rules(name):
+    from mgard_amd import highlevel as hl
+    f = CASES[name]
+    code, first, entry, keys = hl.huffman_codebook(f)
+    lens = (code >> np.uint64(56)).astype(np.int64)
+    used = np.nonzero(f)[0]
+    # what GenerateCW needs from the lengths: optimal, and non-increasing with the frequency along
+    # the reference's sorted order (GetCodebook.hpp:44-57: stable ascending sort)
+    assert int(np.sum(lens[used].astype(object) * f[used].astype(object))) == _optimal_cost(f)
+    order = np.argsort(f.astype(np.uint64), kind="stable")
+    order = order[f[order] > 0]
+    assert np.all(np.diff(lens[order]) <= 0)
+    r_code, r_first, r_entry, r_keys = ref.get_codebook(f, lens)
+    assert [int(x) for x in code] == r_code
+    assert [int(x) for x in keys] == r_keys
+    for l in range(64):
+        if r_first[l] is not None:
+            assert int(first[l]) == r_first[l], ("first", l)
+        if r_entry[l] is not None:
+            assert int(entry[l]) == r_entry[l], ("entry", l)
+
+
+def _encode(symbols, code):
+    bits = []
+    for s in symbols:
+        l, v = int(code[s]) >> 56, int(code[s]) & ((1 << 56) - 1)
+        bits.extend((v >> (l - 1 - k)) & 1 for k in range(l))
+    total = len(bits)
+    bits.extend([0] * (-total % 64))
+    units = [int("".join(map(str, bits[i:i + 64])), 2) for i in range(0, len(bits), 64)]
+    return units, total
+
+
+@pytest.mark.parametrize("name", ["one", "two_equal", "1122", "fib", "plateaus", "random_ties"])
+def test_restated_decoder_reads_the_librarys_code(name):
+    """Symbols encoded with the library's codewords decode through the restated Decode.hpp loop
+    with the library's first / entry / keys tables."""
+    from mgard_amd import highlevel as hl
+    f = CASES[name]
+    code, first, entry, keys = hl.huffman_codebook(f)
+    rng = np.random.default_rng(3)
+    used = np.nonzero(f)[0]
+    sym = rng.choice(used, 500, p=f[used] / f[used].sum())
+    units, total = _encode(sym, code)
+    out = ref.decode(units, total, [int(x) for x in first], [int(x) for x in entry], [int(x) for x in keys])
+    assert out == [int(s) for s in sym]
