@@ -512,6 +512,28 @@ def test_config2_512cube_f64_nonuniform_s0():
     h.close()
 
 
+def test_config2_512cube_f64_nonuniform_s0_rel_roundtrip():
+    """configs[2] as BASELINE.json states it -- REL, s = 0 -- at full size. The integers of a REL
+    run depend on the L2 norm, which no two implementations sum in the same order, so this is
+    the size-independent property instead: with the device's own norm (close to numpy's), the
+    reconstruction error is within tol * norm in the root-mean-square sense the reference bounds
+    for s = 0 (ErrorToleranceCalculator.hpp:69-89), everything on the device."""
+    torch, mg = _gpu()
+    shape = (512, 512, 512)
+    u = smooth_field(shape, np.float64)
+    coords = nonuniform_coords(shape, np.float64)
+    h = mg.Hierarchy(shape, np.float64, coords=coords)
+    ud = torch.from_numpy(u).cuda()
+    tol = 1e-3
+    q, oi, ov, cnt, nrm = h.decompose_quantize(ud, mg.REL, tol, 0.0, outlier_cap=u.size // 8)
+    ref_norm = float(np.sqrt(np.mean(u ** 2)))
+    assert cnt <= u.size // 8 and abs(nrm - ref_norm) <= 1e-9 * ref_norm
+    back = h.dequantize_recompose(q, mg.REL, tol, 0.0, nrm, outlier_idx=oi, outlier_val=ov)
+    err = float(torch.sqrt(torch.mean((back - ud) ** 2)).item())
+    assert 0.0 < err <= tol * nrm
+    h.close()
+
+
 @pytest.mark.parametrize("shape", [(8, 128, 128, 128), (8, 64, 200, 96)])
 def test_config3_4d_slab(shape):
     """BASELINE.json configs[3]: one rank's 4-D slab (8 x n^3 float32; the level count is limited
