@@ -941,6 +941,23 @@ int launch_fused4_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Fused4<T> &Q,
     return MGH_SUCCESS;
 }
 
+// D = 4 work arrays: compact nodal arrays of the levels below the top, per-slice load vectors
+// (padded positions of t) and the correction of the biggest coarse box
+template <typename T> int ensure_state4(mgh_hierarchy *h) {
+  auto *ds = DS<T>(h);
+  auto *hh = HH<T>(h);
+  const int L = h->L;
+  const auto &sh = hh->level_shape;
+  if (!ds->nodal4.empty()) return MGH_SUCCESS;
+  ds->nodal4.assign(L + 1, nullptr);
+  for (int l = 0; l < L; l++)
+    TRY(dev_alloc(h, &ds->nodal4[l], (size_t)sh[l][0] * sh[l][1] * sh[l][2] * sh[l][3]));
+  const size_t M = (size_t)sh[L - 1][1] * sh[L - 1][2] * sh[L - 1][3];
+  TRY(dev_alloc(h, &ds->load4, (2 * (size_t)sh[L - 1][0] - 1) * M));
+  TRY(dev_alloc(h, &ds->corr4, (size_t)sh[L - 1][0] * M));
+  return MGH_SUCCESS;
+}
+
 template <typename T, int OUT, typename AfterFirst>
 int decompose_fused4(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams<T> *qp,
                      hipStream_t s, AfterFirst &&after_first) {
@@ -950,14 +967,7 @@ int decompose_fused4(mgh_hierarchy *h, const T *data, T *coeff, const QuantParam
   const auto &sh = hh->level_shape;  // [l][d]
   const size_t full[4] = {(size_t)sh[L][1] * sh[L][2] * sh[L][3], (size_t)sh[L][2] * sh[L][3],
                           (size_t)sh[L][3], 1};
-  if (ds->nodal4.empty()) {
-    ds->nodal4.assign(L + 1, nullptr);
-    for (int l = 0; l < L; l++)
-      TRY(dev_alloc(h, &ds->nodal4[l], (size_t)sh[l][0] * sh[l][1] * sh[l][2] * sh[l][3]));
-    const size_t M = (size_t)sh[L - 1][1] * sh[L - 1][2] * sh[L - 1][3];
-    TRY(dev_alloc(h, &ds->load4, (2 * (size_t)sh[L - 1][0] - 1) * M));
-    TRY(dev_alloc(h, &ds->corr4, (size_t)sh[L - 1][0] * M));
-  }
+  TRY(ensure_state4<T>(h));
   FusedArgs<T> A{};
   A.coef = coeff;
   A.dI = full[1];
@@ -1274,9 +1284,26 @@ template <typename T, typename QT>
 int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> &level_qv, T *data,
                      hipStream_t st);
 
+template <typename T, typename QT>
+int recompose_levels4(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> &level_qv, T *data,
+                      hipStream_t st);
+inline bool fused4_ok(const mgh_hierarchy *h);
+
 template <typename T>
 int recompose_impl(mgh_hierarchy *h, const T *coeff, T *data, hipStream_t s) {
   auto *ds = DS<T>(h);
+  if (fused4_ok(h) && !h->force_v1) {
+    // D = 4 on the slice-by-slice level loop, reading floating-point coefficients
+    const T *C = coeff;
+    if ((const void *)data == (const void *)coeff) {
+      TRY(ensure_scratch<T>(h));
+      HIP_TRY(hipMemcpyAsync(ds->scratch_full, coeff, h->total * sizeof(T), hipMemcpyDeviceToDevice, s));
+      C = ds->scratch_full;
+    }
+    RecomposeArgs<T> A{};
+    A.coef = C;
+    return recompose_levels4<T, T>(h, A, std::vector<T>(h->L + 1, (T)1), data, s);
+  }
   if (h->D > 3 || h->force_nd) {
     if ((const void *)data != (const void *)coeff)
       HIP_TRY(hipMemcpyAsync(data, coeff, h->total * sizeof(T), hipMemcpyDeviceToDevice, s));
@@ -1425,6 +1452,115 @@ int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> 
   return MGH_SUCCESS;
 }
 
+// D = 4, the mirror of decompose_fused4: per level (coarse to fine) the load vector of every
+// t-slice with the 3-D kernel (odd slices: every node is a coefficient), the t-sweep, four Thomas
+// solves subtracting the correction from the coarse nodes, then the node restore slice by slice
+// (odd slices interpolate across t between the two neighbouring coarse slices).
+template <typename T, typename QT>
+int recompose_levels4(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> &level_qv, T *data,
+                      hipStream_t st) {
+  auto *ds = DS<T>(h);
+  auto *hh = HH<T>(h);
+  const int L = h->L;
+  const auto &sh = hh->level_shape;
+  const size_t full[4] = {(size_t)sh[L][1] * sh[L][2] * sh[L][3], (size_t)sh[L][2] * sh[L][3],
+                          (size_t)sh[L][3], 1};
+  TRY(ensure_state4<T>(h));
+  A.dI = full[1];
+  A.dJ = full[2];
+  {
+    const auto &M0 = sh[0];
+    const size_t tot = (size_t)M0[0] * M0[1] * M0[2] * M0[3];
+    A.qv = level_qv[0];
+    TRY(launch(h, "head_in", st, [&] {
+      k_head_in4_q<T, QT><<<(unsigned)std::min<size_t>((tot + 255) / 256, 1024), 256, 0, st>>>(
+          (int)M0[0], (int)M0[1], (int)M0[2], (int)M0[3], A, full[0], ds->nodal4[0]);
+    }));
+  }
+  constexpr int TC = 8, TF = 32;
+  for (int l = 1; l <= L; l++) {
+    const auto &N = sh[l], &Mc = sh[l - 1];
+    Box3 b;
+    for (int k = 0; k < 3; k++) {
+      b.n[k] = (uint32_t)N[1 + k];
+      b.m[k] = (uint32_t)Mc[1 + k];
+      A.n[k] = (int)N[1 + k];
+      A.m[k] = (int)Mc[1 + k];
+      A.ratio[k] = ds->nd[l].ratio[1 + k];
+      A.mass[k] = ds->nd[l].mass[1 + k];
+    }
+    A.qv = level_qv[l];
+    A.ratio_t = ds->nd[l].ratio[0];
+    const size_t M = (size_t)Mc[1] * Mc[2] * Mc[3];
+    const int n_t = (int)N[0], m_t = (int)Mc[0];
+    // ---- load vectors of the padded t positions
+    const unsigned gx = (b.m[2] + TF - 1) / TF, gy = (b.m[1] + TC - 1) / TC;
+    for (int P = 0; P <= 2 * m_t - 2; P++) {
+      if (n_t % 2 == 0 && P == n_t - 1) {  // ghost slice
+        HIP_TRY(hipMemsetAsync(ds->load4 + (size_t)P * M, 0, M * sizeof(T), st));
+        continue;
+      }
+      A.allcoef = P & 1;
+      A.lin_base = (size_t)((P & 1) ? m_t + (P - 1) / 2 : P / 2) * full[0];
+      A.load = ds->load4 + (size_t)P * M;
+      if ((size_t)gx * gy * ((b.m[0] + 15) / 16) >= 2048) {
+        TRY(launch(h, "loadvec_q", st, [&] {
+          k_level_loadvec_q<T, QT, TC, TF, 16><<<dim3(gx, gy, (b.m[0] + 15) / 16), 256, 0, st>>>(A);
+        }));
+      } else if ((size_t)gx * gy * ((b.m[0] + 3) / 4) >= 256) {
+        TRY(launch(h, "loadvec_q_small", st, [&] {
+          k_level_loadvec_q<T, QT, TC, TF, 4><<<dim3(gx, gy, (b.m[0] + 3) / 4), 256, 0, st>>>(A);
+        }));
+      } else {
+        TRY(launch(h, "loadvec_q_small", st, [&] {
+          k_level_loadvec_q<T, QT, TC, TF, 1><<<dim3(gx, gy, b.m[0]), 256, 0, st>>>(A);
+        }));
+      }
+    }
+    A.allcoef = 0;
+    // ---- t-sweep, Thomas solves f, c, r, t; the last one subtracts from the coarse nodes
+    {
+      const dim3 grid((unsigned)std::min<size_t>((M + 255) / 256, 4096), (unsigned)m_t, 1);
+      TRY(launch(h, "tsweep", st, [&] {
+        k_tsweep<T><<<grid, 256, 0, st>>>(ds->load4, ds->corr4, M, m_t, ds->nd[l].mass[0]);
+      }));
+    }
+    const uint32_t m3a[3] = {(uint32_t)(m_t * Mc[1]), (uint32_t)Mc[2], (uint32_t)Mc[3]};
+    TRY(ipk_launch<T>(h, 2, m3a, ds->corr4, ds->nd[l].thomas[3], nullptr, +1, st));
+    TRY(ipk_launch<T>(h, 1, m3a, ds->corr4, ds->nd[l].thomas[2], nullptr, +1, st));
+    for (int t = 0; t < m_t; t++)
+      TRY(ipk_launch<T>(h, 0, b.m, ds->corr4 + (size_t)t * M, ds->nd[l].thomas[1], nullptr, +1, st));
+    const uint32_t m3t[3] = {(uint32_t)m_t, (uint32_t)(Mc[1] * Mc[2]), (uint32_t)Mc[3]};
+    TRY(ipk_launch<T>(h, 0, m3t, ds->corr4, ds->nd[l].thomas[0], ds->nodal4[l - 1], -1, st));
+    // ---- node restore, slice by slice
+    T *fine = (l == L) ? data : ds->nodal4[l];
+    const size_t fT = (l == L) ? full[0] : (size_t)N[1] * N[2] * N[3];
+    A.fI = (l == L) ? full[1] : (size_t)N[2] * N[3];
+    A.fJ = (l == L) ? full[2] : (size_t)N[3];
+    const dim3 blk(64, 4, 1);
+    const dim3 grid(1, ((b.n[1] + 1) / 2 + 3) / 4, b.n[0]);
+    for (int tp = 0; tp < n_t; tp++) {
+      const bool last_even = n_t % 2 == 0 && tp == n_t - 1;  // the real last node: coarse m_t - 1
+      A.fine = fine + (size_t)tp * fT;
+      if (!(tp & 1) || last_even) {
+        const int zi = last_even ? m_t - 1 : tp / 2;
+        A.coarse = ds->nodal4[l - 1] + (size_t)zi * M;
+        A.lin_base = (size_t)zi * full[0];
+        TRY(launch(h, "restore_q", st, [&] { k_level_restore2_q<T, QT, false><<<grid, blk, 0, st>>>(A); }));
+      } else {
+        const int zi = (tp - 1) / 2;
+        A.coarse = ds->nodal4[l - 1] + (size_t)zi * M;
+        A.coarse_b = ds->nodal4[l - 1] + (size_t)(zi + 1) * M;
+        A.tpos = tp;
+        A.lin_base = (size_t)(m_t + zi) * full[0];
+        TRY(launch(h, "restore_q_odd", st, [&] { k_level_restore2_q<T, QT, true><<<grid, blk, 0, st>>>(A); }));
+      }
+    }
+    A.lin_base = 0;
+  }
+  return MGH_SUCCESS;
+}
+
 template <typename T>
 int dequantize_recompose_fused(mgh_hierarchy *h, int64_t *q, int ebtype, double tol, double s,
                                double norm, uint64_t dict_size, int prep_huffman,
@@ -1448,6 +1584,7 @@ int dequantize_recompose_fused(mgh_hierarchy *h, int64_t *q, int ebtype, double 
   A.half = prep_huffman ? (int64_t)(dict_size / 2) : 0;
   std::vector<T> level_qv(L + 1);
   for (int l = 0; l <= L; l++) level_qv[l] = qz[l] * (calc_vol ? hh->level_volume(l, true) : (T)1);
+  if (h->D == 4) return recompose_levels4<T, int64_t>(h, A, level_qv, data, st);
   return recompose_levels<T, int64_t>(h, A, level_qv, data, st);
 }
 
@@ -2075,7 +2212,7 @@ int mgh_dequantize_recompose(mgh_hierarchy *h, int64_t *d_quantized, int ebtype,
                              const uint64_t *d_outlier_idx, const int64_t *d_outlier_val,
                              uint64_t outlier_count, void *d_data, void *stream) {
   if (!h || !d_data || !d_quantized) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
-  if (fused_ok(h) && !h->force_v1) {
+  if (fusedc_ok(h) && !h->force_v1) {
     HIP_TRY(hipSetDevice(h->device));
     return DISPATCH(h,
                     dequantize_recompose_fused<float>(h, d_quantized, ebtype, tol, s, norm, dict_size,

@@ -37,6 +37,12 @@ template <typename T> struct RecomposeArgs {
   const T *mass[3];
   T qv;              // quantizer * reciprocal volume of this level (dequantize factor)
   int64_t half;      // dict_size / 2 if the Huffman shift was applied, else 0
+  // D = 4 (recompose_levels4, capi.hip): the kernels work on ONE slice of the slowest dimension t
+  size_t lin_base;   // element offset of the slice inside q / coef / q16
+  int allcoef;       // odd t-slice: every node of the slice is a coefficient of this level
+  const T *coarse_b; // odd t-slice: corrected coarse nodes of the slice above (coarse: below)
+  const T *ratio_t;  // ... interpolation ratios along t of the level,
+  int tpos;          // ... and the slice's (odd) position: ratio_t[tpos - 1] applies
 };
 
 template <typename T> __device__ __forceinline__ T dequant_one(int64_t qd, int64_t half, T qv) {
@@ -158,10 +164,10 @@ k_level_loadvec_q(RecomposeArgs<T> A) {
     const bool pv = p >= 0 && p <= Pmax_r && p != ghost_r;
     const bool p_odd = p & 1;
     const int oi = p_odd ? mr + (p - 1) / 2 : p / 2;
-    const QT *base = qsrc<T>(A, QT()) + (size_t)(pv ? oi : 0) * A.dI;
+    const QT *base = qsrc<T>(A, QT()) + A.lin_base + (size_t)(pv ? oi : 0) * A.dI;
 #pragma unroll
     for (int k = 0; k < NL; k++)
-      reg[k] = (pv && qoff[k] != kNone && (p_odd || !evn[k])) ? qload<T>(A, base + qoff[k]) : qmissing<T>(A, QT());
+      reg[k] = (pv && qoff[k] != kNone && (p_odd || !evn[k] || A.allcoef)) ? qload<T>(A, base + qoff[k]) : qmissing<T>(A, QT());
   };
   QR cur[NL], nxt[NL];
   fetch(r_lo, cur);
@@ -170,7 +176,7 @@ k_level_loadvec_q(RecomposeArgs<T> A) {
     // Phase A': dequantized coefficient field of the window (0 at coarse / missing nodes:
     // a missing value was fetched as `half`, which dequantizes to exactly 0)
     {
-      const size_t pb = (size_t)((p & 1) ? mr + (p - 1) / 2 : p / 2) * A.dI;  // (index of a looked-up value)
+      const size_t pb = A.lin_base + (size_t)((p & 1) ? mr + (p - 1) / 2 : p / 2) * A.dI;  // (index of a looked-up value)
 #pragma unroll
       for (int k = 0; k < NL; k++)
         if (lds[k] >= 0) Cs[lds[k]] = qdecode(A, cur[k], pb + qoff[k]);
@@ -296,7 +302,12 @@ k_level_restore_q(RecomposeArgs<T> A) {
 // once for the two, and the row-level set-up is paid once (466 instead of 565 us over the levels
 // of 512^3). Every output is computed with the operations of k_level_restore_q, in the same
 // order. (A 2 x 2 group -- two planes x two rows per wave -- was slower again: 570 us.)
-template <typename T, typename QT>
+//
+// TODD (D = 4, an ODD slice of the slowest dimension t): every node of the slice is a coefficient
+// node of the level -- value = coefficient + lerp_t(X_a, X_b), X = the 3-D interpolant (f, then c,
+// then r) of the coarse slice below (A.coarse) / above (A.coarse_b), the mirror of the TODD tiles
+// of kernels_fused2.hpp (CalcCoefficientsND.hpp:25-236: nested lerps, fastest dim innermost).
+template <typename T, typename QT, bool TODD = false>
 __global__ void __launch_bounds__(256)
 k_level_restore2_q(RecomposeArgs<T> A) {
   const int nr = A.n[0], nc = A.n[1], nf = A.n[2];
@@ -316,12 +327,13 @@ k_level_restore2_q(RecomposeArgs<T> A) {
   const int jO = coO ? mc + J : mc - 1;
   const T rr = ro ? A.ratio[0][rp - 1] : (T)0, rc = coO ? A.ratio[1][cpO - 1] : (T)0;
   const size_t mJ = mf, mI = (size_t)mc * mf;
-  const size_t qlinE = (size_t)i * A.dI + (size_t)jE * A.dJ, qlinO = (size_t)i * A.dI + (size_t)jO * A.dJ;
+  const size_t qlinE = A.lin_base + (size_t)i * A.dI + (size_t)jE * A.dJ,
+               qlinO = A.lin_base + (size_t)i * A.dI + (size_t)jO * A.dJ;
   const QT *qrowE = qsrc<T>(A, QT()) + qlinE, *qrowO = qsrc<T>(A, QT()) + qlinO;
   T *outE = A.fine + (size_t)rp * A.fI + (size_t)cpE * A.fJ;
   T *outO = outE + A.fJ;
-  const bool pureE = !ro;          // row E: coarse in c; a pure copy unless r is odd
-  const bool pureO = !ro && !coO;  // (row O as the coarse last row of an even-sized dim)
+  const bool pureE = !TODD && !ro;          // row E: coarse in c; a pure copy unless r is odd
+  const bool pureO = !TODD && !ro && !coO;  // (row O as the coarse last row of an even-sized dim)
   const int cJ1 = min(J + 1, mc - 1);
   const T *rowJ[2], *rowJ1[2];
 #pragma unroll
@@ -329,6 +341,8 @@ k_level_restore2_q(RecomposeArgs<T> A) {
     rowJ[a] = A.coarse + (size_t)(r0 + (ro ? a : 0)) * mI + (size_t)J * mJ;
     rowJ1[a] = A.coarse + (size_t)(r0 + (ro ? a : 0)) * mI + (size_t)cJ1 * mJ;
   }
+  const ptrdiff_t to_b = TODD ? A.coarse_b - A.coarse : 0;
+  const T rt = TODD ? A.ratio_t[A.tpos - 1] : (T)0;
   const bool alE = (reinterpret_cast<uintptr_t>(outE) & (2 * sizeof(T) - 1)) == 0;
   const bool alO = (reinterpret_cast<uintptr_t>(outO) & (2 * sizeof(T) - 1)) == 0;
   const int npair = (nf + 1) / 2;
@@ -339,30 +353,57 @@ k_level_restore2_q(RecomposeArgs<T> A) {
     const bool fo = hasO && !(nf % 2 == 0 && fpO == nf - 1);
     const T rf = fo ? A.ratio[2][fpO - 1] : (T)0;
     const int t1 = min(t + 1, mf - 1);
-    // f-level values of the coarse rows J and J+1 at the (up to) two r-planes
-    T eJ[2], oJ[2], eJ1[2], oJ1[2];
+    // the four interpolants (row E: nodes E, O; row O: nodes E, O) from one coarse slice
+    // (`off` = element offset of the slice relative to A.coarse)
+    auto interp = [&](ptrdiff_t off, T &iEE, T &iEO, T &iOE, T &iOO) {
+      // f-level values of the coarse rows J and J+1 at the (up to) two r-planes
+      T eJ[2], oJ[2], eJ1[2], oJ1[2];
 #pragma unroll
-    for (int a = 0; a < 2; a++) {
-      if (a == 1 && !ro) break;
-      const T v0 = rowJ[a][t], v1 = rowJ[a][t1];
-      eJ[a] = v0;
-      oJ[a] = fo ? lerp_ref(v0, v1, rf) : v1;
-      if (hasRowO) {
-        const T w0 = rowJ1[a][t], w1 = rowJ1[a][t1];
-        eJ1[a] = w0;
-        oJ1[a] = fo ? lerp_ref(w0, w1, rf) : w1;
+      for (int a = 0; a < 2; a++) {
+        if (a == 1 && !ro) break;
+        const T v0 = rowJ[a][off + t], v1 = rowJ[a][off + t1];
+        eJ[a] = v0;
+        oJ[a] = fo ? lerp_ref(v0, v1, rf) : v1;
+        if (hasRowO) {
+          const T w0 = rowJ1[a][off + t], w1 = rowJ1[a][off + t1];
+          eJ1[a] = w0;
+          oJ1[a] = fo ? lerp_ref(w0, w1, rf) : w1;
+        }
       }
+      // row E (c even): the row-J values, then r
+      iEE = ro ? lerp_ref(eJ[0], eJ[1], rr) : eJ[0];
+      iEO = ro ? lerp_ref(oJ[0], oJ[1], rr) : oJ[0];
+      // row O: c-interpolation between rows J and J+1 (or the coarse last row J+1), then r
+      if (hasRowO) {
+        T hE[2], hO[2];
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+          if (a == 1 && !ro) break;
+          hE[a] = coO ? lerp_ref(eJ[a], eJ1[a], rc) : eJ1[a];
+          hO[a] = coO ? lerp_ref(oJ[a], oJ1[a], rc) : oJ1[a];
+        }
+        iOE = ro ? lerp_ref(hE[0], hE[1], rr) : hE[0];
+        iOO = ro ? lerp_ref(hO[0], hO[1], rr) : hO[0];
+      }
+    };
+    T iEE, iEO, iOE = 0, iOO = 0;
+    interp(0, iEE, iEO, iOE, iOO);
+    if (TODD) {
+      T bEE, bEO, bOE = 0, bOO = 0;
+      interp(to_b, bEE, bEO, bOE, bOO);
+      iEE = lerp_ref(iEE, bEE, rt);
+      iEO = lerp_ref(iEO, bEO, rt);
+      iOE = lerp_ref(iOE, bOE, rt);
+      iOO = lerp_ref(iOO, bOO, rt);
     }
-    // ---- row E (c even): interpolant = the row-J values, then r
+    // ---- row E
     {
-      const T iE = ro ? lerp_ref(eJ[0], eJ[1], rr) : eJ[0];
-      const T iO = ro ? lerp_ref(oJ[0], oJ[1], rr) : oJ[0];
-      T vE = iE;
-      if (!pureE) vE = qdecode(A, qload<T>(A, qrowE + t), qlinE + t) + iE;
-      T vO = iO;
+      T vE = iEE;
+      if (!pureE) vE = qdecode(A, qload<T>(A, qrowE + t), qlinE + t) + iEE;
+      T vO = iEO;
       if (hasO) {
-        if (fo) vO = qdecode(A, qload<T>(A, qrowE + mf + t), qlinE + mf + t) + iO;
-        else if (!pureE) vO = qdecode(A, qload<T>(A, qrowE + mf - 1), qlinE + mf - 1) + iO;
+        if (fo) vO = qdecode(A, qload<T>(A, qrowE + mf + t), qlinE + mf + t) + iEO;
+        else if (!pureE) vO = qdecode(A, qload<T>(A, qrowE + mf - 1), qlinE + mf - 1) + iEO;
       }
       T *dst = outE + 2 * t;
       if (hasO && alE) {
@@ -372,23 +413,14 @@ k_level_restore2_q(RecomposeArgs<T> A) {
         if (hasO) dst[1] = vO;
       }
     }
-    // ---- row O: c-interpolation between rows J and J+1 (or the coarse last row J+1), then r
+    // ---- row O
     if (hasRowO) {
-      T hE[2], hO[2];
-#pragma unroll
-      for (int a = 0; a < 2; a++) {
-        if (a == 1 && !ro) break;
-        hE[a] = coO ? lerp_ref(eJ[a], eJ1[a], rc) : eJ1[a];
-        hO[a] = coO ? lerp_ref(oJ[a], oJ1[a], rc) : oJ1[a];
-      }
-      const T iE = ro ? lerp_ref(hE[0], hE[1], rr) : hE[0];
-      const T iO = ro ? lerp_ref(hO[0], hO[1], rr) : hO[0];
-      T vE = iE;
-      if (!pureO) vE = qdecode(A, qload<T>(A, qrowO + t), qlinO + t) + iE;
-      T vO = iO;
+      T vE = iOE;
+      if (!pureO) vE = qdecode(A, qload<T>(A, qrowO + t), qlinO + t) + iOE;
+      T vO = iOO;
       if (hasO) {
-        if (fo) vO = qdecode(A, qload<T>(A, qrowO + mf + t), qlinO + mf + t) + iO;
-        else if (!pureO) vO = qdecode(A, qload<T>(A, qrowO + mf - 1), qlinO + mf - 1) + iO;
+        if (fo) vO = qdecode(A, qload<T>(A, qrowO + mf + t), qlinO + mf + t) + iOO;
+        else if (!pureO) vO = qdecode(A, qload<T>(A, qrowO + mf - 1), qlinO + mf - 1) + iOO;
       }
       T *dst = outO + 2 * t;
       if (hasO && alO) {
@@ -398,6 +430,19 @@ k_level_restore2_q(RecomposeArgs<T> A) {
         if (hasO) dst[1] = vO;
       }
     }
+  }
+}
+
+// D = 4: level-0 nodal values (compact (m0, m1, m2, m3)) out of the head of the quantized array;
+// dT = element stride of t in that array.
+template <typename T, typename QT>
+__global__ void __launch_bounds__(256)
+k_head_in4_q(int m0, int m1, int m2, int m3, RecomposeArgs<T> A, size_t dT, T *__restrict__ nodal) {
+  const int total = m0 * m1 * m2 * m3;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int k = e % m3, j = (e / m3) % m2, i = (e / (m3 * m2)) % m1, t = e / (m3 * m2 * m1);
+    const size_t lin = (size_t)t * dT + (size_t)i * A.dI + (size_t)j * A.dJ + k;
+    nodal[e] = qdecode(A, qload<T>(A, qsrc<T>(A, QT()) + lin), lin);
   }
 }
 

@@ -574,6 +574,14 @@ def test_fused_4d_path_equals_generic_nd(shape, dt, monkeypatch):
     c = h.decompose(ud)
     assert_bit_equal(c.cpu().numpy(), ref, "fused 4-D decompose %r" % (shape,))
     q, oi, ov, cnt, nrm = h.decompose_quantize(ud, mg.REL, 1e-3, np.inf, outlier_cap=u.size)
+    # the way back on the same slice-by-slice level loop (recompose_levels4): coefficients ->
+    # nodal values equal to the oracle's recomposition, out of place and in place; integers ->
+    # reconstruction
+    ref_back = o.recompose(ref)
+    assert_bit_equal(h.recompose(c).cpu().numpy(), ref_back, "fused 4-D recompose %r" % (shape,))
+    c_in = c.clone()
+    assert_bit_equal(h.recompose(c_in, out=c_in).cpu().numpy(), ref_back, "fused 4-D recompose in place")
+    back = h.dequantize_recompose(q.clone(), mg.REL, 1e-3, np.inf, nrm, outlier_idx=oi[:cnt], outlier_val=ov[:cnt])
     h.close()
     monkeypatch.setenv("MGH_FUSED4", "0")
     g = mg.Hierarchy(shape, dt)
@@ -581,13 +589,16 @@ def test_fused_4d_path_equals_generic_nd(shape, dt, monkeypatch):
     assert cnt == cnt2 and nrm == nrm2 and torch.equal(q, q2)
     a, b = _outlier_set(oi.cpu().numpy(), ov.cpu().numpy()), _outlier_set(oi2.cpu().numpy(), ov2.cpu().numpy())
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    back2 = g.dequantize_recompose(q2.clone(), mg.REL, 1e-3, np.inf, nrm, outlier_idx=oi2[:cnt2], outlier_val=ov2[:cnt2])
+    assert torch.equal(back, back2)
+    assert float((back - ud).abs().max().item()) <= 1e-3 * nrm
     g.close()
 
 
 def test_config3_full_size_slab():
     """BASELINE.json configs[3] at FULL per-rank size, 8 x 512^3 float32 (the oracle would need
     minutes): the fused 4-D path against the generic N-D kernels bit for bit, and the round trip
-    through the (generic) recomposition within the tolerance."""
+    through the slice-by-slice recomposition within the tolerance."""
     torch, mg = _gpu()
     shape = (8, 512, 512, 512)
     if _host_mem_gb() < 24 or torch.cuda.mem_get_info()[0] < (40 << 30):
