@@ -1630,6 +1630,7 @@ int dequantize_recompose_fused16(mgh_hierarchy *h, const uint16_t *sym, int ebty
   A.half = (int64_t)(dict_size / 2);
   std::vector<T> level_qv(L + 1);
   for (int l = 0; l <= L; l++) level_qv[l] = qz[l] * (calc_vol ? hh->level_volume(l, true) : (T)1);
+  if (h->D == 4) return recompose_levels4<T, uint16_t>(h, A, level_qv, data, st);
   return recompose_levels<T, uint16_t>(h, A, level_qv, data, st);
 }
 
@@ -2087,7 +2088,7 @@ int mgh_decompose_quantize_sym16(mgh_hierarchy *h, const void *d_data, int error
 }
 
 int mgh_sym16_supported(const mgh_hierarchy *h) {
-  return h && fused_ok(h) && !h->force_v1 && !h->split ? 1 : 0;
+  return h && fusedc_ok(h) && !h->force_v1 && !h->split ? 1 : 0;
 }
 
 int mgh_dequantize_recompose_sym16(mgh_hierarchy *h, const uint16_t *d_symbols, int error_bound_type,
@@ -2099,7 +2100,7 @@ int mgh_dequantize_recompose_sym16(mgh_hierarchy *h, const uint16_t *d_symbols, 
   if (dict_size == 0 || dict_size > 65536) return fail(MGH_ERR_INVALID_ARGUMENT, "dict_size must be in 1..65536");
   HIP_TRY(hipSetDevice(h->device));
   if (!mgh_sym16_supported(h))
-    return fail(MGH_ERR_UNSUPPORTED_DIMENSION, "16-bit symbols: only on the fused 3-D path");
+    return fail(MGH_ERR_UNSUPPORTED_DIMENSION, "16-bit symbols: only on the fused 3-D / 4-D path");
   return DISPATCH(h,
                   dequantize_recompose_fused16<float>(h, d_symbols, error_bound_type, tol, s, norm, dict_size,
                                                       d_outlier_idx, d_outlier_val, outlier_count,

@@ -661,7 +661,8 @@ def test_split_stream_schedule_bit_exact(shape, mode, s, split, dt, monkeypatch)
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,dt,mode,tol,s,dict_size", [
     ((65, 70, 129), np.float32, "REL", 1e-3, np.inf, 8192), ((33, 40, 36), np.float64, "ABS", 1e-4, 0.0, 8192),
-    ((129, 129, 129), np.float32, "REL", 1e-4, np.inf, 64), ((20, 17, 300), np.float32, "REL", 1e-2, 1.0, 65536)])
+    ((129, 129, 129), np.float32, "REL", 1e-4, np.inf, 64), ((20, 17, 300), np.float32, "REL", 1e-2, 1.0, 65536),
+    ((8, 66, 70, 129), np.float32, "REL", 1e-3, np.inf, 8192), ((7, 33, 40, 65), np.float64, "ABS", 1e-5, np.inf, 64)])
 def test_sym16_output_equals_the_int64_output(shape, dt, mode, tol, s, dict_size):
     """mgh_decompose_quantize_sym16 = mgh_decompose_quantize(prep_huffman=1) narrowed to 16 bits,
     same outlier list (the small dictionary forces many outliers)."""
