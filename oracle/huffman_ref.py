@@ -1,8 +1,8 @@
 """TEST INFRASTRUCTURE ONLY -- never imported by the product (mgard_amd/), only by tests/.
 
-CPU restatement (numpy / plain Python, small inputs) of the three pieces of the reference's
-MGARD-X Huffman stage that decide whether a payload written by this repository is what the stock
-decoder expects:
+CPU restatement (numpy / plain Python, small inputs) of the pieces of the reference's MGARD-X
+Huffman stage that decide whether a payload written by this repository is what the stock decoder
+expects, and whether a payload the stock encoder writes is read by this repository's decoder:
 
   * generate_cw()   -- canonical codewords + the first[] / entry[] tables from sorted code lengths
                        (include/mgard-x/Lossless/ParallelHuffman/GenerateCW.hpp:40-232, the ten
@@ -11,13 +11,15 @@ decoder expects:
                        the first non-zero frequency, GenerateCW, the two array reversals and the
                        reordering by symbol (GetCodebook.hpp:23-147)
   * decode()        -- the bit-serial canonical decoder (Decode.hpp:52-106)
-
-What is NOT restated: GenerateCL.hpp (the parallel code-LENGTH construction). Code lengths are an
-input here; the tests take them from the library's own codebook and check the two properties
-GenerateCW relies on (lengths optimal; non-increasing with frequency along the sorted order).
-Among several optimal length assignments the reference's GenerateCL may pick another one than
-this repository's two-queue construction; the decodebook travels with the payload
-(Huffman.hpp:163-239), so either is decodable by the other side.
+  * generate_cl()   -- the parallel code-LENGTH construction (GenerateCL.hpp:58-690), sequentially.
+                       The reference reads histogram[lNodesCur + curLeavesNum] (:331-336), one
+                       element past the array whenever every remaining leaf joins a merge (4 of
+                       10 random histograms): its result is then not a function of the histogram
+                       and generate_cl raises ReferenceReadsOutOfBounds. Where it is defined it is
+                       optimal and monotone (asserted), and equals the library's two-queue
+                       construction except for how some ties are broken (5 of 153 random cases);
+                       the decodebook travels with the payload (Huffman.hpp:163-239), so either
+                       side decodes the other's records (tests/test_huffman_reference_rules.py).
 
 Pin status: no golden vectors exist for this stage (the reference's tests round-trip the legacy
 CPU Huffman only: tests/src/test_compressors.cpp:15-39); this file is pinned by being a
@@ -149,3 +151,124 @@ def decode(units, total_bits, first, entry, keys, max_symbols=None):
             v = bit(i)
         l = 1
     return out
+
+
+class ReferenceReadsOutOfBounds(Exception):
+    """GenerateCL.hpp:331-336 reads histogram[lNodesCur + curLeavesNum]; when every remaining leaf
+    takes part in the merge that index is one past the end of the array (undefined in the
+    reference, so there is nothing to restate for such an input)."""
+
+
+UINT_MAX = 0xFFFFFFFF
+
+
+def generate_cl(freq_ascending):
+    """GenerateCLFunctor (GenerateCL.hpp:58-690), the Operations executed sequentially: the
+    two-phase parallel Huffman code-LENGTH construction (select the two smallest nodes, then meld
+    every leaf not heavier than their sum with the queued internal nodes pairwise). Input: the
+    non-zero frequencies in ASCENDING order (GetCodebook.hpp:70-88 passes the same array as
+    `histogram` and `lNodesFreq`). Returns CL[i] per sorted position.
+
+    Unpinned: no reference-held vector exists for this stage; the tests only compare it with the
+    library's own construction and say where the two differ."""
+    f = [int(x) for x in freq_ascending]
+    n = len(f)
+    MOD = lambda a, b: ((a % b) + b) % b                     # GenerateCL.hpp:14-16
+    CL = [0] * n                                             # Operation1 (:58-81)
+    lLeader = [-1] * n
+    iFreq = [0] * n
+    iLeader = [-1] * n
+    front = rear = cur = size = 0
+    while cur < n or size > 1:                               # LoopCondition1 (:83-93)
+        # ---- Operation2 (:95-296): the two least frequent of {2 leaves, 2 internal nodes}
+        mid = [[UINT_MAX, 0] for _ in range(4)]
+        if cur < n:
+            mid[0] = [f[cur], 1]
+        if cur < n - 1:
+            mid[1] = [f[cur + 1], 1]
+        if size >= 1:
+            mid[2] = [iFreq[front], 0]
+        if size >= 2:
+            mid[3] = [iFreq[MOD(front + 1, n)], 0]
+        for a, b in ((1, 3), (0, 2), (0, 1), (2, 3), (1, 2)):  # the sorting network (:141-182)
+            if mid[a][0] > mid[b][0]:
+                mid[a], mid[b] = mid[b], mid[a]
+        minFreq = mid[0][0]
+        if mid[1][0] < UINT_MAX:                             # only one node left: no merge
+            minFreq += mid[1][0]
+        iFreq[rear] = minFreq
+        iLeader[rear] = -1
+        for k in (0, 1):
+            if mid[k][0] < UINT_MAX:
+                if mid[k][1]:
+                    lLeader[cur] = rear
+                    CL[cur] += 1
+                    cur += 1
+                else:
+                    iLeader[front] = rear
+                    front = MOD(front + 1, n)
+        size = MOD(rear - front, n)
+        # ---- Operation3/4 (:298-330): leaves not heavier than the node just made
+        curLeavesNum = 0
+        for i in range(cur, n):
+            if f[i] <= minFreq:
+                curLeavesNum = max(curLeavesNum, i - cur + 1)
+        # ---- Operation5 (:332-403)
+        mergeRear, mergeFront = rear, front
+        if (curLeavesNum + size) % 2 == 0:
+            front = rear
+        else:
+            cond = False
+            if size != 0:
+                if curLeavesNum == 0:
+                    cond = True
+                else:
+                    if cur + curLeavesNum >= n:
+                        raise ReferenceReadsOutOfBounds()
+                    cond = f[cur + curLeavesNum] <= iFreq[MOD(rear - 1, n)]
+            if cond:
+                mergeRear = MOD(mergeRear - 1, n)
+                front = MOD(rear - 1, n)
+            else:
+                front = rear
+                curLeavesNum -= 1
+        copy_idx = list(range(cur, cur + curLeavesNum))      # Operation4's copy (before cur moves)
+        cur += curLeavesNum
+        rear = MOD(rear + 1, n)
+        tempLength = curLeavesNum + MOD(mergeRear - mergeFront, n)
+        if tempLength > 0:                                   # BranchCondition1 (:405-408)
+            # ---- Operations 6-11 (:410-606): merge path = stable merge, leaf first on ties
+            temp = []
+            a, b = 0, mergeFront
+            while a < len(copy_idx) and MOD(mergeRear - b, n) > 0:
+                if f[copy_idx[a]] <= iFreq[b]:
+                    temp.append((f[copy_idx[a]], copy_idx[a], 1))
+                    a += 1
+                else:
+                    temp.append((iFreq[b], b, 0))
+                    b = MOD(b + 1, n)
+            while a < len(copy_idx):
+                temp.append((f[copy_idx[a]], copy_idx[a], 1))
+                a += 1
+            while MOD(mergeRear - b, n) > 0:
+                temp.append((iFreq[b], b, 0))
+                b = MOD(b + 1, n)
+            # ---- Operation12 (:608-632): meld pairwise into new internal nodes
+            for i in range(tempLength // 2):
+                ind = MOD(rear + i, n)
+                iFreq[ind] = temp[2 * i][0] + temp[2 * i + 1][0]
+                iLeader[ind] = -1
+                for fr, idx, leaf in (temp[2 * i], temp[2 * i + 1]):
+                    if leaf:
+                        lLeader[idx] = ind
+                        CL[idx] += 1
+                    else:
+                        iLeader[idx] = ind
+            rear = MOD(rear + tempLength // 2, n)            # Operation13 (:634-642)
+        # ---- Operation14 (:644-658): leaves follow their leader one step up
+        for i in range(n):
+            if lLeader[i] != -1 and iLeader[lLeader[i]] != -1:
+                lLeader[i] = iLeader[lLeader[i]]
+                CL[i] += 1
+        size = MOD(rear - front, n)                          # Operation15 (:660-668)
+    return CL

@@ -60,6 +60,52 @@ def decode_huffman_record(rec, max_chunks=None):
     return out
 
 
+def write_huffman_record(symbols, dict_size, chunk, codebook, first, entry, keys,
+                         outlier_idx=(), outliers=()):
+    """The serialized record of Huffman.hpp:163-239 written from a codebook given as the reference
+    holds it (codebook[s] = (length << 56) | codeword, first[64] / entry[64] / keys[dict]; None
+    entries -- never written by GenerateCW -- become 0 like the reference's zero-filled workspace):
+    what the stock ENCODER would hand to a decoder. Small inputs only."""
+    symbols = [int(x) for x in symbols]
+    n = len(symbols)
+    nchunk = (n - 1) // chunk + 1
+    bits_per_chunk, units = [], []
+    for c in range(nchunk):
+        word, nb, out = 0, 0, []
+        total = 0
+        for sy in symbols[c * chunk:(c + 1) * chunk]:
+            cw = int(codebook[sy])
+            l, v = cw >> 56, cw & ((1 << 56) - 1)
+            total += l
+            for k in range(l):                      # MSB first into H = u64 units (Deflate.hpp:33-76)
+                word = (word << 1) | ((v >> (l - 1 - k)) & 1)
+                nb += 1
+                if nb == 64:
+                    out.append(word)
+                    word, nb = 0, 0
+        if nb:
+            out.append(word << (64 - nb))
+        bits_per_chunk.append(total)
+        units.append(out)
+    offs, acc = [], 0
+    for u in units:
+        offs.append(acc)
+        acc += len(u)
+    b = bytearray()
+    b += struct.pack("<Q", n) + struct.pack("<ii", dict_size, chunk)
+    b += struct.pack("<Q", 2 * nchunk)
+    b += np.asarray(bits_per_chunk + offs, dtype="<u8").tobytes()
+    b += struct.pack("<Q", 8 * 128 + 8 * dict_size)
+    b += np.asarray([0 if x is None else int(x) for x in first], dtype="<u8").tobytes()
+    b += np.asarray([0 if x is None else int(x) for x in entry], dtype="<u8").tobytes()
+    b += np.asarray([int(x) for x in keys], dtype="<u8").tobytes()
+    b += struct.pack("<Q", acc)
+    b += np.asarray([w for u in units for w in u], dtype="<u8").tobytes()
+    b += struct.pack("<Q", len(outlier_idx))
+    b += np.asarray(outlier_idx, dtype="<u8").tobytes() + np.asarray(outliers, dtype="<i8").tobytes()
+    return np.frombuffer(bytes(b), dtype=np.uint8).copy()
+
+
 def split_container(buf, metadata_size):
     """[(size, payload bytes)] of the subdomain records behind the header."""
     b = bytes(buf)
