@@ -11,7 +11,7 @@
 //   * dev_type AUTO, HIP and CUDA select the HIP device `dev_id`; SERIAL / OPENMP / SYCL return
 //     BackendNotAvailableFailure (there is no CPU implementation in the product);
 //   * decomposition must be MultiDim, compressor MGARD, lossless Huffman or Huffman_Zstd,
-//     reorder 0 -- anything else returns Failure instead of silently doing something different;
+//     reorder 0 or 1 -- anything else returns Failure instead of silently doing something different;
 //   * the fields that only steer the reference's runtime (log_level, prefetch, lz4_block_size,
 //     total_num_bitplanes, mdr_*, adjust_shape, compress_with_dryrun,
 //     num_local_refactoring_level, auto_cache_release, cpu_mode) are accepted and ignored;
@@ -109,7 +109,7 @@ inline compress_status_type check(const Config &c) {
   if (c.dev_type != device_type::AUTO && c.dev_type != device_type::HIP && c.dev_type != device_type::CUDA)
     return compress_status_type::BackendNotAvailableFailure;
   if (c.decomposition != decomposition_type::MultiDim || c.compressor != compressor_type::MGARD ||
-      c.reorder != 0 || c.adjust_shape)
+      (c.reorder != 0 && c.reorder != 1) || c.adjust_shape)
     return compress_status_type::Failure;
   if (c.lossless != lossless_type::Huffman && c.lossless != lossless_type::Huffman_Zstd)
     return compress_status_type::Failure;
@@ -133,6 +133,7 @@ inline mgh_config to_c(const Config &c) {
   m.max_larget_level = c.max_larget_level;
   m.max_memory_footprint = c.max_memory_footprint;
   m.auto_pin_host_buffers = c.auto_pin_host_buffers ? 1 : 0;
+  m.reorder = c.reorder;
   return m;
 }
 } // namespace detail

@@ -187,6 +187,23 @@ int mgh_dequantize_recompose(mgh_hierarchy *h, int64_t *d_quantized, int error_b
                              const int64_t *d_outlier_val, uint64_t outlier_count, void *d_data,
                              void *stream);
 
+/* OutlierRestore (LinearQuantization.hpp:304-350) on its own: d_q[idx[i]] = val[i]; indices
+ * outside [0, n) are ignored. */
+int mgh_outlier_restore(int64_t *d_q, uint64_t n, const uint64_t *d_outlier_idx,
+                        const int64_t *d_outlier_val, uint64_t outlier_count, void *stream);
+
+/* config.reorder == 1 of the reference ("level linearised" quantized output,
+ * Quantization/LinearQuantization.hpp:46-146 calc_level_offset, :588-605 slot of a level): the
+ * quantized array with the entries of level 0 first, then the coefficients of level 1 in the
+ * natural row-major order of the level-1 grid, and so on. A permutation of the reordered N-D
+ * array mgh_quantize / mgh_decompose_quantize write; inverse != 0 undoes it. d_in != d_out.
+ * d_outlier_idx (optional, forward only): outlier indices are rewritten in place to positions in
+ * the linearised array, as the reference records them in this mode (:226-232); their number is
+ * outlier_count, or *d_outlier_count (device) capped at outlier_capacity when that is given. */
+int mgh_level_linearize(mgh_hierarchy *h, const int64_t *d_in, int64_t *d_out, int inverse,
+                        uint64_t *d_outlier_idx, const uint64_t *d_outlier_count, uint64_t outlier_count,
+                        uint64_t outlier_capacity, void *stream);
+
 /* Per-kernel timing hook used by bench.py for the roofline line: when enabled,
  * every kernel launched through this handle is bracketed by HIP events on the
  * launch stream; mgh_profile_read() synchronises and returns accumulated

@@ -70,6 +70,8 @@ typedef struct mgh_config {
   uint64_t max_larget_level;
   uint64_t max_memory_footprint; /* bytes of device memory the call may plan with */
   int auto_pin_host_buffers; /* default 0 here (reference: 1), see mgh_config_default */
+  int reorder;               /* 0 (default): quantized integers in the N-D layout; 1: level by level
+                                (Config::reorder, LinearQuantization.hpp:46-146) -- recorded in the header */
 } mgh_config;
 
 void mgh_config_default(mgh_config *config);

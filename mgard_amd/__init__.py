@@ -26,6 +26,7 @@ SYMBOLS = [
     "mgh_norm_device", "mgh_decompose_quantize_dn", "mgh_decompose_quantize_sym16",
     "mgh_dequantize_recompose_sym16", "mgh_sym16_supported",
     "mgh_profile_enable", "mgh_profile_filter", "mgh_profile_read", "mgh_stream_calibrate",
+    "mgh_level_linearize", "mgh_outlier_restore",
 ]
 
 
@@ -86,6 +87,8 @@ def load_library():
     L.mgh_profile_filter.argtypes = [vp, C.c_char_p]
     L.mgh_profile_read.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), u64p,
                                    C.c_int, C.c_int]
+    L.mgh_outlier_restore.argtypes = [vp, u64, vp, vp, u64, vp]
+    L.mgh_level_linearize.argtypes = [vp, vp, vp, C.c_int, vp, vp, u64, u64, vp]
     L.mgh_stream_calibrate.argtypes = [C.c_int, vp, vp, vp, u64, C.c_int, C.POINTER(C.c_double), vp]
     _lib = L
     return L
@@ -305,6 +308,17 @@ class Hierarchy:
             self._h, self._chk(q, torch.int64), ebtype, tol, s, norm, dict_size, int(prep_huffman),
             C.c_void_p(outlier_idx.data_ptr() if n else 0),
             C.c_void_p(outlier_val.data_ptr() if n else 0), n, self._chk(out), _stream()))
+        return out
+
+    def level_linearize(self, q, inverse=False, outlier_idx=None):
+        """mgh_level_linearize: the quantized array level by level (config.reorder == 1) or back;
+        forward, `outlier_idx` (int64/uint64 device tensor) is rewritten in place."""
+        import torch
+        out = torch.empty_like(q)
+        n = 0 if outlier_idx is None else int(outlier_idx.numel())
+        _check(load_library().mgh_level_linearize(
+            self._h, self._chk(q, torch.int64), C.c_void_p(out.data_ptr()), int(inverse),
+            C.c_void_p(outlier_idx.data_ptr() if n else 0), None, n, 0, _stream()))
         return out
 
     # ---- per-kernel timing (HIP events on the launch stream) ----

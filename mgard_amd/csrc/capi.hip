@@ -2285,6 +2285,59 @@ int mgh_profile_read(mgh_hierarchy *h, const char **names, double *total_ms, uin
   return n;
 }
 
+int mgh_outlier_restore(int64_t *d_q, uint64_t n, const uint64_t *d_outlier_idx,
+                        const int64_t *d_outlier_val, uint64_t outlier_count, void *stream) {
+  if (!d_q || (outlier_count && (!d_outlier_idx || !d_outlier_val)))
+    return fail(MGH_ERR_INVALID_ARGUMENT, "mgh_outlier_restore: null argument");
+  if (!outlier_count) return MGH_SUCCESS;
+  hipStream_t st = (hipStream_t)stream;
+  mgh::k_outlier_restore<<<(unsigned)((outlier_count + 255) / 256), 256, 0, st>>>(d_q, n, d_outlier_idx,
+                                                                                 d_outlier_val, outlier_count);
+  HIP_TRY(hipGetLastError());
+  return MGH_SUCCESS;
+}
+
+int mgh_level_linearize(mgh_hierarchy *h, const int64_t *d_in, int64_t *d_out, int inverse,
+                        uint64_t *d_outlier_idx, const uint64_t *d_outlier_count, uint64_t outlier_count,
+                        uint64_t outlier_capacity, void *stream) {
+  if (!h || !d_in || !d_out || d_in == d_out) return fail(MGH_ERR_INVALID_ARGUMENT, "mgh_level_linearize: null or aliasing argument");
+  if (inverse && d_outlier_idx) return fail(MGH_ERR_INVALID_ARGUMENT, "mgh_level_linearize: indices are mapped forward only");
+  if (h->L + 1 > mgh::kLinMaxLevels + 1) return fail(MGH_ERR_INVALID_ARGUMENT, "too many levels");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  mgh::LinMeta m{};
+  const int *marks = nullptr;
+  auto fill = [&](auto *hh, auto *ds) {
+    m.D = hh->D;
+    m.L = hh->L;
+    for (int d = 0; d < hh->D; d++) {
+      m.shape[d] = (uint32_t)hh->shape[d];
+      m.markoff[d] = ds->qmeta.markoff[d];
+      for (int l = 0; l <= hh->L; l++) m.lshape[l][d] = (uint32_t)hh->level_shape[l][d];
+    }
+    marks = ds->marks;
+  };
+  if (h->dtype == MGH_FLOAT) fill(HH<float>(h), DS<float>(h));
+  else fill(HH<double>(h), DS<double>(h));
+  const size_t total = h->total;
+  const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
+  TRY(launch(h, "level_linearize", st, [&] {
+    if (inverse) mgh::k_level_linearize<int64_t, true><<<grid, 256, 0, st>>>(m, marks, total, d_in, d_out);
+    else mgh::k_level_linearize<int64_t, false><<<grid, 256, 0, st>>>(m, marks, total, d_in, d_out);
+  }));
+  if (d_outlier_idx && (d_outlier_count || outlier_count)) {
+    const unsigned long long cap = outlier_capacity ? outlier_capacity : (d_outlier_count ? ~0ull : outlier_count);
+    const size_t work = d_outlier_count ? (size_t)std::min<unsigned long long>(cap, total) : (size_t)outlier_count;
+    const unsigned g2 = (unsigned)std::max<size_t>(1, std::min<size_t>((work + 255) / 256, 4096));
+    TRY(launch(h, "linearize_indices", st, [&] {
+      mgh::k_linearize_indices<<<g2, 256, 0, st>>>(m, marks, total, d_outlier_idx,
+                                                   (const unsigned long long *)d_outlier_count,
+                                                   (unsigned long long)outlier_count, cap);
+    }));
+  }
+  return MGH_SUCCESS;
+}
+
 int mgh_stream_calibrate(int dtype, const void *d_in, int64_t *d_out, void *d_side, uint64_t n,
                          int reps, double *ms_out, void *stream) {
   if (!d_in || !d_out || !d_side || !ms_out || n < 8 || reps < 1 || (dtype != MGH_FLOAT && dtype != MGH_DOUBLE)) {

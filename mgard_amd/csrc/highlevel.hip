@@ -1016,7 +1016,7 @@ int copy_subdomain(const Decomposer &dd, uint64_t id, size_t elem, void *sub, co
 // (CompressorCache, CompressionLowLevel/CompressorCache.hpp:139-142) -------------------------
 struct HlCache {
   std::map<std::vector<uint64_t>, mgh_hierarchy *> hier;  // key: dtype, normalize, max_level, shape...
-  DevBuf in[2], q, ocount, oidx, oval;
+  DevBuf in[2], q, q2, ocount, oidx, oval;  // q2: level-linearised copy (config.reorder == 1)
   mgh_lossless_ctx *ll = nullptr;
   hipStream_t streams[3] = {nullptr, nullptr, nullptr};
   int dev = -1;
@@ -1026,6 +1026,7 @@ struct HlCache {
     in[0].release();
     in[1].release();
     q.release();
+    q2.release();
     ocount.release();
     oidx.release();
     oval.release();
@@ -1144,7 +1145,7 @@ int header_from(const Decomposer &dd, int dtype, int ebtype, double tol, double 
   h.dd_size = dd.size;
   h.hierarchy = fmt::HIER_MULTIDIM;
   h.l_target = 0;  // never filled by the reference (Metadata.hpp:78-113)
-  h.reorder = false;
+  h.reorder = cfg.reorder != 0;
   h.compressor = cfg.lossless == MGH_LOSSLESS_HUFFMAN ? fmt::COMP_X_HUFFMAN : fmt::COMP_X_HUFFMAN_ZSTD;
   h.huff_dict_size = cfg.huff_dict_size;
   h.huff_block_size = cfg.huff_block_size;
@@ -1219,6 +1220,7 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
       if (dd.num > 1) HL_TRY(g_cache.in[1].ensure(max_elems * elem));
     }
     HL_TRY(g_cache.q.ensure(max_elems * 8));
+    if (cfg.reorder) HL_TRY(g_cache.q2.ensure(max_elems * 8));
     HL_TRY(g_cache.ocount.ensure(8));
     HL_TRY(g_cache.oidx.ensure(ocap * 8));
     HL_TRY(g_cache.oval.ensure(ocap * 8));
@@ -1295,7 +1297,7 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
       // 16-bit symbols straight from the quantizer where the fused kernels run (a quarter of the
       // bytes written by the quantizer and read twice by the lossless stage); int64 otherwise
       bool sym16 = false;
-      if (rc == MGH_SUCCESS && lossless_sym16_ok(cfg.huff_dict_size, cfg.huff_block_size)) {
+      if (rc == MGH_SUCCESS && !cfg.reorder && lossless_sym16_ok(cfg.huff_dict_size, cfg.huff_block_size)) {
         const int r16 = mgh_decompose_quantize_sym16(
             h, sub_in(id, buf), local_eb, (double)local_tol, s_d, local_eb == MGH_REL ? 0.0 : (double)norm,
             local_eb == MGH_REL ? &norm_out : nullptr, cfg.huff_dict_size, (uint16_t *)g_cache.q.p,
@@ -1311,8 +1313,16 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
                                     (uint64_t *)g_cache.oidx.p, (int64_t *)g_cache.oval.p, ocap_now, nullptr, st);
       hl_debug("compress: decompose + quantize done");
       if (rc == MGH_SUCCESS && local_eb == MGH_REL) norm = (T)norm_out;
+      const int64_t *q_enc = (const int64_t *)g_cache.q.p;
+      if (rc == MGH_SUCCESS && cfg.reorder) {
+        // config.reorder == 1: the lossless stage sees the integers level by level, outlier
+        // indices are positions in that array (LinearQuantization.hpp:226-232, 588-605)
+        rc = mgh_level_linearize(h, (const int64_t *)g_cache.q.p, (int64_t *)g_cache.q2.p, 0,
+                                 (uint64_t *)g_cache.oidx.p, (const uint64_t *)g_cache.ocount.p, 0, ocap_now, st);
+        q_enc = (const int64_t *)g_cache.q2.p;
+      }
       if (rc == MGH_SUCCESS)  // (the outlier count is read back together with the encoder's results)
-        rc = lossless_compress(g_cache.ll, (const int64_t *)g_cache.q.p, n, cfg.huff_dict_size,
+        rc = lossless_compress(g_cache.ll, q_enc, n, cfg.huff_dict_size,
                                cfg.huff_block_size, cfg.lossless, cfg.zstd_compress_level,
                                (const uint64_t *)g_cache.oidx.p, (const int64_t *)g_cache.oval.p, 0, st,
                                (const uint64_t *)g_cache.ocount.p, ocap_now, n * elem / 8 + 1, sym16);
@@ -1450,7 +1460,6 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
   else if (hd.compressor == fmt::COMP_X_HUFFMAN_ZSTD) lossless = MGH_LOSSLESS_HUFFMAN_ZSTD;
   else return hl_fail(MGH_ERR_FORMAT, "this lossless compressor is not supported");
   if (hd.hierarchy != fmt::HIER_MULTIDIM) return hl_fail(MGH_ERR_FORMAT, "only the multi-dimensional decomposition is supported");
-  if (hd.reorder) return hl_fail(MGH_ERR_FORMAT, "reordered (shuffled) streams are not supported");
   const bool in_dev = is_device_pointer(compressed);
   if (!prealloc) {
     if (in_dev) HL_HIP(hipMalloc(out, total * elem));
@@ -1470,6 +1479,7 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
   auto ensure_all = [&]() -> int {
     if (!zero_copy) HL_TRY(g_cache.in[0].ensure(max_elems * elem));
     HL_TRY(g_cache.q.ensure(max_elems * 8));
+    if (hd.reorder) HL_TRY(g_cache.q2.ensure(max_elems * 8));
     return MGH_SUCCESS;
   };
   if ((rc = ensure_all()) != MGH_SUCCESS) return cleanup(rc);
@@ -1508,7 +1518,7 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
       // bandwidth-bound, and the outlier look-ups of the coarse levels cost more than the
       // outlier-restore pass they replace) -- opt-in, MGH_SYM16_DECODE=1
       static const bool sym16_decode = std::getenv("MGH_SYM16_DECODE") != nullptr;
-      bool sym16 = sym16_decode && mgh_sym16_supported(h) && hd.huff_dict_size <= 65536;
+      bool sym16 = sym16_decode && !hd.reorder && mgh_sym16_supported(h) && hd.huff_dict_size <= 65536;
       rc = lossless_decompress(g_cache.ll, payload, csize, lossless, (int64_t *)g_cache.q.p, n, &ocount, st,
                                &sym16);
       if (rc == MGH_SUCCESS) {
@@ -1517,7 +1527,18 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
                                               (double)s, (double)norm, hd.huff_dict_size,
                                               (const uint64_t *)g_cache.ll->oidx.p,
                                               (const int64_t *)g_cache.ll->oval.p, ocount, sub, st);
-        else
+        else if (hd.reorder) {
+          // level-linearised integers: outliers back at their linearised positions, the
+          // permutation undone, then the ordinary path with nothing left to restore
+          rc = mgh_outlier_restore((int64_t *)g_cache.q.p, n, (const uint64_t *)g_cache.ll->oidx.p,
+                                   (const int64_t *)g_cache.ll->oval.p, ocount, st);
+          if (rc == MGH_SUCCESS)
+            rc = mgh_level_linearize(h, (const int64_t *)g_cache.q.p, (int64_t *)g_cache.q2.p, 1, nullptr,
+                                     nullptr, 0, 0, st);
+          if (rc == MGH_SUCCESS)
+            rc = mgh_dequantize_recompose(h, (int64_t *)g_cache.q2.p, local_eb, (double)local_tol, (double)s,
+                                          (double)norm, hd.huff_dict_size, 1, nullptr, nullptr, 0, sub, st);
+        } else
           rc = mgh_dequantize_recompose(h, (int64_t *)g_cache.q.p, local_eb, (double)local_tol, (double)s,
                                         (double)norm, hd.huff_dict_size, 1,
                                         (const uint64_t *)g_cache.ll->oidx.p,
@@ -1547,6 +1568,7 @@ int check_config(const mgh_config *cfg) {
     return hl_fail(MGH_ERR_INVALID_ARGUMENT, "lossless: only Huffman and Huffman_Zstd are supported");
   if (cfg->huff_dict_size < 2 || cfg->huff_dict_size > 16384 || cfg->huff_block_size == 0)
     return hl_fail(MGH_ERR_INVALID_ARGUMENT, "huff_dict_size (2..16384) / huff_block_size");
+  if (cfg->reorder != 0 && cfg->reorder != 1) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "reorder must be 0 or 1");
   int ndev = mgh_device_count();
   if (ndev <= 0) return hl_fail(MGH_ERR_NO_DEVICE, "no HIP device");
   if (cfg->dev_id < 0 || cfg->dev_id >= ndev) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "dev_id");
@@ -1572,6 +1594,7 @@ void mgh_config_default(mgh_config *c) {
   c->normalize_coordinates = 1;
   c->max_larget_level = std::numeric_limits<uint64_t>::max();
   c->max_memory_footprint = std::numeric_limits<uint64_t>::max();
+  c->reorder = 0;
   // The reference defaults to true. Here it is opt-in: on ROCm 7.0 registering and unregistering
   // caller memory (hipHostRegister / hipHostUnregister) was observed to leave the runtime
   // treating later allocations at the same addresses as pinned -- a copy into such a buffer

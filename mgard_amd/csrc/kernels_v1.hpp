@@ -422,6 +422,77 @@ k_outlier_restore(int64_t *__restrict__ q, uint64_t total, const uint64_t *__res
 }
 
 // ---------------------------------------------------------------------------
+// config.reorder == 1: the quantized array level by level ("level linearised",
+// Quantization/LinearQuantization.hpp:46-146 calc_level_offset + :588-605 slot of a level).
+// A pure permutation of the reordered N-D array; one thread per element.
+// ---------------------------------------------------------------------------
+constexpr int kLinMaxLevels = 40;
+struct LinMeta {
+  int D, L;
+  uint32_t shape[5];
+  uint32_t markoff[5];
+  uint32_t lshape[kLinMaxLevels + 1][5];  // shape of level l
+};
+
+__device__ __forceinline__ uint64_t linearized_position(const LinMeta &m, const int *__restrict__ marks,
+                                                        uint64_t lin) {
+  uint32_t idx[5];
+  int mk[5];
+  int level = 0;
+  for (int d = m.D - 1; d >= 0; d--) {
+    idx[d] = (uint32_t)(lin % m.shape[d]);
+    lin /= m.shape[d];
+    mk[d] = marks[m.markoff[d] + idx[d]];
+    level = mk[d] > level ? mk[d] : level;
+  }
+  uint64_t stride = 1, cstride = 1, thread_offset = 0, coarse_offset = 0, base = level > 0 ? 1 : 0;
+  for (int d = m.D - 1; d >= 0; d--) {
+    const uint32_t fine = m.lshape[level][d];
+    const uint32_t coarse = level > 0 ? m.lshape[level - 1][d] : 0u;
+    const uint32_t bit = mk[d] == level ? 1u : 0u;  // the node is a level-`level` node along d
+    const uint32_t r = bit ? idx[d] - coarse : idx[d];
+    uint32_t g;  // natural position in the level's fine grid
+    if (level == 0) g = r;
+    else if (fine % 2 == 0 && r == fine / 2) g = fine - 1;
+    else g = r * 2 + bit;
+    thread_offset += (uint64_t)g * stride;
+    stride *= fine;
+    if ((g & 1u) && g != fine - 1) coarse_offset = 0;
+    if (g) coarse_offset += (uint64_t)((g - 1) / 2 + 1) * cstride;
+    cstride *= fine / 2 + 1;
+    if (level > 0) base *= coarse;
+  }
+  if (level == 0) coarse_offset = 0;
+  return base + (thread_offset - coarse_offset);
+}
+
+template <typename QT, bool INV>
+__global__ void __launch_bounds__(256)
+k_level_linearize(LinMeta m, const int *__restrict__ marks, size_t total, const QT *__restrict__ in,
+                  QT *__restrict__ out) {
+  for (size_t lin = (size_t)blockIdx.x * blockDim.x + threadIdx.x; lin < total;
+       lin += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t p = linearized_position(m, marks, lin);
+    if (INV) out[lin] = in[p];
+    else out[p] = in[lin];
+  }
+}
+
+// outlier indices (reordered N-D linear index -> linearised position); the count stays on the
+// device (capped at `cap`), indices outside the array are left alone
+__global__ void __launch_bounds__(256)
+k_linearize_indices(LinMeta m, const int *__restrict__ marks, size_t total, uint64_t *__restrict__ idx,
+                    const unsigned long long *__restrict__ d_count, unsigned long long count,
+                    unsigned long long cap) {
+  unsigned long long n = d_count ? *d_count : count;
+  n = n < cap ? n : cap;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t lin = idx[i];
+    if (lin < total) idx[i] = linearized_position(m, marks, lin);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Norm reductions (CompressionLowLevel/NormCalculator.hpp:44-71). absmax is
 // order independent; the square sum is accumulated per thread / wave / block in
 // T and combined with one atomic per block on a double, so it is deterministic

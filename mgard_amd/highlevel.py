@@ -44,6 +44,7 @@ class Config(C.Structure):
         ("max_larget_level", C.c_uint64),
         ("max_memory_footprint", C.c_uint64),
         ("auto_pin_host_buffers", C.c_int),
+        ("reorder", C.c_int),
     ]
 
     def __init__(self, **kw):

@@ -81,6 +81,12 @@ def _declare(L):
         g = getattr(L, "mgxo_norm" + sfx)
         g.argtypes = [rp, C.c_uint64, ct, C.c_int]
         g.restype = ct
+        g = getattr(L, "mgxo_linearized_position" + sfx)
+        g.argtypes = [C.c_void_p, C.c_uint64]
+        g.restype = C.c_uint64
+        g = getattr(L, "mgxo_level_linearize" + sfx)
+        g.argtypes = [C.c_void_p, i64p, i64p, C.c_int]
+        g.restype = None
     L.mgxo_num_threads.restype = C.c_int
     L.mgxo_set_num_threads.argtypes = [C.c_int]
 
@@ -203,6 +209,26 @@ class Hierarchy:
             int(prep_huffman), oi.ctypes.data_as(C.POINTER(C.c_uint64)),
             ov.ctypes.data_as(C.POINTER(C.c_int64)), len(oi), self._rp(out))
         return out
+
+
+def _level_linearize(self, q, inverse=False):
+    """config.reorder == 1: the quantized array level by level (LinearQuantization.hpp:46-146,
+    588-605); inverse=True undoes it. Returns a flat int64 array (forward) / an array of the
+    hierarchy's shape (inverse)."""
+    a = np.ascontiguousarray(q, dtype=np.int64).reshape(-1)
+    out = np.empty_like(a)
+    getattr(lib(), "mgxo_level_linearize" + self.sfx)(
+        self._h, a.ctypes.data_as(C.POINTER(C.c_int64)), out.ctypes.data_as(C.POINTER(C.c_int64)),
+        int(inverse))
+    return out.reshape(self.shape) if inverse else out
+
+
+def _linearized_position(self, lin):
+    return int(getattr(lib(), "mgxo_linearized_position" + self.sfx)(self._h, int(lin)))
+
+
+Hierarchy.level_linearize = _level_linearize
+Hierarchy.linearized_position = _linearized_position
 
 
 def norm(data, s, normalize_coordinates=True):

@@ -939,6 +939,78 @@ void FN(mgxo_dequantize)(const FN(mgxo_hier) * h, int64_t *qv, int ebtype, REAL 
   }
 }
 
+/* config.reorder == 1 ("level linearised" quantized output): position of the element with
+ * reordered N-D linear index `lin` in the 1-D array whose slot for level l starts where the
+ * levels below it end (Quantization/LinearQuantization.hpp:588-605: level_size(l) - level_size(l-1)
+ * elements behind quantized_data(last_level_size)), at the offset calc_level_offset() gives it
+ * inside that slot (:46-146, restated statement by statement; the region offsets it also
+ * computes are not used by its result). */
+uint64_t FN(mgxo_linearized_position)(const FN(mgxo_hier) * h, uint64_t lin) {
+  const int D = h->D;
+  uint64_t idx[MGXO_MAXD], rem = lin;
+  for (int d = D - 1; d >= 0; d--) {
+    idx[d] = rem % h->shape[d];
+    rem /= h->shape[d];
+  }
+  int level = 0;
+  for (int d = D - 1; d >= 0; d--)
+    if (h->marks[d][idx[d]] > level) level = h->marks[d][idx[d]]; /* :47-49 */
+  uint64_t curr_region = 0;
+  for (int d = D - 1; d >= 0; d--)
+    curr_region += (uint64_t)(level == h->marks[d][idx[d]]) << d; /* :51-55 */
+  /* level_ranges(l, d) = shape of level l-1 (0 for l = 0), Hierarchy.hpp:240-259 */
+  uint64_t coarse_level_size[MGXO_MAXD], fine[MGXO_MAXD];
+  for (int d = D - 1; d >= 0; d--) {
+    coarse_level_size[d] = level == 0 ? 0 : h->lshape[level - 1][d]; /* level_ranges(level, d) */
+    fine[d] = h->lshape[level][d];                                   /* level_ranges(level + 1, d) */
+  }
+  uint64_t curr_region_thread_idx[MGXO_MAXD], global_data_idx[MGXO_MAXD];
+  for (int d = D - 1; d >= 0; d--) {
+    uint64_t bit = (curr_region >> d) & 1u;
+    curr_region_thread_idx[d] = bit ? idx[d] - coarse_level_size[d] : idx[d]; /* :92-96 */
+  }
+  for (int d = D - 1; d >= 0; d--) { /* :98-110 */
+    uint64_t bit = (curr_region >> d) & 1u;
+    if (level == 0) {
+      global_data_idx[d] = curr_region_thread_idx[d];
+    } else if (fine[d] % 2 == 0 && curr_region_thread_idx[d] == fine[d] / 2) {
+      global_data_idx[d] = fine[d] - 1;
+    } else {
+      global_data_idx[d] = curr_region_thread_idx[d] * 2 + bit;
+    }
+  }
+  uint64_t stride = 1, curr_thread_offset = 0, coarse_level_offset = 0;
+  for (int d = D - 1; d >= 0; d--) { /* :112-116 */
+    curr_thread_offset += global_data_idx[d] * stride;
+    stride *= fine[d];
+  }
+  stride = 1;
+  for (int d = D - 1; d >= 0; d--) { /* :118-128 */
+    if (global_data_idx[d] % 2 != 0 && global_data_idx[d] != fine[d] - 1) coarse_level_offset = 0;
+    if (global_data_idx[d]) coarse_level_offset += ((global_data_idx[d] - 1) / 2 + 1) * stride;
+    stride *= fine[d] / 2 + 1;
+  }
+  if (level == 0) coarse_level_offset = 0;
+  uint64_t base = 0;
+  if (level > 0) {
+    base = 1;
+    for (int d = 0; d < D; d++) base *= h->lshape[level - 1][d];
+  }
+  return base + (curr_thread_offset - coarse_level_offset);
+}
+
+/* out[position(lin)] = in[lin] (inverse: out[lin] = in[position(lin)]) */
+void FN(mgxo_level_linearize)(const FN(mgxo_hier) * h, const int64_t *in, int64_t *out, int inverse) {
+  uint64_t total = 1;
+  for (int d = 0; d < h->D; d++) total *= h->shape[d];
+#pragma omp parallel for schedule(static)
+  for (uint64_t lin = 0; lin < total; lin++) {
+    const uint64_t p = FN(mgxo_linearized_position)(h, lin);
+    if (inverse) out[lin] = in[p];
+    else out[p] = in[lin];
+  }
+}
+
 /* CompressionLowLevel/NormCalculator.hpp:12-80. s=inf: max |x|; else
  * sqrt(sum x^2 [/N]) with the SERIAL backend's sequential accumulation in T
  * (RuntimeX/DeviceAdapters/DeviceAdapterSerial.h:1376-1381). 0 -> epsilon. */

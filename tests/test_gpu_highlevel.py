@@ -547,3 +547,47 @@ def test_multi_device_api_nonuniform_coordinates(shape, dt, ndev):
     # the multi-device reader
     w = hl.decompress_multi(hl.compress(u, 1e-3, np.inf, mg.ABS, coords=coords), devices=devs)
     assert float(np.max(np.abs(w.astype(np.float64) - u.astype(np.float64)))) <= 1e-3
+
+
+@pytest.mark.parametrize("shape,dt,dict_size,dd", [
+    ((65, 70, 129), np.float32, 8192, False), ((33, 40, 36), np.float64, 64, False),
+    ((8, 20, 17, 33), np.float32, 8192, False), ((30001,), np.float32, 8192, False),
+    ((48, 33, 40), np.float32, 8192, True)])
+def test_reorder_1_level_linearised_stream(shape, dt, dict_size, dd):
+    """Config::reorder = 1: the lossless stage is fed the integers level by level
+    (LinearQuantization.hpp:46-146, 588-605) and the header says so. The record decodes -- with
+    the restated reference decoder -- to exactly the oracle's linearisation of the integers the
+    ordinary path produces, outliers sit at their linearised positions, and mgh_decompress
+    reconstructs the same values as from a reorder = 0 stream."""
+    torch, mg, hl = _mods()
+    import oracle
+    u = smooth_field(shape, dt)
+    kw = dict(huff_dict_size=dict_size, reorder=1)
+    if dd:
+        kw.update(domain_decomposition=hl.DD_MAXDIM, max_memory_footprint=40 * u.size)
+    buf = hl.compress(u, 1e-3, np.inf, mg.REL, config=hl.Config(**kw))
+    meta = hl.metadata_parse(bytes(buf[:4096]) if buf.size > 4096 else bytes(buf))
+    assert meta["reorder"] == 1
+    kw0 = dict(kw, reorder=0)
+    buf0 = hl.compress(u, 1e-3, np.inf, mg.REL, config=hl.Config(**kw0))
+    assert hl.metadata_parse(bytes(buf0[:4096]) if buf0.size > 4096 else bytes(buf0))["reorder"] == 0
+    v1, v0 = hl.decompress(buf), hl.decompress(buf0)
+    assert np.array_equal(v1, v0)
+    nrm = float(np.max(np.abs(u)))
+    assert float(np.max(np.abs(v1.astype(np.float64) - u))) <= 1e-3 * nrm
+    if not dd and u.size <= 40000:
+        recs = pl.split_container(buf, meta["metadata_size"])
+        assert len(recs) == 1 and len(recs[0]) < u.nbytes      # (not stored raw)
+        r = pl.parse_huffman_record(recs[0])
+        lin = pl.decode_huffman_record(r)
+        h = mg.Hierarchy(shape, dt)
+        q, oi, ov, cnt, _ = h.decompose_quantize(torch.from_numpy(u).cuda(), mg.REL, 1e-3, np.inf,
+                                                 dict_size=dict_size, outlier_cap=u.size)
+        o = oracle.Hierarchy(shape, dt)
+        assert np.array_equal(lin, o.level_linearize(q.cpu().numpy()))
+        want = sorted((o.linearized_position(int(i)), int(v)) for i, v in zip(oi.cpu().numpy()[:cnt], ov.cpu().numpy()[:cnt]))
+        got = sorted(zip(r["outlier_idx"].tolist(), r["outliers"].tolist()))
+        assert want == got
+        if dict_size == 64:
+            assert cnt > 50
+        h.close()

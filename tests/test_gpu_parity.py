@@ -733,3 +733,34 @@ def test_quantizer_known_answers_gpu():
     back = h.dequantize(ns, mg.ABS, 6 * dq["quantum"], np.inf, 1.0, prep_huffman=False)
     assert back.cpu().tolist() == dq["x"] + [0.0]
     h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(9,), (8,), (1000,), (5, 9), (33, 20), (5, 9, 17), (6, 8, 10), (65, 70, 129),
+                                   (5, 5, 5, 5), (7, 6, 9, 12), (3, 4, 5, 6, 7)])
+def test_level_linearize_equals_the_oracle(shape):
+    """config.reorder == 1 (LinearQuantization.hpp:46-146, 588-605): mgh_level_linearize is the
+    permutation the restated calc_level_offset defines, its inverse undoes it, and outlier indices
+    map to the positions of their values."""
+    import torch
+    import mgard_amd as mg
+    h = mg.Hierarchy(shape, np.float32)
+    o = oracle.Hierarchy(shape, np.float32)
+    n = int(np.prod(shape))
+    q = np.arange(n, dtype=np.int64).reshape(shape) * 3 - 7
+    ref = o.level_linearize(q)
+    assert np.array_equal(np.sort(ref), np.sort(q.reshape(-1)))          # a permutation
+    qd = torch.from_numpy(q).cuda()
+    rng = np.random.default_rng(4)
+    oi = rng.choice(n, size=min(n, 50), replace=False).astype(np.int64)
+    oid = torch.from_numpy(oi.copy()).cuda()
+    lin = h.level_linearize(qd, outlier_idx=oid)
+    assert np.array_equal(lin.cpu().numpy().reshape(-1), ref)
+    assert np.array_equal(oid.cpu().numpy(), np.array([o.linearized_position(i) for i in oi], dtype=np.int64))
+    assert np.array_equal(lin.cpu().numpy().reshape(-1)[oid.cpu().numpy()], q.reshape(-1)[oi])
+    back = h.level_linearize(lin, inverse=True)
+    assert torch.equal(back, qd)
+    # level 0 comes first and keeps its order: the first entries are the coarsest nodes
+    l0 = int(np.prod(o.level_shape(0)))
+    h.close()
+    assert l0 >= 1

@@ -198,3 +198,35 @@ def test_roundtrip_error_bound(shape, s):
     else:
         err = np.sqrt(np.mean((back - u) ** 2))
         assert err <= tol * nrm
+
+
+def test_level_linearise_hand_derived_3x3_and_bijection():
+    """config.reorder == 1 (LinearQuantization.hpp:46-146, 588-605), restated in the oracle.
+    3 x 3 grid, one level: the four level-0 nodes come first (row-major in the 2 x 2 grid), then
+    the five level-1 coefficients in the row-major order of their NATURAL positions
+    (0,1) (1,0) (1,1) (1,2) (2,1). In the reordered layout (coarse index first along each
+    dim: natural 0, 2, 1) those sit at (0,2) (2,0) (2,2) (2,1) (1,2)."""
+    import numpy as np
+    import oracle
+    o = oracle.Hierarchy((3, 3), np.float32)
+    q = np.arange(9, dtype=np.int64).reshape(3, 3)      # value = reordered linear index
+    lin = o.level_linearize(q)
+    want = [0 * 3 + 0, 0 * 3 + 1, 1 * 3 + 0, 1 * 3 + 1,            # level 0
+            0 * 3 + 2, 2 * 3 + 0, 2 * 3 + 2, 2 * 3 + 1, 1 * 3 + 2]  # level 1
+    assert lin.tolist() == want
+    for shape in [(5,), (8,), (9, 6), (5, 9, 17), (6, 8, 10), (5, 5, 5, 5), (3, 4, 5, 6, 7), (33, 20, 17)]:
+        h = oracle.Hierarchy(shape, np.float64)
+        n = int(np.prod(shape))
+        a = np.arange(n, dtype=np.int64)
+        f = h.level_linearize(a)
+        assert np.array_equal(np.sort(f), a)                       # a permutation
+        assert np.array_equal(h.level_linearize(f, inverse=True).reshape(-1), a)
+        # level by level: the slot of level l holds exactly the elements whose level is l
+        pos = np.array([h.linearized_position(i) for i in range(n)])
+        sizes = [int(np.prod(h.level_shape(l))) for l in range(h.l_target + 1)]
+        marks = [np.asarray(h.marks(d)) for d in range(len(shape))]
+        idx = np.unravel_index(np.arange(n), shape)
+        lev = np.max([marks[d][idx[d]] for d in range(len(shape))], axis=0)
+        for l in range(h.l_target + 1):
+            lo = sizes[l - 1] if l else 0
+            assert np.all((pos[lev == l] >= lo) & (pos[lev == l] < sizes[l]))
