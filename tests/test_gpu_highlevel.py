@@ -552,7 +552,7 @@ def test_multi_device_api_nonuniform_coordinates(shape, dt, ndev):
 @pytest.mark.parametrize("shape,dt,dict_size,dd", [
     ((65, 70, 129), np.float32, 8192, False), ((33, 40, 36), np.float64, 64, False),
     ((8, 20, 17, 33), np.float32, 8192, False), ((30001,), np.float32, 8192, False),
-    ((48, 33, 40), np.float32, 8192, True)])
+    ((130, 70, 129), np.float32, 8192, True)])
 def test_reorder_1_level_linearised_stream(shape, dt, dict_size, dd):
     """Config::reorder = 1: the lossless stage is fed the integers level by level
     (LinearQuantization.hpp:46-146, 588-605) and the header says so. The record decodes -- with
@@ -567,7 +567,9 @@ def test_reorder_1_level_linearised_stream(shape, dt, dict_size, dd):
         kw.update(domain_decomposition=hl.DD_MAXDIM, max_memory_footprint=40 * u.size)
     buf = hl.compress(u, 1e-3, np.inf, mg.REL, config=hl.Config(**kw))
     meta = hl.metadata_parse(bytes(buf[:4096]) if buf.size > 4096 else bytes(buf))
-    assert meta["reorder"] == 1
+    assert meta["reorder"] == 1 and meta["domain_decomposed"] is dd
+    if dd:
+        assert buf.size < 0.95 * u.nbytes      # (Huffman records, not raw subdomains)
     kw0 = dict(kw, reorder=0)
     buf0 = hl.compress(u, 1e-3, np.inf, mg.REL, config=hl.Config(**kw0))
     assert hl.metadata_parse(bytes(buf0[:4096]) if buf0.size > 4096 else bytes(buf0))["reorder"] == 0
