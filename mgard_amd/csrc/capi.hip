@@ -84,6 +84,7 @@ struct mgh_hierarchy {
   // MGH_FUSED_FACES: 1 = face tiles for the remainder columns / rows of a level (default), 0 = off
   int fused_faces = 1;
   int fused_xcd = 1;  // MGH_FUSED_XCD: tiles of a level in contiguous ranges per XCD (default 1)
+  int fused_fixed = 1; // MGH_FUSED_FIXED: the int64 + dictionary variant of the level kernel (default 1)
   int fused_wide = 1; // MGH_FUSED_WIDE: 4 x 64 tiles for 0 = no level, 1 = long marches, 2 = all
   int fused4 = 1;     // MGH_FUSED4: D = 4 through the 3-D tile code, slice by slice (default 1)
   std::map<std::string, ProfileEntry> prof;
@@ -821,7 +822,10 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
       if (v2) {
         const char *nm = cls == 2 ? (OUT == OUT_Q ? "level_fused_q" : "level_fused")
                                   : (OUT == OUT_Q ? "level_fused_q_small" : "level_fused_small");
-        TRY((launch_fused2<T, OUT>(h, A, b, cls, nm, s)));
+        if (OUT == OUT_Q && A.prep_huffman && !A.q16 && h->fused_fixed)
+          TRY((launch_fused2<T, OUT == OUT_Q ? OUT_QH : OUT>(h, A, b, cls, nm, s)));
+        else
+          TRY((launch_fused2<T, OUT>(h, A, b, cls, nm, s)));
       } else if (cls == 2) {
         const dim3 grid(gx, gy, (b.m[0] + 15) / 16);
         TRY(launch(h, OUT == OUT_Q ? "level_fused_q" : "level_fused", s, [&] {
@@ -1910,6 +1914,8 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     if (e8 && e8[0] >= '0' && e8[0] <= '1') h->fused_faces = e8[0] - '0';
     const char *e9 = std::getenv("MGH_FUSED_XCD");
     if (e9 && e9[0] >= '0' && e9[0] <= '1') h->fused_xcd = e9[0] - '0';
+    const char *e12 = std::getenv("MGH_FUSED_FIXED");
+    if (e12 && e12[0] >= '0' && e12[0] <= '1') h->fused_fixed = e12[0] - '0';
     const char *e11 = std::getenv("MGH_FUSED_WIDE");
     if (e11 && e11[0] >= '0' && e11[0] <= '2') h->fused_wide = e11[0] - '0';
     const char *e10 = std::getenv("MGH_FUSED4");

@@ -67,7 +67,10 @@ template <typename T> struct FusedArgs {
 
 // OUT_NONE: coarse nodes + load vector only; the coefficients of the level are produced by
 // k_level_emit (kernels_emit.hpp) on another stream
-enum { OUT_T = 0, OUT_Q = 1, OUT_NONE = 2 };
+// OUT_QH (second-generation kernel only): OUT_Q with the options fixed at compile time to what
+// the hot path runs -- dictionary shift on, int64 output -- so that the other variants' code and
+// their scalar registers are not in the loop.
+enum { OUT_T = 0, OUT_Q = 1, OUT_NONE = 2, OUT_QH = 3 };
 
 template <typename T>
 __device__ __forceinline__ T mass_apply(T a, T b, T c, T d, T e, const T (&w)[9]) {

@@ -355,11 +355,12 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
       }
       return;
     }
-    if (OUT != OUT_Q) return;
+    if (OUT != OUT_Q && OUT != OUT_QH) return;
+    constexpr bool kFixed = OUT == OUT_QH;
     const bool on[4] = {own.s0, own.s1, own.s2, own.s3};
     int32_t qs[4];
     bool slow = false;
-    if (A.prep_huffman) {
+    if (kFixed || A.prep_huffman) {
       bool ol[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -398,7 +399,7 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
           before += __popcll(masks[k]);
         }
       }
-      if (A.q16) {
+      if (!kFixed && A.q16) {
         uint16_t *o = A.q16 + ob;
 #pragma unroll
         for (int k = 0; k < 4; k++)
@@ -669,7 +670,7 @@ k_level_fused2(FusedArgs<T> A, Fused2Grid G, Fused4<T> Q) {
                 e2 = Fused2Geom<4, 64, RCH, TODD>::elems;
   constexpr int elems = FACES ? (e0 > e1 ? (e0 > e2 ? e0 : e2) : (e1 > e2 ? e1 : e2)) : e0;
   __shared__ __attribute__((aligned(16))) T lds[elems];
-  if (OUT == OUT_Q && A.qp) {
+  if ((OUT == OUT_Q || OUT == OUT_QH) && A.qp) {
     A.quantizer = A.qp[A.level];
     A.volume = A.qp[A.nlev + A.level];
   }
@@ -724,7 +725,7 @@ k_level_fused2(FusedArgs<T> A, Fused2Grid G, Fused4<T> Q) {
 template <typename T, int OUT>
 __global__ void __launch_bounds__(256)
 k_head_out4(int m0, int m1, int m2, int m3, const T *__restrict__ nodal, FusedArgs<T> A, size_t dT) {
-  if (OUT == OUT_Q && A.qp) {
+  if ((OUT == OUT_Q || OUT == OUT_QH) && A.qp) {
     A.quantizer = A.qp[0];
     A.volume = A.qp[A.nlev];
   }
