@@ -12,7 +12,10 @@ from mgard_amd import highlevel as hl  # noqa: E402
 from tests.util import smooth_field  # noqa: E402
 
 out = []
-for shape, dt, tol in [((65, 97, 130), np.float32, 1e-2), ((40, 129, 66), np.float64, 1e-3), ((300, 70), np.float32, 1e-2)]:
+# (the last 3-D shape is big enough for the long-march class of the level kernel: 4 x 64 tiles,
+# chunks of 16 coarse planes; the 4-D one runs the slice-by-slice path in both directions)
+for shape, dt, tol in [((65, 97, 130), np.float32, 1e-2), ((40, 129, 66), np.float64, 1e-3), ((300, 70), np.float32, 1e-2),
+                       ((257, 260, 300), np.float32, 1e-3), ((6, 66, 70, 129), np.float32, 1e-3)]:
     u = smooth_field(shape, dt)
     buf = hl.compress(u, tol, np.inf, mg.REL)
     v = hl.decompress(buf)

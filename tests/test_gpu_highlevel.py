@@ -415,6 +415,10 @@ def test_alternative_kernels_give_the_same_result():
     assert run({"MGH_RESTORE_ROWS": "1", "MGH_NO_RECOMPOSE_HEAD": "1", "MGH_HUFF_PAR_DECODE": "1"}) == ref
     assert run({"MGH_SYM16_DECODE": "1", "MGH_HUFF_SERIAL_DECODE": "1"}) == ref
     assert run({"MGH_FORCE_V1": "1"}) == ref
+    # the round-2 level kernel's tile shapes / chunk lengths / variants and the Thomas solvers
+    assert run({"MGH_FUSED_WIDE": "0", "MGH_FUSED_FIXED": "0", "MGH_RCH": "2,3,8"}) == ref
+    assert run({"MGH_FUSED_WIDE": "2", "MGH_FUSED_XCD": "0", "MGH_FUSED_FACES": "0", "MGH_IPK_STREAM": "0"}) == ref
+    assert run({"MGH_FUSED_V": "1", "MGH_FUSED4": "0", "MGH_IPK_W": "32"}) == ref
 
 
 def test_incompressible_subdomain_is_stored_raw():
