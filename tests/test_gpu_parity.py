@@ -764,3 +764,33 @@ def test_level_linearize_equals_the_oracle(shape):
     l0 = int(np.prod(o.level_shape(0)))
     h.close()
     assert l0 >= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,dt,nonuni,mode,s", [
+    ((258, 515, 517), np.float32, False, "REL", np.inf),
+    ((260, 515, 520), np.float64, True, "ABS", 0.0),
+    ((257, 516, 513), np.float32, True, "ABS", np.inf)])
+def test_long_march_class_with_odd_remainders(shape, dt, nonuni, mode, s):
+    """Shapes big enough for the long-march class of the level kernel (4 x 64 tiles, chunks of 16
+    coarse planes, XCD ranges) whose coarse sizes are NOT tile multiples plus one: partial main
+    tiles, f- and c-face tiles with 1-4 columns / rows, an even and an odd slowest dimension (last
+    chunk with and without the extra plane), ghost nodes in some dims. Bit-exact integers and
+    outlier sets against the oracle, reconstruction through the fused way back."""
+    torch, mg = _gpu()
+    if _host_mem_gb() < 24:
+        pytest.skip("not enough host memory for the oracle run")
+    u = smooth_field(shape, dt)
+    coords = nonuniform_coords(shape, dt) if nonuni else None
+    h = mg.Hierarchy(shape, dt, coords=coords)
+    o = oracle.Hierarchy(shape, dt, coords=coords)
+    ud = torch.from_numpy(u).cuda()
+    eb = mg.REL if mode == "REL" else mg.ABS
+    nrm = float(np.max(np.abs(u))) if mode == "REL" else 1.0
+    q, oi, ov = _compare_quantized(mg, h, o, u, ud, eb, 1e-3, s, nrm, u.size // 8)
+    back = h.dequantize_recompose(q.clone(), eb, 1e-3, s, nrm, outlier_idx=oi, outlier_val=ov)
+    if np.isinf(s):
+        assert float((back - ud).abs().max().item()) <= 1e-3 * nrm
+    c = h.decompose(ud)
+    assert_bit_equal(h.recompose(c).cpu().numpy(), o.recompose(o.decompose(u)), "recompose %r" % (shape,))
+    h.close()
