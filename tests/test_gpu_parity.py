@@ -794,3 +794,36 @@ def test_long_march_class_with_odd_remainders(shape, dt, nonuni, mode, s):
     c = h.decompose(ud)
     assert_bit_equal(h.recompose(c).cpu().numpy(), o.recompose(o.decompose(u)), "recompose %r" % (shape,))
     h.close()
+
+
+@pytest.mark.gpu
+def test_4d_long_march_class_with_odd_remainders():
+    """D = 4 with slices big enough for the long-march class (4 x 64 tiles) and sizes that leave
+    partial / face tiles and ghost nodes in every dimension, odd number of t-slices: the
+    slice-by-slice path against the generic N-D kernels, both directions, bit for bit."""
+    torch, mg = _gpu()
+    shape = (5, 258, 515, 517)
+    if torch.cuda.mem_get_info()[0] < (24 << 30):
+        pytest.skip("not enough device memory")
+    u = _slab4d(shape)
+    ud = torch.from_numpy(u).cuda()
+    nrm = float(np.max(np.abs(u)))
+    del u
+    cap = ud.numel() // 4
+    h = mg.Hierarchy(shape, np.float32)
+    q, oi, ov, cnt, n1 = h.decompose_quantize(ud, mg.REL, 1e-3, np.inf, outlier_cap=cap)
+    back = h.dequantize_recompose(q.clone(), mg.REL, 1e-3, np.inf, nrm, outlier_idx=oi, outlier_val=ov)
+    os.environ["MGH_FUSED4"] = "0"
+    try:
+        g = mg.Hierarchy(shape, np.float32)
+    finally:
+        del os.environ["MGH_FUSED4"]
+    q2, oi2, ov2, cnt2, n2 = g.decompose_quantize(ud, mg.REL, 1e-3, np.inf, outlier_cap=cap)
+    assert cnt == cnt2 and cnt <= cap and n1 == n2 == nrm and torch.equal(q, q2)
+    a, b = _outlier_set(oi.cpu().numpy(), ov.cpu().numpy()), _outlier_set(oi2.cpu().numpy(), ov2.cpu().numpy())
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    back2 = g.dequantize_recompose(q2, mg.REL, 1e-3, np.inf, nrm, outlier_idx=oi2, outlier_val=ov2)
+    assert torch.equal(back, back2)
+    assert float((back - ud).abs().max().item()) <= 1e-3 * nrm
+    g.close()
+    h.close()
