@@ -14,6 +14,12 @@ include/mgard-x/DomainDecomposer/DomainDecomposer.hpp:260-303). The only data-pa
 the scalar all-reduce (MAX over RCCL) of the subdomain norms that a REL bound needs
 (include/mgard-x/CompressionHighLevel/ErrorToleranceCalculator.hpp:69-89,134-155).
 
+`python3 bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment is a LAUNCHER: before
+anything touches a GPU it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+as a child process (one rank per GPU over RCCL), relays rank 0's JSON line and adds a second
+leg from another child -- `mgh_compress_multi`, one process driving N devices -- as
+`native_multi`. Under `torch.distributed.run` (WORLD_SIZE set) it is a rank.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -79,8 +85,12 @@ def algorithmic_bytes_per_step(h, esz):
         # (int64), the coarse nodes and the load vector
         # (capi.hip: levels with >= 2048 tiles of 8x32x16 coarse nodes use the long-march
         # variant "level_fused_q", smaller ones "level_fused_q_small")
-        big = -(-m[2] // 32) * -(-m[1] // 8) * -(-m[0] // 16) >= 2048
-        add("level_fused_q" if big else "level_fused_q_small",
+        # march classes of capi.hip (level_class): long marches "level_fused_q", mid-size
+        # "level_fused_q_small", few tiles: the box kernel "level_box_q" (kernels_box.hpp)
+        tiles = -(-m[2] // 32) * -(-m[1] // 8)
+        big = tiles * -(-m[0] // 16) >= 2048
+        mid = tiles * -(-m[0] // 4) >= 256
+        add("level_fused_q" if big else ("level_fused_q_small" if mid else "level_box_q"),
             vol(n) * esz + (vol(n) - vol(m)) * 8 + 2 * vol(m) * esz)
     add("copy_box", 2 * vol((1,) * (3 - len(h.shape)) + tuple(h.level_shape(0))) * esz)
     return out
@@ -93,6 +103,20 @@ def _oracle_step(o, oracle, u, tol, s):
     c = o.decompose(u)
     q, oi, ov, n = o.quantize(c, oracle.REL, u.dtype.type(tol), u.dtype.type(s), u.dtype.type(nrm))
     return time.perf_counter() - t0, q
+
+
+def physical_cores():
+    """Distinct (physical id, core id) pairs of /proc/cpuinfo; None when the file does not say."""
+    try:
+        seen, phys = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                seen.add((phys, line.split(":")[1].strip()))
+        return len(seen) or None
+    except OSError:
+        return None
 
 
 def cpu_baseline(u, tol, s, coords=None):
@@ -113,7 +137,12 @@ def cpu_baseline(u, tol, s, coords=None):
         ts.append(dt)
     med = sorted(ts)[len(ts) // 2]
     out = {"value": u.nbytes / med / 1e9, "unit": "GB/s", "cores": cores, "kind": "port",
-           "nproc": os.cpu_count(),
+           "nproc": os.cpu_count(), "physical_cores": physical_cores(),
+           "affinity_cpus": len(os.sched_getaffinity(0)),
+           "threads_note": "cores = OpenMP threads used = omp_get_max_threads() of this process (the "
+                           "OpenMP default: one per CPU of the process's affinity mask); nproc = "
+                           "logical CPUs of the host; physical_cores = distinct (socket, core) pairs "
+                           "of /proc/cpuinfo",
            "sample": "the same %s %s workload (norm+decompose+quantize): 1 warm-up, median of 5 "
                      "steps = %.2f s (min %.2f, max %.2f)"
                      % ("x".join(map(str, u.shape)), u.dtype.name, med, min(ts), max(ts))}
@@ -161,6 +190,234 @@ CONFIGS = {
 }
 
 
+def _last_json_line(text):
+    for line in reversed(text.strip().splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                continue
+    return None
+
+
+def launch_ranks(args, argv):
+    """N > 1 without WORLD_SIZE: this process never initialises a GPU. It starts the ranks with
+    torch.distributed.run (fresh child processes), relays rank 0's JSON line, then runs the
+    one-process / N-devices leg (mgh_compress_multi) in another child and attaches its result."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    sys.stderr.write(p.stderr[-4000:])
+    res = _last_json_line(p.stdout)
+    if p.returncode != 0 or res is None:
+        sys.stdout.write(p.stdout[-4000:])
+        raise SystemExit(p.returncode or 1)
+    if not args.dist_dry_run and not args.no_native_multi:
+        cmd2 = [sys.executable, os.path.abspath(__file__), "--native-multi", "--gpus", str(args.gpus)]
+        try:
+            p2 = subprocess.run(cmd2, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                text=True, timeout=600)
+            r2 = _last_json_line(p2.stdout)
+            res["native_multi"] = r2 if (p2.returncode == 0 and r2) else {
+                "error": "rc %d: %s" % (p2.returncode, p2.stderr[-300:])}
+        except subprocess.TimeoutExpired:
+            res["native_multi"] = {"error": "timeout"}
+    print(json.dumps(res), flush=True)
+
+
+def dist_dry_run(args):
+    """GPU-less check of the N > 1 control flow (tests/test_distributed_cpu.py): the ranks the
+    launcher started form a gloo group, exchange the scalar norm exactly like the GPU path (MAX
+    all-reduce), count each other, and rank 0 prints a line of the usual shape."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    nrm = torch.tensor([1.0 + rank], dtype=torch.float64)
+    seen = torch.ones(1, dtype=torch.int64)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dist.all_reduce(nrm, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    el = time.perf_counter() - t0
+    dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+    ok = float(nrm.item()) == float(world)
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (gloo, no GPU): launcher + norm exchange only", "value": 0.0,
+                          "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(el / max(args.steps, 1) * 1e3, 4), "dry_run": True,
+                          "rccl_ranks_seen": int(seen.item()), "norm_exchange_ok": ok}), flush=True)
+    if not ok:
+        raise SystemExit(3)
+
+
+def native_multi(args):
+    """One process, N devices: mgh_compress_multi / mgh_decompress_multi (include/mgard_hip_compress.h)
+    on a host volume of N slabs of 128 x 512 x 512 f32 -- host buffers in and out, so the figure is
+    PCIe-inclusive and informational; the point of the leg is that the native path runs on N
+    physical devices and reconstructs within the bound."""
+    import numpy as np
+    import torch
+    from mgard_amd import highlevel as hl
+    import mgard_amd
+    from tests.util import smooth_field
+    n = min(args.gpus, torch.cuda.device_count())
+    u = smooth_field((128 * n, 512, 512), np.float32)
+    devs = tuple(range(n))
+    buf = hl.compress_multi(u, TOL, float("inf"), mgard_amd.REL, devices=devs)
+    t0 = time.perf_counter()
+    buf = hl.compress_multi(u, TOL, float("inf"), mgard_amd.REL, devices=devs)
+    c_s = time.perf_counter() - t0
+    v = hl.decompress_multi(buf, devices=devs)
+    t1 = time.perf_counter()
+    v = hl.decompress_multi(buf, devices=devs)
+    d_s = time.perf_counter() - t1
+    err = float(np.max(np.abs(v.astype(np.float64) - u)))
+    nrm = float(np.max(np.abs(u)))
+    print(json.dumps({"what": "mgh_compress_multi / mgh_decompress_multi: one process, one host thread per "
+                              "device, host buffers (PCIe-inclusive, informational)",
+                      "devices": list(devs), "shape": list(u.shape),
+                      "compress_GBps": round(u.nbytes / c_s / 1e9, 3),
+                      "decompress_GBps": round(u.nbytes / d_s / 1e9, 3),
+                      "compression_ratio": round(u.nbytes / buf.size, 3),
+                      "within_tolerance": bool(err <= TOL * nrm)}), flush=True)
+
+
+def gpu_field(torch, shape, dtype, dev, seed=20260101):
+    """The recipe of tests/util.smooth_field evaluated on the device (the legs that are not
+    compared with the CPU oracle do not need the host copy; 1024^3 takes ~20 s in numpy)."""
+    D = len(shape)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    ax = []
+    for d, n in enumerate(shape):
+        x = torch.arange(n, dtype=torch.float64, device=dev) / max(n - 1, 1)
+        ax.append(x.reshape([n if k == d else 1 for k in range(D)]))
+    f = [3.0, 2.0, 5.0, 1.0, 4.0]
+    two_pi = 2 * 3.141592653589793
+    u = torch.sin(two_pi * f[0] * ax[D - 1]).to(dtype)
+    if D >= 2:
+        u = u * torch.cos(two_pi * f[1] * ax[D - 2]).to(dtype)
+    if D >= 3:
+        u = u + (0.5 * torch.sin(two_pi * f[2] * ax[D - 3])).to(dtype)
+    for d in range(D - 3):
+        u = u + (0.25 * torch.cos(two_pi * f[3 + (d % 2)] * ax[d])).to(dtype)
+    u = u.expand(shape).contiguous()
+    noise = torch.rand(shape, generator=g, dtype=dtype, device=dev)
+    u.add_(noise.mul_(2e-3).sub_(1e-3))
+    return u
+
+
+def config_leg(torch, mgard_amd, name, dev, local_rank, steps=5, end_to_end=False, dist=None, world=1,
+               rank=0):
+    """One of the other BASELINE.json configurations as a step-only leg of the default run
+    (`other_configs`): input generated on the device, `steps` timed steps after 2 warm-ups."""
+    import numpy as np
+    from tests.util import nonuniform_coords
+    cfg = CONFIGS[name]
+    shape = cfg["shape"]
+    np_dt = np.dtype(cfg["dtype"])
+    t_dt = torch.float32 if np_dt.itemsize == 4 else torch.float64
+    S = cfg["s"]
+    coords = nonuniform_coords(shape, np_dt) if cfg["nonuniform"] else None
+    if len(shape) == 4:
+        base = gpu_field(torch, shape[1:], t_dt, dev, seed=20260101 + rank)
+        d_u = torch.stack([base * (1.0 + 0.002 * t) + 1e-4 * t for t in range(shape[0])])
+        del base
+    else:
+        d_u = gpu_field(torch, shape, t_dt, dev)
+    h = mgard_amd.Hierarchy(shape, np_dt, coords=coords, device=local_rank)
+    N = h.total
+    cap = N // (16 if len(shape) == 3 else 8)
+    q = torch.empty(shape, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    oidx = torch.empty(cap, dtype=torch.int64, device=dev)
+    oval = torch.empty(cap, dtype=torch.int64, device=dev)
+    bufs = (q, cnt, oidx, oval)
+    nrm_t = torch.zeros(1, dtype=h.torch_dtype, device=dev)
+
+    def step():
+        if dist is None:
+            h.decompose_quantize(d_u, mgard_amd.REL, TOL, S, 0.0, bufs=bufs, want_norm=False)
+        else:  # one subdomain per rank: global norm by one scalar all-reduce, then an ABS bound
+            h.norm_device(d_u, S, out=nrm_t)
+            dist.all_reduce(nrm_t, op=dist.ReduceOp.MAX)
+            h.decompose_quantize_dn(d_u, mgard_amd.REL, TOL, S, nrm_t, world, bufs)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+    for _ in range(2):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    ms = el / steps * 1e3
+    in_bytes = N * np_dt.itemsize
+    out = {"workload": cfg["what"] + ("" if dist is None else "; one slab per rank, %d ranks (weak scaling)" % world),
+           "steps": steps, "ms_per_step": round(ms, 4),
+           "value": round(world * in_bytes / ms / 1e6, 2), "unit": "GB/s (input, all ranks)",
+           "hbm_frac_whole_step": round((np_dt.itemsize + 8.0) * N / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "outliers_per_step": int(cnt.item()),
+           "data": "synthetic, generated on the device (same recipe as the metric's field)"}
+    assert out["outliers_per_step"] <= cap
+    if end_to_end:
+        # configs[4]: compress + decompress round trip through the container, error against the
+        # tolerance, end-to-end GB/s (device-resident in and out)
+        from mgard_amd import highlevel
+        nrm_host = float(h.norm(d_u, S))
+        del q, oidx, oval, bufs
+        obuf = torch.empty(in_bytes + 1000000, dtype=torch.uint8, device=dev)
+        stream = highlevel.compress(d_u, TOL, S, mgard_amd.REL, out=obuf)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        NE = 3
+        for _ in range(NE):
+            stream = highlevel.compress(d_u, TOL, S, mgard_amd.REL, out=obuf)
+        torch.cuda.synchronize()
+        c_ms = (time.perf_counter() - t1) / NE * 1e3
+        back = torch.empty_like(d_u)
+        highlevel.decompress(stream, out=back)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(NE):
+            highlevel.decompress(stream, out=back)
+        torch.cuda.synchronize()
+        x_ms = (time.perf_counter() - t2) / NE * 1e3
+        err = float((back - d_u).abs().max().item())
+        out["end_to_end"] = {"what": "mgh_compress + mgh_decompress round trip, device-resident, MGARD-X container",
+                             "compress_ms": round(c_ms, 3), "compress_GBps": round(in_bytes / c_ms / 1e6, 2),
+                             "decompress_ms": round(x_ms, 3), "decompress_GBps": round(in_bytes / x_ms / 1e6, 2),
+                             "roundtrip_GBps": round(in_bytes / (c_ms + x_ms) / 1e6, 2),
+                             "compression_ratio": round(in_bytes / int(stream.numel()), 3),
+                             "roundtrip_linf_error": err, "tolerance_abs": TOL * nrm_host,
+                             "within_tolerance": bool(err <= TOL * nrm_host)}
+        del back, obuf, stream
+        highlevel.release_cache()
+    h.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,10 +431,27 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="512f32",
                     help="BASELINE.json configuration: 512f32 = configs[1] (the metric's, default), "
                          "512f64nu = configs[2], 1024f32 = configs[4]")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the step-only legs of configs[2], [3], [4] in the default run")
+    ap.add_argument("--no-native-multi", action="store_true",
+                    help="N > 1 launcher: skip the one-process / N-devices leg (mgh_compress_multi)")
+    ap.add_argument("--native-multi", action="store_true",
+                    help="run ONLY the one-process / N-devices leg (what the launcher starts as its second child)")
+    ap.add_argument("--dist-dry-run", action="store_true",
+                    help="GPU-less check of the N > 1 launcher: gloo ranks, norm exchange only")
     ap.add_argument("--force-dist-path", action="store_true",
                     help="exercise the N>1 code path (process group + norm all-reduce) with any "
                          "world size, e.g. 1 (developer check)")
     args = ap.parse_args()
+
+    # ---- N > 1 as the driver calls it (`python3 bench.py --gpus N ...`): become the launcher
+    # BEFORE anything imports torch or touches a GPU ----
+    if args.native_multi:
+        return native_multi(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, sys.argv[1:])
+    if args.dist_dry_run:
+        return dist_dry_run(args)
 
     import numpy as np
     import torch
@@ -188,9 +462,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run "
-                         "--nproc-per-node N bench.py --gpus N ...")
     dist = None
     if world > 1 or args.force_dist_path:
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -478,6 +749,34 @@ def main():
             highlevel.release_cache()
         except mgard_amd.MgardHipError as e:  # the headline metric does not depend on this path
             result["end_to_end"] = {"error": str(e)}
+    q_host = None
+    # ---- the other BASELINE.json configurations, on the driver's line (step-only legs; `value`
+    # stays configs[1]) ----
+    if args.config == "512f32" and not args.shape and not args.only_step and not args.no_other_configs:
+        q_host = q.cpu().numpy() if (rank == 0 and dist is None and not args.no_cpu_baseline) else None
+        del q, oidx, oval, bufs, d_u
+        h.close()
+        torch.cuda.empty_cache()
+        oc = {}
+        if dist is None:
+            for name, e2e in (("512f64nu", False), ("4d", False), ("1024f32", True)):
+                try:
+                    oc[name] = config_leg(torch, mgard_amd, name, dev, local_rank, end_to_end=e2e)
+                except (mgard_amd.MgardHipError, RuntimeError, AssertionError) as e:
+                    oc[name] = {"error": str(e)[:300]}
+                torch.cuda.empty_cache()
+        else:
+            # N > 1: configs[3] as it is meant -- the 64 x 512^3 volume split on dim 0, one
+            # 8 x 512^3 slab per rank (weak scaling), scalar norm all-reduce over RCCL
+            try:
+                oc["4d"] = config_leg(torch, mgard_amd, "4d", dev, local_rank, dist=dist, world=world, rank=rank)
+            except (mgard_amd.MgardHipError, RuntimeError, AssertionError) as e:
+                oc["4d"] = {"error": str(e)[:300]}
+        result["other_configs"] = oc
+    if dist is not None:
+        seen = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+        result["rccl_ranks_seen"] = int(seen.item())
     if rank == 0 and dist is None and not args.no_cpu_baseline and args.config not in ("1024f32", "4d"):
         base, rq = cpu_baseline(u, TOL, S, coords)
         result["cpu_baseline"] = base
@@ -485,7 +784,8 @@ def main():
         # (s = inf only: with an L2 norm the two norms differ in the last bits by nature --
         # sequential vs tree sum -- and so may the integers; tests inject the norm instead)
         if S == float("inf"):
-            result["parity_vs_cpu"] = bool(np.array_equal(q.cpu().numpy(), rq))
+            qh = q_host if q_host is not None else q.cpu().numpy()
+            result["parity_vs_cpu"] = bool(np.array_equal(qh, rq))
     else:
         result["cpu_baseline"] = None
     if dist is not None:

@@ -18,12 +18,14 @@
 #include <string>
 #include <vector>
 
+#include "env.hpp"
 #include "hierarchy.hpp"
 #include "kernels_v1.hpp"
 #include "kernels_ipk.hpp"
 #include "kernels_ipk_stream.hpp"
 #include "kernels_fused.hpp"
 #include "kernels_fused2.hpp"
+#include "kernels_box.hpp"
 #include "kernels_emit.hpp"
 #include "kernels_tail.hpp"
 #include "kernels_recompose.hpp"
@@ -57,6 +59,7 @@ struct ProfileEntry {
 struct mgh_hierarchy {
   int dtype = MGH_FLOAT;
   int device = 0;
+  size_t num_cu = 256;  // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   int D = 0, L = 0;
   uint64_t total = 0;
   uint64_t plane_elems = 0;  // product of the two fastest dimensions
@@ -87,6 +90,36 @@ struct mgh_hierarchy {
   int fused_fixed = 1; // MGH_FUSED_FIXED: the int64 + dictionary variant of the level kernel (default 1)
   int fused_wide = 1; // MGH_FUSED_WIDE: 4 x 64 tiles for 0 = no level, 1 = long marches, 2 = all
   int fused4 = 1;     // MGH_FUSED4: D = 4 through the 3-D tile code, slice by slice (default 1)
+  // MGH_SLABS: big levels run their fused pass in this many r-slabs, and the f- and c-solves of a
+  // slab (independent per r-plane) start on a second stream as soon as the slab's load vector
+  // exists, beside the pass of the next slab (0 / 1 = off). MGH_SLABS_MIN: smallest coarse box
+  // (elements) that is worth the fork/join.
+  int slabs = 0;
+  // MGH_BOX: levels up to this march class (0 = few tiles, 1 = mid-size, 2 = long marches) run
+  // the box kernel (kernels_box.hpp: no march, every phase once over a 4 x 4 x 8 box) instead of
+  // the marching tile kernel; 0 = none, 1 = class 0 (default), 2 = classes 0-1, 3 = every level
+  int box = 1;
+  int tail_solves = 1;  // MGH_TAIL_SOLVES: the tail kernel runs the Thomas solves of the level above it
+  // (the rest of the developer switches, env.hpp; all read when the hierarchy is created)
+  size_t cls1 = 256, cls2 = 2048;  // MGH_CLS1 / MGH_CLS2: tile-count thresholds of the march classes
+  int rch[3] = {1, 4, 16};         // MGH_RCH=a,b,c: coarse planes per workgroup of the three classes
+  uint32_t ipk_w = 64;             // MGH_IPK_W: widest solver wave of the streaming Thomas solves
+  int ipk_pd = 1;                  // MGH_IPK_PD: their load-pipeline depth
+  size_t ipk_wpc = 8;              // MGH_IPK_WPC: most one-wave solver workgroups per CU the host plans with
+  bool split_serial = false;       // MGH_SPLIT_SERIAL
+  bool no_head = false;            // MGH_NO_RECOMPOSE_HEAD
+  bool restore_rows = false;       // MGH_RESTORE_ROWS
+  bool debug_sync = false;         // MGH_DEBUG_SYNC: name every launch on stderr and synchronise behind it
+  uint64_t slabs_min = (uint64_t)4 << 20;
+  // MGH_IPK_SLAB=1 (default): a solve tile of the slab schedule asks for no more LDS than a
+  // workgroup of the pass beside it owns (else a freed slot is always refilled by the pass, whose
+  // request fits at once, and the solves starve until the pass has drained); MGH_SLAB_PRIO: stream
+  // priority of the solve stream (1 = highest, 0 = default)
+  int ipk_slab = 1, slab_prio = 1;
+  size_t solve_max_lds = 0;           // in force while the slab schedule issues its solves (0 = no limit)
+  hipStream_t solve = nullptr;        // the second stream (it carries the critical path)
+  std::vector<hipEvent_t> slab_ev;    // pass of slab i done
+  hipEvent_t solve_done = nullptr;
   std::map<std::string, ProfileEntry> prof;
   size_t device_bytes = 0;
 };
@@ -123,6 +156,7 @@ template <typename T> struct DeviceState {
   // of the biggest level (padded slice positions), t-swept load vector / correction
   std::vector<T *> nodal4;
   T *load4 = nullptr, *corr4 = nullptr;
+  bool state4_ready = false;       // set only once every allocation of ensure_state4 succeeded
   std::vector<T *> nodal;          // [l] compact nodal buffers, l = 0..L-1
   T *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;
   T *scratch_full = nullptr;       // lazily allocated full-size copy
@@ -152,8 +186,7 @@ template <typename T> DeviceState<T> *DS(const mgh_hierarchy *h) {
 template <typename F> int launch(mgh_hierarchy *h, const char *name, hipStream_t s, F &&f) {
   // MGH_DEBUG_SYNC=1: name every launch on stderr and synchronise behind it, so that a GPU
   // memory fault can be attributed to a kernel (developer aid)
-  static const bool debug_sync = std::getenv("MGH_DEBUG_SYNC") != nullptr;
-  if (debug_sync) {
+  if (h->debug_sync) {
     std::fprintf(stderr, "[mgh] %s\n", name);
     std::fflush(stderr);
     f();
@@ -399,42 +432,56 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
   for (int w : {64, 48, 32, 16}) {
     const size_t lds = w * pencil_bytes;
     if (lds > kLdsPerCU) continue;
+    if (h->solve_max_lds && lds > h->solve_max_lds && w > 16) continue;
     const size_t per_cu = std::min<size_t>(kLdsPerCU / lds, 8);
     const size_t blocks = (npencil + w - 1) / w;
-    const size_t rounds = (blocks + per_cu * 256 - 1) / (per_cu * 256);
+    const size_t rounds = (blocks + per_cu * h->num_cu - 1) / (per_cu * h->num_cu);
     if (rounds < best_rounds) {
       best_rounds = rounds;
       best_w = w;
     }
   }
-  // Streaming solves (float): when the LDS-staged tiles need more than one round, park half of
-  // every pencil in registers and only the rest in LDS, so that ALL tiles are resident at once
+  // Streaming solves (float): every wave a solver, forward results parked in registers + LDS +
+  // (the leading n_glob elements) in place in global memory. Where the forward results are parked
+  // decides how many pencils a CU works on at once, and residency is the throughput of these
+  // latency-bound chains: the host picks the tile width W and n_glob that need the FEWEST rounds
+  // of resident workgroups (up to ipk_wpc one-wave workgroups per CU), then the least global
+  // parking. Used when the LDS-staged tiles need more than one round (strided pencils), or --
+  // contiguous pencils, where the LDS-staged kernel is the better one at one or two rounds --
+  // from four rounds on (1024^3: 2 KB pencils leave ONE staged tile per CU, 16 rounds).
   if constexpr (sizeof(T) == 4) {
     constexpr uint32_t U = 16, KR = 8;
     const uint32_t nb = n / U;
     const size_t box_bytes = (size_t)m[0] * m[1] * m[2] * sizeof(T);
-    // (strided pencils only: measured inside the step at 512^3, ipk_c 59 -> 52 us, ipk_r of
+    // (strided pencils: measured inside the step at 512^3, ipk_c 59 -> 52 us, ipk_r of
     // all levels 128 -> 103 us, but the contiguous solve 60 -> 65 us)
-    if (h->ipk_stream && axis != 2 && best_w && best_rounds >= 2 && nb >= KR &&
+    const size_t min_rounds = axis == 2 ? 4 : 2;
+    if (h->ipk_stream && best_w && best_rounds >= min_rounds && nb >= KR &&
         box_bytes < ((size_t)1 << 32)) {
       const uint32_t parked = (nb - KR) * U;  // elements per pencil outside the registers
       uint32_t W = 0, n_glob = 0;
-      static const uint32_t w_max = std::getenv("MGH_IPK_W") ? (uint32_t)std::atoi(std::getenv("MGH_IPK_W")) : 64u;
-      for (uint32_t ng = 0; ng <= parked && !W; ng += U) {
+      size_t w_rounds = ~(size_t)0;
+      const uint32_t w_max = h->ipk_w;
+      for (uint32_t ng = 0; ng <= parked; ng += U) {
         for (uint32_t w : {64u, 60u, 56u, 48u, 40u, 32u, 24u, 16u}) {
           if (w > w_max) continue;
           const size_t lds = (size_t)w * (parked - ng) * sizeof(T);
-          // 230-odd VGPRs: two waves per SIMD
+          if (h->solve_max_lds && lds > h->solve_max_lds) continue;
+          // 116 VGPRs: four waves per SIMD = 16 one-wave workgroups per CU at most
           // (five 32 KB allocations do not fit one CU although 5 * 32 KB = 160 KB: leave a margin)
-          const size_t per_cu = lds ? std::min<size_t>((kLdsPerCU - 4096) / lds, 8) : 8;
-          if (per_cu && ((size_t)npencil + w - 1) / w <= per_cu * 256) {
+          const size_t per_cu = lds ? std::min<size_t>((kLdsPerCU - 4096) / lds, h->ipk_wpc) : h->ipk_wpc;
+          if (!per_cu) continue;
+          const size_t blocks = ((size_t)npencil + w - 1) / w;
+          const size_t rounds = (blocks + per_cu * h->num_cu - 1) / (per_cu * h->num_cu);
+          if (rounds < w_rounds) {
+            w_rounds = rounds;
             W = w;
             n_glob = ng;
-            break;
           }
         }
+        if (w_rounds == 1) break;
       }
-      if (W) {
+      if (W && w_rounds < best_rounds) {
         const size_t lds = (size_t)W * (parked - n_glob) * sizeof(T);
         const unsigned blocks = ((npencil + W - 1) / W + 7) / 8 * 8;
         uint32_t n_inner;
@@ -452,7 +499,8 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
           sign);                                                                              \
     });                                                                                       \
   }
-        static const int pd = std::getenv("MGH_IPK_PD") ? std::atoi(std::getenv("MGH_IPK_PD")) : 1;
+        const int pd = h->ipk_pd;
+        if (axis == 2) MGH_STREAM(true, 1)
         if (pd == 4) MGH_STREAM(false, 4)
         if (pd == 2) MGH_STREAM(false, 2)
         MGH_STREAM(false, 1)
@@ -606,35 +654,41 @@ QuantParams<T> make_quant_params(mgh_hierarchy *h, int ebtype, double tol, doubl
 
 // Size class of a level for the fused kernels: 2 = plenty of tiles (long marches, RCH = 16),
 // 1 = mid-size (RCH = 4), 0 = few tiles (one coarse plane per workgroup).
-inline int level_class(const Box3 &b) {
+inline int level_class(const mgh_hierarchy *h, const Box3 &b) {
   constexpr int TC = 8, TF = 32;
   const size_t gx = (b.m[2] + TF - 1) / TF, gy = (b.m[1] + TC - 1) / TC;
-  static const size_t t2 = std::getenv("MGH_CLS2") ? (size_t)std::atoi(std::getenv("MGH_CLS2")) : 2048;
-  static const size_t t1 = std::getenv("MGH_CLS1") ? (size_t)std::atoi(std::getenv("MGH_CLS1")) : 256;
-  if (gx * gy * ((b.m[0] + 15) / 16) >= t2) return 2;
-  if (gx * gy * ((b.m[0] + 3) / 4) >= t1) return 1;
+  if (gx * gy * ((b.m[0] + 15) / 16) >= h->cls2) return 2;
+  if (gx * gy * ((b.m[0] + 3) / 4) >= h->cls1) return 1;
   return 0;
 }
 
 // Coarse planes per workgroup of the fused level kernel (the kernel is compiled for up to 16).
-inline int fused_rch(const mgh_hierarchy *h, int cls) {
-  static const char *e = std::getenv("MGH_RCH");  // "a,b,c": classes 0, 1, 2
-  static int v[3] = {1, 4, 16};
-  static bool parsed = false;
-  if (!parsed) {
-    parsed = true;
-    if (e) std::sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]);
-    for (int &x : v) x = std::min(16, std::max(1, x));
-  }
-  (void)h;
-  return v[cls];
-}
+inline int fused_rch(const mgh_hierarchy *h, int cls) { return h->rch[cls]; }
+
+// r-chunks of a level on the fused kernel: chunks of rch coarse planes, the last one takes what is
+// left (one plane more for sizes 2^k + 1)
+inline int fused_nchunk(int m_r, int rch) { return std::max(1, (m_r - 1 + rch - 1) / rch); }
 
 // Does level l run split (load-vector pass on the caller's stream, coefficient/quantize pass on
 // the side stream)? Only the quantizing path splits.
 template <typename T> bool level_is_split(const mgh_hierarchy *h, int l) {
-  const int c = level_class(DS<T>(h)->lt[l].box);
+  const int c = level_class(h, DS<T>(h)->lt[l].box);
   return (h->split >= 1 && c == 2) || (h->split >= 2 && c == 1);
+}
+
+inline int ensure_solve_stream(mgh_hierarchy *h, int nslab) {
+  if (!h->solve) {
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_TRY(hipStreamCreateWithPriority(&h->solve, hipStreamNonBlocking, h->slab_prio ? hi : 0));
+    HIP_TRY(hipEventCreateWithFlags(&h->solve_done, hipEventDisableTiming));
+  }
+  while ((int)h->slab_ev.size() < nslab) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h->slab_ev.push_back(e);
+  }
+  return MGH_SUCCESS;
 }
 
 inline int ensure_side_stream(mgh_hierarchy *h) {
@@ -665,7 +719,7 @@ inline int ensure_side_stream(mgh_hierarchy *h) {
 // 2^k + 1).
 template <typename T, int OUTK, int TC, int TF>
 int launch_fused2_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int cls, const char *nm,
-                    hipStream_t s) {
+                    hipStream_t s, int chunk_lo, int chunk_hi) {
   const int RCHv = fused_rch(h, cls);
   Fused2Grid G{};
   G.rch = RCHv;
@@ -681,10 +735,12 @@ int launch_fused2_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int 
   G.n_ff = face_f ? (mci + 63) / 64 : 0;
   G.cf_C0 = nfull_c * TC;
   G.n_cf = face_c ? ((face_f ? G.ff_F0 : mfi) + 63) / 64 : 0;
-  G.nchunk = std::max(1, (mri - 1 + RCHv - 1) / RCHv);
+  G.nchunk = fused_nchunk(mri, RCHv);
+  if (chunk_hi < 0) chunk_hi = G.nchunk;
+  G.chunk_hi = chunk_hi;
   G.xcd_ranges = h->fused_xcd;
   const unsigned ntile = (unsigned)(G.n_main + G.n_ff + G.n_cf);
-  const dim3 grid(G.xcd_ranges ? (ntile + 7) / 8 * 8 : ntile, (unsigned)G.nchunk, 1);
+  const dim3 grid(G.xcd_ranges ? (ntile + 7) / 8 * 8 : ntile, (unsigned)(chunk_hi - chunk_lo), 1);
   const bool faces = G.n_ff || G.n_cf;
 #define MGH_F2(RCH)                                                                           \
   return launch(h, nm, s, [&] {                                                               \
@@ -701,10 +757,10 @@ int launch_fused2_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int 
 // box, alternating runs. The short marches of the lower levels are a few us faster on 8 x 32.
 template <typename T, int OUTK>
 int launch_fused2(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int cls, const char *nm,
-                  hipStream_t s) {
+                  hipStream_t s, int chunk_lo = 0, int chunk_hi = -1) {
   if (h->fused_wide >= 2 || (h->fused_wide == 1 && cls == 2))
-    return launch_fused2_t<T, OUTK, 4, 64>(h, A, b, cls, nm, s);
-  return launch_fused2_t<T, OUTK, 8, 32>(h, A, b, cls, nm, s);
+    return launch_fused2_t<T, OUTK, 4, 64>(h, A, b, cls, nm, s, chunk_lo, chunk_hi);
+  return launch_fused2_t<T, OUTK, 8, 32>(h, A, b, cls, nm, s, chunk_lo, chunk_hi);
 }
 
 template <typename T, int OUT, typename AfterFirst>
@@ -749,6 +805,7 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
     }
   }
   bool forked = false;
+  bool tail_pre = false;  // the tail kernel also runs the solves of level l_tail + 1
   for (int l = L; l > l_tail; l--) {
     const LevelTables<T> &t = ds->lt[l];
     const Box3 &b = t.box;
@@ -769,7 +826,7 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
       A.volume = qp->vol[l];
     }
     const unsigned gx = (b.m[2] + TF - 1) / TF, gy = (b.m[1] + TC - 1) / TC;
-    const int cls = level_class(b);
+    const int cls = level_class(h, b);
     const bool split = OUT == OUT_Q && level_is_split<T>(h, l);
     if (split) {
       TRY(ensure_side_stream(h));
@@ -791,7 +848,7 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
       if (l == L) TRY(after_first());
       // fork: everything the emit pass reads (nodal input of level l, quantizers) is ordered
       // before this point of the caller's stream
-      static const bool serial = std::getenv("MGH_SPLIT_SERIAL") != nullptr;  // (experiments)
+      const bool serial = h->split_serial;  // (experiments)
       hipStream_t es = serial ? s : h->side;
       if (!serial) {
         HIP_TRY(hipEventRecord(h->fork_ev[l], s));
@@ -819,13 +876,59 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
       // (RCH = 4) on the small levels where the march length is pure latency
       // second generation: needs the dictionary test in 32 bits
       const bool v2 = h->fused_v == 2 && (OUT != OUT_Q || (qp->dict_size >= 0 && qp->dict_size <= ((int64_t)1 << 30)));
-      if (v2) {
+      if (h->fused_v == 2 && cls < h->box) {
+        // small level: no march (kernels_box.hpp)
+        constexpr int BR = 4, BC = 4, BF = 8;
+        const int bx = ((int)b.m[2] + BF - 1) / BF, by = ((int)b.m[1] + BC - 1) / BC,
+                  bz = ((int)b.m[0] + BR - 1) / BR;
+        TRY(launch(h, OUT == OUT_Q ? "level_box_q" : "level_box", s, [&] {
+          k_level_box<T, OUT, BR, BC, BF><<<(unsigned)(bx * by * bz), 256, 0, s>>>(A, bx, by);
+        }));
+      } else if (v2) {
         const char *nm = cls == 2 ? (OUT == OUT_Q ? "level_fused_q" : "level_fused")
                                   : (OUT == OUT_Q ? "level_fused_q_small" : "level_fused_small");
-        if (OUT == OUT_Q && A.prep_huffman && !A.q16 && h->fused_fixed)
-          TRY((launch_fused2<T, OUT == OUT_Q ? OUT_QH : OUT>(h, A, b, cls, nm, s)));
-        else
-          TRY((launch_fused2<T, OUT>(h, A, b, cls, nm, s)));
+        // Slab schedule: the pass of a big level runs in r-slabs (whole chunks, last chunks first
+        // like the chunks of one launch), and the f- and c-solves of a slab -- independent per
+        // r-plane -- follow on the solve stream while the caller's stream runs the next slab's
+        // pass: the latency-bound solves sit beside a bandwidth-bound pass instead of behind it.
+        const int nchunk = fused_nchunk((int)b.m[0], fused_rch(h, cls));
+        const size_t cbox = (size_t)b.m[0] * b.m[1] * b.m[2];
+        const int ns = (h->slabs >= 2 && cbox >= h->slabs_min) ? std::min(h->slabs, nchunk) : 1;
+        auto pass = [&](int c_lo, int c_hi) {
+          if (OUT == OUT_Q && A.prep_huffman && !A.q16 && h->fused_fixed)
+            return launch_fused2<T, OUT == OUT_Q ? OUT_QH : OUT>(h, A, b, cls, nm, s, c_lo, c_hi);
+          return launch_fused2<T, OUT>(h, A, b, cls, nm, s, c_lo, c_hi);
+        };
+        if (ns >= 2) {
+          TRY(ensure_solve_stream(h, ns));
+          const int rchv = fused_rch(h, cls);
+          struct LdsLimit {  // (in force for the solves issued below only)
+            mgh_hierarchy *h;
+            ~LdsLimit() { h->solve_max_lds = 0; }
+          } lds_limit{h};
+          if (h->ipk_slab) h->solve_max_lds = 33 * 1024;
+          for (int i = 0; i < ns; i++) {
+            // slab i: chunks [c_lo, c_hi), coarse planes [R_lo, R_hi)
+            const int c_hi = nchunk - (int)((int64_t)nchunk * i / ns);
+            const int c_lo = nchunk - (int)((int64_t)nchunk * (i + 1) / ns);
+            TRY(pass(c_lo, c_hi));
+            HIP_TRY(hipEventRecord(h->slab_ev[i], s));
+            HIP_TRY(hipStreamWaitEvent(h->solve, h->slab_ev[i], 0));
+            const uint32_t R_lo = (uint32_t)(c_lo * rchv);
+            const uint32_t R_hi = c_hi == nchunk ? b.m[0] : (uint32_t)(c_hi * rchv);
+            const uint32_t ms[3] = {R_hi - R_lo, b.m[1], b.m[2]};
+            TRY(ipk_fc_launch<T>(h, ms, ds->t3 + (size_t)R_lo * b.m[1] * b.m[2], t.thomas[2],
+                                 t.thomas[1], h->solve));
+          }
+          HIP_TRY(hipEventRecord(h->solve_done, h->solve));
+          HIP_TRY(hipStreamWaitEvent(s, h->solve_done, 0));
+          TRY(ipk_launch<T>(h, 0, b.m, ds->t3, t.thomas[0], ds->nodal[l - 1], +1, s));
+          src = ds->nodal[l - 1];
+          sJ = b.m[2];
+          sI = (size_t)b.m[1] * b.m[2];
+          continue;
+        }
+        TRY(pass(0, nchunk));
       } else if (cls == 2) {
         const dim3 grid(gx, gy, (b.m[0] + 15) / 16);
         TRY(launch(h, OUT == OUT_Q ? "level_fused_q" : "level_fused", s, [&] {
@@ -844,8 +947,13 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
         }));
       }
     }
-    TRY(ipk_fc_launch<T>(h, b.m, ds->t3, t.thomas[2], t.thomas[1], s));
-    TRY(ipk_launch<T>(h, 0, b.m, ds->t3, t.thomas[0], ds->nodal[l - 1], +1, s));
+    // (the level right above the tail leaves its three solves to the tail kernel, which needs the
+    // box in LDS anyway)
+    tail_pre = h->tail_solves && l == l_tail + 1 && l_tail >= 1;
+    if (!tail_pre) {
+      TRY(ipk_fc_launch<T>(h, b.m, ds->t3, t.thomas[2], t.thomas[1], s));
+      TRY(ipk_launch<T>(h, 0, b.m, ds->t3, t.thomas[0], ds->nodal[l - 1], +1, s));
+    }
     src = ds->nodal[l - 1];
     sJ = b.m[2];
     sI = (size_t)b.m[1] * b.m[2];
@@ -857,6 +965,10 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
     TA.fine = src;
     TA.fI = sI;
     TA.fJ = sJ;
+    if (tail_pre) {
+      TA.pre_load = ds->t3;
+      for (int k = 0; k < 3; k++) TA.pre_thomas[k] = ds->lt[l_tail + 1].thomas[k];
+    }
     for (int l = l_tail; l >= 1; l--) {
       TailLevel<T> &tl = TA.lv[l_tail - l];
       const LevelTables<T> &t = ds->lt[l];
@@ -925,7 +1037,8 @@ int launch_fused4_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Fused4<T> &Q,
     G.n_ff = face_f ? (mci + 63) / 64 : 0;
     G.cf_C0 = nfull_c * TC;
     G.n_cf = face_c ? ((face_f ? G.ff_F0 : mfi) + 63) / 64 : 0;
-    G.nchunk = std::max(1, (mri - 1 + RCHv - 1) / RCHv);
+    G.nchunk = fused_nchunk(mri, RCHv);
+    G.chunk_hi = G.nchunk;
     G.xcd_ranges = h->fused_xcd;
     const unsigned ntile = (unsigned)(G.n_main + G.n_ff + G.n_cf);
     const unsigned gx = G.xcd_ranges ? (ntile + 7) / 8 * 8 : ntile;
@@ -952,13 +1065,28 @@ template <typename T> int ensure_state4(mgh_hierarchy *h) {
   auto *hh = HH<T>(h);
   const int L = h->L;
   const auto &sh = hh->level_shape;
-  if (!ds->nodal4.empty()) return MGH_SUCCESS;
+  if (ds->state4_ready) return MGH_SUCCESS;
+  // a failed attempt (out of memory on a big slab) leaves nothing behind: the next call starts over
+  auto drop = [&] {
+    for (T *p : ds->nodal4) (void)hipFree(p);
+    ds->nodal4.clear();
+    (void)hipFree(ds->load4);
+    (void)hipFree(ds->corr4);
+    ds->load4 = ds->corr4 = nullptr;
+  };
+  drop();
   ds->nodal4.assign(L + 1, nullptr);
-  for (int l = 0; l < L; l++)
-    TRY(dev_alloc(h, &ds->nodal4[l], (size_t)sh[l][0] * sh[l][1] * sh[l][2] * sh[l][3]));
   const size_t M = (size_t)sh[L - 1][1] * sh[L - 1][2] * sh[L - 1][3];
-  TRY(dev_alloc(h, &ds->load4, (2 * (size_t)sh[L - 1][0] - 1) * M));
-  TRY(dev_alloc(h, &ds->corr4, (size_t)sh[L - 1][0] * M));
+  int rc = MGH_SUCCESS;
+  for (int l = 0; l < L && rc == MGH_SUCCESS; l++)
+    rc = dev_alloc(h, &ds->nodal4[l], (size_t)sh[l][0] * sh[l][1] * sh[l][2] * sh[l][3]);
+  if (rc == MGH_SUCCESS) rc = dev_alloc(h, &ds->load4, (2 * (size_t)sh[L - 1][0] - 1) * M);
+  if (rc == MGH_SUCCESS) rc = dev_alloc(h, &ds->corr4, (size_t)sh[L - 1][0] * M);
+  if (rc != MGH_SUCCESS) {
+    drop();
+    return rc;
+  }
+  ds->state4_ready = true;
   return MGH_SUCCESS;
 }
 
@@ -1024,7 +1152,7 @@ int decompose_fused4(mgh_hierarchy *h, const T *data, T *coeff, const QuantParam
     // an even n_t has a ghost slice (padded position n_t - 1): its load vector is zero
     if (n_t % 2 == 0)
       HIP_TRY(hipMemsetAsync(ds->load4 + (size_t)(n_t - 1) * M, 0, M * sizeof(T), s));
-    const int cls = level_class(b);
+    const int cls = level_class(h, b);
     if (h->fused_wide >= 2 || (h->fused_wide == 1 && cls == 2))
       TRY((launch_fused4_t<T, OUT, 4, 64>(h, A, Q, b, cls, n_t, m_t, s)));
     else
@@ -1371,7 +1499,7 @@ int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> 
   const int L = h->L;
   // levels 1 .. l_head run inside ONE single-workgroup kernel (their working set fits in LDS);
   // MGH_NO_RECOMPOSE_HEAD=1: every level with its own launches (cross-check)
-  static const bool no_head = std::getenv("MGH_NO_RECOMPOSE_HEAD") != nullptr;
+  const bool no_head = h->no_head;
   int l_head = 0;
   if (!no_head) {
     for (int l = 1; l <= std::min(L, kTailMaxLevels); l++) {
@@ -1446,7 +1574,7 @@ int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> 
     TRY(launch(h, "restore_q", st, [&] {
       // one 64-lane wave per PAIR of fine rows, 4 pairs per block (MGH_RESTORE_ROWS=1: one row
       // per wave, the previous kernel: cross-check)
-      static const bool single = std::getenv("MGH_RESTORE_ROWS") != nullptr;
+      const bool single = h->restore_rows;
       if (single)
         k_level_restore_q<T, QT><<<dim3(1, (b.n[1] + 3) / 4, b.n[0]), blk, 0, st>>>(A);
       else
@@ -1898,36 +2026,49 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
   if (mgh_device_count() <= device || device < 0)
     return fail(MGH_ERR_NO_DEVICE, "HIP device " + std::to_string(device) + " not available");
   HIP_TRY(hipSetDevice(device));
+  {
+    const std::string bad = env_validate();
+    if (!bad.empty()) return fail(MGH_ERR_INVALID_ARGUMENT, bad);
+  }
   auto *h = new mgh_hierarchy();
   {
-    const char *e = std::getenv("MGH_FORCE_V1");
-    h->force_v1 = e && e[0] == '1';
-    const char *e2 = std::getenv("MGH_FORCE_ND");
-    h->force_nd = e2 && e2[0] == '1';
-    const char *e3 = std::getenv("MGH_SPLIT");
-    if (e3 && e3[0] >= '0' && e3[0] <= '2') h->split = e3[0] - '0';
-    const char *e6 = std::getenv("MGH_FUSED_V");
-    if (e6 && e6[0] >= '1' && e6[0] <= '2') h->fused_v = e6[0] - '0';
-    const char *e7 = std::getenv("MGH_IPK_STREAM");
-    if (e7 && e7[0] >= '0' && e7[0] <= '1') h->ipk_stream = e7[0] - '0';
-    const char *e8 = std::getenv("MGH_FUSED_FACES");
-    if (e8 && e8[0] >= '0' && e8[0] <= '1') h->fused_faces = e8[0] - '0';
-    const char *e9 = std::getenv("MGH_FUSED_XCD");
-    if (e9 && e9[0] >= '0' && e9[0] <= '1') h->fused_xcd = e9[0] - '0';
-    const char *e12 = std::getenv("MGH_FUSED_FIXED");
-    if (e12 && e12[0] >= '0' && e12[0] <= '1') h->fused_fixed = e12[0] - '0';
-    const char *e11 = std::getenv("MGH_FUSED_WIDE");
-    if (e11 && e11[0] >= '0' && e11[0] <= '2') h->fused_wide = e11[0] - '0';
-    const char *e10 = std::getenv("MGH_FUSED4");
-    if (e10 && e10[0] >= '0' && e10[0] <= '1') h->fused4 = e10[0] - '0';
-    const char *e4 = std::getenv("MGH_EMIT_BPC");
-    if (e4 && std::atoi(e4) > 0) h->emit_bpc = (unsigned)std::atoi(e4);
-    const char *e5 = std::getenv("MGH_EMIT_CCH");
-    if (e5 && std::atoi(e5) > 0) h->emit_cch = (unsigned)std::atoi(e5);
+    h->force_v1 = env_get("MGH_FORCE_V1", 0) != 0;
+    h->force_nd = env_get("MGH_FORCE_ND", 0) != 0;
+    h->split = (int)env_get("MGH_SPLIT", h->split);
+    h->fused_v = (int)env_get("MGH_FUSED_V", h->fused_v);
+    h->ipk_stream = (int)env_get("MGH_IPK_STREAM", h->ipk_stream);
+    h->fused_faces = (int)env_get("MGH_FUSED_FACES", h->fused_faces);
+    h->fused_xcd = (int)env_get("MGH_FUSED_XCD", h->fused_xcd);
+    h->fused_fixed = (int)env_get("MGH_FUSED_FIXED", h->fused_fixed);
+    h->fused_wide = (int)env_get("MGH_FUSED_WIDE", h->fused_wide);
+    h->fused4 = (int)env_get("MGH_FUSED4", h->fused4);
+    h->emit_bpc = (unsigned)env_get("MGH_EMIT_BPC", h->emit_bpc);
+    h->emit_cch = (unsigned)env_get("MGH_EMIT_CCH", h->emit_cch);
+    h->slabs = (int)env_get("MGH_SLABS", h->slabs);
+    h->box = (int)env_get("MGH_BOX", h->box);
+    h->tail_solves = (int)env_get("MGH_TAIL_SOLVES", h->tail_solves);
+    h->slabs_min = (uint64_t)env_get("MGH_SLABS_MIN", (long)h->slabs_min);
+    h->ipk_slab = (int)env_get("MGH_IPK_SLAB", h->ipk_slab);
+    h->slab_prio = (int)env_get("MGH_SLAB_PRIO", h->slab_prio);
+    h->cls1 = (size_t)env_get("MGH_CLS1", (long)h->cls1);
+    h->cls2 = (size_t)env_get("MGH_CLS2", (long)h->cls2);
+    if (const char *e = std::getenv("MGH_RCH")) std::sscanf(e, "%d,%d,%d", &h->rch[0], &h->rch[1], &h->rch[2]);
+    h->ipk_w = (uint32_t)env_get("MGH_IPK_W", h->ipk_w);
+    h->ipk_pd = (int)env_get("MGH_IPK_PD", h->ipk_pd);
+    h->ipk_wpc = (size_t)env_get("MGH_IPK_WPC", (long)h->ipk_wpc);
+    h->split_serial = env_get("MGH_SPLIT_SERIAL", 0) != 0;
+    h->no_head = env_get("MGH_NO_RECOMPOSE_HEAD", 0) != 0;
+    h->restore_rows = env_get("MGH_RESTORE_ROWS", 0) != 0;
+    h->debug_sync = env_get("MGH_DEBUG_SYNC", 0) != 0;
     if (h->force_nd) h->force_v1 = true;  // keeps the fused entry points off
   }
   h->dtype = dtype;
   h->device = device;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+      h->num_cu = (size_t)cus;
+  }
   h->D = D;
   bool ok;
   if (dtype == MGH_FLOAT) {
@@ -1970,6 +2111,9 @@ void mgh_hierarchy_destroy(mgh_hierarchy *h) {
       (void)hipEventDestroy(ev.second);
     }
   for (hipEvent_t e : h->fork_ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->slab_ev) (void)hipEventDestroy(e);
+  if (h->solve_done) (void)hipEventDestroy(h->solve_done);
+  if (h->solve) (void)hipStreamDestroy(h->solve);
   if (h->join_ev) (void)hipEventDestroy(h->join_ev);
   if (h->side) (void)hipStreamDestroy(h->side);
   if (h->dtype == MGH_FLOAT) destroy_state<float>(h); else destroy_state<double>(h);

@@ -1,0 +1,92 @@
+// MGH_* developer switches (cross-checks and experiments; DESIGN.md lists them). They are read when
+// a hierarchy / a high-level call is set up, and they are VALIDATED: a value outside the range of
+// its switch, or an MGH_* variable this library does not know (a typo), is an error -- never a
+// silent default.
+#pragma once
+#include <cerrno>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+extern char **environ;
+
+namespace mgh {
+
+struct EnvSwitch {
+  const char *name;
+  long lo, hi;  // accepted range (MGH_RCH: every one of its three comma-separated values)
+};
+
+inline const EnvSwitch *env_switches(size_t *count) {
+  static const EnvSwitch k[] = {
+      {"MGH_FORCE_V1", 0, 1},       {"MGH_FORCE_ND", 0, 1},        {"MGH_SPLIT", 0, 2},
+      {"MGH_FUSED_V", 1, 2},        {"MGH_IPK_STREAM", 0, 1},      {"MGH_FUSED_FACES", 0, 1},
+      {"MGH_FUSED_XCD", 0, 1},      {"MGH_FUSED_FIXED", 0, 1},     {"MGH_FUSED_WIDE", 0, 2},
+      {"MGH_FUSED4", 0, 1},         {"MGH_EMIT_BPC", 1, 64},       {"MGH_EMIT_CCH", 1, 4096},
+      {"MGH_CLS1", 0, 1 << 30},     {"MGH_CLS2", 0, 1 << 30},      {"MGH_RCH", 1, 16},
+      {"MGH_IPK_W", 16, 64},        {"MGH_IPK_PD", 1, 4},          {"MGH_SPLIT_SERIAL", 0, 1},
+      {"MGH_NO_RECOMPOSE_HEAD", 0, 1}, {"MGH_RESTORE_ROWS", 0, 1}, {"MGH_DEBUG_SYNC", 0, 1},
+      {"MGH_HL_TIMING", 0, 1},      {"MGH_HUFF_TB", 8, 15},        {"MGH_HUFF_SERIAL_DECODE", 0, 1},
+      {"MGH_HUFF_PAR_DECODE", 0, 1}, {"MGH_SYM16_DECODE", 0, 1},   {"MGH_SLABS", 0, 64},
+      {"MGH_SLABS_MIN", 0, 1 << 30}, {"MGH_BOX", 0, 3},            {"MGH_IPK_SLAB", 0, 1},
+      {"MGH_SLAB_PRIO", 0, 1},      {"MGH_IPK_WPC", 1, 16},
+      {"MGH_TAIL_SOLVES", 0, 1},
+  };
+  *count = sizeof(k) / sizeof(k[0]);
+  return k;
+}
+
+inline bool env_parse_long(const char *txt, long &v) {
+  if (!txt || !*txt) return false;
+  char *end = nullptr;
+  errno = 0;
+  v = std::strtol(txt, &end, 10);
+  return errno == 0 && end && *end == '\0';
+}
+
+// Checks every MGH_* variable of the process environment; empty string = fine.
+inline std::string env_validate() {
+  size_t n = 0;
+  const EnvSwitch *k = env_switches(&n);
+  for (char **e = environ; e && *e; e++) {
+    if (std::strncmp(*e, "MGH_", 4) != 0) continue;
+    const char *eq = std::strchr(*e, '=');
+    if (!eq) continue;
+    const std::string name(*e, eq - *e);
+    const EnvSwitch *sw = nullptr;
+    for (size_t i = 0; i < n; i++)
+      if (name == k[i].name) sw = &k[i];
+    if (!sw) return "unknown developer switch " + name + " (see DESIGN.md for the list)";
+    std::string val(eq + 1);
+    if (name == "MGH_RCH") {
+      int parts = 0;
+      size_t pos = 0;
+      while (true) {
+        const size_t c = val.find(',', pos);
+        long v;
+        if (!env_parse_long(val.substr(pos, c == std::string::npos ? c : c - pos).c_str(), v) ||
+            v < sw->lo || v > sw->hi)
+          return "MGH_RCH=" + val + ": expected a,b,c with every value in 1..16";
+        parts++;
+        if (c == std::string::npos) break;
+        pos = c + 1;
+      }
+      if (parts != 3) return "MGH_RCH=" + val + ": expected three comma-separated values";
+      continue;
+    }
+    long v;
+    if (!env_parse_long(val.c_str(), v) || v < sw->lo || v > sw->hi)
+      return name + "=" + val + ": expected an integer in " + std::to_string(sw->lo) + ".." +
+             std::to_string(sw->hi);
+  }
+  return std::string();
+}
+
+// value of a (validated) switch, or `dflt` when it is not set
+inline long env_get(const char *name, long dflt) {
+  const char *e = std::getenv(name);
+  long v;
+  return env_parse_long(e, v) ? v : dflt;
+}
+
+} // namespace mgh

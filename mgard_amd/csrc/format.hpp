@@ -48,16 +48,19 @@ struct Header {
 
 // ---- CRC-32 (zlib / IEEE 802.3, reflected 0xEDB88320) ------------------------------------
 inline uint32_t crc32(const uint8_t *p, size_t n) {
-  static uint32_t table[256];
-  static bool init = false;
-  if (!init) {
-    for (uint32_t i = 0; i < 256; i++) {
-      uint32_t c = i;
-      for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-      table[i] = c;
+  // (function-local static object: initialised once, safely from several threads)
+  struct Table {
+    uint32_t t[256];
+    Table() {
+      for (uint32_t i = 0; i < 256; i++) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        t[i] = c;
+      }
     }
-    init = true;
-  }
+  };
+  static const Table tab;
+  const uint32_t *table = tab.t;
   uint32_t c = 0xFFFFFFFFu;
   for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
   return c ^ 0xFFFFFFFFu;

@@ -28,19 +28,27 @@
 
 #include "format.hpp"
 #include "huffman.hpp"
+#include "env.hpp"
 
 extern "C" void mgh_set_last_error_(const char *msg);  // capi.hip
 
 namespace {
 constexpr int kOutlierOverflow = -1000;  // internal: more outliers than the buffers hold
 
-// true exactly once per device ordinal for the given flag word (kernel attributes such as the
-// dynamic-LDS limit belong to the function on the current device); safe from several threads
-inline bool hl_once_per_device(std::atomic<uint64_t> &done) {
+// Kernel attributes such as the dynamic-LDS limit belong to the function on the current device and
+// are set once per device ordinal: `if (hl_attr_pending(once)) { set ...; hl_attr_done(once); }`.
+// The bit is set AFTER the attributes exist, so a second host thread on the same device can never
+// launch before them (two threads setting them twice is harmless).
+inline uint64_t hl_device_bit() {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return true;
-  const uint64_t bit = (uint64_t)1 << (dev & 63);
-  return !(done.fetch_or(bit, std::memory_order_acq_rel) & bit);
+  (void)hipGetDevice(&dev);
+  return (uint64_t)1 << (dev & 63);
+}
+inline bool hl_attr_pending(const std::atomic<uint64_t> &done) {
+  return !(done.load(std::memory_order_acquire) & hl_device_bit());
+}
+inline void hl_attr_done(std::atomic<uint64_t> &done) {
+  done.fetch_or(hl_device_bit(), std::memory_order_release);
 }
 
 
@@ -48,8 +56,8 @@ using namespace mgh;
 
 // MGH_DEBUG_SYNC=1: name the stages on stderr and synchronise (developer aid, see capi.hip)
 inline void hl_debug(const char *what) {
-  static const bool on = std::getenv("MGH_DEBUG_SYNC") != nullptr;
-  static const bool timing = std::getenv("MGH_HL_TIMING") != nullptr;  // + microseconds since the last mark
+  static const bool on = env_get("MGH_DEBUG_SYNC", 0) != 0;
+  static const bool timing = env_get("MGH_HL_TIMING", 0) != 0;  // + microseconds since the last mark
   if (on || timing) {
     (void)hipDeviceSynchronize();
     static auto last = std::chrono::steady_clock::now();
@@ -351,7 +359,7 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
     HL_TRY(c->state.ensure((3 + nchunk) * 8));
     HL_HIP(hipMemsetAsync(c->state.p, 0, (3 + nchunk) * 8, st));
     static std::atomic<uint64_t> once{0};
-    if (hl_once_per_device(once)) {
+    if (hl_attr_pending(once)) {
       const int lim = 144 * 1024;
       HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_encode_chain<int64_t, uint64_t>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -361,6 +369,7 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lim));
       HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_encode_chain<uint16_t, uint32_t>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+      hl_attr_done(once);
     }
     auto enc = [&](auto sym_tag, auto code_tag) {
       using SYM = decltype(sym_tag);
@@ -558,16 +567,17 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
   int tb = 15;
   const size_t lds_keys_ring = ((size_t)dict * 2 + 7) / 8 * 8 + 16 * 64 * 8;
   while (tb > 8 && ((size_t)4 << tb) + lds_keys_ring > 154 * 1024) tb--;
-  if (const char *e = std::getenv("MGH_HUFF_TB")) tb = std::max(8, std::min(tb, atoi(e)));  // developer switch
+  tb = std::max(8, std::min(tb, (int)env_get("MGH_HUFF_TB", tb)));  // developer switch
   const size_t lds = ((size_t)4 << tb) + lds_keys_ring;
   static std::atomic<uint64_t> once{0};
-  if (hl_once_per_device(once)) {
+  if (hl_attr_pending(once)) {
     HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_decode),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    hl_attr_done(once);
   }
-  static const bool serial_decode = std::getenv("MGH_HUFF_SERIAL_DECODE") != nullptr;  // cross-check
+  static const bool serial_decode = env_get("MGH_HUFF_SERIAL_DECODE", 0) != 0;  // cross-check
   hl_debug("lossless_decompress: uploads done (units, tables, outliers)");
-  static const bool par_decode = std::getenv("MGH_HUFF_PAR_DECODE") != nullptr;           // cross-check
+  static const bool par_decode = env_get("MGH_HUFF_PAR_DECODE", 0) != 0;           // cross-check
   int book_max_len = 0;  // longest code of the decodebook (unused lengths carry first = 2^64-1)
   {
     const uint64_t *first = reinterpret_cast<const uint64_t *>(head.data() + L.decodebook);
@@ -581,7 +591,7 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
     // code units through per-lane LDS rings. 16 waves per workgroup when the table leaves room.
     const uint64_t *book = reinterpret_cast<const uint64_t *>(head.data() + L.decodebook);
     int rtb = 12;
-    if (const char *e = std::getenv("MGH_HUFF_TB")) rtb = std::max(8, std::min(14, atoi(e)));  // developer switch
+    rtb = std::max(8, std::min(14, (int)env_get("MGH_HUFF_TB", rtb)));  // developer switch
     const size_t lds_cap = 150 * 1024;
     const size_t per_wave = huff::decode_ring_lds(0, 1);
     const std::vector<uint32_t> dt = huff::build_decode_table(book, book + 64, book + 128, (int)dict, rtb,
@@ -590,11 +600,12 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
     HL_TRY(c->dtable.ensure(dt.size() * 4));
     HL_HIP(hipMemcpyAsync(c->dtable.p, dt.data(), dt.size() * 4, hipMemcpyHostToDevice, st));
     static std::atomic<uint64_t> once3{0};
-    if (hl_once_per_device(once3)) {
+    if (hl_attr_pending(once3)) {
       HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_decode_ring<int64_t>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
       HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_decode_ring<uint16_t>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+      hl_attr_done(once3);
     }
     if (sym16 && *sym16)
       huff::k_decode_ring<uint16_t><<<(unsigned)((nchunk + waves - 1) / waves), 64 * waves,
@@ -614,9 +625,10 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
     if (sym16) *sym16 = false;
     // parallel decoding inside the chunks (one wave per chunk)
     static std::atomic<uint64_t> once2{0};
-    if (hl_once_per_device(once2)) {
+    if (hl_attr_pending(once2)) {
       HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_decode_par),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+      hl_attr_done(once2);
     }
     // 14-bit prefix table at most, so that the write-out staging (4 KiB per wave) fits beside it
     while (tb > 8 && ((size_t)4 << tb) + ((size_t)dict + 3) / 4 * 8 + huff::kParWaves * 64 * huff::kParBatch * 2 >
@@ -1517,7 +1529,7 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
       // (3.0 vs 2.9 ms at 512^3: decoder and node restore are instruction-bound, not
       // bandwidth-bound, and the outlier look-ups of the coarse levels cost more than the
       // outlier-restore pass they replace) -- opt-in, MGH_SYM16_DECODE=1
-      static const bool sym16_decode = std::getenv("MGH_SYM16_DECODE") != nullptr;
+      static const bool sym16_decode = env_get("MGH_SYM16_DECODE", 0) != 0;
       bool sym16 = sym16_decode && !hd.reorder && mgh_sym16_supported(h) && hd.huff_dict_size <= 65536;
       rc = lossless_decompress(g_cache.ll, payload, csize, lossless, (int64_t *)g_cache.q.p, n, &ocount, st,
                                &sym16);
@@ -1612,6 +1624,10 @@ int mgh_compress(int D, int dtype, const uint64_t *shape, double tol, double s, 
   if (dtype != MGH_FLOAT && dtype != MGH_DOUBLE) return hl_fail(MGH_ERR_UNSUPPORTED_DTYPE, "dtype");
   if (ebtype != MGH_REL && ebtype != MGH_ABS) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "error_bound_type");
   if (output_pre_allocated && !*compressed_data) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "pre-allocated output is NULL");
+  {
+    const std::string bad = env_validate();  // MGH_* developer switches: a typo is an error
+    if (!bad.empty()) return hl_fail(MGH_ERR_INVALID_ARGUMENT, bad);
+  }
   HL_TRY(check_config(config));
   if (hipSetDevice(config->dev_id) != hipSuccess) return hl_fail(MGH_ERR_DEVICE, "hipSetDevice");
   try {
@@ -1629,6 +1645,10 @@ int mgh_decompress(const void *compressed_data, size_t compressed_size, void **d
                    const mgh_config *config, int output_pre_allocated) {
   if (!compressed_data || !decompressed_data) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");
   if (output_pre_allocated && !*decompressed_data) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "pre-allocated output is NULL");
+  {
+    const std::string bad = env_validate();
+    if (!bad.empty()) return hl_fail(MGH_ERR_INVALID_ARGUMENT, bad);
+  }
   mgh_config def;
   if (!config) {
     mgh_config_default(&def);
@@ -1741,6 +1761,7 @@ int compress_multi_impl(int ndev, const int *devs, int D, int dtype, const uint6
     std::vector<std::thread> th;
     for (int k = 0; k < nthr; k++)
       th.emplace_back([&, k] {
+        try {
         mgh_config c = cfg0;
         c.dev_id = devs[k];
         if (hipSetDevice(c.dev_id) != hipSuccess || cache_prepare(c.dev_id) != MGH_SUCCESS) {
@@ -1761,6 +1782,10 @@ int compress_multi_impl(int ndev, const int *devs, int D, int dtype, const uint6
           if (rc != MGH_SUCCESS) err.set(rc);
         }
         mgh_release_cache();
+        } catch (const std::exception &e) {
+          // (an exception must not leave a worker thread: std::terminate)
+          err.set(hl_fail(MGH_ERR_OUT_OF_MEMORY, std::string("worker thread: ") + e.what()));
+        }
       });
     for (auto &t : th) t.join();
     if (err.rc != MGH_SUCCESS) {
@@ -1784,6 +1809,7 @@ int compress_multi_impl(int ndev, const int *devs, int D, int dtype, const uint6
     std::vector<std::thread> th;
     for (int k = 0; k < nthr; k++)
       th.emplace_back([&, k] {
+        try {
         mgh_config c = cfg0;
         c.dev_id = devs[k];
         c.domain_decomposition = MGH_DD_MAXDIM;  // (a slab that does not fit is split further)
@@ -1798,6 +1824,10 @@ int compress_multi_impl(int ndev, const int *devs, int D, int dtype, const uint6
           if (rc != MGH_SUCCESS) err.set(rc);
         }
         mgh_release_cache();
+        } catch (const std::exception &e) {
+          // (an exception must not leave a worker thread: std::terminate)
+          err.set(hl_fail(MGH_ERR_OUT_OF_MEMORY, std::string("worker thread: ") + e.what()));
+        }
       });
     for (auto &t : th) t.join();
   }
@@ -1888,6 +1918,7 @@ int decompress_multi_impl(int ndev, const int *devs, const fmt::Header &hd, size
   std::vector<std::thread> th;
   for (int k = 0; k < nthr; k++)
     th.emplace_back([&, k] {
+        try {
       mgh_config c = cfg0;
       c.dev_id = devs[k];
       for (uint64_t id = k; id < num && err.rc == MGH_SUCCESS; id += nthr) {
@@ -1903,12 +1934,17 @@ int decompress_multi_impl(int ndev, const int *devs, const fmt::Header &hd, size
           const uint64_t o0 = dd.subdomain_offset(id)[0];
           sc[0].assign(hd.coords[0].begin() + o0, hd.coords[0].begin() + o0 + one.shape[0]);
         }
-        fmt::Header sh;
-        header_from(one, hd.is_double ? MGH_DOUBLE : MGH_FLOAT, MGH_ABS, (double)local_tol, hd.s, 0.0,
-                    hd.uniform ? nullptr : &sc, c, sh);
-        sh.compressor = hd.compressor;
-        sh.huff_dict_size = hd.huff_dict_size;
-        sh.huff_block_size = hd.huff_block_size;
+        // everything the stream says about itself (reorder, lossless choice, dictionary, ...) comes
+        // from ITS header, never from the caller's config; only what describes the slab changes
+        fmt::Header sh = hd;
+        sh.shape = one.shape;
+        if (!hd.uniform) sh.coords = sc;
+        sh.rel = false;
+        sh.tol = (double)local_tol;
+        sh.norm = 0.0;
+        sh.dd_method = fmt::DD_NOOP;
+        sh.dd_dim = 0;
+        sh.dd_size = 0;
         const std::vector<uint8_t> meta = fmt::serialize_metadata(sh);
         std::vector<uint8_t> mini(meta.size() + len[id]);
         std::memcpy(mini.data(), meta.data(), meta.size());
@@ -1918,7 +1954,11 @@ int decompress_multi_impl(int ndev, const int *devs, const fmt::Header &hd, size
         if (rc != MGH_SUCCESS) err.set(rc);
       }
       mgh_release_cache();
-    });
+      } catch (const std::exception &e) {
+          // (an exception must not leave a worker thread: std::terminate)
+          err.set(hl_fail(MGH_ERR_OUT_OF_MEMORY, std::string("worker thread: ") + e.what()));
+        }
+      });
   for (auto &t : th) t.join();
   if (err.rc != MGH_SUCCESS) {
     mgh_set_last_error_(err.msg.c_str());

@@ -643,6 +643,7 @@ struct Fused2Grid {
   int ff_F0, n_ff;    // f-face: tiles of 64 x 4 at F0 = ff_F0, C0 = k * 64 (n_ff = 0: none)
   int cf_C0, n_cf;    // c-face: tiles of 4 x 64 at C0 = cf_C0, F0 = k * 64 (n_cf = 0: none)
   int rch, nchunk;    // r-chunks of rch <= RCH coarse planes; the last one takes what is left (<= rch + 1)
+  int chunk_hi;       // this launch covers the chunks [chunk_hi - gridDim.y, chunk_hi) (a slab of the level)
   int xcd_ranges;     // tiles handed to the XCDs in contiguous ranges (grid.x padded to 8)
 };
 
@@ -695,7 +696,7 @@ k_level_fused2(FusedArgs<T> A, Fused2Grid G, Fused4<T> Q) {
   }
   // r-chunks in reverse launch order: whatever ran before this kernel (the norm reduction,
   // the level above) leaves the END of the level's input in the memory-side cache
-  const int chunk = G.nchunk - 1 - (int)blockIdx.y;
+  const int chunk = G.chunk_hi - 1 - (int)blockIdx.y;
   const int R0 = chunk * G.rch;
   const int rch = chunk == G.nchunk - 1 ? A.m[0] - R0 : G.rch;
   // workgroups go round-robin to the 8 XCDs (own L2 each): every XCD gets a contiguous range of

@@ -34,6 +34,12 @@ template <typename T> struct TailArgs {
   TailLevel<T> lv[kTailMaxLevels];
   const T *fine;  // nodal array of lv[0], strides (fI, fJ, 1)
   size_t fI, fJ;
+  // The three Thomas solves + AddND of the level ABOVE lv[0] (whose coarse box is lv[0]'s fine
+  // box), or nullptr: `fine` then holds that level's coarse nodes WITHOUT the correction,
+  // pre_load its load vector (compact), pre_thomas the tables of its coarse grid -- two launches
+  // and one round trip through global memory less (the box fits in LDS by construction).
+  const T *pre_load;
+  const T *pre_thomas[3];
   T head_quantizer, head_volume;
   FusedArgs<T> out;    // coefficient / quantized output + outlier list
 };
@@ -103,10 +109,24 @@ k_tail(TailArgs<T> A) {
       }
     }
     // bring the nodal values of the first tail level into LDS
-    const uint32_t n1 = b.n[1], n2 = b.n[2];
+    const uint32_t n0 = b.n[0], n1 = b.n[1], n2 = b.n[2];
     for (uint32_t e = tid; e < nf; e += NT) {
       const uint32_t k = e % n2, j = (e / n2) % n1, i = e / (n2 * n1);
       X[e] = A.fine[i * A.fI + j * A.fJ + k];
+    }
+    if (A.pre_load) {
+      // correction of the level above: f-, c-, r-solve of its load vector (IPKFunctor.h:127,147),
+      // added to the coarse nodes (LevelwiseProcessingKernel.hpp:69-74)
+      for (uint32_t e = tid; e < nf; e += NT) C[e] = A.pre_load[e];
+      __syncthreads();
+      for (uint32_t p = tid; p < n0 * n1; p += NT) thomas_lds<T, false>(C + (size_t)p * n2, 1, n2, A.pre_thomas[2]);
+      __syncthreads();
+      for (uint32_t p = tid; p < n0 * n2; p += NT)
+        thomas_lds<T, false>(C + (size_t)(p / n2) * n1 * n2 + (p % n2), n2, n1, A.pre_thomas[1]);
+      __syncthreads();
+      for (uint32_t p = tid; p < n1 * n2; p += NT) thomas_lds<T, false>(C + p, n1 * n2, n0, A.pre_thomas[0]);
+      __syncthreads();
+      for (uint32_t e = tid; e < nf; e += NT) X[e] = X[e] + C[e];
     }
   }
   __syncthreads();

@@ -162,3 +162,23 @@ def test_scatter_gather_inside_a_subgroup():
         assert p.exitcode == 0
     assert all(res[r][1] for r in range(world))
     assert res[1][2] == struct.pack("<Q", 4) + b"\x07" * 4 + struct.pack("<Q", 6) + b"\x08" * 6
+
+
+def test_bench_launcher_starts_the_ranks_itself():
+    """`python3 bench.py --gpus N` (what the driver runs) with no WORLD_SIZE in the environment must
+    start N ranks itself -- fresh child processes under torch.distributed.run, never a re-exec of a
+    process that has touched a GPU -- and relay rank 0's JSON line. GPU-less dry run: gloo ranks,
+    the scalar norm exchange of the N > 1 path (MAX all-reduce) and the rank count."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-dry-run",
+                        "--steps", "3", "--warmup", "1"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.strip().splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and r["rccl_ranks_seen"] == 2 and r["norm_exchange_ok"] is True
+    assert r["steps"] == 3 and r["dry_run"] is True

@@ -597,3 +597,51 @@ def test_reorder_1_level_linearised_stream(shape, dt, dict_size, dd):
         if dict_size == 64:
             assert cnt > 50
         h.close()
+
+
+@pytest.mark.parametrize("writer_reorder,reader_reorder", [(1, 0), (0, 1)])
+def test_multi_device_reader_takes_reorder_from_the_stream(writer_reorder, reader_reorder):
+    """The slabs of mgh_decompress_multi are decoded with what the STREAM's header says
+    (reorder, lossless choice, dictionary), never with the caller's config: a reorder = 1
+    container read with the default config -- and the converse -- reconstructs exactly what
+    mgh_decompress reconstructs from the same bytes."""
+    torch, mg, hl = _mods()
+    shape = (24, 33, 40)
+    u = smooth_field(shape, np.float32)
+    devs = (0, 0, 0)
+    buf = hl.compress_multi(u, 1e-3, np.inf, mg.REL, devices=devs, config=hl.Config(reorder=writer_reorder))
+    meta = hl.metadata_parse(bytes(buf[:4096]) if buf.size > 4096 else bytes(buf))
+    assert meta["reorder"] == writer_reorder and meta["domain_decomposed"] is True
+    ref = hl.decompress(buf)
+    got = hl.decompress_multi(buf, devices=devs, config=hl.Config(reorder=reader_reorder))
+    assert np.array_equal(got, ref)
+    assert float(np.max(np.abs(ref.astype(np.float64) - u))) <= 1e-3 * float(np.max(np.abs(u)))
+    # the single-device writer with MaxDim on dim 0 produces the same kind of container
+    kw = dict(reorder=writer_reorder, domain_decomposition=hl.DD_MAXDIM, max_memory_footprint=30 * u.size)
+    buf2 = hl.compress(u, 1e-3, np.inf, mg.REL, config=hl.Config(**kw))
+    if hl.metadata_parse(bytes(buf2[:4096]))["domain_decomposed"]:
+        assert np.array_equal(hl.decompress_multi(buf2, devices=devs, config=hl.Config(reorder=reader_reorder)),
+                              hl.decompress(buf2))
+
+
+def test_developer_switches_are_validated(monkeypatch):
+    """An MGH_* variable with a value outside its range, or one the library does not know (a
+    typo), is an error when a hierarchy is created or a high-level call starts -- never a silent
+    default."""
+    torch, mg, hl = _mods()
+    u = smooth_field((9, 9, 9), np.float32)
+    monkeypatch.setenv("MGH_FUSED_WIDE", "7")
+    with pytest.raises(mg.MgardHipError, match="MGH_FUSED_WIDE"):
+        mg.Hierarchy((9, 9, 9), np.float32)
+    with pytest.raises(mg.MgardHipError, match="MGH_FUSED_WIDE"):
+        hl.compress(u, 1e-3, np.inf, mg.REL)
+    monkeypatch.delenv("MGH_FUSED_WIDE")
+    monkeypatch.setenv("MGH_FUSED_WIDTH", "1")       # (typo of MGH_FUSED_WIDE)
+    with pytest.raises(mg.MgardHipError, match="unknown developer switch MGH_FUSED_WIDTH"):
+        mg.Hierarchy((9, 9, 9), np.float32)
+    monkeypatch.delenv("MGH_FUSED_WIDTH")
+    monkeypatch.setenv("MGH_RCH", "2,3")
+    with pytest.raises(mg.MgardHipError, match="MGH_RCH"):
+        mg.Hierarchy((9, 9, 9), np.float32)
+    monkeypatch.setenv("MGH_RCH", "2,3,8")
+    mg.Hierarchy((9, 9, 9), np.float32).close()
