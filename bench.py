@@ -66,7 +66,8 @@ def algorithmic_bytes_per_step(h, esz):
             add("tsweep", ((2 * m[0] - 1) + m[0]) * m3 * esz)
             add("ipk_f", 2 * vol(m) * esz)
             add("ipk_c", 2 * vol(m) * esz)
-            add("ipk_r", 2 * vol(m) * esz + 4 * vol(m) * esz)  # r solves + the t solve with the add
+            add("ipk_r", 2 * vol(m) * esz)
+            add("ipk_t", 3 * vol(m) * esz)  # the t solve reads the correction and applies it to the coarse nodes
         return out
     for l in range(L, 0, -1):
         n = h.level_shape(l)
@@ -139,10 +140,11 @@ def cpu_baseline(u, tol, s, coords=None):
     out = {"value": u.nbytes / med / 1e9, "unit": "GB/s", "cores": cores, "kind": "port",
            "nproc": os.cpu_count(), "physical_cores": physical_cores(),
            "affinity_cpus": len(os.sched_getaffinity(0)),
-           "threads_note": "cores = OpenMP threads used = omp_get_max_threads() of this process (the "
-                           "OpenMP default: one per CPU of the process's affinity mask); nproc = "
-                           "logical CPUs of the host; physical_cores = distinct (socket, core) pairs "
-                           "of /proc/cpuinfo",
+           "threads_note": "cores = OpenMP threads used = omp_get_max_threads() of this process, which "
+                           "importing torch sets to one per PHYSICAL core (128 of the 256 logical CPUs on "
+                           "the MI355X hosts seen so far); nproc = logical CPUs of the host, "
+                           "physical_cores = distinct (socket, core) pairs of /proc/cpuinfo, "
+                           "affinity_cpus = CPUs this process may run on",
            "sample": "the same %s %s workload (norm+decompose+quantize): 1 warm-up, median of 5 "
                      "steps = %.2f s (min %.2f, max %.2f)"
                      % ("x".join(map(str, u.shape)), u.dtype.name, med, min(ts), max(ts))}

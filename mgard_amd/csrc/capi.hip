@@ -417,16 +417,18 @@ template <typename K> int allow_big_lds_once(K kernel, std::atomic<uint64_t> &do
 }
 
 // Thomas solve along `axis` of the compact (m[0], m[1], m[2]) box.
+// axis 0 only: `nbatch` boxes `batch_stride` elements apart in ONE launch (the slices of a 4-D level).
 template <typename T>
 int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt, T *add_to,
-               int sign, hipStream_t s) {
+               int sign, hipStream_t s, uint32_t nbatch = 1, size_t batch_stride = 0) {
+  if (nbatch > 1 && axis != 0) return fail(MGH_ERR_INVALID_ARGUMENT, "ipk_launch: batches along the slowest axis only");
   const uint32_t n = m[axis];
   static const char *names[3] = {"ipk_r", "ipk_c", "ipk_f"};
   const char *name = names[axis];
   // tile width (pencils per workgroup): whole pencils must fit in LDS; among the fitting
   // widths take the one that needs the fewest "rounds" of resident workgroups
   const size_t pencil_bytes = (size_t)(n + (axis == 2 && n % 2 == 0 ? 1 : 0)) * sizeof(T);
-  const uint32_t npencil = axis == 2 ? m[0] * m[1] : (axis == 1 ? m[0] * m[2] : m[1] * m[2]);
+  const uint32_t npencil = axis == 2 ? m[0] * m[1] : (axis == 1 ? m[0] * m[2] : nbatch * m[1] * m[2]);
   int best_w = 0;
   size_t best_rounds = ~(size_t)0;
   for (int w : {64, 48, 32, 16}) {
@@ -452,7 +454,7 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
   if constexpr (sizeof(T) == 4) {
     constexpr uint32_t U = 16, KR = 8;
     const uint32_t nb = n / U;
-    const size_t box_bytes = (size_t)m[0] * m[1] * m[2] * sizeof(T);
+    const size_t box_bytes = (nbatch > 1 ? nbatch * batch_stride : (size_t)m[0] * m[1] * m[2]) * sizeof(T);
     // (strided pencils: measured inside the step at 512^3, ipk_c 59 -> 52 us, ipk_r of
     // all levels 128 -> 103 us, but the contiguous solve 60 -> 65 us)
     const size_t min_rounds = axis == 2 ? 4 : 2;
@@ -488,7 +490,7 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
         size_t outer_stride, inner_stride, stride;
         if (axis == 2) { n_inner = npencil; outer_stride = 0; inner_stride = n; stride = 1; }
         else if (axis == 1) { n_inner = m[2]; outer_stride = (size_t)m[1] * m[2]; inner_stride = 1; stride = m[2]; }
-        else { n_inner = npencil; outer_stride = 0; inner_stride = 1; stride = (size_t)m[1] * m[2]; }
+        else { n_inner = m[1] * m[2]; outer_stride = batch_stride; inner_stride = 1; stride = (size_t)m[1] * m[2]; }
 #define MGH_STREAM(CONTIG, PD)                                                                \
   {                                                                                           \
     static std::atomic<uint64_t> once{0};                                                     \
@@ -520,9 +522,9 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
     });
   }
   if (axis != 2 && best_w) {
-    const uint32_t n_outer = axis == 1 ? m[0] : 1;
+    const uint32_t n_outer = axis == 1 ? m[0] : nbatch;
     const uint32_t n_inner = axis == 1 ? m[2] : m[1] * m[2];
-    const size_t outer_stride = (size_t)m[1] * m[2];
+    const size_t outer_stride = axis == 1 ? (size_t)m[1] * m[2] : batch_stride;
     const size_t stride = axis == 1 ? (size_t)m[2] : (size_t)m[1] * m[2];
     const size_t lds = best_w * pencil_bytes;
     const unsigned blocks = ((npencil + best_w - 1) / best_w + 7) / 8 * 8;  // XCD-contiguous tile ranges
@@ -542,6 +544,12 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
 #undef MGH_STRIDED
   }
   // pencils too long for LDS: one thread per pencil straight from global memory
+  if (nbatch > 1) {
+    for (uint32_t bi = 0; bi < nbatch; bi++)
+      TRY(ipk_launch<T>(h, axis, m, x + (size_t)bi * batch_stride, tt,
+                        add_to ? add_to + (size_t)bi * batch_stride : nullptr, sign, s));
+    return MGH_SUCCESS;
+  }
   const dim3 pb(64, 1, 1);
   if (axis == 2) {
     const dim3 g((m[1] + 63) / 64, m[0], 1);
@@ -1058,6 +1066,23 @@ int launch_fused4_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Fused4<T> &Q,
     return MGH_SUCCESS;
 }
 
+// D = 4: Thomas solve along t of the correction (m_t, M) with the result added to / subtracted
+// from the coarse array: short pencils go through registers (k_tsolve_apply), others through the
+// generic strided solve.
+template <typename T>
+int tsolve_apply(mgh_hierarchy *h, T *corr, T *coarse, size_t M, int m_t, size_t m_rc, size_t m_f,
+                 const T *tt, int sign, hipStream_t s) {
+  constexpr int MT = 9;
+  if (m_t <= MT) {
+    const unsigned blocks = (unsigned)std::min<size_t>((M + 255) / 256, (size_t)h->num_cu * 32);
+    return launch(h, "ipk_t", s, [&] {
+      k_tsolve_apply<T, MT><<<blocks, 256, 0, s>>>(corr, coarse, M, m_t, tt, sign);
+    });
+  }
+  const uint32_t m3t[3] = {(uint32_t)m_t, (uint32_t)m_rc, (uint32_t)m_f};
+  return ipk_launch<T>(h, 0, m3t, corr, tt, coarse, sign, s);
+}
+
 // D = 4 work arrays: compact nodal arrays of the levels below the top, per-slice load vectors
 // (padded positions of t) and the correction of the biggest coarse box
 template <typename T> int ensure_state4(mgh_hierarchy *h) {
@@ -1167,10 +1192,8 @@ int decompose_fused4(mgh_hierarchy *h, const T *data, T *coeff, const QuantParam
     const uint32_t m3a[3] = {(uint32_t)(m_t * Mc[1]), (uint32_t)Mc[2], (uint32_t)Mc[3]};
     TRY(ipk_launch<T>(h, 2, m3a, ds->corr4, ds->nd[l].thomas[3], nullptr, +1, s));
     TRY(ipk_launch<T>(h, 1, m3a, ds->corr4, ds->nd[l].thomas[2], nullptr, +1, s));
-    for (int t = 0; t < m_t; t++)
-      TRY(ipk_launch<T>(h, 0, b.m, ds->corr4 + (size_t)t * M, ds->nd[l].thomas[1], nullptr, +1, s));
-    const uint32_t m3t[3] = {(uint32_t)m_t, (uint32_t)(Mc[1] * Mc[2]), (uint32_t)Mc[3]};
-    TRY(ipk_launch<T>(h, 0, m3t, ds->corr4, ds->nd[l].thomas[0], ds->nodal4[l - 1], +1, s));
+    TRY(ipk_launch<T>(h, 0, b.m, ds->corr4, ds->nd[l].thomas[1], nullptr, +1, s, (uint32_t)m_t, M));
+    TRY((tsolve_apply<T>(h, ds->corr4, ds->nodal4[l - 1], M, m_t, Mc[1] * Mc[2], Mc[3], ds->nd[l].thomas[0], +1, s)));
     src = ds->nodal4[l - 1];
     sT = M;
     sI = (size_t)Mc[2] * Mc[3];
@@ -1660,10 +1683,8 @@ int recompose_levels4(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T>
     const uint32_t m3a[3] = {(uint32_t)(m_t * Mc[1]), (uint32_t)Mc[2], (uint32_t)Mc[3]};
     TRY(ipk_launch<T>(h, 2, m3a, ds->corr4, ds->nd[l].thomas[3], nullptr, +1, st));
     TRY(ipk_launch<T>(h, 1, m3a, ds->corr4, ds->nd[l].thomas[2], nullptr, +1, st));
-    for (int t = 0; t < m_t; t++)
-      TRY(ipk_launch<T>(h, 0, b.m, ds->corr4 + (size_t)t * M, ds->nd[l].thomas[1], nullptr, +1, st));
-    const uint32_t m3t[3] = {(uint32_t)m_t, (uint32_t)(Mc[1] * Mc[2]), (uint32_t)Mc[3]};
-    TRY(ipk_launch<T>(h, 0, m3t, ds->corr4, ds->nd[l].thomas[0], ds->nodal4[l - 1], -1, st));
+    TRY(ipk_launch<T>(h, 0, b.m, ds->corr4, ds->nd[l].thomas[1], nullptr, +1, st, (uint32_t)m_t, M));
+    TRY((tsolve_apply<T>(h, ds->corr4, ds->nodal4[l - 1], M, m_t, Mc[1] * Mc[2], Mc[3], ds->nd[l].thomas[0], -1, st)));
     // ---- node restore, slice by slice
     T *fine = (l == L) ? data : ds->nodal4[l];
     const size_t fT = (l == L) ? full[0] : (size_t)N[1] * N[2] * N[3];

@@ -731,27 +731,24 @@ k_head_out4(int m0, int m1, int m2, int m3, const T *__restrict__ nodal, FusedAr
     A.volume = A.qp[A.nlev];
   }
   const int total = m0 * m1 * m2 * m3;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    const int k = e % m3, j = (e / m3) % m2, i = (e / (m3 * m2)) % m1, t = e / (m3 * m2 * m1);
+  // (whole waves walk the loop together: the outlier slots of a wave come from ONE atomicAdd --
+  // at level 0 every value is out of the dictionary, and one atomic per value on the single
+  // counter costs ~11 ns each: 110 us for the 2 x 65^3 head of an 8 x 512^3 slab)
+  const int stride = gridDim.x * blockDim.x;
+  for (int e0 = blockIdx.x * blockDim.x; e0 < total; e0 += stride) {
+    const int e = e0 + (int)threadIdx.x;
+    const bool live = e < total;
+    const int ee = live ? e : 0;
+    const int k = ee % m3, j = (ee / m3) % m2, i = (ee / (m3 * m2)) % m1, t = ee / (m3 * m2 * m1);
     const size_t lin = (size_t)t * dT + (size_t)i * A.dI + (size_t)j * A.dJ + k;
-    const T v = nodal[e];
+    const T v = nodal[ee];
     if (OUT == OUT_T) {
-      A.coef[lin] = v;
+      if (live) A.coef[lin] = v;
     } else {
-      int64_t qd = quantize_one(v, A.quantizer, A.volume);
-      if (A.prep_huffman) {
-        qd += A.dict_size / 2;
-        if (!(qd >= 0 && qd < A.dict_size)) {
-          const unsigned long long o = atomicAdd(A.outlier_count, 1ULL);
-          if (o < A.outlier_cap) {
-            A.outlier_idx[o] = lin;
-            A.outlier_val[o] = qd;
-          }
-          qd = 0;
-        }
-      }
-      if (A.q16) A.q16[lin] = (uint16_t)qd;
-      else A.q[lin] = qd;
+      const T vv[1] = {v};
+      const size_t ll[1] = {lin};
+      const bool on[1] = {live};
+      emit_quantized<T, 1>(A, vv, ll, on);
     }
   }
 }
@@ -775,6 +772,51 @@ k_tsweep(const T *__restrict__ L, T *__restrict__ out, size_t M, int m_t, const 
       v[k] = (P >= 0 && P < np) ? L[(size_t)P * M + j] : (T)0;
     }
     out[(size_t)Tt * M + j] = mass_apply(v[0], v[1], v[2], v[3], v[4], w);
+  }
+}
+
+// D = 4: the Thomas solve along t -- pencils of m_t <= MT values, one per thread, entirely in
+// registers, every access coalesced across the threads -- with the correction applied to the
+// coarse array on the way out (AddND / SubtractND): out[t][j] +/-= solve(corr[.][j])[t].
+// tt = thomas table of dim t: [0,n) forward multiplier, [n,2n) am[i+1], [2n,3n) bm[i+1]
+// (IPKFunctor.h:127,147; same expressions, same order as thomas_lds).
+template <typename T, int MT>
+__global__ void __launch_bounds__(256)
+k_tsolve_apply(const T *__restrict__ corr, T *__restrict__ out, size_t M, int m_t,
+               const T *__restrict__ tt, int sign) {
+  T fw[MT], am[MT], bm[MT];
+#pragma unroll
+  for (int k = 0; k < MT; k++) {
+    const int kk = k < m_t ? k : 0;
+    fw[k] = tt[kk];
+    am[k] = tt[m_t + kk];
+    bm[k] = tt[2 * m_t + kk];
+  }
+  for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < M; j += (size_t)gridDim.x * 256) {
+    T x[MT], o[MT];
+#pragma unroll
+    for (int k = 0; k < MT; k++)
+      if (k < m_t) {
+        x[k] = corr[(size_t)k * M + j];
+        o[k] = out[(size_t)k * M + j];
+      }
+    T prev = 0;
+#pragma unroll
+    for (int k = 0; k < MT; k++)
+      if (k < m_t) {
+        x[k] = x[k] - prev * fw[k];
+        prev = x[k];
+      }
+    prev = 0;
+#pragma unroll
+    for (int k = MT - 1; k >= 0; k--)
+      if (k < m_t) {
+        x[k] = (x[k] - am[k] * prev) / bm[k];
+        prev = x[k];
+      }
+#pragma unroll
+    for (int k = 0; k < MT; k++)
+      if (k < m_t) out[(size_t)k * M + j] = sign > 0 ? o[k] + x[k] : o[k] - x[k];
   }
 }
 

@@ -645,3 +645,101 @@ def test_developer_switches_are_validated(monkeypatch):
         mg.Hierarchy((9, 9, 9), np.float32)
     monkeypatch.setenv("MGH_RCH", "2,3,8")
     mg.Hierarchy((9, 9, 9), np.float32).close()
+
+
+def _records_on_device(torch, stream, metadata_size):
+    """[(offset, size)] of the `[u64 size][payload]` records of a device-resident container."""
+    out, at, end = [], int(metadata_size), int(stream.numel())
+    while at < end:
+        size = int(np.frombuffer(stream[at:at + 8].cpu().numpy().tobytes(), dtype="<u8")[0])
+        out.append((at + 8, size))
+        at += 8 + size
+    assert at == end
+    return out
+
+
+def _config3_volume(torch, nt=64):
+    """64 x 512^3 f32 on the device: the 3-D field of the metric drifting slowly along dim 0
+    (what bench.py --config 4d uses per slab)."""
+    base = torch.from_numpy(smooth_field((512, 512, 512), np.float32)).cuda()
+    vol = torch.empty((nt, 512, 512, 512), dtype=torch.float32, device="cuda")
+    for t in range(nt):
+        vol[t] = base * (1.0 + 0.002 * t) + 1e-4 * t
+    return vol
+
+
+def test_config3_whole_volume_on_one_gpu():
+    """BASELINE.json configs[3] as ONE volume: 4-D 64 x 512^3 f32 (34 GB, device-resident), split
+    on dim 0 into the 8 slabs of 8 x 512^3 that the 8 ranks of the weak-scaling run own
+    (`Variable` decomposition, sizes {8} x 8: DomainDecomposer.hpp:199-230,260-303), REL bound
+    against the norm of the WHOLE volume (ErrorToleranceCalculator.hpp:69-89,134-155): eight
+    records behind one header (GPUPipelines.hpp:189-193), the round trip within tol * norm, and
+    every slab's record byte-identical to the record a stand-alone compression of that slab
+    writes under the ABS bound tol * norm -- i.e. the integers of a slab do not depend on whether
+    it is compressed as a subdomain or on its own rank."""
+    torch, mg, hl = _mods()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150e9:
+        pytest.skip("needs ~130 GB of device memory")
+    vol = _config3_volume(torch)
+    nbytes = vol.numel() * 4
+    cfg = hl.Config(domain_decomposition=hl.DD_VARIABLE, domain_decomposition_dim=0,
+                    domain_decomposition_sizes=[8] * 8)
+    obuf = torch.empty(nbytes // 2, dtype=torch.uint8, device="cuda")
+    stream = hl.compress(vol, 1e-3, np.inf, mg.REL, config=cfg, out=obuf)
+    meta = hl.metadata_parse(bytes(stream[:8192].cpu().numpy()))
+    assert meta["shape"] == [64, 512, 512, 512] and meta["domain_decomposed"] is True
+    assert meta["dd_method"] == hl.DD_VARIABLE and meta["dd_dim"] == 0
+    nrm = float(vol.abs().max().item())
+    assert np.float32(meta["norm"]) == np.float32(nrm)
+    recs = _records_on_device(torch, stream, meta["metadata_size"])
+    assert len(recs) == 8
+    assert stream.numel() < 0.5 * nbytes
+    # stand-alone slabs (what a rank of the 8-GPU run compresses after the norm all-reduce)
+    abs_tol = float(np.float32(1e-3) * np.float32(meta["norm"]))
+    for k in (0, 3, 7):
+        alone = hl.compress(vol[8 * k:8 * (k + 1)], abs_tol, np.inf, mg.ABS)
+        am = hl.metadata_parse(bytes(alone[:8192].cpu().numpy()))
+        (aoff, asize), = _records_on_device(torch, alone, am["metadata_size"])
+        off, size = recs[k]
+        assert size == asize and torch.equal(stream[off:off + size], alone[aoff:aoff + asize]), k
+        del alone
+    back = torch.empty_like(vol)
+    hl.decompress(stream, out=back)
+    err = max(float((back[t] - vol[t]).abs().max().item()) for t in range(64))
+    assert err <= 1e-3 * nrm
+    del back, vol, obuf
+    hl.release_cache()
+    torch.cuda.empty_cache()
+
+
+def test_config3_whole_volume_through_the_multi_device_api():
+    """The same volume through mgh_compress_multi / mgh_decompress_multi (one process, one host
+    thread per listed device; device 0 listed eight times on a one-GPU box): host buffers in and
+    out, 8 slabs of 8 x 512^3 behind one MaxDim header that the single-device reader opens too."""
+    torch, mg, hl = _mods()
+    import psutil
+    if psutil.virtual_memory().available < 160e9:
+        pytest.skip("needs ~110 GB of host memory")
+    vol = _config3_volume(torch)
+    nrm = float(vol.abs().max().item())
+    u = vol.cpu().numpy()
+    del vol
+    torch.cuda.empty_cache()
+    devs = (0,) * 8
+    buf = hl.compress_multi(u, 1e-3, np.inf, mg.REL, devices=devs)
+    meta = hl.metadata_parse(bytes(buf[:8192]))
+    assert meta["shape"] == [64, 512, 512, 512] and meta["domain_decomposed"] is True and meta["dd_size"] == 8
+    assert np.float32(meta["norm"]) == np.float32(nrm)
+    assert buf.size < 0.5 * u.nbytes
+    v = hl.decompress_multi(buf, devices=devs)
+    err = max(float(np.max(np.abs(v[t] - u[t]))) for t in range(64))
+    assert err <= 1e-3 * nrm
+    # the single-device reader on the same stream (device-resident out): identical reconstruction
+    back = torch.empty((64, 512, 512, 512), dtype=torch.float32, device="cuda")
+    hl.decompress(torch.from_numpy(np.ascontiguousarray(buf)).cuda(), out=back)
+    for t in (0, 31, 63):
+        assert np.array_equal(back[t].cpu().numpy(), v[t])
+    del back
+    hl.release_cache()
+    torch.cuda.empty_cache()
