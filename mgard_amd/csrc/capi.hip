@@ -1208,7 +1208,7 @@ int decompose_fused4(mgh_hierarchy *h, const T *data, T *coeff, const QuantParam
     const auto &M0 = sh[0];
     const size_t tot = (size_t)M0[0] * M0[1] * M0[2] * M0[3];
     TRY(launch(h, "head_out", s, [&] {
-      k_head_out4<T, OUT><<<(unsigned)std::min<size_t>((tot + 255) / 256, 1024), 256, 0, s>>>(
+      k_head_out4<T, OUT><<<(unsigned)std::min<size_t>((tot + 1023) / 1024, 1024), 1024, 0, s>>>(
           (int)M0[0], (int)M0[1], (int)M0[2], (int)M0[3], ds->nodal4[0], A, full[0]);
     }));
   }

@@ -724,17 +724,21 @@ k_level_fused2(FusedArgs<T> A, Fused2Grid G, Fused4<T> Q) {
 // D = 4: quantize (or copy) the level-0 nodal values (compact (m0, m1, m2, m3)) into the head of
 // the output; dT = element stride of t in the output array.
 template <typename T, int OUT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_head_out4(int m0, int m1, int m2, int m3, const T *__restrict__ nodal, FusedArgs<T> A, size_t dT) {
   if ((OUT == OUT_Q || OUT == OUT_QH) && A.qp) {
     A.quantizer = A.qp[0];
     A.volume = A.qp[A.nlev];
   }
+  __shared__ unsigned wcnt[16];
+  __shared__ unsigned long long gbase;
   const int total = m0 * m1 * m2 * m3;
-  // (whole waves walk the loop together: the outlier slots of a wave come from ONE atomicAdd --
-  // at level 0 every value is out of the dictionary, and one atomic per value on the single
-  // counter costs ~11 ns each: 110 us for the 2 x 65^3 head of an 8 x 512^3 slab)
+  // At level 0 every value is out of the dictionary, and the slots of the one outlier list come
+  // from an atomicAdd on ONE address (~11 ns each once they queue): a whole 1024-thread workgroup
+  // asks once per round -- 2 x 65^3 values of an 8 x 512^3 slab: 110 us with one atomic per value
+  // or per wave, a few us like this.
   const int stride = gridDim.x * blockDim.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
   for (int e0 = blockIdx.x * blockDim.x; e0 < total; e0 += stride) {
     const int e = e0 + (int)threadIdx.x;
     const bool live = e < total;
@@ -745,10 +749,38 @@ k_head_out4(int m0, int m1, int m2, int m3, const T *__restrict__ nodal, FusedAr
     if (OUT == OUT_T) {
       if (live) A.coef[lin] = v;
     } else {
-      const T vv[1] = {v};
-      const size_t ll[1] = {lin};
-      const bool on[1] = {live};
-      emit_quantized<T, 1>(A, vv, ll, on);
+      int64_t qd = quantize_one(v, A.quantizer, A.volume);
+      bool ol = false;
+      if (A.prep_huffman) {
+        qd += A.dict_size / 2;
+        ol = live && !(qd >= 0 && qd < A.dict_size);
+      }
+      const unsigned long long mask = __ballot(ol);
+      if (lane == 0) wcnt[wave] = (unsigned)__popcll(mask);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        unsigned tot = 0;
+        for (int w = 0; w < nwave; w++) {
+          const unsigned c = wcnt[w];
+          wcnt[w] = tot;
+          tot += c;
+        }
+        gbase = tot ? atomicAdd(A.outlier_count, (unsigned long long)tot) : 0ull;
+      }
+      __syncthreads();
+      if (ol) {
+        const unsigned long long o = gbase + wcnt[wave] + __popcll(mask & ((1ULL << lane) - 1ULL));
+        if (o < A.outlier_cap) {
+          A.outlier_idx[o] = lin;
+          A.outlier_val[o] = qd;
+        }
+        qd = 0;
+      }
+      if (live) {
+        if (A.q16) A.q16[lin] = (uint16_t)qd;
+        else A.q[lin] = qd;
+      }
+      __syncthreads();  // (wcnt / gbase are rewritten by the next round)
     }
   }
 }

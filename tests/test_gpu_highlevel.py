@@ -419,6 +419,13 @@ def test_alternative_kernels_give_the_same_result():
     assert run({"MGH_FUSED_WIDE": "0", "MGH_FUSED_FIXED": "0", "MGH_RCH": "2,3,8"}) == ref
     assert run({"MGH_FUSED_WIDE": "2", "MGH_FUSED_XCD": "0", "MGH_FUSED_FACES": "0", "MGH_IPK_STREAM": "0"}) == ref
     assert run({"MGH_FUSED_V": "1", "MGH_FUSED4": "0", "MGH_IPK_W": "32"}) == ref
+    # round 3: no box kernel / box kernel on every level, tail kernel without the solves of the
+    # level above it, the slab schedule (passes in r-slabs, f- and c-solves on a second stream),
+    # other residency plans of the streaming Thomas solves
+    assert run({"MGH_BOX": "0", "MGH_TAIL_SOLVES": "0"}) == ref
+    assert run({"MGH_BOX": "3", "MGH_IPK_WPC": "16"}) == ref
+    assert run({"MGH_SLABS": "3", "MGH_SLABS_MIN": "0", "MGH_IPK_WPC": "2"}) == ref
+    assert run({"MGH_SLABS": "2", "MGH_SLABS_MIN": "0", "MGH_IPK_SLAB": "0", "MGH_SLAB_PRIO": "0"}) == ref
 
 
 def test_incompressible_subdomain_is_stored_raw():
@@ -658,6 +665,21 @@ def _records_on_device(torch, stream, metadata_size):
     return out
 
 
+def _outlier_tail(rec):
+    """Byte offset of outlier_idx[] in a serialized Huffman record held in a device tensor (layout:
+    Huffman.hpp:163-239; every field is 8-byte aligned): what lies before it -- counts, chunk
+    table, decodebook, code units, outlier_count -- is a function of the integers alone."""
+    def u64(at):
+        return int(np.frombuffer(rec[at:at + 8].cpu().numpy().tobytes(), dtype="<u8")[0])
+    hm = u64(16)
+    p = 24 + 8 * hm
+    p += 8 + u64(p)          # decodebook
+    p += 8 + 8 * u64(p)      # code units
+    count = u64(p)
+    assert p + 8 + 16 * count == rec.numel()
+    return p + 8
+
+
 def _config3_volume(torch, nt=64):
     """64 x 512^3 f32 on the device: the 3-D field of the metric drifting slowly along dim 0
     (what bench.py --config 4d uses per slab)."""
@@ -702,8 +724,19 @@ def test_config3_whole_volume_on_one_gpu():
         am = hl.metadata_parse(bytes(alone[:8192].cpu().numpy()))
         (aoff, asize), = _records_on_device(torch, alone, am["metadata_size"])
         off, size = recs[k]
-        assert size == asize and torch.equal(stream[off:off + size], alone[aoff:aoff + asize]), k
-        del alone
+        assert size == asize
+        # identical integers = identical Huffman part of the record (counts, code book, code
+        # stream); the outlier list is in atomic order and is compared as a set
+        ra, rb = stream[off:off + size].clone(), alone[aoff:aoff + asize].clone()
+        tail_a, tail_b = _outlier_tail(ra), _outlier_tail(rb)
+        assert tail_a == tail_b
+        assert torch.equal(ra[:tail_a], rb[:tail_b]), k
+        na = (size - tail_a) // 16
+        ia, va = ra[tail_a:tail_a + 8 * na].view(torch.int64), ra[tail_a + 8 * na:].view(torch.int64)
+        ib, vb = rb[tail_b:tail_b + 8 * na].view(torch.int64), rb[tail_b + 8 * na:].view(torch.int64)
+        oa, ob = torch.argsort(ia), torch.argsort(ib)
+        assert torch.equal(ia[oa], ib[ob]) and torch.equal(va[oa], vb[ob]), k
+        del alone, ra, rb
     back = torch.empty_like(vol)
     hl.decompress(stream, out=back)
     err = max(float((back[t] - vol[t]).abs().max().item()) for t in range(64))
