@@ -105,6 +105,7 @@ struct mgh_hierarchy {
   int rch[3] = {1, 4, 16};         // MGH_RCH=a,b,c: coarse planes per workgroup of the three classes
   uint32_t ipk_w = 64;             // MGH_IPK_W: widest solver wave of the streaming Thomas solves
   int ipk_pd = 1;                  // MGH_IPK_PD: their load-pipeline depth
+  size_t ipk_contig_rounds = 4;    // MGH_IPK_CONTIG: rounds of the LDS-staged contiguous solve from which the streaming one takes over
   size_t ipk_wpc = 8;              // MGH_IPK_WPC: most one-wave solver workgroups per CU the host plans with
   bool split_serial = false;       // MGH_SPLIT_SERIAL
   bool no_head = false;            // MGH_NO_RECOMPOSE_HEAD
@@ -443,7 +444,7 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
       best_w = w;
     }
   }
-  // Streaming solves (float): every wave a solver, forward results parked in registers + LDS +
+  // Streaming solves: every wave a solver, forward results parked in registers + LDS +
   // (the leading n_glob elements) in place in global memory. Where the forward results are parked
   // decides how many pencils a CU works on at once, and residency is the throughput of these
   // latency-bound chains: the host picks the tile width W and n_glob that need the FEWEST rounds
@@ -451,13 +452,14 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
   // parking. Used when the LDS-staged tiles need more than one round (strided pencils), or --
   // contiguous pencils, where the LDS-staged kernel is the better one at one or two rounds --
   // from four rounds on (1024^3: 2 KB pencils leave ONE staged tile per CU, 16 rounds).
-  if constexpr (sizeof(T) == 4) {
-    constexpr uint32_t U = 16, KR = 8;
+  {
+    // batches of 64 bytes per lane: 16 floats / 8 doubles; the last KR batches stay in registers
+    constexpr uint32_t U = sizeof(T) == 4 ? 16 : 8, KR = 8;
     const uint32_t nb = n / U;
     const size_t box_bytes = (nbatch > 1 ? nbatch * batch_stride : (size_t)m[0] * m[1] * m[2]) * sizeof(T);
     // (strided pencils: measured inside the step at 512^3, ipk_c 59 -> 52 us, ipk_r of
     // all levels 128 -> 103 us, but the contiguous solve 60 -> 65 us)
-    const size_t min_rounds = axis == 2 ? 4 : 2;
+    const size_t min_rounds = axis == 2 ? h->ipk_contig_rounds : 2;
     if (h->ipk_stream && best_w && best_rounds >= min_rounds && nb >= KR &&
         box_bytes < ((size_t)1 << 32)) {
       const uint32_t parked = (nb - KR) * U;  // elements per pencil outside the registers
@@ -467,7 +469,8 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
       for (uint32_t ng = 0; ng <= parked; ng += U) {
         for (uint32_t w : {64u, 60u, 56u, 48u, 40u, 32u, 24u, 16u}) {
           if (w > w_max) continue;
-          const size_t lds = (size_t)w * (parked - ng) * sizeof(T);
+          const size_t lds = (size_t)w * (parked - ng) * sizeof(T) +
+                             (axis == 2 ? TileIO<T, U>::stage_elems * sizeof(T) : 0);
           if (h->solve_max_lds && lds > h->solve_max_lds) continue;
           // 116 VGPRs: four waves per SIMD = 16 one-wave workgroups per CU at most
           // (five 32 KB allocations do not fit one CU although 5 * 32 KB = 160 KB: leave a margin)
@@ -484,7 +487,9 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
         if (w_rounds == 1) break;
       }
       if (W && w_rounds < best_rounds) {
-        const size_t lds = (size_t)W * (parked - n_glob) * sizeof(T);
+        // (contiguous pencils: + the staging area of the wave-cooperative loads and stores)
+        const size_t lds = (size_t)W * (parked - n_glob) * sizeof(T) +
+                           (axis == 2 ? TileIO<T, U>::stage_elems * sizeof(T) : 0);
         const unsigned blocks = ((npencil + W - 1) / W + 7) / 8 * 8;
         uint32_t n_inner;
         size_t outer_stride, inner_stride, stride;
@@ -2077,6 +2082,7 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->ipk_w = (uint32_t)env_get("MGH_IPK_W", h->ipk_w);
     h->ipk_pd = (int)env_get("MGH_IPK_PD", h->ipk_pd);
     h->ipk_wpc = (size_t)env_get("MGH_IPK_WPC", (long)h->ipk_wpc);
+    h->ipk_contig_rounds = (size_t)env_get("MGH_IPK_CONTIG", (long)h->ipk_contig_rounds);
     h->split_serial = env_get("MGH_SPLIT_SERIAL", 0) != 0;
     h->no_head = env_get("MGH_NO_RECOMPOSE_HEAD", 0) != 0;
     h->restore_rows = env_get("MGH_RESTORE_ROWS", 0) != 0;

@@ -30,7 +30,7 @@ inline const EnvSwitch *env_switches(size_t *count) {
       {"MGH_HUFF_PAR_DECODE", 0, 1}, {"MGH_SYM16_DECODE", 0, 1},   {"MGH_SLABS", 0, 64},
       {"MGH_SLABS_MIN", 0, 1 << 30}, {"MGH_BOX", 0, 3},            {"MGH_IPK_SLAB", 0, 1},
       {"MGH_SLAB_PRIO", 0, 1},      {"MGH_IPK_WPC", 1, 16},
-      {"MGH_TAIL_SOLVES", 0, 1},
+      {"MGH_TAIL_SOLVES", 0, 1},    {"MGH_IPK_CONTIG", 2, 1 << 20},
   };
   *count = sizeof(k) / sizeof(k[0]);
   return k;

@@ -738,7 +738,9 @@ def test_config3_whole_volume_on_one_gpu():
         assert torch.equal(ia[oa], ib[ob]) and torch.equal(va[oa], vb[ob]), k
         del alone, ra, rb
     back = torch.empty_like(vol)
-    hl.decompress(stream, out=back)
+    # (a Variable decomposition is not recorded in the header -- reference and here alike: the
+    # reader is given the sizes the writer used)
+    hl.decompress(stream, out=back, config=cfg)
     err = max(float((back[t] - vol[t]).abs().max().item()) for t in range(64))
     assert err <= 1e-3 * nrm
     del back, vol, obuf
