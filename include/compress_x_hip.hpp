@@ -78,6 +78,9 @@ struct Config {
   int log_level = log::ERR;
   bool prefetch = false;
   bool auto_pin_host_buffers = false;  // (reference: true -- see the header comment)
+  // (not a field of the reference's Config) decompress a non-uniform grid with the coordinates
+  // rounded through (float) first, as stock MGARD-X does (CompressionHighLevel.hpp:455-462)
+  bool mirror_reference_coord_cast = false;
   SIZE max_larget_level = std::numeric_limits<SIZE>::max();
   SIZE max_memory_footprint = std::numeric_limits<SIZE>::max();
   SIZE total_num_bitplanes = 32;
@@ -134,6 +137,7 @@ inline mgh_config to_c(const Config &c) {
   m.max_memory_footprint = c.max_memory_footprint;
   m.auto_pin_host_buffers = c.auto_pin_host_buffers ? 1 : 0;
   m.reorder = c.reorder;
+  m.mirror_reference_coord_cast = c.mirror_reference_coord_cast ? 1 : 0;
   return m;
 }
 } // namespace detail

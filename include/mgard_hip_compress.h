@@ -72,6 +72,9 @@ typedef struct mgh_config {
   int auto_pin_host_buffers; /* default 0 here (reference: 1), see mgh_config_default */
   int reorder;               /* 0 (default): quantized integers in the N-D layout; 1: level by level
                                 (Config::reorder, LinearQuantization.hpp:46-146) -- recorded in the header */
+  int mirror_reference_coord_cast; /* decompression of a NON-uniform grid: 1 = coordinates through (float)
+                                first, as the reference does even for double data
+                                (CompressionHighLevel.hpp:455-462); 0 (default) = at full precision */
 } mgh_config;
 
 void mgh_config_default(mgh_config *config);

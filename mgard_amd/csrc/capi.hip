@@ -29,6 +29,7 @@
 #include "kernels_emit.hpp"
 #include "kernels_tail.hpp"
 #include "kernels_recompose.hpp"
+#include "kernels_recompose2.hpp"
 #include "kernels_nd.hpp"
 
 namespace {
@@ -99,6 +100,13 @@ struct mgh_hierarchy {
   // the box kernel (kernels_box.hpp: no march, every phase once over a 4 x 4 x 8 box) instead of
   // the marching tile kernel; 0 = none, 1 = class 0 (default), 2 = classes 0-1, 3 = every level
   int box = 1;
+  int restore_v = 3;  // MGH_RESTORE_V: 3 = marching node restore (kernels_recompose2.hpp), 2 = one wave per pair of fine rows
+  int loadvec_wide = 0;  // MGH_LOADVEC_WIDE: 4 x 64 tiles for the long marches of the load-vector pass
+  // MGH_LOADVEC_V: 1 = first-generation load-vector pass of the decompression side (default),
+  // 2 = the pair-step rebuild (kernels_recompose2.hpp; measured the same at the top level of 512^3,
+  // 302 vs 308 us, and slower on the short marches, 122 vs 112 us: the pass is bound by neither its
+  // barriers nor its predicated loads)
+  int loadvec_v = 1;
   int tail_solves = 1;  // MGH_TAIL_SOLVES: the tail kernel runs the Thomas solves of the level above it
   // (the rest of the developer switches, env.hpp; all read when the hierarchy is created)
   size_t cls1 = 256, cls2 = 2048;  // MGH_CLS1 / MGH_CLS2: tile-count thresholds of the march classes
@@ -1520,6 +1528,72 @@ int recompose_impl(mgh_hierarchy *h, const T *coeff, T *data, hipStream_t s) {
 // from the coarse nodes, and the node restore with the dequantizer fused in
 // (Compressor::Decompress lines 256-257 = Dequantize + Recompose). With QT = T the same level
 // loop runs on floating-point coefficients (Compressor::Recompose on its own).
+// Node restore of one level (or one t-slice of a 4-D level): the marching kernel
+// (kernels_recompose2.hpp), or the row-pair / row kernels of kernels_recompose.hpp
+// (MGH_RESTORE_V=2, MGH_RESTORE_ROWS=1: cross-checks).
+template <typename T, typename QT, bool TODD>
+int launch_restore(mgh_hierarchy *h, const RecomposeArgs<T> &A, const Box3 &b, const char *nm, hipStream_t st) {
+  if (h->restore_v == 3 && !h->restore_rows) {
+    constexpr int TC = 4, TF = 64;
+    Restore3Grid G{};
+    G.gxm = ((int)b.m[2] + TF - 1) / TF;
+    G.ntile = G.gxm * (((int)b.m[1] + TC - 1) / TC);
+    // chunk length: long marches where there are plenty of tiles, short ones (more workgroups)
+    // on the small levels -- a chunk costs one extra coarse plane of interpolants only
+    const int want = 2048;
+    G.rch = std::max(1, std::min(16, (int)((int64_t)b.m[0] * G.ntile / want)));
+    G.nchunk = ((int)b.m[0] + G.rch - 1) / G.rch;
+    const dim3 grid((unsigned)G.ntile, (unsigned)G.nchunk, 1);
+    return launch(h, nm, st, [&] { k_level_restore3_q<T, QT, TODD, TC, TF><<<grid, TC * TF, 0, st>>>(A, G); });
+  }
+  const dim3 blk(64, 4, 1);
+  if (h->restore_rows && !TODD)
+    return launch(h, nm, st, [&] {
+      k_level_restore_q<T, QT><<<dim3(1, (b.n[1] + 3) / 4, b.n[0]), blk, 0, st>>>(A);
+    });
+  const dim3 grid(1, ((b.n[1] + 1) / 2 + 3) / 4, b.n[0]);
+  return launch(h, nm, st, [&] { k_level_restore2_q<T, QT, TODD><<<grid, blk, 0, st>>>(A); });
+}
+
+// Load-vector pass of the decompression side (one level, or one t-slice of a 4-D level):
+// second-generation kernel (kernels_recompose2.hpp) with the tile shapes / chunk lengths of the
+// compression side's level kernel, or (MGH_LOADVEC_V=1: cross-check) the first-generation one.
+template <typename T, typename QT>
+int launch_loadvec(mgh_hierarchy *h, const RecomposeArgs<T> &A, const Box3 &b, hipStream_t st) {
+  constexpr int TC = 8, TF = 32;
+  const unsigned gx = (b.m[2] + TF - 1) / TF, gy = (b.m[1] + TC - 1) / TC;
+  if (h->loadvec_v == 2) {
+    const int cls = level_class(h, b);
+    const char *nm = cls == 2 ? "loadvec_q" : "loadvec_q_small";
+    Loadvec2Grid G{};
+    G.rch = fused_rch(h, cls);
+    G.nchunk = fused_nchunk((int)b.m[0], G.rch);
+    G.xcd_ranges = h->fused_xcd;
+    // (8 x 32 tiles unless MGH_LOADVEC_WIDE=1: the window holds 8-byte values here, and the
+    // 1.41 x halo of a 4 x 64 tile costs more than its longer rows save)
+    const bool wide = h->loadvec_wide && cls == 2;
+    const int tc = wide ? 4 : 8, tf = wide ? 64 : 32;
+    G.gxm = ((int)b.m[2] + tf - 1) / tf;
+    G.ntile = G.gxm * (((int)b.m[1] + tc - 1) / tc);
+    const dim3 grid(G.xcd_ranges ? (unsigned)(G.ntile + 7) / 8 * 8 : (unsigned)G.ntile, (unsigned)G.nchunk, 1);
+    return launch(h, nm, st, [&] {
+      if (wide) k_level_loadvec2_q<T, QT, 4, 64, 16><<<grid, 256, 0, st>>>(A, G);
+      else k_level_loadvec2_q<T, QT, 8, 32, 16><<<grid, 256, 0, st>>>(A, G);
+    });
+  }
+  if ((size_t)gx * gy * ((b.m[0] + 15) / 16) >= 2048)
+    return launch(h, "loadvec_q", st, [&] {
+      k_level_loadvec_q<T, QT, TC, TF, 16><<<dim3(gx, gy, (b.m[0] + 15) / 16), 256, 0, st>>>(A);
+    });
+  if ((size_t)gx * gy * ((b.m[0] + 3) / 4) >= 256)
+    return launch(h, "loadvec_q_small", st, [&] {
+      k_level_loadvec_q<T, QT, TC, TF, 4><<<dim3(gx, gy, (b.m[0] + 3) / 4), 256, 0, st>>>(A);
+    });
+  return launch(h, "loadvec_q_small", st, [&] {
+    k_level_loadvec_q<T, QT, TC, TF, 1><<<dim3(gx, gy, b.m[0]), 256, 0, st>>>(A);
+  });
+}
+
 template <typename T, typename QT>
 int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> &level_qv, T *data,
                      hipStream_t st) {
@@ -1566,7 +1640,6 @@ int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> 
       k_head_in_q<T, QT><<<1, 256, 0, st>>>((int)b.m[0], (int)b.m[1], (int)b.m[2], A, ds->nodal[0]);
     }));
   }
-  constexpr int TC = 8, TF = 32;
   for (int l = l_head + 1; l <= L; l++) {
     const LevelTables<T> &t = ds->lt[l];
     const Box3 &b = t.box;
@@ -1579,35 +1652,13 @@ int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> 
     A.qv = level_qv[l];
     A.load = ds->t3;
     A.coarse = ds->nodal[l - 1];
-    const unsigned gx = (b.m[2] + TF - 1) / TF, gy = (b.m[1] + TC - 1) / TC;
-    if ((size_t)gx * gy * ((b.m[0] + 15) / 16) >= 2048) {
-      TRY(launch(h, "loadvec_q", st, [&] {
-        k_level_loadvec_q<T, QT, TC, TF, 16><<<dim3(gx, gy, (b.m[0] + 15) / 16), 256, 0, st>>>(A);
-      }));
-    } else if ((size_t)gx * gy * ((b.m[0] + 3) / 4) >= 256) {
-      TRY(launch(h, "loadvec_q_small", st, [&] {
-        k_level_loadvec_q<T, QT, TC, TF, 4><<<dim3(gx, gy, (b.m[0] + 3) / 4), 256, 0, st>>>(A);
-      }));
-    } else {
-      TRY(launch(h, "loadvec_q_small", st, [&] {
-        k_level_loadvec_q<T, QT, TC, TF, 1><<<dim3(gx, gy, b.m[0]), 256, 0, st>>>(A);
-      }));
-    }
+    TRY((launch_loadvec<T, QT>(h, A, b, st)));
     TRY(ipk_fc_launch<T>(h, b.m, ds->t3, t.thomas[2], t.thomas[1], st));
     TRY(ipk_launch<T>(h, 0, b.m, ds->t3, t.thomas[0], ds->nodal[l - 1], -1, st));
     A.fine = (l == L) ? data : ds->nodal[l];
     A.fJ = (l == L) ? ds->full_J : b.n[2];
     A.fI = (l == L) ? ds->full_I : (size_t)b.n[1] * b.n[2];
-    const dim3 blk(64, 4, 1);
-    TRY(launch(h, "restore_q", st, [&] {
-      // one 64-lane wave per PAIR of fine rows, 4 pairs per block (MGH_RESTORE_ROWS=1: one row
-      // per wave, the previous kernel: cross-check)
-      const bool single = h->restore_rows;
-      if (single)
-        k_level_restore_q<T, QT><<<dim3(1, (b.n[1] + 3) / 4, b.n[0]), blk, 0, st>>>(A);
-      else
-        k_level_restore2_q<T, QT><<<dim3(1, ((b.n[1] + 1) / 2 + 3) / 4, b.n[0]), blk, 0, st>>>(A);
-    }));
+    TRY((launch_restore<T, QT, false>(h, A, b, "restore_q", st)));
   }
   return MGH_SUCCESS;
 }
@@ -1637,7 +1688,6 @@ int recompose_levels4(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T>
           (int)M0[0], (int)M0[1], (int)M0[2], (int)M0[3], A, full[0], ds->nodal4[0]);
     }));
   }
-  constexpr int TC = 8, TF = 32;
   for (int l = 1; l <= L; l++) {
     const auto &N = sh[l], &Mc = sh[l - 1];
     Box3 b;
@@ -1654,7 +1704,6 @@ int recompose_levels4(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T>
     const size_t M = (size_t)Mc[1] * Mc[2] * Mc[3];
     const int n_t = (int)N[0], m_t = (int)Mc[0];
     // ---- load vectors of the padded t positions
-    const unsigned gx = (b.m[2] + TF - 1) / TF, gy = (b.m[1] + TC - 1) / TC;
     for (int P = 0; P <= 2 * m_t - 2; P++) {
       if (n_t % 2 == 0 && P == n_t - 1) {  // ghost slice
         HIP_TRY(hipMemsetAsync(ds->load4 + (size_t)P * M, 0, M * sizeof(T), st));
@@ -1663,19 +1712,7 @@ int recompose_levels4(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T>
       A.allcoef = P & 1;
       A.lin_base = (size_t)((P & 1) ? m_t + (P - 1) / 2 : P / 2) * full[0];
       A.load = ds->load4 + (size_t)P * M;
-      if ((size_t)gx * gy * ((b.m[0] + 15) / 16) >= 2048) {
-        TRY(launch(h, "loadvec_q", st, [&] {
-          k_level_loadvec_q<T, QT, TC, TF, 16><<<dim3(gx, gy, (b.m[0] + 15) / 16), 256, 0, st>>>(A);
-        }));
-      } else if ((size_t)gx * gy * ((b.m[0] + 3) / 4) >= 256) {
-        TRY(launch(h, "loadvec_q_small", st, [&] {
-          k_level_loadvec_q<T, QT, TC, TF, 4><<<dim3(gx, gy, (b.m[0] + 3) / 4), 256, 0, st>>>(A);
-        }));
-      } else {
-        TRY(launch(h, "loadvec_q_small", st, [&] {
-          k_level_loadvec_q<T, QT, TC, TF, 1><<<dim3(gx, gy, b.m[0]), 256, 0, st>>>(A);
-        }));
-      }
+      TRY((launch_loadvec<T, QT>(h, A, b, st)));
     }
     A.allcoef = 0;
     // ---- t-sweep, Thomas solves f, c, r, t; the last one subtracts from the coarse nodes
@@ -1695,8 +1732,6 @@ int recompose_levels4(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T>
     const size_t fT = (l == L) ? full[0] : (size_t)N[1] * N[2] * N[3];
     A.fI = (l == L) ? full[1] : (size_t)N[2] * N[3];
     A.fJ = (l == L) ? full[2] : (size_t)N[3];
-    const dim3 blk(64, 4, 1);
-    const dim3 grid(1, ((b.n[1] + 1) / 2 + 3) / 4, b.n[0]);
     for (int tp = 0; tp < n_t; tp++) {
       const bool last_even = n_t % 2 == 0 && tp == n_t - 1;  // the real last node: coarse m_t - 1
       A.fine = fine + (size_t)tp * fT;
@@ -1704,14 +1739,14 @@ int recompose_levels4(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T>
         const int zi = last_even ? m_t - 1 : tp / 2;
         A.coarse = ds->nodal4[l - 1] + (size_t)zi * M;
         A.lin_base = (size_t)zi * full[0];
-        TRY(launch(h, "restore_q", st, [&] { k_level_restore2_q<T, QT, false><<<grid, blk, 0, st>>>(A); }));
+        TRY((launch_restore<T, QT, false>(h, A, b, "restore_q", st)));
       } else {
         const int zi = (tp - 1) / 2;
         A.coarse = ds->nodal4[l - 1] + (size_t)zi * M;
         A.coarse_b = ds->nodal4[l - 1] + (size_t)(zi + 1) * M;
         A.tpos = tp;
         A.lin_base = (size_t)(m_t + zi) * full[0];
-        TRY(launch(h, "restore_q_odd", st, [&] { k_level_restore2_q<T, QT, true><<<grid, blk, 0, st>>>(A); }));
+        TRY((launch_restore<T, QT, true>(h, A, b, "restore_q_odd", st)));
       }
     }
     A.lin_base = 0;
@@ -2072,6 +2107,9 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->emit_cch = (unsigned)env_get("MGH_EMIT_CCH", h->emit_cch);
     h->slabs = (int)env_get("MGH_SLABS", h->slabs);
     h->box = (int)env_get("MGH_BOX", h->box);
+    h->loadvec_v = (int)env_get("MGH_LOADVEC_V", h->loadvec_v);
+    h->loadvec_wide = (int)env_get("MGH_LOADVEC_WIDE", h->loadvec_wide);
+    h->restore_v = (int)env_get("MGH_RESTORE_V", h->restore_v);
     h->tail_solves = (int)env_get("MGH_TAIL_SOLVES", h->tail_solves);
     h->slabs_min = (uint64_t)env_get("MGH_SLABS_MIN", (long)h->slabs_min);
     h->ipk_slab = (int)env_get("MGH_IPK_SLAB", h->ipk_slab);

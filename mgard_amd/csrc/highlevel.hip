@@ -1503,6 +1503,17 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
     local_eb = MGH_ABS;
   }
   const std::vector<std::vector<double>> *cptr = hd.uniform ? nullptr : &hd.coords;
+  // The reference rebuilds the coordinates of a non-uniform grid through `(float)` when it
+  // decompresses, for double data as well (CompressionHighLevel.hpp:455-462). Mirrored on request
+  // only: with it an f64 non-uniform stream reconstructs exactly like stock MGARD-X does, without
+  // it the coordinates the compressor used are taken at full precision.
+  std::vector<std::vector<double>> coords_f32;
+  if (cptr && cfg.mirror_reference_coord_cast) {
+    coords_f32 = hd.coords;
+    for (auto &c : coords_f32)
+      for (double &x : c) x = (double)(float)x;
+    cptr = &coords_f32;
+  }
   size_t byte_offset = meta_size;
   hipStream_t st = g_cache.streams[0];
   for (uint64_t id = 0; id < dd.num; id++) {
@@ -1607,6 +1618,7 @@ void mgh_config_default(mgh_config *c) {
   c->max_larget_level = std::numeric_limits<uint64_t>::max();
   c->max_memory_footprint = std::numeric_limits<uint64_t>::max();
   c->reorder = 0;
+  c->mirror_reference_coord_cast = 0;
   // The reference defaults to true. Here it is opt-in: on ROCm 7.0 registering and unregistering
   // caller memory (hipHostRegister / hipHostUnregister) was observed to leave the runtime
   // treating later allocations at the same addresses as pinned -- a copy into such a buffer

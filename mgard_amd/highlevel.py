@@ -45,6 +45,7 @@ class Config(C.Structure):
         ("max_memory_footprint", C.c_uint64),
         ("auto_pin_host_buffers", C.c_int),
         ("reorder", C.c_int),
+        ("mirror_reference_coord_cast", C.c_int),
     ]
 
     def __init__(self, **kw):

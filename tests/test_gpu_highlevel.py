@@ -422,7 +422,8 @@ def test_alternative_kernels_give_the_same_result():
     # round 3: no box kernel / box kernel on every level, tail kernel without the solves of the
     # level above it, the slab schedule (passes in r-slabs, f- and c-solves on a second stream),
     # other residency plans of the streaming Thomas solves
-    assert run({"MGH_BOX": "0", "MGH_TAIL_SOLVES": "0"}) == ref
+    assert run({"MGH_BOX": "0", "MGH_TAIL_SOLVES": "0", "MGH_LOADVEC_V": "2", "MGH_RESTORE_V": "2"}) == ref
+    assert run({"MGH_LOADVEC_V": "2", "MGH_LOADVEC_WIDE": "1", "MGH_IPK_CONTIG": "2"}) == ref
     assert run({"MGH_BOX": "3", "MGH_IPK_WPC": "16"}) == ref
     assert run({"MGH_SLABS": "3", "MGH_SLABS_MIN": "0", "MGH_IPK_WPC": "2"}) == ref
     assert run({"MGH_SLABS": "2", "MGH_SLABS_MIN": "0", "MGH_IPK_SLAB": "0", "MGH_SLAB_PRIO": "0"}) == ref
@@ -778,3 +779,30 @@ def test_config3_whole_volume_through_the_multi_device_api():
     del back
     hl.release_cache()
     torch.cuda.empty_cache()
+
+
+def test_mirror_reference_coord_cast_switch():
+    """Config.mirror_reference_coord_cast: stock MGARD-X rebuilds the coordinates of a non-uniform
+    grid through `(float)` when it decompresses, even for double data
+    (CompressionHighLevel.hpp:455-462). With the switch mgh_decompress reconstructs on exactly that
+    grid -- equal to the low-level dequantize + recompose on a hierarchy built from the
+    float-rounded coordinates --, without it on the coordinates the compressor used."""
+    torch, mg, hl = _mods()
+    shape, dt = (33, 40, 65), np.float64
+    u = smooth_field(shape, dt)
+    coords = nonuniform_coords(shape, dt)
+    buf = hl.compress(u, 1e-4, np.inf, mg.ABS, coords=coords)
+    exact = hl.decompress(buf)
+    cast = hl.decompress(buf, config=hl.Config(mirror_reference_coord_cast=1))
+    assert not np.array_equal(exact, cast)               # (the grids differ in the last bits)
+    assert float(np.max(np.abs(cast - u))) <= 2e-4       # still a faithful reconstruction
+    # the same integers recomposed at the low level on the two grids
+    h = mg.Hierarchy(shape, dt, coords=coords)
+    q, oi, ov, cnt, _ = h.decompose_quantize(torch.from_numpy(u).cuda(), mg.ABS, 1e-4, np.inf, outlier_cap=u.size)
+    want_exact = h.dequantize_recompose(q.clone(), mg.ABS, 1e-4, np.inf, 1.0, outlier_idx=oi[:cnt], outlier_val=ov[:cnt])
+    h.close()
+    hf = mg.Hierarchy(shape, dt, coords=[c.astype(np.float32).astype(np.float64) for c in coords])
+    want_cast = hf.dequantize_recompose(q.clone(), mg.ABS, 1e-4, np.inf, 1.0, outlier_idx=oi[:cnt], outlier_val=ov[:cnt])
+    hf.close()
+    assert np.array_equal(exact, want_exact.cpu().numpy())
+    assert np.array_equal(cast, want_cast.cpu().numpy())
