@@ -553,13 +553,14 @@ def main():
     # (a file taken on other kernel sources than the ones this run loads is refused)
     traffic = None
     traffic_note = "no PMC traffic file for this configuration"
-    tpath = os.path.join(ROOT, "profiles", "traffic_512cube_f32.json")
-    if args.config == "512f32" and shape == SHAPE and os.path.exists(tpath):
+    tname = {"512f32": "traffic_512cube_f32.json", "1024f32": "traffic_1024cube_f32.json"}.get(args.config)
+    tpath = os.path.join(ROOT, "profiles", tname or "none")
+    if tname and not args.shape and os.path.exists(tpath):
         tj = json.load(open(tpath))
         t = tj.get(dominant)
         if tj.get("source_hash") != source_hash():
-            traffic_note = "profiles/traffic_512cube_f32.json was taken on other kernel sources (hash %s, now %s): refused" % (
-                tj.get("source_hash"), source_hash())
+            traffic_note = "profiles/%s was taken on other kernel sources (hash %s, now %s): refused" % (
+                tname, tj.get("source_hash"), source_hash())
         elif t:
             traffic = int((t["fetch_kib"] * t["read_correction"] + t["write_kib"]) * 1024)
             traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on these kernel sources, per launch"

@@ -16,6 +16,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "env.hpp"
@@ -114,6 +115,7 @@ struct mgh_hierarchy {
   uint32_t ipk_w = 64;             // MGH_IPK_W: widest solver wave of the streaming Thomas solves
   int ipk_pd = 1;                  // MGH_IPK_PD: their load-pipeline depth
   size_t ipk_contig_rounds = 4;    // MGH_IPK_CONTIG: rounds of the LDS-staged contiguous solve from which the streaming one takes over
+  int ipk_kr16 = 1;                // MGH_IPK_KR16: 16 register-resident batches for float pencils of 512+ elements
   size_t ipk_wpc = 8;              // MGH_IPK_WPC: most one-wave solver workgroups per CU the host plans with
   bool split_serial = false;       // MGH_SPLIT_SERIAL
   bool no_head = false;            // MGH_NO_RECOMPOSE_HEAD
@@ -460,9 +462,16 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
   // parking. Used when the LDS-staged tiles need more than one round (strided pencils), or --
   // contiguous pencils, where the LDS-staged kernel is the better one at one or two rounds --
   // from four rounds on (1024^3: 2 KB pencils leave ONE staged tile per CU, 16 rounds).
-  {
-    // batches of 64 bytes per lane: 16 floats / 8 doubles; the last KR batches stay in registers
-    constexpr uint32_t U = sizeof(T) == 4 ? 16 : 8, KR = 8;
+  // batches of 64 bytes per lane: 16 floats / 8 doubles; the last KR batches stay in registers.
+  // KR = 8 (a third of the register file: two or more waves per SIMD), or -- float pencils of
+  // 512+ elements, MGH_IPK_KR16 -- KR = 16: 256 values of every pencil in registers, one wave per
+  // SIMD, so that most of the rest fits in LDS and little is parked in global memory (1024^3:
+  // PMC traffic of a solve 2.0-2.5 GB for 1.08 GB algorithmic with KR = 8).
+  constexpr int kNotApplicable = 1 << 20;
+  constexpr uint32_t U = sizeof(T) == 4 ? 16 : 8;
+  auto stream_plan = [&](auto KRc, size_t wpc_cap) -> int {
+    constexpr uint32_t KR = decltype(KRc)::value;
+    const size_t wpc = std::min(h->ipk_wpc, wpc_cap);
     const uint32_t nb = n / U;
     const size_t box_bytes = (nbatch > 1 ? nbatch * batch_stride : (size_t)m[0] * m[1] * m[2]) * sizeof(T);
     // (strided pencils: measured inside the step at 512^3, ipk_c 59 -> 52 us, ipk_r of
@@ -480,9 +489,10 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
           const size_t lds = (size_t)w * (parked - ng) * sizeof(T) +
                              (axis == 2 ? TileIO<T, U>::stage_elems * sizeof(T) : 0);
           if (h->solve_max_lds && lds > h->solve_max_lds) continue;
-          // 116 VGPRs: four waves per SIMD = 16 one-wave workgroups per CU at most
+          // ~230 VGPRs (KR = 8): two waves per SIMD = 8 one-wave workgroups per CU; KR = 16:
+          // ~400 VGPRs, one wave per SIMD = 4 per CU (the caps the host plans with)
           // (five 32 KB allocations do not fit one CU although 5 * 32 KB = 160 KB: leave a margin)
-          const size_t per_cu = lds ? std::min<size_t>((kLdsPerCU - 4096) / lds, h->ipk_wpc) : h->ipk_wpc;
+          const size_t per_cu = lds ? std::min<size_t>((kLdsPerCU - 4096) / lds, wpc) : wpc;
           if (!per_cu) continue;
           const size_t blocks = ((size_t)npencil + w - 1) / w;
           const size_t rounds = (blocks + per_cu * h->num_cu - 1) / (per_cu * h->num_cu);
@@ -522,6 +532,17 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
 #undef MGH_STREAM
       }
     }
+    return kNotApplicable;
+  };
+  if constexpr (sizeof(T) == 4) {
+    if (h->ipk_kr16 && n / U >= 32) {
+      const int rc = stream_plan(std::integral_constant<uint32_t, 16>{}, 4);
+      if (rc != kNotApplicable) return rc;
+    }
+  }
+  {
+    const int rc = stream_plan(std::integral_constant<uint32_t, 8>{}, 16);
+    if (rc != kNotApplicable) return rc;
   }
   if (axis == 2 && best_w) {
     const uint32_t pad = (n % 2 == 0) ? 1u : 0u;
@@ -2120,6 +2141,7 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->ipk_w = (uint32_t)env_get("MGH_IPK_W", h->ipk_w);
     h->ipk_pd = (int)env_get("MGH_IPK_PD", h->ipk_pd);
     h->ipk_wpc = (size_t)env_get("MGH_IPK_WPC", (long)h->ipk_wpc);
+    h->ipk_kr16 = (int)env_get("MGH_IPK_KR16", h->ipk_kr16);
     h->ipk_contig_rounds = (size_t)env_get("MGH_IPK_CONTIG", (long)h->ipk_contig_rounds);
     h->split_serial = env_get("MGH_SPLIT_SERIAL", 0) != 0;
     h->no_head = env_get("MGH_NO_RECOMPOSE_HEAD", 0) != 0;

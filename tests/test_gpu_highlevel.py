@@ -791,18 +791,19 @@ def test_mirror_reference_coord_cast_switch():
     shape, dt = (33, 40, 65), np.float64
     u = smooth_field(shape, dt)
     coords = nonuniform_coords(shape, dt)
-    buf = hl.compress(u, 1e-4, np.inf, mg.ABS, coords=coords)
+    buf = hl.compress(u, 1e-2, np.inf, mg.ABS, coords=coords)
+    assert buf.size < u.nbytes // 2                      # (a Huffman record, not a raw subdomain)
     exact = hl.decompress(buf)
     cast = hl.decompress(buf, config=hl.Config(mirror_reference_coord_cast=1))
     assert not np.array_equal(exact, cast)               # (the grids differ in the last bits)
-    assert float(np.max(np.abs(cast - u))) <= 2e-4       # still a faithful reconstruction
+    assert float(np.max(np.abs(cast - u))) <= 2e-2       # still a faithful reconstruction
     # the same integers recomposed at the low level on the two grids
     h = mg.Hierarchy(shape, dt, coords=coords)
-    q, oi, ov, cnt, _ = h.decompose_quantize(torch.from_numpy(u).cuda(), mg.ABS, 1e-4, np.inf, outlier_cap=u.size)
-    want_exact = h.dequantize_recompose(q.clone(), mg.ABS, 1e-4, np.inf, 1.0, outlier_idx=oi[:cnt], outlier_val=ov[:cnt])
+    q, oi, ov, cnt, _ = h.decompose_quantize(torch.from_numpy(u).cuda(), mg.ABS, 1e-2, np.inf, outlier_cap=u.size)
+    want_exact = h.dequantize_recompose(q.clone(), mg.ABS, 1e-2, np.inf, 1.0, outlier_idx=oi[:cnt], outlier_val=ov[:cnt])
     h.close()
     hf = mg.Hierarchy(shape, dt, coords=[c.astype(np.float32).astype(np.float64) for c in coords])
-    want_cast = hf.dequantize_recompose(q.clone(), mg.ABS, 1e-4, np.inf, 1.0, outlier_idx=oi[:cnt], outlier_val=ov[:cnt])
+    want_cast = hf.dequantize_recompose(q.clone(), mg.ABS, 1e-2, np.inf, 1.0, outlier_idx=oi[:cnt], outlier_val=ov[:cnt])
     hf.close()
     assert np.array_equal(exact, want_exact.cpu().numpy())
     assert np.array_equal(cast, want_cast.cpu().numpy())

@@ -5,7 +5,10 @@
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out/fetch -- python3 bench.py --steps 3 --warmup 1 --only-step
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d out/write -- python3 bench.py --steps 3 --warmup 1 --only-step
-  python tools/make_traffic.py out/fetch/*/*.db out/write/*/*.db [raw_out.json]
+  python tools/make_traffic.py out/fetch/*/*.db out/write/*/*.db [raw_out.json [traffic_file_name]]
+
+(traffic_file_name: default traffic_512cube_f32.json; e.g. traffic_1024cube_f32.json for
+`bench.py --config 1024f32`.)
 
 The file records the hash of the kernel sources it was taken on; bench.py refuses it for any
 other sources. Units: KiB per launch (averages over the dispatches of the biggest grid of each
@@ -60,7 +63,8 @@ def main():
             continue
         out[label] = {"fetch_kib": round(f, 1), "write_kib": round(w, 1), "read_correction": corr,
                       "dispatches": [nf, nw]}
-    json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_512cube_f32.json"), "w"), indent=1)
+    name = sys.argv[4] if len(sys.argv) > 4 else "traffic_512cube_f32.json"
+    json.dump(out, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
     if len(sys.argv) > 3:
         raw = {"fetch": [{"kernel": k[0][:90], "grid_threads": k[1], "avg_kib": sum(v) / len(v), "n": len(v)}
                          for k, v in sorted(fetch.items()) if "mgh" in k[0]],

@@ -1,23 +1,32 @@
 #!/bin/bash
 # Round evidence on one GPU box: GPU tests, smoke, bench line, rocprofv3 kernel stats of the bench
-# command, PMC traffic passes. Usage (through gpurun): tools/round_evidence.sh r02b
+# command, step timelines, PMC traffic passes (512^3 and 1024^3). Usage (through gpurun):
+#   tools/round_evidence.sh r03z
 TAG=${1:-rXX}
 R=$PWD
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 python -m pytest tests -q -m gpu 2>&1 | tail -3 > $O/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
-python bench.py > $O/bench.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 10 --warmup 3 > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 10 --warmup 3 --no-other-configs > $O/stats.log 2>&1
 # the same with the timed steps only (no decompress / sym16 / two-stream / end-to-end legs, whose
 # launches of the same kernels -- some of them overlapped on two streams -- enter the averages above)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_step -- python3 $R/bench.py --steps 10 --warmup 3 --only-step > $O/stats_step.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --only-step > $O/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -- python3 $R/bench.py --steps 3 --warmup 1 --only-step > $O/write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch1024 -- python3 $R/bench.py --config 1024f32 --steps 3 --warmup 1 --only-step > $O/fetch1024.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write1024 -- python3 $R/bench.py --config 1024f32 --steps 3 --warmup 1 --only-step > $O/write1024.log 2>&1
 cd $R
 python tools/make_traffic.py $(ls $O/fetch/*/*.db | head -1) $(ls $O/write/*/*.db | head -1) $O/pmc_raw.json > $O/traffic.txt 2>&1
-cp profiles/traffic_512cube_f32.json $O/traffic_512cube_f32.json
+python tools/make_traffic.py $(ls $O/fetch1024/*/*.db | head -1) $(ls $O/write1024/*/*.db | head -1) $O/pmc_raw_1024.json traffic_1024cube_f32.json > $O/traffic1024.txt 2>&1
+cp profiles/traffic_512cube_f32.json profiles/traffic_1024cube_f32.json $O/
+# timelines of one step (kernel trace, no counters)
+tools/trace_step.sh $TAG/tl512
+tools/trace_step.sh $TAG/tl1024 --config 1024f32
+tools/trace_step.sh $TAG/tl4d --config 4d
+tools/trace_step.sh $TAG/tlf64 --config 512f64nu
 python bench.py > $O/bench_with_traffic.log 2>&1
+python bench.py --config 1024f32 --only-step > $O/bench_1024.log 2>&1
+rm -rf $O/fetch $O/write $O/fetch1024 $O/write1024
 cat $O/pytest_gpu.txt $O/smoke.txt; tail -1 $O/bench_with_traffic.log | cut -c1-400
-ls $O/stats/*/ | head
