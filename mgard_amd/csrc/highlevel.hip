@@ -1723,6 +1723,8 @@ inline uint64_t multi_slab_size(uint64_t n0, int ndev) {
   return size;
 }
 
+void worker_thread_teardown();
+
 template <typename T>
 int compress_multi_impl(int ndev, const int *devs, int D, int dtype, const uint64_t *shape,
                         double tol_d, double s_d, int ebtype, const void *original,
@@ -1793,7 +1795,7 @@ int compress_multi_impl(int ndev, const int *devs, int D, int dtype, const uint6
           if (owned) mgh_hierarchy_destroy(h);
           if (rc != MGH_SUCCESS) err.set(rc);
         }
-        mgh_release_cache();
+        worker_thread_teardown();
         } catch (const std::exception &e) {
           // (an exception must not leave a worker thread: std::terminate)
           err.set(hl_fail(MGH_ERR_OUT_OF_MEMORY, std::string("worker thread: ") + e.what()));
@@ -1835,7 +1837,7 @@ int compress_multi_impl(int ndev, const int *devs, int D, int dtype, const uint6
           part_size[id] = sz;
           if (rc != MGH_SUCCESS) err.set(rc);
         }
-        mgh_release_cache();
+        worker_thread_teardown();
         } catch (const std::exception &e) {
           // (an exception must not leave a worker thread: std::terminate)
           err.set(hl_fail(MGH_ERR_OUT_OF_MEMORY, std::string("worker thread: ") + e.what()));
@@ -1965,7 +1967,7 @@ int decompress_multi_impl(int ndev, const int *devs, const fmt::Header &hd, size
         const int rc = mgh_decompress(mini.data(), mini.size(), &dst, &c, 1);
         if (rc != MGH_SUCCESS) err.set(rc);
       }
-      mgh_release_cache();
+      worker_thread_teardown();
       } catch (const std::exception &e) {
           // (an exception must not leave a worker thread: std::terminate)
           err.set(hl_fail(MGH_ERR_OUT_OF_MEMORY, std::string("worker thread: ") + e.what()));
@@ -1977,6 +1979,19 @@ int decompress_multi_impl(int ndev, const int *devs, const fmt::Header &hd, size
     return bail(err.rc);
   }
   return MGH_SUCCESS;
+}
+
+// End of a worker thread of the multi-device calls: release the device state AND delete the
+// per-thread objects themselves (they are deliberately not destroyed by thread_local destructors --
+// HIP calls at process exit -- so a thread that ends has to do it, or every call leaks them).
+void worker_thread_teardown() {
+  mgh_release_cache();
+  delete g_cache_ptr;
+  g_cache_ptr = nullptr;
+  for (auto *&b : g_bounce_ptr) {
+    delete b;
+    b = nullptr;
+  }
 }
 
 int check_devs(int num_dev, const int *dev_ids) {

@@ -596,9 +596,10 @@ def test_fused_4d_path_equals_generic_nd(shape, dt, monkeypatch):
 
 
 def test_config3_full_size_slab():
-    """BASELINE.json configs[3] at FULL per-rank size, 8 x 512^3 float32 (the oracle would need
-    minutes): the fused 4-D path against the generic N-D kernels bit for bit, and the round trip
-    through the slice-by-slice recomposition within the tolerance."""
+    """BASELINE.json configs[3] at FULL per-rank size, 8 x 512^3 float32: the fused 4-D path
+    against the generic N-D kernels bit for bit, against the ORACLE's N-D path at full size where
+    the host has the memory and the cores for it (OpenMP over pencils: seconds on the 128-core
+    GPU hosts), and the round trip through the slice-by-slice recomposition within the tolerance."""
     torch, mg = _gpu()
     shape = (8, 512, 512, 512)
     if _host_mem_gb() < 24 or torch.cuda.mem_get_info()[0] < (40 << 30):
@@ -606,12 +607,22 @@ def test_config3_full_size_slab():
     u = _slab4d(shape)
     ud = torch.from_numpy(u).cuda()
     nrm = float(np.max(np.abs(u)))
-    del u
     cap = ud.numel() // 8
     h = mg.Hierarchy(shape, np.float32)
     assert h.l_target == 3
     q, oi, ov, cnt, n1 = h.decompose_quantize(ud, mg.REL, 1e-3, np.inf, outlier_cap=cap)
     assert n1 == nrm and cnt <= cap
+    if _host_mem_gb() >= 96 and (os.cpu_count() or 1) >= 32:
+        o = oracle.Hierarchy(shape, np.float32)
+        rq, roi, rov, rn = o.quantize(o.decompose(u), oracle.REL, np.float32(1e-3), np.float32(np.inf),
+                                      np.float32(nrm), outlier_cap=cap)
+        assert cnt == rn
+        assert np.array_equal(q.cpu().numpy(), rq)
+        gi, gv = _outlier_set(oi.cpu().numpy()[:cnt], ov.cpu().numpy()[:cnt])
+        ri, rv = _outlier_set(roi[:rn], rov[:rn])
+        assert np.array_equal(gi, ri) and np.array_equal(gv, rv)
+        del o, rq, roi, rov
+    del u
     os.environ["MGH_FUSED4"] = "0"
     try:
         g = mg.Hierarchy(shape, np.float32)
