@@ -13,8 +13,10 @@
 //   * decomposition must be MultiDim, compressor MGARD, lossless Huffman or Huffman_Zstd,
 //     reorder 0 or 1 -- anything else returns Failure instead of silently doing something different;
 //   * the fields that only steer the reference's runtime (log_level, prefetch, lz4_block_size,
-//     total_num_bitplanes, mdr_*, adjust_shape, compress_with_dryrun,
+//     total_num_bitplanes, mdr_*, compress_with_dryrun,
 //     num_local_refactoring_level, auto_cache_release, cpu_mode) are accepted and ignored;
+//   * adjust_shape is honoured (the array is viewed with the balanced shape of
+//     ShapeAdjustment.hpp:43-77 before it is compressed; uniform grids);
 //   * auto_pin_host_buffers defaults to FALSE (reference Config.cpp:33: true): registering and
 //     unregistering the caller's buffer around every call tripped an intermittent GPU memory
 //     fault in the ROCm 7.0 runtime; pageable buffers go through pinned
@@ -112,11 +114,50 @@ inline compress_status_type check(const Config &c) {
   if (c.dev_type != device_type::AUTO && c.dev_type != device_type::HIP && c.dev_type != device_type::CUDA)
     return compress_status_type::BackendNotAvailableFailure;
   if (c.decomposition != decomposition_type::MultiDim || c.compressor != compressor_type::MGARD ||
-      (c.reorder != 0 && c.reorder != 1) || c.adjust_shape)
+      (c.reorder != 0 && c.reorder != 1))
     return compress_status_type::Failure;
   if (c.lossless != lossless_type::Huffman && c.lossless != lossless_type::Huffman_Zstd)
     return compress_status_type::Failure;
   return compress_status_type::Success;
+}
+// Config::adjust_shape (CompressionHighLevel.hpp:62-65, ShapeAdjustment.hpp:43-77): before
+// compressing, the array is VIEWED with a more balanced shape of the same size -- the largest
+// extent is taken apart into its prime factors, which are multiplied, largest first, onto
+// whichever extent is the smallest at that moment; with a Variable decomposition the leading
+// (time) dimension is adjusted per subdomain and put back together. The header records the
+// adjusted shape, which is what decompress hands back.
+inline void adjust_shape(std::vector<SIZE> &shape, const Config &c) {
+  if (shape.empty()) return;
+  SIZE steps = 1;
+  const bool variable = c.domain_decomposition == domain_decomposition_type::Variable &&
+                        c.domain_decomposition_dim == 0 && !c.domain_decomposition_sizes.empty() &&
+                        c.domain_decomposition_sizes[0] > 0;
+  if (variable) {
+    steps = shape[0] / c.domain_decomposition_sizes[0];
+    shape[0] = c.domain_decomposition_sizes[0];
+  }
+  size_t big = 0;
+  for (size_t d = 1; d < shape.size(); d++)
+    if (shape[d] > shape[big]) big = d;  // (the first of equal extents)
+  SIZE rest = shape[big];
+  std::vector<SIZE> primes;
+  for (SIZE z = 2; z * z <= rest;) {
+    if (rest % z == 0) {
+      primes.push_back(z);
+      rest /= z;
+    } else {
+      z++;
+    }
+  }
+  if (rest > 1) primes.push_back(rest);
+  shape[big] = 1;
+  for (size_t k = primes.size(); k-- > 0;) {
+    size_t small = 0;
+    for (size_t d = 1; d < shape.size(); d++)
+      if (shape[d] < shape[small]) small = d;  // (the first of equal extents)
+    shape[small] *= primes[k];
+  }
+  if (variable) shape[0] *= steps;
 }
 inline mgh_config to_c(const Config &c) {
   mgh_config m;
@@ -151,6 +192,7 @@ compress(DIM D, data_type dtype, std::vector<SIZE> shape, double tol, double s,
   const compress_status_type ok = detail::check(config);
   if (ok != compress_status_type::Success) return ok;
   if (shape.size() != D) return compress_status_type::Failure;
+  if (config.adjust_shape) detail::adjust_shape(shape, config);
   const mgh_config c = detail::to_c(config);
   std::vector<const void *> cp(coords.begin(), coords.end());
   return detail::status(mgh_compress(D, (int)dtype, shape.data(), tol, s, (int)mode, original_data,
