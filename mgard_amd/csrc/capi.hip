@@ -1100,6 +1100,19 @@ int launch_fused4_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Fused4<T> &Q,
     return MGH_SUCCESS;
 }
 
+// D = 4: the mass/restriction sweep along t of the per-slice load vectors: every input slice read
+// once where the pencils are short enough for registers (k_tsweep_once), else slice by slice.
+template <typename T>
+int tsweep_launch(mgh_hierarchy *h, const T *load, T *corr, size_t M, int m_t, const T *mass, hipStream_t s) {
+  constexpr int MT = 9;
+  if (m_t <= MT) {
+    const unsigned blocks = (unsigned)std::min<size_t>((M + 255) / 256, (size_t)h->num_cu * 32);
+    return launch(h, "tsweep", s, [&] { k_tsweep_once<T, MT><<<blocks, 256, 0, s>>>(load, corr, M, m_t, mass); });
+  }
+  const dim3 grid((unsigned)std::min<size_t>((M + 255) / 256, 4096), (unsigned)m_t, 1);
+  return launch(h, "tsweep", s, [&] { k_tsweep<T><<<grid, 256, 0, s>>>(load, corr, M, m_t, mass); });
+}
+
 // D = 4: Thomas solve along t of the correction (m_t, M) with the result added to / subtracted
 // from the coarse array: short pencils go through registers (k_tsolve_apply), others through the
 // generic strided solve.
@@ -1218,10 +1231,7 @@ int decompose_fused4(mgh_hierarchy *h, const T *data, T *coeff, const QuantParam
       TRY((launch_fused4_t<T, OUT, 8, 32>(h, A, Q, b, cls, n_t, m_t, s)));
     // t-sweep, then the Thomas solves f, c, r, t on the coarse box (m_t, m_r, m_c, m_f)
     {
-      const dim3 grid((unsigned)std::min<size_t>((M + 255) / 256, 4096), (unsigned)m_t, 1);
-      TRY(launch(h, "tsweep", s, [&] {
-        k_tsweep<T><<<grid, 256, 0, s>>>(ds->load4, ds->corr4, M, m_t, ds->nd[l].mass[0]);
-      }));
+      TRY((tsweep_launch<T>(h, ds->load4, ds->corr4, M, m_t, ds->nd[l].mass[0], s)));
     }
     const uint32_t m3a[3] = {(uint32_t)(m_t * Mc[1]), (uint32_t)Mc[2], (uint32_t)Mc[3]};
     TRY(ipk_launch<T>(h, 2, m3a, ds->corr4, ds->nd[l].thomas[3], nullptr, +1, s));
@@ -1738,10 +1748,7 @@ int recompose_levels4(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T>
     A.allcoef = 0;
     // ---- t-sweep, Thomas solves f, c, r, t; the last one subtracts from the coarse nodes
     {
-      const dim3 grid((unsigned)std::min<size_t>((M + 255) / 256, 4096), (unsigned)m_t, 1);
-      TRY(launch(h, "tsweep", st, [&] {
-        k_tsweep<T><<<grid, 256, 0, st>>>(ds->load4, ds->corr4, M, m_t, ds->nd[l].mass[0]);
-      }));
+      TRY((tsweep_launch<T>(h, ds->load4, ds->corr4, M, m_t, ds->nd[l].mass[0], st)));
     }
     const uint32_t m3a[3] = {(uint32_t)(m_t * Mc[1]), (uint32_t)Mc[2], (uint32_t)Mc[3]};
     TRY(ipk_launch<T>(h, 2, m3a, ds->corr4, ds->nd[l].thomas[3], nullptr, +1, st));
