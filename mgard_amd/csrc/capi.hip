@@ -158,6 +158,9 @@ template <typename T> struct DeviceState {
   T *tables = nullptr;
   int *marks = nullptr;
   std::vector<LevelTables<T>> lt;  // [l], l >= 1 (3-D view, D <= 3)
+  std::vector<size_t> lt_end;      // [l]: element offset in `tables` where the tables of level l end
+                                   // (levels are laid out 1, 2, ... back to back: the tail kernel
+                                   // copies the block of its levels to LDS in one pass)
   struct NdLevel {
     const T *ratio[kNd], *mass[kNd], *thomas[kNd];
   };
@@ -321,6 +324,17 @@ template <typename T> int build_device_state(mgh_hierarchy *h) {
   }
   TRY(dev_alloc(h, &ds->tables, arena.size()));
   HIP_TRY(hipMemcpy(ds->tables, arena.data(), arena.size() * sizeof(T), hipMemcpyHostToDevice));
+  ds->lt_end.assign(L + 1, 0);
+  for (int l = 1; l <= L; l++) {
+    size_t next = arena.size();
+    for (int l2 = l + 1; l2 <= L && next == arena.size(); l2++)
+      for (int k = 0; k < 3; k++)
+        if (ds->lt[l2].active[k]) {
+          next = offs[l2].ratio[k];
+          break;
+        }
+    ds->lt_end[l] = next;
+  }
   for (int l = 1; l <= L; l++)
     for (int k = 0; k < 3; k++)
       if (ds->lt[l].active[k]) {
@@ -839,8 +853,8 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
   constexpr size_t kTailLdsMax = 150 * 1024;
   int l_tail = 0;  // levels l_tail .. 1 go to the tail (0 = none)
   for (int l = std::min(L, kTailMaxLevels); l >= 1; l--) {
-    size_t tab = 0;
-    for (int k = l; k >= 1; k--) tab += tail_table_elems(ds->lt[k].box);
+    // (the table block of the tail's levels, plus the level above whose solves it may run)
+    const size_t tab = ds->lt_end[std::min(l + 1, L)];
     if ((tail_lds_elems(ds->lt[l].box) + tab) * sizeof(T) + tail_header_bytes<T>() <= kTailLdsMax) {
       l_tail = l;
       break;
@@ -1031,8 +1045,9 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
       TA.head_volume = qp->vol[0];
     }
     TA.out = A;
-    size_t tab = 0;
-    for (int k = l_tail; k >= 1; k--) tab += tail_table_elems(ds->lt[k].box);
+    const size_t tab = ds->lt_end[tail_pre ? l_tail + 1 : l_tail];
+    TA.tab_base = ds->tables;
+    TA.tab_count = (uint32_t)tab;
     const size_t lds = (tail_lds_elems(ds->lt[l_tail].box) + tab) * sizeof(T) + tail_header_bytes<T>();
     static std::atomic<uint64_t> once{0};
     TRY(allow_big_lds_once(k_tail<T, OUT>, once));
@@ -1636,7 +1651,7 @@ int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> 
   int l_head = 0;
   if (!no_head) {
     for (int l = 1; l <= std::min(L, kTailMaxLevels); l++) {
-      if (head_lds_elems(ds->lt[l].box) * sizeof(T) > 150 * 1024) break;
+      if ((head_lds_elems(ds->lt[l].box) + ds->lt_end[l]) * sizeof(T) > 150 * 1024) break;
       l_head = l;
     }
   }
@@ -1660,7 +1675,9 @@ int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> 
     HA.out = (l_head == L) ? data : ds->nodal[l_head];
     HA.oJ = (l_head == L) ? ds->full_J : bl.n[2];
     HA.oI = (l_head == L) ? ds->full_I : (size_t)bl.n[1] * bl.n[2];
-    const size_t lds = head_lds_elems(bl) * sizeof(T);
+    HA.tab_base = ds->tables;
+    HA.tab_count = (uint32_t)ds->lt_end[l_head];
+    const size_t lds = (head_lds_elems(bl) + ds->lt_end[l_head]) * sizeof(T);
     static std::atomic<uint64_t> once{0};
     TRY(allow_big_lds_once(k_recompose_head<T, QT>, once));
     TRY(launch(h, "recompose_head", st, [&] { k_recompose_head<T, QT><<<1, 1024, lds, st>>>(HA); }));
@@ -2476,6 +2493,14 @@ int mgh_dequantize_recompose(mgh_hierarchy *h, int64_t *d_quantized, int ebtype,
 }
 
 #ifdef MGH_PHASE_TIMING
+int mgh_debug_tail_read(unsigned long long *out64, int reset) {
+  HIP_TRY(hipMemcpyFromSymbol(out64, HIP_SYMBOL(mgh::g_tail), sizeof(unsigned long long) * 64));
+  if (reset) {
+    unsigned long long z[64] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(mgh::g_tail), z, sizeof z));
+  }
+  return MGH_SUCCESS;
+}
 int mgh_debug_phase_read(unsigned long long *out16, int reset) {
   HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(mgh::g_phase), sizeof(unsigned long long) * 16));
   if (reset) {

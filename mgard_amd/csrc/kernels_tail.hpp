@@ -20,6 +20,19 @@ namespace mgh {
 
 constexpr int kTailMaxLevels = 10;
 
+// Developer build -DMGH_PHASE_TIMING: time (100 MHz wall clock ticks) thread 0 of k_tail spends in
+// every phase, summed over the launches; read back with mgh_debug_tail_read (capi.hip).
+// Slots: 0 tables + first level in, 1 solves of the level above; per tail level li, base 2 + 8 li:
+// coefficients, f-, c-, r-sweep, f-, c-, r-solve, AddND; last slot 63: head.
+#ifdef MGH_PHASE_TIMING
+__device__ unsigned long long g_tail[64];
+#define MGH_TT_DECL unsigned long long tt_t = wall_clock64();
+#define MGH_TT(k) do { if (threadIdx.x == 0) { const unsigned long long tt_n = wall_clock64(); atomicAdd(&g_tail[(k) < 64 ? (k) : 63], tt_n - tt_t); tt_t = tt_n; } } while (0)
+#else
+#define MGH_TT_DECL
+#define MGH_TT(k)
+#endif
+
 template <typename T> struct TailLevel {
   Box3 b;
   const T *ratio[3];
@@ -40,6 +53,11 @@ template <typename T> struct TailArgs {
   // and one round trip through global memory less (the box fits in LDS by construction).
   const T *pre_load;
   const T *pre_thomas[3];
+  // Every table the kernel reads (ratios, mass constants, Thomas coefficients of its levels and
+  // pre_thomas) lies in ONE contiguous block of the hierarchy's table arena: tab_base[0, tab_count).
+  // It is copied to LDS in one pass, and a table at global address p is read at lds + (p - tab_base).
+  const T *tab_base;
+  uint32_t tab_count;
   T head_quantizer, head_volume;
   FusedArgs<T> out;    // coefficient / quantized output + outlier list
 };
@@ -67,11 +85,11 @@ k_tail(TailArgs<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const uint32_t tid = threadIdx.x, NT = blockDim.x;
   FusedArgs<T> O = A.out;
+  MGH_TT_DECL
   // Every phase below reads its tables per element; out of global memory each phase would start
   // with a dependent round trip of a microsecond or two (12 us per level measured). All tables of
   // the tail levels are a few KB: they go to LDS once, behind the data regions.
   // (header of the dynamic LDS: a static __shared__ array would count against the 160 KB)
-  uint32_t(*toff)[9] = reinterpret_cast<uint32_t(*)[9]>(smem_raw);  // ratio[3], mass[3], thomas[3]
   T *qps = reinterpret_cast<T *>(smem_raw + kTailMaxLevels * 9 * sizeof(uint32_t));
   T *tab;
   // carve LDS for the first (largest) level; deeper levels reuse the same regions
@@ -88,48 +106,39 @@ k_tail(TailArgs<T> A) {
     T3 = T2 + (size_t)b.n[0] * b.m[1] * b.m[2];
     Y = T3 + mc;
     tab = Y + mc;
-    if (tid == 0) {
-      uint32_t o = 0;
-      for (int li = 0; li < A.nlevels; li++) {
-        const Box3 &bl = A.lv[li].b;
-        for (int d = 0; d < 3; d++) { toff[li][d] = o; o += bl.n[d]; }
-        for (int d = 0; d < 3; d++) { toff[li][3 + d] = o; o += 9 * bl.m[d]; }
-        for (int d = 0; d < 3; d++) { toff[li][6 + d] = o; o += 3 * bl.m[d]; }
-      }
-    }
+    // One round of loads for everything the kernel starts from -- quantizer table, the table block
+    // (phase-wise table loads from global memory cost a dependent round trip each: 36 small loops
+    // took 12 of the kernel's 62 us), the nodal values of the first level and the load vector of
+    // the level above -- all in flight together, then one barrier.
     if (O.qp)
       for (uint32_t e = tid; e < 2u * (uint32_t)O.nlev && e < 2u * kMaxLevels; e += NT) qps[e] = O.qp[e];
-    __syncthreads();
-    for (int li = 0; li < A.nlevels; li++) {
-      const TailLevel<T> &L = A.lv[li];
-      for (int d = 0; d < 3; d++) {
-        for (uint32_t e = tid; e < L.b.n[d]; e += NT) tab[toff[li][d] + e] = L.ratio[d][e];
-        for (uint32_t e = tid; e < 9 * L.b.m[d]; e += NT) tab[toff[li][3 + d] + e] = L.mass[d][e];
-        for (uint32_t e = tid; e < 3 * L.b.m[d]; e += NT) tab[toff[li][6 + d] + e] = L.thomas[d][e];
-      }
-    }
-    // bring the nodal values of the first tail level into LDS
+    for (uint32_t e = tid; e < A.tab_count; e += NT) tab[e] = A.tab_base[e];
     const uint32_t n0 = b.n[0], n1 = b.n[1], n2 = b.n[2];
     for (uint32_t e = tid; e < nf; e += NT) {
       const uint32_t k = e % n2, j = (e / n2) % n1, i = e / (n2 * n1);
       X[e] = A.fine[i * A.fI + j * A.fJ + k];
     }
+    if (A.pre_load)
+      for (uint32_t e = tid; e < nf; e += NT) C[e] = A.pre_load[e];
+    __syncthreads();
+    MGH_TT(0);
     if (A.pre_load) {
       // correction of the level above: f-, c-, r-solve of its load vector (IPKFunctor.h:127,147),
       // added to the coarse nodes (LevelwiseProcessingKernel.hpp:69-74)
-      for (uint32_t e = tid; e < nf; e += NT) C[e] = A.pre_load[e];
-      __syncthreads();
-      for (uint32_t p = tid; p < n0 * n1; p += NT) thomas_lds<T, false>(C + (size_t)p * n2, 1, n2, A.pre_thomas[2]);
+      const T *pt0 = tab + (A.pre_thomas[0] - A.tab_base), *pt1 = tab + (A.pre_thomas[1] - A.tab_base),
+              *pt2 = tab + (A.pre_thomas[2] - A.tab_base);
+      for (uint32_t p = tid; p < n0 * n1; p += NT) thomas_lds<T, false>(C + (size_t)p * n2, 1, n2, pt2);
       __syncthreads();
       for (uint32_t p = tid; p < n0 * n2; p += NT)
-        thomas_lds<T, false>(C + (size_t)(p / n2) * n1 * n2 + (p % n2), n2, n1, A.pre_thomas[1]);
+        thomas_lds<T, false>(C + (size_t)(p / n2) * n1 * n2 + (p % n2), n2, n1, pt1);
       __syncthreads();
-      for (uint32_t p = tid; p < n1 * n2; p += NT) thomas_lds<T, false>(C + p, n1 * n2, n0, A.pre_thomas[0]);
+      for (uint32_t p = tid; p < n1 * n2; p += NT) thomas_lds<T, false>(C + p, n1 * n2, n0, pt0);
       __syncthreads();
       for (uint32_t e = tid; e < nf; e += NT) X[e] = X[e] + C[e];
     }
   }
   __syncthreads();
+  MGH_TT(1);
   for (int li = 0; li < A.nlevels; li++) {
     const TailLevel<T> &L = A.lv[li];
     const Box3 b = L.b;
@@ -138,9 +147,12 @@ k_tail(TailArgs<T> A) {
     const bool qp_lds = O.qp && O.nlev <= kMaxLevels;
     O.quantizer = qp_lds ? qps[L.level] : (O.qp ? O.qp[L.level] : L.quantizer);
     O.volume = qp_lds ? qps[O.nlev + L.level] : (O.qp ? O.qp[O.nlev + L.level] : L.volume);
-    const T *ratio0 = tab + toff[li][0], *ratio1 = tab + toff[li][1], *ratio2 = tab + toff[li][2];
-    const T *mass0 = tab + toff[li][3], *mass1 = tab + toff[li][4], *mass2 = tab + toff[li][5];
-    const T *thom0 = tab + toff[li][6], *thom1 = tab + toff[li][7], *thom2 = tab + toff[li][8];
+    const T *ratio0 = tab + (L.ratio[0] - A.tab_base), *ratio1 = tab + (L.ratio[1] - A.tab_base),
+            *ratio2 = tab + (L.ratio[2] - A.tab_base);
+    const T *mass0 = tab + (L.mass[0] - A.tab_base), *mass1 = tab + (L.mass[1] - A.tab_base),
+            *mass2 = tab + (L.mass[2] - A.tab_base);
+    const T *thom0 = tab + (L.thomas[0] - A.tab_base), *thom1 = tab + (L.thomas[1] - A.tab_base),
+            *thom2 = tab + (L.thomas[2] - A.tab_base);
     // ---- coefficients (+ output) and coarse nodes ----
     {
       const uint32_t total = n0 * n1 * n2;
@@ -171,6 +183,7 @@ k_tail(TailArgs<T> A) {
       }
     }
     __syncthreads();
+    MGH_TT(2 + 8 * li + 0);
     // ---- mass/restriction sweeps: f, c, r ----
     {
       const uint32_t total = n0 * n1 * m2;
@@ -181,6 +194,7 @@ k_tail(TailArgs<T> A) {
       }
     }
     __syncthreads();
+    MGH_TT(2 + 8 * li + 1);
     {
       const uint32_t total = n0 * m1 * m2;
       for (uint32_t e = tid; e < total; e += NT) {
@@ -190,23 +204,29 @@ k_tail(TailArgs<T> A) {
       }
     }
     __syncthreads();
+    MGH_TT(2 + 8 * li + 2);
     const uint32_t mtot = m0 * m1 * m2;
     for (uint32_t e = tid; e < mtot; e += NT) {
       const uint32_t k = e % m2, j = (e / m2) % m1, i = e / (m2 * m1);
       T3[e] = lpk_elem<T, 0>(n0, m0, (const T *)T2, (size_t)m1 * m2, (size_t)m2, mass0, 0, 0, i, j, k);
     }
     __syncthreads();
+    MGH_TT(2 + 8 * li + 3);
     // ---- Thomas solves in LDS: f, c, r ----
     for (uint32_t p = tid; p < m0 * m1; p += NT) thomas_lds<T, false>(T3 + (size_t)p * m2, 1, m2, thom2);
     __syncthreads();
+    MGH_TT(2 + 8 * li + 4);
     for (uint32_t p = tid; p < m0 * m2; p += NT)
       thomas_lds<T, false>(T3 + (size_t)(p / m2) * m1 * m2 + (p % m2), m2, m1, thom1);
     __syncthreads();
+    MGH_TT(2 + 8 * li + 5);
     for (uint32_t p = tid; p < m1 * m2; p += NT) thomas_lds<T, false>(T3 + p, m1 * m2, m0, thom0);
     __syncthreads();
+    MGH_TT(2 + 8 * li + 6);
     // ---- apply the correction (AddND); the corrected coarse nodes are the next level ----
     for (uint32_t e = tid; e < mtot; e += NT) Y[e] += T3[e];
     __syncthreads();
+    MGH_TT(2 + 8 * li + 7);
     T *tmp = X;
     X = Y;
     Y = tmp;
@@ -236,6 +256,7 @@ k_tail(TailArgs<T> A) {
       }
     }
   }
+  MGH_TT(63);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -261,6 +282,10 @@ template <typename T> struct HeadArgs {
   RecomposeArgs<T> in;  // coefficient source (q / coef / q16, strides dI dJ, half, outlier table)
   T *out;       // nodal values of the finest level handled, strides (oI, oJ, 1)
   size_t oI, oJ;
+  // the tables of all its levels: one contiguous block of the hierarchy's arena, copied to LDS in
+  // one pass (as in k_tail); a table at global address p is read at lds + (p - tab_base)
+  const T *tab_base;
+  uint32_t tab_count;
 };
 
 inline size_t head_lds_elems(const Box3 &b) {
@@ -275,7 +300,7 @@ k_recompose_head(HeadArgs<T> A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const uint32_t tid = threadIdx.x, NT = blockDim.x;
   RecomposeArgs<T> Q = A.in;
-  T *X, *Y, *C, *T1, *T2, *T3;
+  T *X, *Y, *C, *T1, *T2, *T3, *tab;
   {
     const Box3 &b = A.lv[A.nlevels - 1].b;  // the largest level: deeper ones reuse its regions
     const size_t nf = (size_t)b.n[0] * b.n[1] * b.n[2];
@@ -286,7 +311,11 @@ k_recompose_head(HeadArgs<T> A) {
     T1 = C + nf;
     T2 = T1 + (size_t)b.n[0] * b.n[1] * b.m[2];
     T3 = T2 + (size_t)b.n[0] * b.m[1] * b.m[2];
+    tab = T3 + (size_t)b.m[0] * b.m[1] * b.m[2];
   }
+  // (every phase below reads its tables per element: from LDS, not with a round trip to global
+  // memory at the start of each of them)
+  for (uint32_t e = tid; e < A.tab_count; e += NT) tab[e] = A.tab_base[e];
   {  // level-0 nodal values
     const Box3 &b = A.lv[0].b;
     const uint32_t m0 = b.m[0], m1 = b.m[1], m2 = b.m[2];
@@ -305,6 +334,12 @@ k_recompose_head(HeadArgs<T> A) {
     const uint32_t m0 = b.m[0], m1 = b.m[1], m2 = b.m[2];
     const uint32_t nf = n0 * n1 * n2;
     Q.qv = L.qv;
+    const T *mass0 = tab + (L.mass[0] - A.tab_base), *mass1 = tab + (L.mass[1] - A.tab_base),
+            *mass2 = tab + (L.mass[2] - A.tab_base);
+    const T *thom0 = tab + (L.thomas[0] - A.tab_base), *thom1 = tab + (L.thomas[1] - A.tab_base),
+            *thom2 = tab + (L.thomas[2] - A.tab_base);
+    const T *ratio0 = tab + (L.ratio[0] - A.tab_base), *ratio1 = tab + (L.ratio[1] - A.tab_base),
+            *ratio2 = tab + (L.ratio[2] - A.tab_base);
     // ---- dequantized coefficient field in the reordered layout of the level's box (the coarse
     // corner is never read as a coefficient: the f-sweep takes it as zero, the restore skips it)
     for (uint32_t e = tid; e < nf; e += NT) {
@@ -317,27 +352,27 @@ k_recompose_head(HeadArgs<T> A) {
     // ---- mass/restriction sweeps: f, c, r ----
     for (uint32_t e = tid; e < n0 * n1 * m2; e += NT) {
       const uint32_t k = e % m2, j = (e / m2) % n1, i = e / (m2 * n1);
-      T1[e] = lpk_elem<T, 2>(n2, m2, (const T *)C, (size_t)n1 * n2, (size_t)n2, L.mass[2], m0, m1, i, j, k);
+      T1[e] = lpk_elem<T, 2>(n2, m2, (const T *)C, (size_t)n1 * n2, (size_t)n2, mass2, m0, m1, i, j, k);
     }
     __syncthreads();
     for (uint32_t e = tid; e < n0 * m1 * m2; e += NT) {
       const uint32_t k = e % m2, j = (e / m2) % m1, i = e / (m2 * m1);
-      T2[e] = lpk_elem<T, 1>(n1, m1, (const T *)T1, (size_t)n1 * m2, (size_t)m2, L.mass[1], 0, 0, i, j, k);
+      T2[e] = lpk_elem<T, 1>(n1, m1, (const T *)T1, (size_t)n1 * m2, (size_t)m2, mass1, 0, 0, i, j, k);
     }
     __syncthreads();
     const uint32_t mtot = m0 * m1 * m2;
     for (uint32_t e = tid; e < mtot; e += NT) {
       const uint32_t k = e % m2, j = (e / m2) % m1, i = e / (m2 * m1);
-      T3[e] = lpk_elem<T, 0>(n0, m0, (const T *)T2, (size_t)m1 * m2, (size_t)m2, L.mass[0], 0, 0, i, j, k);
+      T3[e] = lpk_elem<T, 0>(n0, m0, (const T *)T2, (size_t)m1 * m2, (size_t)m2, mass0, 0, 0, i, j, k);
     }
     __syncthreads();
     // ---- Thomas solves: f, c, r ----
-    for (uint32_t p = tid; p < m0 * m1; p += NT) thomas_lds<T, false>(T3 + (size_t)p * m2, 1, m2, L.thomas[2]);
+    for (uint32_t p = tid; p < m0 * m1; p += NT) thomas_lds<T, false>(T3 + (size_t)p * m2, 1, m2, thom2);
     __syncthreads();
     for (uint32_t p = tid; p < m0 * m2; p += NT)
-      thomas_lds<T, false>(T3 + (size_t)(p / m2) * m1 * m2 + (p % m2), m2, m1, L.thomas[1]);
+      thomas_lds<T, false>(T3 + (size_t)(p / m2) * m1 * m2 + (p % m2), m2, m1, thom1);
     __syncthreads();
-    for (uint32_t p = tid; p < m1 * m2; p += NT) thomas_lds<T, false>(T3 + p, m1 * m2, m0, L.thomas[0]);
+    for (uint32_t p = tid; p < m1 * m2; p += NT) thomas_lds<T, false>(T3 + p, m1 * m2, m0, thom0);
     __syncthreads();
     // ---- subtract the correction from the coarse nodes (SubtractND) ----
     for (uint32_t e = tid; e < mtot; e += NT) X[e] = X[e] - T3[e];
@@ -346,8 +381,8 @@ k_recompose_head(HeadArgs<T> A) {
     for (uint32_t e = tid; e < nf; e += NT) {
       const uint32_t k = e % n2, j = (e / n2) % n1, i = e / (n2 * n1);
       uint32_t rp, cp, fp;
-      const T v = gpk_rev_elem(b, (const T *)X, (const T *)C, (size_t)n1 * n2, (size_t)n2, L.ratio[0],
-                               L.ratio[1], L.ratio[2], i, j, k, rp, cp, fp);
+      const T v = gpk_rev_elem(b, (const T *)X, (const T *)C, (size_t)n1 * n2, (size_t)n2, ratio0,
+                               ratio1, ratio2, i, j, k, rp, cp, fp);
       Y[((size_t)rp * n1 + cp) * n2 + fp] = v;
     }
     __syncthreads();
