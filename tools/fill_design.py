@@ -1,0 +1,60 @@
+"""Fills section 6 of DESIGN.md (between the sec6 markers) from tools/design_sec6.template.md and the
+bench lines / timeline of a tools/round_evidence.sh run: python tools/fill_design.py TAG. Dev tool."""
+import json, re, sys
+tag = sys.argv[1]
+O = "gpurun_out/%s" % tag
+d = json.loads(open(O + "/bench_with_traffic.log").read().strip().splitlines()[-1])
+d1024 = json.loads(open(O + "/bench_1024.log").read().strip().splitlines()[-1])
+oc = d["other_configs"]
+k = d["roofline"]["kernel_ms_per_step_all"]
+k1024 = d1024["roofline"]["kernel_ms_per_step_all"]
+e2e = oc["1024f32"]["end_to_end"]
+R = {
+ "MS512": "%.3f" % d["ms_per_step"], "GB512": "%.0f" % d["value"], "FR512": "%.1f" % (100 * d["hbm_frac_whole_step"]),
+ "DOMMS": "%.3f" % d["roofline"]["avg_launch_ms"], "DOMFR": "%.1f" % (100 * d["roofline"]["frac"]),
+ "MSF64": "%.2f" % oc["512f64nu"]["ms_per_step"], "GBF64": "%.0f" % oc["512f64nu"]["value"],
+ "MS4D": "%.2f" % oc["4d"]["ms_per_step"], "GB4D": "%.0f" % oc["4d"]["value"],
+ "MS1024": "%.2f" % oc["1024f32"]["ms_per_step"], "GB1024": "%.0f" % oc["1024f32"]["value"],
+ "IPK1024": "%.2f" % (k1024["ipk_f"] + k1024["ipk_c"] + k1024["ipk_r"]),
+ "C1024": "%.0f" % (1000 * k1024["ipk_c"]), "R1024": "%.0f" % (1000 * k1024["ipk_r"]), "F1024": "%.0f" % (1000 * k1024["ipk_f"]),
+ "E2EC": "%.1f" % e2e["compress_ms"], "E2ED": "%.1f" % e2e["decompress_ms"], "E2EERR": "%.1e" % e2e["roundtrip_linf_error"],
+ "E2ETOL": "%.1e" % e2e["tolerance_abs"],
+ "DEC512": "%.2f" % d["decompress"]["ms_per_step"], "HLC": "%.2f" % d["end_to_end"]["compress_ms"], "HLD": "%.2f" % d["end_to_end"]["decompress_ms"],
+ "TWO": "%.3f" % d["two_streams"]["ms_per_step"], "CPU": "%.2f" % d["cpu_baseline"]["value"], "CPU1": "%.2f" % d["cpu_baseline"]["serial"]["value"],
+}
+# kernel table
+sys.path.insert(0, ".")
+alg = {"absmax": 536870912, "level_fused_q": 1610612736}
+rows = ["| kernel | ms/step | what |", "|---|---|---|"]
+names = {"absmax": "norm read (REL bound)", "make_qparams": "quantizer table on the device", "level_fused_q": "top-level pass 512³ → 257³ (dominant)",
+         "ipk_f": "top-level f-solve", "ipk_c": "top-level c-solve", "ipk_r": "r-solves + AddND, levels 9…6",
+         "level_fused_q_small": "passes of levels 8, 7", "ipk_fc": "f+c solves of levels 8, 7, 6 (one launch each)",
+         "level_box_q": "box-kernel passes of levels 6, 5", "tail": "levels 4…1 + head + the solves of level 5, one workgroup"}
+for kk, v in sorted(k.items(), key=lambda kv: -kv[1]):
+    extra = ""
+    if kk in alg:
+        extra = " — %.2f TB/s algorithmic = %.0f %% of 8 TB/s" % (alg[kk] / v / 1e9, alg[kk] / v / 1e9 / 8 * 100)
+    rows.append("| `%s` | %.3f | %s%s |" % (kk, v, names.get(kk, ""), extra))
+rows.append("| sum | %.3f | (step: %.3f ms; the HIP events of the per-kernel pass add a few µs) |" % (sum(k.values()), d["ms_per_step"]))
+R["KERNELTABLE"] = "\n".join(rows)
+# per level from timeline
+tl = [l.split() for l in open(O + "/tl512/timeline.txt").read().splitlines() if "dur" in l]
+durs = [(float(x[3]), x[-1]) for x in tl]
+def fmt(xs): return " + ".join("%.0f" % v for v in xs) + " = %.0f" % sum(xs)
+names_seq = [n for _, n in durs]
+vals = [v for v, _ in durs]
+# expected order: absmax, qparams, [L9: pass, f, c, r], [L8: pass, fc, r], [L7: pass, fc, r], [L6: box, fc, r], [L5: box], tail
+print(len(vals), names_seq)
+if len(vals) == 17:
+    R["L_NORM"] = fmt(vals[0:2]); R["L9"] = fmt(vals[2:6]); R["L8"] = fmt(vals[6:9]); R["L7"] = fmt(vals[9:12])
+    R["L6"] = fmt(vals[12:15]); R["L5"] = "%.0f" % vals[15]; R["TAIL"] = "%.0f" % vals[16]
+t = open("tools/design_sec6.template.md").read()
+for kk, v in R.items():
+    t = t.replace("@@%s@@" % kk, v)
+print("unfilled:", re.findall(r"@@\w+@@", t))
+s = open("DESIGN.md").read()
+a = s.index("<!-- sec6-begin")
+a = s.index("\n", a) + 1
+b = s.index("<!-- sec6-end -->")
+open("DESIGN.md", "w").write(s[:a] + t.rstrip() + "\n" + s[b:])
+print(json.dumps({a: R[a] for a in ("MS512", "GB512", "DOMFR", "MS4D", "MS1024", "MSF64", "DEC512")}))
