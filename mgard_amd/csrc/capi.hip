@@ -115,6 +115,7 @@ struct mgh_hierarchy {
   uint32_t ipk_w = 64;             // MGH_IPK_W: widest solver wave of the streaming Thomas solves
   int ipk_pd = 1;                  // MGH_IPK_PD: their load-pipeline depth
   size_t ipk_contig_rounds = 4;    // MGH_IPK_CONTIG: rounds of the LDS-staged contiguous solve from which the streaming one takes over
+  int ipk_range_mb = 128;          // MGH_IPK_RANGE_MB: f- and c-solve of a load vector bigger than twice this run in r-plane ranges of this size (0 = off)
   int ipk_kr16 = 1;                // MGH_IPK_KR16: 16 register-resident batches for float pencils of 512+ elements
   size_t ipk_wpc = 8;              // MGH_IPK_WPC: most one-wave solver workgroups per CU the host plans with
   bool split_serial = false;       // MGH_SPLIT_SERIAL
@@ -1007,7 +1008,22 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
     // box in LDS anyway)
     tail_pre = h->tail_solves && l == l_tail + 1 && l_tail >= 1;
     if (!tail_pre) {
-      TRY(ipk_fc_launch<T>(h, b.m, ds->t3, t.thomas[2], t.thomas[1], s));
+      // A load vector that does not fit the 256 MB memory-side cache (1024^3: 540 MB) is solved
+      // in ranges of r-planes, f then c per range (both are independent per plane): the c-solve
+      // finds what the f-solve just wrote in the cache instead of in HBM. MGH_IPK_RANGE_MB = size of
+      // a range (0 = never).
+      const size_t box_b = (size_t)b.m[0] * b.m[1] * b.m[2] * sizeof(T);
+      const size_t range_b = (size_t)h->ipk_range_mb << 20;
+      if (range_b && box_b > 2 * range_b) {
+        const uint32_t nrange = (uint32_t)((box_b + range_b - 1) / range_b);
+        for (uint32_t k = 0; k < nrange; k++) {
+          const uint32_t R_lo = (uint32_t)((uint64_t)b.m[0] * k / nrange), R_hi = (uint32_t)((uint64_t)b.m[0] * (k + 1) / nrange);
+          const uint32_t ms[3] = {R_hi - R_lo, b.m[1], b.m[2]};
+          TRY(ipk_fc_launch<T>(h, ms, ds->t3 + (size_t)R_lo * b.m[1] * b.m[2], t.thomas[2], t.thomas[1], s));
+        }
+      } else {
+        TRY(ipk_fc_launch<T>(h, b.m, ds->t3, t.thomas[2], t.thomas[1], s));
+      }
       TRY(ipk_launch<T>(h, 0, b.m, ds->t3, t.thomas[0], ds->nodal[l - 1], +1, s));
     }
     src = ds->nodal[l - 1];
@@ -2166,6 +2182,7 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->ipk_pd = (int)env_get("MGH_IPK_PD", h->ipk_pd);
     h->ipk_wpc = (size_t)env_get("MGH_IPK_WPC", (long)h->ipk_wpc);
     h->ipk_kr16 = (int)env_get("MGH_IPK_KR16", h->ipk_kr16);
+    h->ipk_range_mb = (int)env_get("MGH_IPK_RANGE_MB", h->ipk_range_mb);
     h->ipk_contig_rounds = (size_t)env_get("MGH_IPK_CONTIG", (long)h->ipk_contig_rounds);
     h->split_serial = env_get("MGH_SPLIT_SERIAL", 0) != 0;
     h->no_head = env_get("MGH_NO_RECOMPOSE_HEAD", 0) != 0;

@@ -33,6 +33,7 @@ inline const EnvSwitch *env_switches(size_t *count) {
       {"MGH_TAIL_SOLVES", 0, 1},    {"MGH_IPK_CONTIG", 2, 1 << 20},
       {"MGH_LOADVEC_V", 1, 2},        {"MGH_RESTORE_V", 2, 3},
       {"MGH_LOADVEC_WIDE", 0, 1},     {"MGH_IPK_KR16", 0, 1},
+      {"MGH_IPK_RANGE_MB", 0, 1 << 20},
   };
   *count = sizeof(k) / sizeof(k[0]);
   return k;
