@@ -420,6 +420,52 @@ def config_leg(torch, mgard_amd, name, dev, local_rank, steps=5, end_to_end=Fals
     return out
 
 
+def volume_leg(torch, mgard_amd, dev):
+    """BASELINE.json configs[3] as ONE volume on one GPU: 64 x 512^3 f32 (34 GB, device-resident),
+    `Variable` decomposition {8} x 8 on dim 0 (the 8 slabs the 8 ranks of the weak-scaling run own)
+    through mgh_compress / mgh_decompress: 8 records behind one header, REL bound against the norm
+    of the whole volume, round trip checked. End to end (Huffman stage and container included)."""
+    from mgard_amd import highlevel
+    free, _ = torch.cuda.mem_get_info()
+    if free < 140e9:
+        return {"skipped": "needs ~130 GB of free device memory, %.0f GB free" % (free / 1e9)}
+    base = gpu_field(torch, (512, 512, 512), torch.float32, dev)
+    vol = torch.empty((64, 512, 512, 512), dtype=torch.float32, device=dev)
+    for t in range(64):
+        vol[t] = base * (1.0 + 0.002 * t) + 1e-4 * t
+    del base
+    in_bytes = vol.numel() * 4
+    cfg = highlevel.Config(domain_decomposition=highlevel.DD_VARIABLE, domain_decomposition_dim=0,
+                           domain_decomposition_sizes=[8] * 8)
+    obuf = torch.empty(in_bytes // 2, dtype=torch.uint8, device=dev)
+    stream = highlevel.compress(vol, TOL, float("inf"), mgard_amd.REL, config=cfg, out=obuf)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stream = highlevel.compress(vol, TOL, float("inf"), mgard_amd.REL, config=cfg, out=obuf)
+    torch.cuda.synchronize()
+    c_ms = (time.perf_counter() - t0) * 1e3
+    back = torch.empty_like(vol)
+    highlevel.decompress(stream, out=back, config=cfg)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    highlevel.decompress(stream, out=back, config=cfg)
+    torch.cuda.synchronize()
+    x_ms = (time.perf_counter() - t1) * 1e3
+    nrm = float(vol.abs().max().item())
+    err = max(float((back[t] - vol[t]).abs().max().item()) for t in range(64))
+    out = {"workload": "4D 64x512x512x512 float32 (34 GB) as ONE device-resident volume, Variable decomposition "
+                       "{8} x 8 on dim 0, mgh_compress / mgh_decompress (Huffman, container), REL 1e-3 "
+                       "against the norm of the whole volume",
+           "compress_ms": round(c_ms, 2), "compress_GBps": round(in_bytes / c_ms / 1e6, 2),
+           "decompress_ms": round(x_ms, 2), "decompress_GBps": round(in_bytes / x_ms / 1e6, 2),
+           "compression_ratio": round(in_bytes / int(stream.numel()), 3), "subdomains": 8,
+           "roundtrip_linf_error": err, "tolerance_abs": TOL * nrm, "within_tolerance": bool(err <= TOL * nrm)}
+    del back, vol, obuf, stream
+    highlevel.release_cache()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -768,6 +814,11 @@ def main():
                 except (mgard_amd.MgardHipError, RuntimeError, AssertionError) as e:
                     oc[name] = {"error": str(e)[:300]}
                 torch.cuda.empty_cache()
+            try:
+                oc["4d_volume"] = volume_leg(torch, mgard_amd, dev)
+            except (mgard_amd.MgardHipError, RuntimeError, AssertionError) as e:
+                oc["4d_volume"] = {"error": str(e)[:300]}
+            torch.cuda.empty_cache()
         else:
             # N > 1: configs[3] as it is meant -- the 64 x 512^3 volume split on dim 0, one
             # 8 x 512^3 slab per rank (weak scaling), scalar norm all-reduce over RCCL
