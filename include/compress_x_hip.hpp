@@ -192,7 +192,28 @@ compress(DIM D, data_type dtype, std::vector<SIZE> shape, double tol, double s,
   const compress_status_type ok = detail::check(config);
   if (ok != compress_status_type::Success) return ok;
   if (shape.size() != D) return compress_status_type::Failure;
-  if (config.adjust_shape) detail::adjust_shape(shape, config);
+  if (config.adjust_shape) {
+    // The re-view only makes sense on a uniform grid: coords[d] are sized by the ORIGINAL extents
+    // (the reference re-views anyway and reads past them, CompressionHighLevel.hpp:62-65,85).
+    if (!coords.empty()) return compress_status_type::Failure;
+    const bool variable = config.domain_decomposition == domain_decomposition_type::Variable;
+    if (variable) {
+      // (ShapeAdjustment.hpp:47-52 takes sizes[0] as THE subdomain extent: equal time steps only)
+      if (config.domain_decomposition_dim != 0 || config.domain_decomposition_sizes.empty() ||
+          config.domain_decomposition_sizes[0] == 0)
+        return compress_status_type::Failure;
+      SIZE sum = 0;
+      for (SIZE z : config.domain_decomposition_sizes) {
+        if (z != config.domain_decomposition_sizes[0]) return compress_status_type::Failure;
+        sum += z;
+      }
+      if (sum != shape[0]) return compress_status_type::Failure;
+    }
+    const size_t steps = config.domain_decomposition_sizes.size();
+    detail::adjust_shape(shape, config);
+    // the subdomain sizes follow the adjusted leading extent, so that they still add up to it
+    if (variable) config.domain_decomposition_sizes.assign(steps, shape[0] / (SIZE)steps);
+  }
   const mgh_config c = detail::to_c(config);
   std::vector<const void *> cp(coords.begin(), coords.end());
   return detail::status(mgh_compress(D, (int)dtype, shape.data(), tol, s, (int)mode, original_data,

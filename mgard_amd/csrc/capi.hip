@@ -27,7 +27,6 @@
 #include "kernels_fused.hpp"
 #include "kernels_fused2.hpp"
 #include "kernels_box.hpp"
-#include "kernels_emit.hpp"
 #include "kernels_tail.hpp"
 #include "kernels_recompose.hpp"
 #include "kernels_recompose2.hpp"
@@ -71,15 +70,6 @@ struct mgh_hierarchy {
   bool force_v1 = false;  // MGH_FORCE_V1=1: run the one-thread-per-element kernels only
   bool force_nd = false;  // MGH_FORCE_ND=1: run the generic N-D kernels also for D <= 3 (cross-check)
   std::string prof_filter;  // empty = every kernel
-  // second stream for the coefficient/quantize passes that run beside the correction chain
-  hipStream_t side = nullptr;
-  std::vector<hipEvent_t> fork_ev;  // one per level
-  hipEvent_t join_ev = nullptr;
-  unsigned emit_bpc = 2;   // MGH_EMIT_BPC: workgroups per CU of the (persistent) emit pass
-  unsigned emit_cch = 32;  // MGH_EMIT_CCH: cells per march of the emit pass
-  // MGH_SPLIT: 0 = never split a level (default: measured within 5% of the split schedules
-  // and single-stream), 1 = split the biggest size class, 2 = also the mid-size class
-  int split = 0;
   // MGH_FUSED_V: 2 = second-generation fused level kernel (kernels_fused2.hpp, default),
   // 1 = first generation (kernels_fused.hpp; cross-check)
   int fused_v = 2;
@@ -92,22 +82,11 @@ struct mgh_hierarchy {
   int fused_fixed = 1; // MGH_FUSED_FIXED: the int64 + dictionary variant of the level kernel (default 1)
   int fused_wide = 1; // MGH_FUSED_WIDE: 4 x 64 tiles for 0 = no level, 1 = long marches, 2 = all
   int fused4 = 1;     // MGH_FUSED4: D = 4 through the 3-D tile code, slice by slice (default 1)
-  // MGH_SLABS: big levels run their fused pass in this many r-slabs, and the f- and c-solves of a
-  // slab (independent per r-plane) start on a second stream as soon as the slab's load vector
-  // exists, beside the pass of the next slab (0 / 1 = off). MGH_SLABS_MIN: smallest coarse box
-  // (elements) that is worth the fork/join.
-  int slabs = 0;
   // MGH_BOX: levels up to this march class (0 = few tiles, 1 = mid-size, 2 = long marches) run
   // the box kernel (kernels_box.hpp: no march, every phase once over a 4 x 4 x 8 box) instead of
   // the marching tile kernel; 0 = none, 1 = class 0 (default), 2 = classes 0-1, 3 = every level
   int box = 1;
   int restore_v = 3;  // MGH_RESTORE_V: 3 = marching node restore (kernels_recompose2.hpp), 2 = one wave per pair of fine rows
-  int loadvec_wide = 0;  // MGH_LOADVEC_WIDE: 4 x 64 tiles for the long marches of the load-vector pass
-  // MGH_LOADVEC_V: 1 = first-generation load-vector pass of the decompression side (default),
-  // 2 = the pair-step rebuild (kernels_recompose2.hpp; measured the same at the top level of 512^3,
-  // 302 vs 308 us, and slower on the short marches, 122 vs 112 us: the pass is bound by neither its
-  // barriers nor its predicated loads)
-  int loadvec_v = 1;
   int tail_solves = 1;  // MGH_TAIL_SOLVES: the tail kernel runs the Thomas solves of the level above it
   // (the rest of the developer switches, env.hpp; all read when the hierarchy is created)
   size_t cls1 = 256, cls2 = 2048;  // MGH_CLS1 / MGH_CLS2: tile-count thresholds of the march classes
@@ -118,20 +97,9 @@ struct mgh_hierarchy {
   int ipk_range_mb = 128;          // MGH_IPK_RANGE_MB: f- and c-solve of a load vector bigger than twice this run in r-plane ranges of this size (0 = off)
   int ipk_kr16 = 1;                // MGH_IPK_KR16: 16 register-resident batches for float pencils of 512+ elements
   size_t ipk_wpc = 8;              // MGH_IPK_WPC: most one-wave solver workgroups per CU the host plans with
-  bool split_serial = false;       // MGH_SPLIT_SERIAL
   bool no_head = false;            // MGH_NO_RECOMPOSE_HEAD
   bool restore_rows = false;       // MGH_RESTORE_ROWS
   bool debug_sync = false;         // MGH_DEBUG_SYNC: name every launch on stderr and synchronise behind it
-  uint64_t slabs_min = (uint64_t)4 << 20;
-  // MGH_IPK_SLAB=1 (default): a solve tile of the slab schedule asks for no more LDS than a
-  // workgroup of the pass beside it owns (else a freed slot is always refilled by the pass, whose
-  // request fits at once, and the solves starve until the pass has drained); MGH_SLAB_PRIO: stream
-  // priority of the solve stream (1 = highest, 0 = default)
-  int ipk_slab = 1, slab_prio = 1;
-  size_t solve_max_lds = 0;           // in force while the slab schedule issues its solves (0 = no limit)
-  hipStream_t solve = nullptr;        // the second stream (it carries the critical path)
-  std::vector<hipEvent_t> slab_ev;    // pass of slab i done
-  hipEvent_t solve_done = nullptr;
   std::map<std::string, ProfileEntry> prof;
   size_t device_bytes = 0;
 };
@@ -241,6 +209,13 @@ template <typename T> int dev_alloc(mgh_hierarchy *h, T **p, size_t count) {
   HIP_TRY(hipMalloc((void **)p, count * sizeof(T)));
   h->device_bytes += count * sizeof(T);
   return MGH_SUCCESS;
+}
+
+// mirror of dev_alloc: frees *p (if any) and takes its bytes out of the handle's footprint
+template <typename T> void dev_free(mgh_hierarchy *h, T **p, size_t count) {
+  if (!*p) return;
+  if (hipFree(*p) == hipSuccess) h->device_bytes -= std::min(h->device_bytes, count * sizeof(T));
+  *p = nullptr;
 }
 
 template <typename T> int build_device_state(mgh_hierarchy *h) {
@@ -460,7 +435,6 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
   for (int w : {64, 48, 32, 16}) {
     const size_t lds = w * pencil_bytes;
     if (lds > kLdsPerCU) continue;
-    if (h->solve_max_lds && lds > h->solve_max_lds && w > 16) continue;
     const size_t per_cu = std::min<size_t>(kLdsPerCU / lds, 8);
     const size_t blocks = (npencil + w - 1) / w;
     const size_t rounds = (blocks + per_cu * h->num_cu - 1) / (per_cu * h->num_cu);
@@ -503,7 +477,6 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
           if (w > w_max) continue;
           const size_t lds = (size_t)w * (parked - ng) * sizeof(T) +
                              (axis == 2 ? TileIO<T, U>::stage_elems * sizeof(T) : 0);
-          if (h->solve_max_lds && lds > h->solve_max_lds) continue;
           // ~230 VGPRs (KR = 8): two waves per SIMD = 8 one-wave workgroups per CU; KR = 16:
           // ~400 VGPRs, one wave per SIMD = 4 per CU (the caps the host plans with)
           // (five 32 KB allocations do not fit one CU although 5 * 32 KB = 160 KB: leave a margin)
@@ -726,57 +699,17 @@ inline int fused_rch(const mgh_hierarchy *h, int cls) { return h->rch[cls]; }
 // left (one plane more for sizes 2^k + 1)
 inline int fused_nchunk(int m_r, int rch) { return std::max(1, (m_r - 1 + rch - 1) / rch); }
 
-// Does level l run split (load-vector pass on the caller's stream, coefficient/quantize pass on
-// the side stream)? Only the quantizing path splits.
-template <typename T> bool level_is_split(const mgh_hierarchy *h, int l) {
-  const int c = level_class(h, DS<T>(h)->lt[l].box);
-  return (h->split >= 1 && c == 2) || (h->split >= 2 && c == 1);
-}
-
-inline int ensure_solve_stream(mgh_hierarchy *h, int nslab) {
-  if (!h->solve) {
-    int lo = 0, hi = 0;
-    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    HIP_TRY(hipStreamCreateWithPriority(&h->solve, hipStreamNonBlocking, h->slab_prio ? hi : 0));
-    HIP_TRY(hipEventCreateWithFlags(&h->solve_done, hipEventDisableTiming));
-  }
-  while ((int)h->slab_ev.size() < nslab) {
-    hipEvent_t e;
-    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    h->slab_ev.push_back(e);
-  }
-  return MGH_SUCCESS;
-}
-
-inline int ensure_side_stream(mgh_hierarchy *h) {
-  if (h->side) return MGH_SUCCESS;
-  int lo = 0, hi = 0;
-  HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-  // lowest priority: the latency-bound chain on the caller's stream gets the CUs it asks for
-  HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo));
-  HIP_TRY(hipEventCreateWithFlags(&h->join_ev, hipEventDisableTiming));
-  h->fork_ev.resize(h->L + 1, nullptr);
-  for (auto &e : h->fork_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  return MGH_SUCCESS;
-}
-
 // Level loop on the fused kernels (3 active dims): per level one fused
 // coefficient/quantize/load-vector pass, three Thomas solves (the last one adds
 // the correction into the coarse nodal array), then the head.
-//
-// OUT_Q, big levels: the pass is split (kernels_emit.hpp). The caller's stream carries only
-// what the next level waits for -- load vector + coarse nodes, Thomas solves -- and the
-// coefficient/quantize pass of level l starts on the side stream as soon as that level's
-// nodal input (and the quantizers) exist; the caller's stream joins the side stream at the
-// end. `norm_in_first`: the top-level pass also reduces abs-max(input) into ds->scalar, and
-// `after_first` (the quantizer set-up that consumes it) is issued right behind it.
+// `after_first` (the quantizer set-up) is issued right in front of the first launch that needs it.
 // One level on the second-generation fused kernel (kernels_fused2.hpp). Tiles of the launch
 // (Fused2Grid): a remainder of up to 4 coarse columns / rows beyond the full tiles goes to face
 // tiles, the last r-chunk owns what is left of the planes (one more than the others for sizes
 // 2^k + 1).
 template <typename T, int OUTK, int TC, int TF>
 int launch_fused2_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int cls, const char *nm,
-                    hipStream_t s, int chunk_lo, int chunk_hi) {
+                    hipStream_t s) {
   const int RCHv = fused_rch(h, cls);
   Fused2Grid G{};
   G.rch = RCHv;
@@ -793,11 +726,10 @@ int launch_fused2_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int 
   G.cf_C0 = nfull_c * TC;
   G.n_cf = face_c ? ((face_f ? G.ff_F0 : mfi) + 63) / 64 : 0;
   G.nchunk = fused_nchunk(mri, RCHv);
-  if (chunk_hi < 0) chunk_hi = G.nchunk;
-  G.chunk_hi = chunk_hi;
+  G.chunk_hi = G.nchunk;
   G.xcd_ranges = h->fused_xcd;
   const unsigned ntile = (unsigned)(G.n_main + G.n_ff + G.n_cf);
-  const dim3 grid(G.xcd_ranges ? (ntile + 7) / 8 * 8 : ntile, (unsigned)(chunk_hi - chunk_lo), 1);
+  const dim3 grid(G.xcd_ranges ? (ntile + 7) / 8 * 8 : ntile, (unsigned)G.nchunk, 1);
   const bool faces = G.n_ff || G.n_cf;
 #define MGH_F2(RCH)                                                                           \
   return launch(h, nm, s, [&] {                                                               \
@@ -814,10 +746,10 @@ int launch_fused2_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int 
 // box, alternating runs. The short marches of the lower levels are a few us faster on 8 x 32.
 template <typename T, int OUTK>
 int launch_fused2(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int cls, const char *nm,
-                  hipStream_t s, int chunk_lo = 0, int chunk_hi = -1) {
+                  hipStream_t s) {
   if (h->fused_wide >= 2 || (h->fused_wide == 1 && cls == 2))
-    return launch_fused2_t<T, OUTK, 4, 64>(h, A, b, cls, nm, s, chunk_lo, chunk_hi);
-  return launch_fused2_t<T, OUTK, 8, 32>(h, A, b, cls, nm, s, chunk_lo, chunk_hi);
+    return launch_fused2_t<T, OUTK, 4, 64>(h, A, b, cls, nm, s);
+  return launch_fused2_t<T, OUTK, 8, 32>(h, A, b, cls, nm, s);
 }
 
 template <typename T, int OUT, typename AfterFirst>
@@ -826,7 +758,7 @@ int decompose_fused4(mgh_hierarchy *h, const T *data, T *coeff, const QuantParam
 
 template <typename T, int OUT, typename AfterFirst>
 int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams<T> *qp,
-                    hipStream_t s, bool norm_in_first, AfterFirst &&after_first) {
+                    hipStream_t s, AfterFirst &&after_first) {
   if (h->D == 4) return decompose_fused4<T, OUT>(h, data, coeff, qp, s, after_first);
   auto *ds = DS<T>(h);
   const int L = h->L;
@@ -861,7 +793,6 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
       break;
     }
   }
-  bool forked = false;
   bool tail_pre = false;  // the tail kernel also runs the solves of level l_tail + 1
   for (int l = L; l > l_tail; l--) {
     const LevelTables<T> &t = ds->lt[l];
@@ -884,50 +815,7 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
     }
     const unsigned gx = (b.m[2] + TF - 1) / TF, gy = (b.m[1] + TC - 1) / TC;
     const int cls = level_class(h, b);
-    const bool split = OUT == OUT_Q && level_is_split<T>(h, l);
-    if (split) {
-      TRY(ensure_side_stream(h));
-      A.absmax_bits = (l == L && norm_in_first) ? ds->fscal + ds->scalar_slot : nullptr;
-      if (h->fused_v == 2) {
-        TRY((launch_fused2<T, OUT_NONE>(h, A, b, cls, cls == 2 ? "level_load" : "level_load_small", s)));
-      } else if (cls == 2) {
-        const dim3 grid(gx, gy, (b.m[0] + 15) / 16);
-        TRY(launch(h, "level_load", s, [&] {
-          k_level_fused<T, OUT_NONE, TC, TF, 16, false><<<grid, 256, 0, s>>>(A);
-        }));
-      } else {
-        const dim3 grid(gx, gy, (b.m[0] + 3) / 4);
-        TRY(launch(h, "level_load_small", s, [&] {
-          k_level_fused<T, OUT_NONE, TC, TF, 4, false><<<grid, 256, 0, s>>>(A);
-        }));
-      }
-      A.absmax_bits = nullptr;
-      if (l == L) TRY(after_first());
-      // fork: everything the emit pass reads (nodal input of level l, quantizers) is ordered
-      // before this point of the caller's stream
-      const bool serial = h->split_serial;  // (experiments)
-      hipStream_t es = serial ? s : h->side;
-      if (!serial) {
-        HIP_TRY(hipEventRecord(h->fork_ev[l], s));
-        HIP_TRY(hipStreamWaitEvent(h->side, h->fork_ev[l], 0));
-      }
-      // emit pass: persistent, a bounded number of workgroups per CU (kernels_emit.hpp)
-      const unsigned nstrip = (b.m[2] - 1 + 63) / 64;
-      const unsigned ncch = std::max(1u, (b.m[1] + h->emit_cch - 1) / h->emit_cch);
-      const unsigned cch = (b.m[1] + ncch - 1) / ncch;
-      const unsigned nwork = nstrip * ncch * ((b.m[0] + 3) / 4);
-      const unsigned eblocks = std::min(nwork, 256u * h->emit_bpc);
-      const char *ename = cls == 2 ? "level_emit_q" : "level_emit_q_small";
-      if (nstrip > 0)
-        TRY(launch(h, ename, es, [&] {
-          k_level_emit<T, OUT_Q, 2><<<eblocks, 256, 0, es>>>(A, nstrip, ncch, cch, nwork);
-        }));
-      const unsigned lblocks = std::min(256u, (b.m[0] * b.m[1] + 255) / 256);
-      TRY(launch(h, "level_emit_lastcol", es, [&] {
-        k_level_emit_lastcol<T, OUT_Q><<<lblocks, 256, 0, es>>>(A);
-      }));
-      forked = true;
-    } else {
+    {
       if (l == L) TRY(after_first());
       // long marches (RCH = 16: 9% r-halo) when there are plenty of tiles, short ones
       // (RCH = 4) on the small levels where the march length is pure latency
@@ -944,48 +832,10 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
       } else if (v2) {
         const char *nm = cls == 2 ? (OUT == OUT_Q ? "level_fused_q" : "level_fused")
                                   : (OUT == OUT_Q ? "level_fused_q_small" : "level_fused_small");
-        // Slab schedule: the pass of a big level runs in r-slabs (whole chunks, last chunks first
-        // like the chunks of one launch), and the f- and c-solves of a slab -- independent per
-        // r-plane -- follow on the solve stream while the caller's stream runs the next slab's
-        // pass: the latency-bound solves sit beside a bandwidth-bound pass instead of behind it.
-        const int nchunk = fused_nchunk((int)b.m[0], fused_rch(h, cls));
-        const size_t cbox = (size_t)b.m[0] * b.m[1] * b.m[2];
-        const int ns = (h->slabs >= 2 && cbox >= h->slabs_min) ? std::min(h->slabs, nchunk) : 1;
-        auto pass = [&](int c_lo, int c_hi) {
-          if (OUT == OUT_Q && A.prep_huffman && !A.q16 && h->fused_fixed)
-            return launch_fused2<T, OUT == OUT_Q ? OUT_QH : OUT>(h, A, b, cls, nm, s, c_lo, c_hi);
-          return launch_fused2<T, OUT>(h, A, b, cls, nm, s, c_lo, c_hi);
-        };
-        if (ns >= 2) {
-          TRY(ensure_solve_stream(h, ns));
-          const int rchv = fused_rch(h, cls);
-          struct LdsLimit {  // (in force for the solves issued below only)
-            mgh_hierarchy *h;
-            ~LdsLimit() { h->solve_max_lds = 0; }
-          } lds_limit{h};
-          if (h->ipk_slab) h->solve_max_lds = 33 * 1024;
-          for (int i = 0; i < ns; i++) {
-            // slab i: chunks [c_lo, c_hi), coarse planes [R_lo, R_hi)
-            const int c_hi = nchunk - (int)((int64_t)nchunk * i / ns);
-            const int c_lo = nchunk - (int)((int64_t)nchunk * (i + 1) / ns);
-            TRY(pass(c_lo, c_hi));
-            HIP_TRY(hipEventRecord(h->slab_ev[i], s));
-            HIP_TRY(hipStreamWaitEvent(h->solve, h->slab_ev[i], 0));
-            const uint32_t R_lo = (uint32_t)(c_lo * rchv);
-            const uint32_t R_hi = c_hi == nchunk ? b.m[0] : (uint32_t)(c_hi * rchv);
-            const uint32_t ms[3] = {R_hi - R_lo, b.m[1], b.m[2]};
-            TRY(ipk_fc_launch<T>(h, ms, ds->t3 + (size_t)R_lo * b.m[1] * b.m[2], t.thomas[2],
-                                 t.thomas[1], h->solve));
-          }
-          HIP_TRY(hipEventRecord(h->solve_done, h->solve));
-          HIP_TRY(hipStreamWaitEvent(s, h->solve_done, 0));
-          TRY(ipk_launch<T>(h, 0, b.m, ds->t3, t.thomas[0], ds->nodal[l - 1], +1, s));
-          src = ds->nodal[l - 1];
-          sJ = b.m[2];
-          sI = (size_t)b.m[1] * b.m[2];
-          continue;
-        }
-        TRY(pass(0, nchunk));
+        if (OUT == OUT_Q && A.prep_huffman && !A.q16 && h->fused_fixed)
+          TRY((launch_fused2<T, OUT == OUT_Q ? OUT_QH : OUT>(h, A, b, cls, nm, s)));
+        else
+          TRY((launch_fused2<T, OUT>(h, A, b, cls, nm, s)));
       } else if (cls == 2) {
         const dim3 grid(gx, gy, (b.m[0] + 15) / 16);
         TRY(launch(h, OUT == OUT_Q ? "level_fused_q" : "level_fused", s, [&] {
@@ -1078,10 +928,6 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
       k_head_out<T, OUT><<<1, 256, 0, s>>>((int)b.m[0], (int)b.m[1], (int)b.m[2], ds->nodal[0], A);
     }));
   }
-  if (forked) {
-    HIP_TRY(hipEventRecord(h->join_ev, h->side));
-    HIP_TRY(hipStreamWaitEvent(s, h->join_ev, 0));
-  }
   return MGH_SUCCESS;
 }
 
@@ -1169,22 +1015,23 @@ template <typename T> int ensure_state4(mgh_hierarchy *h) {
   const int L = h->L;
   const auto &sh = hh->level_shape;
   if (ds->state4_ready) return MGH_SUCCESS;
-  // a failed attempt (out of memory on a big slab) leaves nothing behind: the next call starts over
+  // a failed attempt (out of memory on a big slab) leaves nothing behind -- neither memory nor its
+  // share of mgh_device_bytes(): the next call starts over
+  const size_t M = (size_t)sh[L - 1][1] * sh[L - 1][2] * sh[L - 1][3];
+  auto nodal_count = [&](int l) { return (size_t)sh[l][0] * sh[l][1] * sh[l][2] * sh[l][3]; };
+  const size_t load_count = (2 * (size_t)sh[L - 1][0] - 1) * M, corr_count = (size_t)sh[L - 1][0] * M;
   auto drop = [&] {
-    for (T *p : ds->nodal4) (void)hipFree(p);
+    for (size_t l = 0; l < ds->nodal4.size(); l++) dev_free(h, &ds->nodal4[l], nodal_count((int)l));
     ds->nodal4.clear();
-    (void)hipFree(ds->load4);
-    (void)hipFree(ds->corr4);
-    ds->load4 = ds->corr4 = nullptr;
+    dev_free(h, &ds->load4, load_count);
+    dev_free(h, &ds->corr4, corr_count);
   };
   drop();
   ds->nodal4.assign(L + 1, nullptr);
-  const size_t M = (size_t)sh[L - 1][1] * sh[L - 1][2] * sh[L - 1][3];
   int rc = MGH_SUCCESS;
-  for (int l = 0; l < L && rc == MGH_SUCCESS; l++)
-    rc = dev_alloc(h, &ds->nodal4[l], (size_t)sh[l][0] * sh[l][1] * sh[l][2] * sh[l][3]);
-  if (rc == MGH_SUCCESS) rc = dev_alloc(h, &ds->load4, (2 * (size_t)sh[L - 1][0] - 1) * M);
-  if (rc == MGH_SUCCESS) rc = dev_alloc(h, &ds->corr4, (size_t)sh[L - 1][0] * M);
+  for (int l = 0; l < L && rc == MGH_SUCCESS; l++) rc = dev_alloc(h, &ds->nodal4[l], nodal_count(l));
+  if (rc == MGH_SUCCESS) rc = dev_alloc(h, &ds->load4, load_count);
+  if (rc == MGH_SUCCESS) rc = dev_alloc(h, &ds->corr4, corr_count);
   if (rc != MGH_SUCCESS) {
     drop();
     return rc;
@@ -1293,7 +1140,7 @@ int decompose_fused4(mgh_hierarchy *h, const T *data, T *coeff, const QuantParam
 template <typename T, int OUT>
 int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams<T> *qp,
                     hipStream_t s) {
-  return decompose_fused<T, OUT>(h, data, coeff, qp, s, false, [] { return (int)MGH_SUCCESS; });
+  return decompose_fused<T, OUT>(h, data, coeff, qp, s, [] { return (int)MGH_SUCCESS; });
 }
 
 // The fused kernels index inside an r-plane with 32-bit offsets (and the emit pass with 32-bit
@@ -1618,31 +1465,11 @@ int launch_restore(mgh_hierarchy *h, const RecomposeArgs<T> &A, const Box3 &b, c
 }
 
 // Load-vector pass of the decompression side (one level, or one t-slice of a 4-D level):
-// second-generation kernel (kernels_recompose2.hpp) with the tile shapes / chunk lengths of the
-// compression side's level kernel, or (MGH_LOADVEC_V=1: cross-check) the first-generation one.
+// one plane per step, march length by the number of tiles.
 template <typename T, typename QT>
 int launch_loadvec(mgh_hierarchy *h, const RecomposeArgs<T> &A, const Box3 &b, hipStream_t st) {
   constexpr int TC = 8, TF = 32;
   const unsigned gx = (b.m[2] + TF - 1) / TF, gy = (b.m[1] + TC - 1) / TC;
-  if (h->loadvec_v == 2) {
-    const int cls = level_class(h, b);
-    const char *nm = cls == 2 ? "loadvec_q" : "loadvec_q_small";
-    Loadvec2Grid G{};
-    G.rch = fused_rch(h, cls);
-    G.nchunk = fused_nchunk((int)b.m[0], G.rch);
-    G.xcd_ranges = h->fused_xcd;
-    // (8 x 32 tiles unless MGH_LOADVEC_WIDE=1: the window holds 8-byte values here, and the
-    // 1.41 x halo of a 4 x 64 tile costs more than its longer rows save)
-    const bool wide = h->loadvec_wide && cls == 2;
-    const int tc = wide ? 4 : 8, tf = wide ? 64 : 32;
-    G.gxm = ((int)b.m[2] + tf - 1) / tf;
-    G.ntile = G.gxm * (((int)b.m[1] + tc - 1) / tc);
-    const dim3 grid(G.xcd_ranges ? (unsigned)(G.ntile + 7) / 8 * 8 : (unsigned)G.ntile, (unsigned)G.nchunk, 1);
-    return launch(h, nm, st, [&] {
-      if (wide) k_level_loadvec2_q<T, QT, 4, 64, 16><<<grid, 256, 0, st>>>(A, G);
-      else k_level_loadvec2_q<T, QT, 8, 32, 16><<<grid, 256, 0, st>>>(A, G);
-    });
-  }
   if ((size_t)gx * gy * ((b.m[0] + 15) / 16) >= 2048)
     return launch(h, "loadvec_q", st, [&] {
       k_level_loadvec_q<T, QT, TC, TF, 16><<<dim3(gx, gy, (b.m[0] + 15) / 16), 256, 0, st>>>(A);
@@ -2070,11 +1897,7 @@ int fused_q_entry_device(mgh_hierarchy *h, const T *data, int ebtype, double tol
                          uint64_t *oidx, int64_t *oval, uint64_t ocap, hipStream_t st,
                          uint16_t *q16 = nullptr) {
   auto *ds = DS<T>(h);
-  // s = inf, REL, no norm given, top level split: abs-max(input) comes out of the top level's
-  // load-vector pass (it reads every input element anyway) -- no separate norm pass
   const bool need_norm = !d_norm && ebtype == MGH_REL;
-  const bool norm_in_first = need_norm && (T)s == std::numeric_limits<T>::infinity() &&
-                             h->D == 3 && h->L >= 1 && level_is_split<T>(h, h->L);
   // The norm scalar has two slots used alternately: this call reduces into scalar[slot] (zero on
   // entry) and k_make_qparams zeroes the other one for the next call, together with the outlier
   // counter -- two memset launches less per step.
@@ -2082,7 +1905,7 @@ int fused_q_entry_device(mgh_hierarchy *h, const T *data, int ebtype, double tol
   ds->fscal_dirty = true;
   unsigned long long *slot = ds->fscal + ds->scalar_slot;
   unsigned long long *other = ds->fscal + (1 - ds->scalar_slot);
-  if (need_norm && !norm_in_first) {
+  if (need_norm) {
     const size_t total = h->total;
     const unsigned grid = (unsigned)std::min<size_t>((total + 1023) / 1024, 256 * 8);
     if ((T)s == std::numeric_limits<T>::infinity())
@@ -2110,7 +1933,7 @@ int fused_q_entry_device(mgh_hierarchy *h, const T *data, int ebtype, double tol
   qp.oidx = oidx;
   qp.oval = oval;
   qp.ocap = ocap;
-  TRY((decompose_fused<T, OUT_Q>(h, data, nullptr, &qp, st, norm_in_first, qparams)));
+  TRY((decompose_fused<T, OUT_Q>(h, data, nullptr, &qp, st, qparams)));
   if (h_norm_out) {
     T nv = 0;
     HIP_TRY(hipMemcpyAsync(&nv, ds->normval, sizeof(T), hipMemcpyDeviceToHost, st));
@@ -2156,7 +1979,6 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
   {
     h->force_v1 = env_get("MGH_FORCE_V1", 0) != 0;
     h->force_nd = env_get("MGH_FORCE_ND", 0) != 0;
-    h->split = (int)env_get("MGH_SPLIT", h->split);
     h->fused_v = (int)env_get("MGH_FUSED_V", h->fused_v);
     h->ipk_stream = (int)env_get("MGH_IPK_STREAM", h->ipk_stream);
     h->fused_faces = (int)env_get("MGH_FUSED_FACES", h->fused_faces);
@@ -2164,17 +1986,9 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->fused_fixed = (int)env_get("MGH_FUSED_FIXED", h->fused_fixed);
     h->fused_wide = (int)env_get("MGH_FUSED_WIDE", h->fused_wide);
     h->fused4 = (int)env_get("MGH_FUSED4", h->fused4);
-    h->emit_bpc = (unsigned)env_get("MGH_EMIT_BPC", h->emit_bpc);
-    h->emit_cch = (unsigned)env_get("MGH_EMIT_CCH", h->emit_cch);
-    h->slabs = (int)env_get("MGH_SLABS", h->slabs);
     h->box = (int)env_get("MGH_BOX", h->box);
-    h->loadvec_v = (int)env_get("MGH_LOADVEC_V", h->loadvec_v);
-    h->loadvec_wide = (int)env_get("MGH_LOADVEC_WIDE", h->loadvec_wide);
     h->restore_v = (int)env_get("MGH_RESTORE_V", h->restore_v);
     h->tail_solves = (int)env_get("MGH_TAIL_SOLVES", h->tail_solves);
-    h->slabs_min = (uint64_t)env_get("MGH_SLABS_MIN", (long)h->slabs_min);
-    h->ipk_slab = (int)env_get("MGH_IPK_SLAB", h->ipk_slab);
-    h->slab_prio = (int)env_get("MGH_SLAB_PRIO", h->slab_prio);
     h->cls1 = (size_t)env_get("MGH_CLS1", (long)h->cls1);
     h->cls2 = (size_t)env_get("MGH_CLS2", (long)h->cls2);
     if (const char *e = std::getenv("MGH_RCH")) std::sscanf(e, "%d,%d,%d", &h->rch[0], &h->rch[1], &h->rch[2]);
@@ -2184,7 +1998,6 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->ipk_kr16 = (int)env_get("MGH_IPK_KR16", h->ipk_kr16);
     h->ipk_range_mb = (int)env_get("MGH_IPK_RANGE_MB", h->ipk_range_mb);
     h->ipk_contig_rounds = (size_t)env_get("MGH_IPK_CONTIG", (long)h->ipk_contig_rounds);
-    h->split_serial = env_get("MGH_SPLIT_SERIAL", 0) != 0;
     h->no_head = env_get("MGH_NO_RECOMPOSE_HEAD", 0) != 0;
     h->restore_rows = env_get("MGH_RESTORE_ROWS", 0) != 0;
     h->debug_sync = env_get("MGH_DEBUG_SYNC", 0) != 0;
@@ -2238,12 +2051,6 @@ void mgh_hierarchy_destroy(mgh_hierarchy *h) {
       (void)hipEventDestroy(ev.first);
       (void)hipEventDestroy(ev.second);
     }
-  for (hipEvent_t e : h->fork_ev) (void)hipEventDestroy(e);
-  for (hipEvent_t e : h->slab_ev) (void)hipEventDestroy(e);
-  if (h->solve_done) (void)hipEventDestroy(h->solve_done);
-  if (h->solve) (void)hipStreamDestroy(h->solve);
-  if (h->join_ev) (void)hipEventDestroy(h->join_ev);
-  if (h->side) (void)hipStreamDestroy(h->side);
   if (h->dtype == MGH_FLOAT) destroy_state<float>(h); else destroy_state<double>(h);
   delete h;
 }
@@ -2331,7 +2138,7 @@ int mgh_decompose_quantize_sym16(mgh_hierarchy *h, const void *d_data, int error
     return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
   if (dict_size == 0 || dict_size > 65536) return fail(MGH_ERR_INVALID_ARGUMENT, "dict_size must be in 1..65536");
   HIP_TRY(hipSetDevice(h->device));
-  if (!(fusedc_ok(h) && !h->force_v1 && !h->split))
+  if (!(fusedc_ok(h) && !h->force_v1))
     return fail(MGH_ERR_UNSUPPORTED_DIMENSION, "16-bit symbols: only on the fused 3-D / 4-D path");
   // (the norm and the quantizers stay on the device; a given norm is uploaded first)
   const void *d_norm = nullptr;
@@ -2366,7 +2173,7 @@ int mgh_decompose_quantize_sym16(mgh_hierarchy *h, const void *d_data, int error
 }
 
 int mgh_sym16_supported(const mgh_hierarchy *h) {
-  return h && fusedc_ok(h) && !h->force_v1 && !h->split ? 1 : 0;
+  return h && fusedc_ok(h) && !h->force_v1 ? 1 : 0;
 }
 
 int mgh_dequantize_recompose_sym16(mgh_hierarchy *h, const uint16_t *d_symbols, int error_bound_type,

@@ -1,11 +1,13 @@
 // MGH_* developer switches (cross-checks and experiments; DESIGN.md lists them). They are read when
-// a hierarchy / a high-level call is set up, and they are VALIDATED: a value outside the range of
-// its switch, or an MGH_* variable this library does not know (a typo), is an error -- never a
-// silent default.
+// a hierarchy / a high-level call is set up, and their values are VALIDATED: a value outside the
+// range of its switch is an error, never a silent default. An MGH_* name the library does not know
+// gets one warning on stderr per process.
 #pragma once
 #include <cerrno>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 extern char **environ;
@@ -19,20 +21,15 @@ struct EnvSwitch {
 
 inline const EnvSwitch *env_switches(size_t *count) {
   static const EnvSwitch k[] = {
-      {"MGH_FORCE_V1", 0, 1},       {"MGH_FORCE_ND", 0, 1},        {"MGH_SPLIT", 0, 2},
-      {"MGH_FUSED_V", 1, 2},        {"MGH_IPK_STREAM", 0, 1},      {"MGH_FUSED_FACES", 0, 1},
+      {"MGH_FORCE_V1", 0, 1},       {"MGH_FORCE_ND", 0, 1},        {"MGH_FUSED_V", 1, 2},        {"MGH_IPK_STREAM", 0, 1},      {"MGH_FUSED_FACES", 0, 1},
       {"MGH_FUSED_XCD", 0, 1},      {"MGH_FUSED_FIXED", 0, 1},     {"MGH_FUSED_WIDE", 0, 2},
-      {"MGH_FUSED4", 0, 1},         {"MGH_EMIT_BPC", 1, 64},       {"MGH_EMIT_CCH", 1, 4096},
-      {"MGH_CLS1", 0, 1 << 30},     {"MGH_CLS2", 0, 1 << 30},      {"MGH_RCH", 1, 16},
-      {"MGH_IPK_W", 16, 64},        {"MGH_IPK_PD", 1, 4},          {"MGH_SPLIT_SERIAL", 0, 1},
-      {"MGH_NO_RECOMPOSE_HEAD", 0, 1}, {"MGH_RESTORE_ROWS", 0, 1}, {"MGH_DEBUG_SYNC", 0, 1},
+      {"MGH_FUSED4", 0, 1},         {"MGH_CLS1", 0, 1 << 30},     {"MGH_CLS2", 0, 1 << 30},      {"MGH_RCH", 1, 16},
+      {"MGH_IPK_W", 16, 64},        {"MGH_IPK_PD", 1, 4},          {"MGH_NO_RECOMPOSE_HEAD", 0, 1}, {"MGH_RESTORE_ROWS", 0, 1}, {"MGH_DEBUG_SYNC", 0, 1},
       {"MGH_HL_TIMING", 0, 1},      {"MGH_HUFF_TB", 8, 15},        {"MGH_HUFF_SERIAL_DECODE", 0, 1},
-      {"MGH_HUFF_PAR_DECODE", 0, 1}, {"MGH_SYM16_DECODE", 0, 1},   {"MGH_SLABS", 0, 64},
-      {"MGH_SLABS_MIN", 0, 1 << 30}, {"MGH_BOX", 0, 3},            {"MGH_IPK_SLAB", 0, 1},
-      {"MGH_SLAB_PRIO", 0, 1},      {"MGH_IPK_WPC", 1, 16},
+      {"MGH_HUFF_PAR_DECODE", 0, 1}, {"MGH_SYM16_DECODE", 0, 1},   {"MGH_BOX", 0, 3},            {"MGH_IPK_WPC", 1, 16},
       {"MGH_TAIL_SOLVES", 0, 1},    {"MGH_IPK_CONTIG", 2, 1 << 20},
-      {"MGH_LOADVEC_V", 1, 2},        {"MGH_RESTORE_V", 2, 3},
-      {"MGH_LOADVEC_WIDE", 0, 1},     {"MGH_IPK_KR16", 0, 1},
+      {"MGH_RESTORE_V", 2, 3},
+      {"MGH_IPK_KR16", 0, 1},
       {"MGH_IPK_RANGE_MB", 0, 1 << 20},
   };
   *count = sizeof(k) / sizeof(k[0]);
@@ -47,20 +44,40 @@ inline bool env_parse_long(const char *txt, long &v) {
   return errno == 0 && end && *end == '\0';
 }
 
-// Checks every MGH_* variable of the process environment; empty string = fine.
+// MGH_* names this library does not know (a typo, or another product's variable): ONE warning on
+// stderr per process, never an error -- an unrelated MGH_-prefixed variable in a production
+// environment must not break every call. The walk over `environ` happens once.
+inline void env_warn_unknown_once() {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    size_t n = 0;
+    const EnvSwitch *k = env_switches(&n);
+    for (char **e = environ; e && *e; e++) {
+      if (std::strncmp(*e, "MGH_", 4) != 0) continue;
+      const char *eq = std::strchr(*e, '=');
+      if (!eq) continue;
+      const std::string name(*e, eq - *e);
+      bool known = false;
+      for (size_t i = 0; i < n; i++) known |= name == k[i].name;
+      if (!known)
+        std::fprintf(stderr, "libmgard_hip: unknown developer switch %s ignored (DESIGN.md lists them)\n",
+                     name.c_str());
+    }
+  });
+}
+
+// Checks the value of every KNOWN switch that is set (one getenv per switch, no walk over the
+// process environment); empty string = fine. A value outside the range of its switch is an error,
+// never a silent default.
 inline std::string env_validate() {
+  env_warn_unknown_once();
   size_t n = 0;
   const EnvSwitch *k = env_switches(&n);
-  for (char **e = environ; e && *e; e++) {
-    if (std::strncmp(*e, "MGH_", 4) != 0) continue;
-    const char *eq = std::strchr(*e, '=');
-    if (!eq) continue;
-    const std::string name(*e, eq - *e);
-    const EnvSwitch *sw = nullptr;
-    for (size_t i = 0; i < n; i++)
-      if (name == k[i].name) sw = &k[i];
-    if (!sw) return "unknown developer switch " + name + " (see DESIGN.md for the list)";
-    std::string val(eq + 1);
+  for (size_t i = 0; i < n; i++) {
+    const EnvSwitch *sw = &k[i];
+    const char *txt = std::getenv(sw->name);
+    if (!txt) continue;
+    const std::string name(sw->name), val(txt);
     if (name == "MGH_RCH") {
       int parts = 0;
       size_t pos = 0;

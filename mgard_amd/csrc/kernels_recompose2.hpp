@@ -1,17 +1,4 @@
-// Decompression side, second generation of the load-vector pass (gfx950).
-//
-// k_level_loadvec_q (kernels_recompose.hpp) has the structure of the first-generation level kernel:
-// one plane per step, two barriers per plane, every window load in its own predicated basic block.
-// This one is the mirror of kernels_fused2.hpp:
-//   * planes in (odd, even) PAIRS, two barriers per pair;
-//   * the window of quantized coefficients is loaded UNCONDITIONALLY from clamped positions of the
-//     reordered array, one pair ahead of its use (all loads of a pair in flight together), and
-//     positions that carry no coefficient of this level -- outside the grid, ghost nodes, the
-//     coarse corner of an even plane -- become 0 by a select on a lane-constant mask;
-//   * sweep constants in LDS, r-sweep with tb(R+1) = td(R), r-chunks of a run-time length with
-//     the last one taking what is left, tiles handed to the XCDs in contiguous ranges.
-// Per value the operations and their order are those of k_level_loadvec_q (dequantize:
-// LinearQuantization.hpp:246-264; sweeps: LPKFunctor.h:77-93) -- bit-identical.
+// Decompression side, marching node restore (gfx950).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,191 +7,6 @@
 #include "kernels_recompose.hpp"
 
 namespace mgh {
-
-template <int TC, int TF, int RCH> struct Loadvec2Geom {
-  static constexpr int WC = 2 * TC + 3, WF = 2 * TF + 3, HF = TF + 2, ROW = 2 * HF, PL = WC * ROW;
-  static constexpr int TP = TF + 1;
-  static constexpr int o_t1 = 2 * PL, o_wr = (o_t1 + 2 * WC * TP + 3) / 4 * 4, o_wf = o_wr + (RCH + 1) * 12,
-                       o_wc = o_wf + 9 * TF, elems = o_wc + 9 * TC;
-};
-
-struct Loadvec2Grid {
-  int gxm, ntile;   // tiles of TC x TF coarse nodes: gxm along f, ntile in all
-  int rch, nchunk;  // r-chunks of rch <= RCH coarse planes, the last one takes what is left (<= rch + 1)
-  int xcd_ranges;   // grid.x padded to a multiple of 8, tiles in contiguous ranges per XCD
-};
-
-template <typename T, typename QT, int TC, int TF, int RCH>
-__global__ void __launch_bounds__(TC * TF)
-k_level_loadvec2_q(RecomposeArgs<T> A, Loadvec2Grid G) {
-  using GM = Loadvec2Geom<TC, TF, RCH>;
-  constexpr int WC = GM::WC, WF = GM::WF, HF = GM::HF, ROW = GM::ROW, PL = GM::PL, TP = GM::TP;
-  constexpr int NT = TC * TF;
-  constexpr int BX = (WC * TF - 2 * NT);  // f-sweep items of the third round (per plane)
-  static_assert(BX >= 0 && BX <= NT && BX % TF == 0, "f-sweep: two full rounds + one partial");
-  __shared__ __attribute__((aligned(16))) T lds[GM::elems];
-  T *const Cs0 = lds, *const Cs1 = lds + PL;                        // coefficient fields: odd / even plane
-  T *const t1s0 = lds + GM::o_t1, *const t1s1 = t1s0 + WC * TP;      // f-swept rows of the pair
-  T *const wrs = lds + GM::o_wr, *const wfs = lds + GM::o_wf, *const wcs = lds + GM::o_wc;
-#define LI(lc, lf) ((lc) * ROW + ((lf) & 1) * HF + ((lf) >> 1))
-  int b = blockIdx.x;
-  if (G.xcd_ranges) {
-    const int per = gridDim.x / 8;
-    b = (b % 8) * per + b / 8;
-    if (b >= G.ntile) return;
-  }
-  const int chunk = G.nchunk - 1 - (int)blockIdx.y;
-  const int tid = threadIdx.x;
-  const int nr = A.n[0], nc = A.n[1], nf = A.n[2];
-  const int mr = A.m[0], mc = A.m[1], mf = A.m[2];
-  const int F0 = (b % G.gxm) * TF, C0 = (b / G.gxm) * TC, R0 = chunk * G.rch;
-  const int rch = chunk == G.nchunk - 1 ? mr - R0 : G.rch;
-  const int c_lo = 2 * C0 - 2, f_lo = 2 * F0 - 2, r_lo = 2 * R0 - 2;
-  const int r_hi = min(2 * R0 + 2 * rch, 2 * mr);
-  const int Pmax_r = 2 * mr - 2, Pmax_c = 2 * mc - 2, Pmax_f = 2 * mf - 2;
-  const int ghost_r = (nr % 2 == 0) ? nr - 1 : -7;
-  const int ghost_c = (nc % 2 == 0) ? nc - 1 : -7;
-  const int ghost_f = (nf % 2 == 0) ? nf - 1 : -7;
-
-  for (int e = tid; e < rch * 9; e += NT) {
-    const int R = R0 + e / 9, k = e % 9;
-    wrs[(e / 9) * 12 + k] = R < mr ? A.mass[0][k * mr + R] : (T)0;
-  }
-  const int jf = tid % TF, jc = tid / TF;
-  for (int e = tid; e < 9 * TF; e += NT) {
-    const int k = e / TF, J = F0 + e % TF;
-    wfs[e] = J < mf ? A.mass[2][k * mf + J] : (T)0;
-  }
-  for (int e = tid; e < 9 * TC; e += NT) {
-    const int k = e / TC, J = C0 + e % TC;
-    wcs[e] = J < mc ? A.mass[1][k * mc + J] : (T)0;
-  }
-
-  // ---- window elements of this thread: LDS index, offset inside an r-plane of the reordered
-  // array (clamped: always a valid address), does the position carry a coefficient ------------
-  constexpr int NL = (WC * WF + NT - 1) / NT;
-  uint32_t lidx[NL], qoff[NL];
-  bool okm[NL], evn[NL];
-  auto reordered = [](int P, int m) { return (P & 1) ? m + (P - 1) / 2 : P / 2; };
-#pragma unroll
-  for (int k = 0; k < NL; k++) {
-    const int e = min(tid + k * NT, WC * WF - 1);
-    const int lc = e / WF, lf = e - lc * WF;
-    const int Pc = c_lo + lc, Pf = f_lo + lf;
-    okm[k] = Pc >= 0 && Pc <= Pmax_c && Pc != ghost_c && Pf >= 0 && Pf <= Pmax_f && Pf != ghost_f;
-    evn[k] = !(lc & 1) && !(lf & 1);
-    int Pca = min(max(Pc, 0), Pmax_c), Pfa = min(max(Pf, 0), Pmax_f);
-    if (Pca == ghost_c) Pca--;
-    if (Pfa == ghost_f) Pfa--;
-    lidx[k] = LI(lc, lf);
-    qoff[k] = (uint32_t)reordered(Pca, mc) * (uint32_t)A.dJ + (uint32_t)reordered(Pfa, mf);
-  }
-  using QR = typename QReg<T, QT>::type;
-  const QT *const src = qsrc<T>(A, QT()) + A.lin_base;
-  auto plane_ok = [&](int p) { return p >= 0 && p <= Pmax_r && p != ghost_r; };
-  auto plane_off = [&](int p) {
-    int pa = min(max(p, 0), Pmax_r);
-    if (pa == ghost_r) pa--;
-    return (size_t)reordered(pa, mr) * A.dI;
-  };
-  // (an even plane holds no coefficient at its (even c, even f) positions -- a quarter of its
-  // window: those lanes read the first element of the plane instead, one line that stays hot,
-  // so that no memory traffic is spent on values the mask drops)
-  auto fetch = [&](int p, QR(&reg)[NL]) {
-    const QT *base = src + plane_off(p);
-    const bool all = (p & 1) || A.allcoef;
-#pragma unroll
-    for (int k = 0; k < NL; k++) reg[k] = qload<T>(A, base + ((all || !evn[k]) ? qoff[k] : 0u));
-  };
-  // dequantized coefficient field of plane p into cs (0 where the position carries no
-  // coefficient of this level: an even plane holds none at its (even c, even f) nodes)
-  auto put = [&](int p, const QR(&reg)[NL], T *cs) {
-    const bool pv = plane_ok(p);
-    const bool all = (p & 1) || A.allcoef;
-    const size_t pb = A.lin_base + plane_off(p);  // (index of a looked-up 16-bit symbol)
-#pragma unroll
-    for (int k = 0; k < NL; k++) {
-      const T v = qdecode(A, reg[k], pb + qoff[k]);
-      cs[lidx[k]] = (pv && okm[k] && (all || !evn[k])) ? v : (T)0;
-    }
-  };
-
-  auto f_sweep_row = [&](const T *cs, T *t1, int lc) {
-    const T *row = cs + lc * ROW;
-    const T a = row[jf], bq = row[HF + jf], c = row[jf + 1], d = row[HF + jf + 1], e = row[jf + 2];
-    T wf[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) wf[k] = wfs[k * TF + jf];
-    const T tb = mass_tb(a, bq, c, wf);
-    T tc = mass_tc(bq, c, d, wf);
-    const T td = mass_td(c, d, e, wf);
-    tc += tb * wf[7] + td * wf[8];
-    t1[lc * TP + jf] = tc;
-  };
-  auto phase_b = [&](const T *cs, T *t1) {
-    f_sweep_row(cs, t1, jc);
-    f_sweep_row(cs, t1, jc + TC);
-    if (BX > 0 && jc >= TC - BX / TF) f_sweep_row(cs, t1, jc + 2 * TC - (TC - BX / TF));
-  };
-  auto c_sweep = [&](const T *t1) {
-    const T *col = t1 + (2 * jc) * TP + jf;
-    const T a = col[0], bq = col[TP], c = col[2 * TP], d = col[3 * TP], e = col[4 * TP];
-    T wc[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) wc[k] = wcs[k * TC + jc];
-    const T tb = mass_tb(a, bq, c, wc);
-    T tc = mass_tc(bq, c, d, wc);
-    const T td = mass_td(c, d, e, wc);
-    tc += tb * wc[7] + td * wc[8];
-    return tc;
-  };
-
-  // ---- march: plane r_lo (even) on its own, then pairs (odd, even) --------------------------
-  QR Po[NL], Pe[NL];
-  fetch(r_lo, Pe);
-  put(r_lo, Pe, Cs1);
-  fetch(r_lo + 1, Po);
-  fetch(r_lo + 2, Pe);
-  __syncthreads();
-  phase_b(Cs1, t1s1);
-  __syncthreads();
-  T e_prev = c_sweep(t1s1), o_prev = 0, td_prev = 0;
-  const bool store_ok = C0 + jc < mc && F0 + jf < mf;
-  const size_t load_off = (size_t)(C0 + jc) * mf + (F0 + jf);
-  for (int p = r_lo + 1; p < r_hi; p += 2) {
-    put(p, Po, Cs0);
-    put(p + 1, Pe, Cs1);
-    if (p + 2 < r_hi) {
-      fetch(p + 2, Po);
-      fetch(p + 3, Pe);
-    }
-    __syncthreads();
-    phase_b(Cs0, t1s0);
-    phase_b(Cs1, t1s1);
-    __syncthreads();
-    const T vo = c_sweep(t1s0);
-    const T ve = c_sweep(t1s1);
-    if (p + 1 == 2 * R0) {
-      // first pair of the chunk: planes 2R0-2, 2R0-1, 2R0 give tb of coarse plane R0
-      td_prev = e_prev * wrs[0] + vo * wrs[1] + ve * wrs[2];
-    } else {
-      const int R = (p - 1) / 2;
-      if (R < mr) {
-        T wr[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) wr[k] = wrs[(R - R0) * 12 + k];
-        T tc = mass_tc(o_prev, e_prev, vo, wr);
-        const T td = mass_td(e_prev, vo, ve, wr);
-        tc += td_prev * wr[7] + td * wr[8];
-        td_prev = td;
-        if (store_ok) A.load[(size_t)R * mc * mf + load_off] = tc;
-      }
-    }
-    o_prev = vo;
-    e_prev = ve;
-  }
-#undef LI
-}
 
 // ---------------------------------------------------------------------------------------------
 // Node restore, marching: fine nodal array from the corrected coarse nodes and the quantized

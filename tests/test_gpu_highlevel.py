@@ -420,13 +420,9 @@ def test_alternative_kernels_give_the_same_result():
     assert run({"MGH_FUSED_WIDE": "2", "MGH_FUSED_XCD": "0", "MGH_FUSED_FACES": "0", "MGH_IPK_STREAM": "0"}) == ref
     assert run({"MGH_FUSED_V": "1", "MGH_FUSED4": "0", "MGH_IPK_W": "32"}) == ref
     # round 3: no box kernel / box kernel on every level, tail kernel without the solves of the
-    # level above it, the slab schedule (passes in r-slabs, f- and c-solves on a second stream),
-    # other residency plans of the streaming Thomas solves
-    assert run({"MGH_BOX": "0", "MGH_TAIL_SOLVES": "0", "MGH_LOADVEC_V": "2", "MGH_RESTORE_V": "2"}) == ref
-    assert run({"MGH_LOADVEC_V": "2", "MGH_LOADVEC_WIDE": "1", "MGH_IPK_CONTIG": "2"}) == ref
+    # level above it, other residency plans of the streaming Thomas solves
+    assert run({"MGH_BOX": "0", "MGH_TAIL_SOLVES": "0", "MGH_RESTORE_V": "2", "MGH_IPK_CONTIG": "2"}) == ref
     assert run({"MGH_BOX": "3", "MGH_IPK_WPC": "16"}) == ref
-    assert run({"MGH_SLABS": "3", "MGH_SLABS_MIN": "0", "MGH_IPK_WPC": "2"}) == ref
-    assert run({"MGH_SLABS": "2", "MGH_SLABS_MIN": "0", "MGH_IPK_SLAB": "0", "MGH_SLAB_PRIO": "0"}) == ref
 
 
 def test_incompressible_subdomain_is_stored_raw():
@@ -633,9 +629,9 @@ def test_multi_device_reader_takes_reorder_from_the_stream(writer_reorder, reade
 
 
 def test_developer_switches_are_validated(monkeypatch):
-    """An MGH_* variable with a value outside its range, or one the library does not know (a
-    typo), is an error when a hierarchy is created or a high-level call starts -- never a silent
-    default."""
+    """An MGH_* variable with a value outside its range is an error when a hierarchy is created or
+    a high-level call starts -- never a silent default. A name the library does not know (a typo,
+    another product's variable) is a warning on stderr, once per process, and breaks nothing."""
     torch, mg, hl = _mods()
     u = smooth_field((9, 9, 9), np.float32)
     monkeypatch.setenv("MGH_FUSED_WIDE", "7")
@@ -645,8 +641,7 @@ def test_developer_switches_are_validated(monkeypatch):
         hl.compress(u, 1e-3, np.inf, mg.REL)
     monkeypatch.delenv("MGH_FUSED_WIDE")
     monkeypatch.setenv("MGH_FUSED_WIDTH", "1")       # (typo of MGH_FUSED_WIDE)
-    with pytest.raises(mg.MgardHipError, match="unknown developer switch MGH_FUSED_WIDTH"):
-        mg.Hierarchy((9, 9, 9), np.float32)
+    mg.Hierarchy((9, 9, 9), np.float32).close()
     monkeypatch.delenv("MGH_FUSED_WIDTH")
     monkeypatch.setenv("MGH_RCH", "2,3")
     with pytest.raises(mg.MgardHipError, match="MGH_RCH"):

@@ -640,39 +640,8 @@ def test_config3_full_size_slab():
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-@pytest.mark.parametrize("split", ["1", "2"])
-@pytest.mark.parametrize("shape,mode,s", [((257, 300, 258), "REL", np.inf), ((200, 130, 513), "ABS", 0.0),
-                                          ((129, 512, 130), "REL", np.inf)])
-def test_split_stream_schedule_bit_exact(shape, mode, s, split, dt, monkeypatch):
-    """MGH_SPLIT=1/2: big levels run as a load-vector pass on the caller's stream (with the
-    abs-max of the input fused into the top level's pass) plus an LDS-free coefficient/quantize
-    pass on a second stream (kernels_emit.hpp). Same integers, outliers and norm as the oracle."""
-    torch, mg = _gpu()
-    monkeypatch.setenv("MGH_SPLIT", split)
-    u = smooth_field(shape, dt, noise=3e-3)
-    h = mg.Hierarchy(shape, dt)
-    o = oracle.Hierarchy(shape, dt)
-    ud = torch.from_numpy(u).cuda()
-    m = mg.REL if mode == "REL" else mg.ABS
-    q, oi, ov, cnt, nrm = h.decompose_quantize(ud, m, 1e-3, s, outlier_cap=u.size)
-    if mode == "REL":
-        assert nrm == float(np.max(np.abs(u)))
-    else:
-        nrm = 1.0
-    rq, roi, rov, rn = o.quantize(o.decompose(u), oracle.REL if mode == "REL" else oracle.ABS,
-                                  dt(1e-3), dt(s), dt(nrm), outlier_cap=u.size)
-    assert cnt == rn
-    assert np.array_equal(q.cpu().numpy(), rq)
-    gi, gv = _outlier_set(oi.cpu().numpy(), ov.cpu().numpy())
-    ri, rv = _outlier_set(roi, rov)
-    assert np.array_equal(gi, ri) and np.array_equal(gv, rv)
-    h.close()
-
-
-@pytest.mark.parametrize("dt", [np.float32, np.float64])
 @pytest.mark.parametrize("env", [
     {"MGH_BOX": "0"}, {"MGH_BOX": "2"}, {"MGH_BOX": "3", "MGH_TAIL_SOLVES": "0"},
-    {"MGH_SLABS": "4", "MGH_SLABS_MIN": "0"}, {"MGH_SLABS": "2", "MGH_SLABS_MIN": "0", "MGH_IPK_SLAB": "0"},
     {"MGH_IPK_WPC": "1"}, {"MGH_IPK_WPC": "16", "MGH_CLS1": "0"}])
 @pytest.mark.parametrize("shape,mode,s,dict_size", [((130, 97, 258), "REL", np.inf, 8192), ((67, 66, 65), "ABS", 0.0, 64),
                                                     ((36, 260, 100), "REL", np.inf, 64)])
@@ -680,9 +649,8 @@ def test_round3_schedules_bit_exact(shape, mode, s, dict_size, env, dt, monkeypa
     """The round-3 pieces against the oracle, each switched on every level it can run on and
     switched off: the box kernel (kernels_box.hpp: no march, workgroup-wide outlier slots; the
     small dictionary makes most values outliers), the tail kernel with / without the Thomas
-    solves of the level above it, the slab schedule (passes in r-slabs, f- and c-solves of a slab
-    on a second stream), the residency plans of the streaming Thomas solves. Same integers,
-    same outlier set."""
+    solves of the level above it, the residency plans of the streaming Thomas solves. Same
+    integers, same outlier set."""
     torch, mg = _gpu()
     for k, v in env.items():
         monkeypatch.setenv(k, v)
