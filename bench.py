@@ -203,21 +203,38 @@ def _last_json_line(text):
     return None
 
 
+LAUNCH_TIMEOUT_S = 1800   # a hung rank (collective left by a failed peer) must not hang the driver
+COLLECTIVE_TIMEOUT_S = 300
+
+
 def launch_ranks(args, argv):
     """N > 1 without WORLD_SIZE: this process never initialises a GPU. It starts the ranks with
     torch.distributed.run (fresh child processes), relays rank 0's JSON line, then runs the
     one-process / N-devices leg (mgh_compress_multi) in another child and attaches its result."""
     import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-           "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + argv
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    p = None
+    for attempt in range(3):
+        # (a port found by bind-then-close can be taken by the time the ranks rendezvous when several
+        # launches run side by side: retry on a fresh one if the rendezvous fails to bind)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + argv
+        try:
+            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                               timeout=LAUNCH_TIMEOUT_S)
+        except subprocess.TimeoutExpired as e:
+            sys.stderr.write("bench.py: the ranks did not finish within %d s\n%s\n" % (
+                LAUNCH_TIMEOUT_S, (e.stderr or "")[-2000:] if isinstance(e.stderr, str) else ""))
+            raise SystemExit(2)
+        if p.returncode != 0 and "Address already in use" in p.stderr and attempt < 2:
+            continue
+        break
     sys.stderr.write(p.stderr[-4000:])
     res = _last_json_line(p.stdout)
     if p.returncode != 0 or res is None:
@@ -333,21 +350,33 @@ def config_leg(torch, mgard_amd, name, dev, local_rank, steps=5, end_to_end=Fals
     t_dt = torch.float32 if np_dt.itemsize == 4 else torch.float64
     S = cfg["s"]
     coords = nonuniform_coords(shape, np_dt) if cfg["nonuniform"] else None
-    if len(shape) == 4:
-        base = gpu_field(torch, shape[1:], t_dt, dev, seed=20260101 + rank)
-        d_u = torch.stack([base * (1.0 + 0.002 * t) + 1e-4 * t for t in range(shape[0])])
-        del base
-    else:
-        d_u = gpu_field(torch, shape, t_dt, dev)
-    h = mgard_amd.Hierarchy(shape, np_dt, coords=coords, device=local_rank)
-    N = h.total
-    cap = N // (16 if len(shape) == 3 else 8)
-    q = torch.empty(shape, dtype=torch.int64, device=dev)
-    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
-    oidx = torch.empty(cap, dtype=torch.int64, device=dev)
-    oval = torch.empty(cap, dtype=torch.int64, device=dev)
-    bufs = (q, cnt, oidx, oval)
-    nrm_t = torch.zeros(1, dtype=h.torch_dtype, device=dev)
+    setup_error = None
+    try:
+        if len(shape) == 4:
+            base = gpu_field(torch, shape[1:], t_dt, dev, seed=20260101 + rank)
+            d_u = torch.stack([base * (1.0 + 0.002 * t) + 1e-4 * t for t in range(shape[0])])
+            del base
+        else:
+            d_u = gpu_field(torch, shape, t_dt, dev)
+        h = mgard_amd.Hierarchy(shape, np_dt, coords=coords, device=local_rank)
+        N = h.total
+        cap = N // (16 if len(shape) == 3 else 8)
+        q = torch.empty(shape, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        oidx = torch.empty(cap, dtype=torch.int64, device=dev)
+        oval = torch.empty(cap, dtype=torch.int64, device=dev)
+        bufs = (q, cnt, oidx, oval)
+        nrm_t = torch.zeros(1, dtype=h.torch_dtype, device=dev)
+    except (mgard_amd.MgardHipError, RuntimeError) as e:
+        if dist is None:
+            raise
+        setup_error = str(e)[:200]
+    if dist is not None:
+        # a rank that could not set up must not leave the others inside the collectives of the step
+        okt = torch.tensor([0 if setup_error else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if not bool(okt.item()):
+            return {"error": "set-up failed on some rank: %s" % setup_error}
 
     def step():
         if dist is None:
@@ -466,6 +495,116 @@ def volume_leg(torch, mgard_amd, dev):
     return out
 
 
+def scatter_gather_leg(torch, mgard_amd, dist, dev, local_rank, rank, world, slab_t=8):
+    """N > 1: BASELINE.json configs[3] the way north_star words it -- one rank holds the whole
+    (slab_t * N) x 512^3 volume device-resident; block scatter of the slabs of the slowest dimension
+    over RCCL point-to-point sends (mgard_amd.distributed.scatter_slabs), global norm by one scalar
+    MAX all-reduce, every rank compresses its slab through mgh_compress with the local ABS bound
+    (calc_local_abs_tol), payload gather to rank 0 (gather_payloads), ONE container behind a header
+    that declares the decomposition; rank 0 opens it with mgh_decompress and checks the bound.
+    Every phase timed on its own (barrier + synchronize around it, MAX over ranks)."""
+    import numpy as np
+    from mgard_amd import distributed as mdist
+    from mgard_amd import highlevel
+    shape = (slab_t * world, 512, 512, 512)
+    slab_shape = (slab_t,) + shape[1:]
+    slab_bytes = int(np.prod(slab_shape)) * 4
+
+    def sync():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def agree(ok):
+        # every rank learns whether ALL ranks got through the phase: a rank that failed must not leave
+        # the others inside a collective (ADVICE r03)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    vol, err = None, None
+    try:
+        if rank == 0:
+            base = gpu_field(torch, shape[1:], torch.float32, dev)
+            vol = torch.empty(shape, dtype=torch.float32, device=dev)
+            for t in range(shape[0]):
+                vol[t] = base * (1.0 + 0.002 * t) + 1e-4 * t
+            del base
+        obuf = torch.empty(slab_bytes // 2 + 1000000, dtype=torch.uint8, device=dev)
+    except RuntimeError as e:
+        err = str(e)[:200]
+    if not agree(err is None):
+        return {"error": "set-up failed on some rank: %s" % err}
+    cfg = highlevel.Config(dev_id=local_rank)
+    times = {}
+
+    def timed(name, fn):
+        sync()
+        t0 = time.perf_counter()
+        out = fn()
+        sync()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        times[name] = float(t.item())
+        return out
+
+    def round_trip():
+        slab = timed("scatter", lambda: mdist.scatter_slabs(vol, shape, src=0, device=dev, dtype=torch.float32))
+        h = mgard_amd.Hierarchy(slab_shape, np.float32, device=local_rank)
+        nrm_t = torch.zeros(1, dtype=torch.float32, device=dev)
+
+        def norm():
+            h.norm_device(slab, float("inf"), out=nrm_t)
+            dist.all_reduce(nrm_t, op=dist.ReduceOp.MAX)
+            return float(nrm_t.item())
+        nrm = timed("norm_exchange", norm)
+        h.close()
+        atol = mdist.local_abs_tol(mdist.REL, nrm, TOL, float("inf"), world)
+        stream = timed("compress", lambda: highlevel.compress(slab, atol, float("inf"), mgard_amd.ABS, config=cfg, out=obuf))
+        ms = highlevel.metadata_parse(bytes(stream[:8192].cpu().numpy()))["metadata_size"]
+        record = stream[ms + 8:]          # the subdomain's record without its own size prefix
+        payloads = timed("gather", lambda: mdist.gather_payloads(record, dst=0))
+        return slab, nrm, payloads
+
+    slab, nrm, payloads = round_trip()     # warm-up: allocations, hierarchies, RCCL channels
+    del slab, payloads
+    slab, nrm, payloads = round_trip()
+    out = {"workload": "4D %dx512x512x512 float32 device-resident on rank 0: RCCL block scatter -> norm all-reduce "
+                       "-> mgh_compress per slab -> RCCL payload gather -> one container" % shape[0],
+           "ranks": world, "volume_GB": round(world * slab_bytes / 1e9, 2)}
+    for k, v in times.items():
+        out[k + "_ms"] = round(v * 1e3, 3)
+    moved = (world - 1) * slab_bytes
+    out["scatter_GBps"] = round(moved / max(times["scatter"], 1e-9) / 1e9, 2)
+    total = sum(times.values())
+    out["end_to_end_ms"] = round(total * 1e3, 3)
+    out["end_to_end_GBps"] = round(world * slab_bytes / total / 1e9, 2)
+    out["compress_only_GBps"] = round(world * slab_bytes / max(times["compress"], 1e-9) / 1e9, 2)
+    ok, detail = True, None
+    if rank == 0:
+        try:
+            header = highlevel.metadata_serialize(mgard_amd.FLOAT, list(shape),
+                                                  mgard_amd.REL, TOL, float("inf"), norm=nrm,
+                                                  dd=(highlevel.DD_MAXDIM, 0, slab_t))
+            container = mdist.assemble_container(header, payloads)
+            out["container_bytes"] = int(container.numel())
+            out["compression_ratio"] = round(world * slab_bytes / int(container.numel()), 3)
+            back = torch.empty(shape, dtype=torch.float32, device=dev)
+            highlevel.decompress(container, out=back, config=cfg)
+            e = max(float((back[t] - vol[t]).abs().max().item()) for t in range(shape[0]))
+            out["roundtrip_linf_error"], out["tolerance_abs"] = e, TOL * nrm
+            out["within_tolerance"] = bool(e <= TOL * nrm)
+            del back, container
+        except (mgard_amd.MgardHipError, RuntimeError) as e:
+            ok, detail = False, str(e)[:300]
+    if not agree(ok):
+        out["error"] = detail or "rank 0 could not open the container"
+    del vol, slab, payloads, obuf
+    highlevel.release_cache()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -487,6 +626,8 @@ def main():
                     help="run ONLY the one-process / N-devices leg (what the launcher starts as its second child)")
     ap.add_argument("--dist-dry-run", action="store_true",
                     help="GPU-less check of the N > 1 launcher: gloo ranks, norm exchange only")
+    ap.add_argument("--sg-slab", type=int, default=8,
+                    help="N > 1 scatter_gather leg: time steps (dim 0) per rank, default 8 (= 8 x 512^3 per rank)")
     ap.add_argument("--force-dist-path", action="store_true",
                     help="exercise the N>1 code path (process group + norm all-reduce) with any "
                          "world size, e.g. 1 (developer check)")
@@ -518,7 +659,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        import datetime
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                timeout=datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cfg = CONFIGS[args.config]
@@ -822,10 +965,13 @@ def main():
         else:
             # N > 1: configs[3] as it is meant -- the 64 x 512^3 volume split on dim 0, one
             # 8 x 512^3 slab per rank (weak scaling), scalar norm all-reduce over RCCL
+            oc["4d"] = config_leg(torch, mgard_amd, "4d", dev, local_rank, dist=dist, world=world, rank=rank)
+            # ... and with the block scatter / payload gather north_star names, timed phase by phase
             try:
-                oc["4d"] = config_leg(torch, mgard_amd, "4d", dev, local_rank, dist=dist, world=world, rank=rank)
+                oc["scatter_gather"] = scatter_gather_leg(torch, mgard_amd, dist, dev, local_rank, rank, world,
+                                                          slab_t=args.sg_slab)
             except (mgard_amd.MgardHipError, RuntimeError, AssertionError) as e:
-                oc["4d"] = {"error": str(e)[:300]}
+                oc["scatter_gather"] = {"error": str(e)[:300]}
         result["other_configs"] = oc
     if dist is not None:
         seen = torch.ones(1, dtype=torch.int64, device=dev)

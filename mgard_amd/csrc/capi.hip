@@ -24,6 +24,7 @@
 #include "kernels_v1.hpp"
 #include "kernels_ipk.hpp"
 #include "kernels_ipk_stream.hpp"
+#include "kernels_ipk_dma.hpp"
 #include "kernels_fused.hpp"
 #include "kernels_fused2.hpp"
 #include "kernels_box.hpp"
@@ -76,6 +77,10 @@ struct mgh_hierarchy {
   // MGH_IPK_STREAM: 1 = streaming Thomas solves (kernels_ipk_stream.hpp) on the levels whose
   // LDS-staged solve needs more than one round of resident workgroups (default), 0 = never
   int ipk_stream = 1;
+  // MGH_IPK_DMA: 1 = strided float pencils whose tiles are all resident at once run k_ipk_dma
+  // (kernels_ipk_dma.hpp: LDS-DMA front end, everything requested up front; default), 0 = never
+  int ipk_dma = 1;
+  int absmax_warm_mb = 192;  // MGH_ABSMAX_WARM_MB: the norm pass reads all but the last so many MB of the input with nontemporal loads
   // MGH_FUSED_FACES: 1 = face tiles for the remainder columns / rows of a level (default), 0 = off
   int fused_faces = 1;
   int fused_xcd = 1;  // MGH_FUSED_XCD: tiles of a level in contiguous ranges per XCD (default 1)
@@ -458,6 +463,45 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
   // PMC traffic of a solve 2.0-2.5 GB for 1.08 GB algorithmic with KR = 8).
   constexpr int kNotApplicable = 1 << 20;
   constexpr uint32_t U = sizeof(T) == 4 ? 16 : 8;
+  // Strided float pencils, every tile of the level resident at once: the LDS-DMA variant
+  // (kernels_ipk_dma.hpp). KR register-resident batches: as many as keep two waves per SIMD.
+  if constexpr (sizeof(T) == 4) {
+    const size_t box_bytes = (nbatch > 1 ? nbatch * batch_stride : (size_t)m[0] * m[1] * m[2]) * sizeof(T);
+    if (h->ipk_dma && axis != 2 && box_bytes < ((size_t)1 << 32)) {
+      auto try_kr = [&](auto KRc) -> int {
+        constexpr uint32_t KR = decltype(KRc)::value;
+        if (n < KR * U) return kNotApplicable;
+        const uint32_t nl = n - KR * U;
+        const size_t lds = (size_t)nl * 64 * sizeof(T);
+        if (lds > kLdsPerCU - 4096) return kNotApplicable;
+        const size_t per_cu = lds ? std::min<size_t>((kLdsPerCU - 4096) / lds, 8) : 8;
+        const size_t tiles = ((size_t)npencil + 63) / 64;
+        // (a level with fewer than two tiles per CU is served better by the LDS-staged kernels, whose
+        // four waves per tile stream it in and out: 129^3, 261 tiles, 18.8 vs 16.1 us)
+        if (tiles > per_cu * h->num_cu || tiles < 2 * h->num_cu) return kNotApplicable;
+        const unsigned blocks = (unsigned)((tiles + 7) / 8 * 8);
+        uint32_t n_inner;
+        size_t outer_stride, stride;
+        if (axis == 1) { n_inner = m[2]; outer_stride = (size_t)m[1] * m[2]; stride = m[2]; }
+        else { n_inner = m[1] * m[2]; outer_stride = batch_stride; stride = (size_t)m[1] * m[2]; }
+#define MGH_DMA(ADD)                                                                          \
+  {                                                                                           \
+    static std::atomic<uint64_t> once{0};                                                     \
+    TRY(allow_big_lds_once(k_ipk_dma<T, U, KR, ADD>, once));                                  \
+    return launch(h, name, s, [&] {                                                           \
+      k_ipk_dma<T, U, KR, ADD><<<blocks, 64, lds, s>>>(npencil, n_inner, outer_stride, 1,     \
+                                                       stride, n, x, tt, add_to);             \
+    });                                                                                       \
+  }
+        if (!add_to) MGH_DMA(0)
+        if (sign > 0) MGH_DMA(1)
+        MGH_DMA(-1)
+#undef MGH_DMA
+      };
+      const int rc = try_kr(std::integral_constant<uint32_t, 10>{});
+      if (rc != kNotApplicable) return rc;
+    }
+  }
   auto stream_plan = [&](auto KRc, size_t wpc_cap) -> int {
     constexpr uint32_t KR = decltype(KRc)::value;
     const size_t wpc = std::min(h->ipk_wpc, wpc_cap);
@@ -1909,7 +1953,14 @@ int fused_q_entry_device(mgh_hierarchy *h, const T *data, int ebtype, double tol
     const size_t total = h->total;
     const unsigned grid = (unsigned)std::min<size_t>((total + 1023) / 1024, 256 * 8);
     if ((T)s == std::numeric_limits<T>::infinity())
-      TRY(launch(h, "absmax", st, [&] { k_absmax<T><<<grid, 256, 0, st>>>(data, total, slot); }));
+      TRY(launch(h, "absmax", st, [&] {
+        // all but the last MGH_ABSMAX_WARM_MB of the input with nontemporal loads: the level pass
+        // re-reads the input from its end, and only what the norm pass read last can still be in
+        // the 256 MB memory-side cache (512^3 f32, same box, 60 steps each: absmax 109 -> 93 us,
+        // top-level pass 384 -> 397 us, step 0.894 -> 0.889 ms)
+        const size_t warm = ((size_t)h->absmax_warm_mb << 20) / sizeof(T);
+        k_absmax<T><<<grid, 256, 0, st>>>(data, total, slot, total > warm ? total - warm : 0);
+      }));
     else
       TRY(launch(h, "sqsum", st, [&] { k_sqsum<T><<<grid, 256, 0, st>>>(data, total, (double *)slot); }));
   }
@@ -1981,6 +2032,8 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->force_nd = env_get("MGH_FORCE_ND", 0) != 0;
     h->fused_v = (int)env_get("MGH_FUSED_V", h->fused_v);
     h->ipk_stream = (int)env_get("MGH_IPK_STREAM", h->ipk_stream);
+    h->ipk_dma = (int)env_get("MGH_IPK_DMA", h->ipk_dma);
+    h->absmax_warm_mb = (int)env_get("MGH_ABSMAX_WARM_MB", h->absmax_warm_mb);
     h->fused_faces = (int)env_get("MGH_FUSED_FACES", h->fused_faces);
     h->fused_xcd = (int)env_get("MGH_FUSED_XCD", h->fused_xcd);
     h->fused_fixed = (int)env_get("MGH_FUSED_FIXED", h->fused_fixed);

@@ -68,16 +68,18 @@ def scatter_slabs(full, shape, src=0, group=None, device=None, dtype=None):
     g = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
     lo, hi = split_slowest(shape, world, rank)
     if rank == src:
+        # slabs of the slowest dimension are contiguous views: every send streams straight out of
+        # `full` (no staging copy), all of them in flight at once -- one xGMI link per peer
+        assert full.is_contiguous(), "the array to scatter must be C-contiguous"
         reqs = []
         for r in range(world):
             if r == src:
                 continue
             a, b = split_slowest(shape, world, r)
-            reqs.append(dist.isend(full[a:b].contiguous(), dst=g(r), group=group))
-        mine = full[lo:hi].clone()
+            reqs.append(dist.isend(full[a:b], dst=g(r), group=group))
         for q in reqs:
             q.wait()
-        return mine
+        return full[lo:hi]  # (a view: the caller's own slab is not copied either)
     mine = torch.empty((hi - lo,) + tuple(shape[1:]), dtype=dtype, device=device)
     dist.recv(mine, src=g(src), group=group)
     return mine
@@ -110,6 +112,21 @@ def gather_payloads(payload, dst=0, group=None):
             dist.recv(buf, src=g(r), group=group)
             out.append(buf)
     return out
+
+
+def assemble_container(header, payloads):
+    """The container `mgh_decompress` opens, on the device the payloads live on: `header` (bytes:
+    preamble + header of the WHOLE domain, declaring the decomposition) followed by
+    `[u64 LE size][payload]` per subdomain in id order (GPUPipelines.hpp:189-193). `payloads`: 1-D
+    uint8 tensors. Returns one uint8 tensor."""
+    import struct
+    import torch
+    dev = payloads[0].device
+    parts = [torch.frombuffer(bytearray(header), dtype=torch.uint8).to(dev)]
+    for p in payloads:
+        parts.append(torch.frombuffer(bytearray(struct.pack("<Q", int(p.numel()))), dtype=torch.uint8).to(dev))
+        parts.append(p)
+    return torch.cat(parts)
 
 
 def frame_payloads(payloads):

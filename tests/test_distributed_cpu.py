@@ -182,3 +182,73 @@ def test_bench_launcher_starts_the_ranks_itself():
     r = json.loads(line)
     assert r["n_gpus"] == 2 and r["rccl_ranks_seen"] == 2 and r["norm_exchange_ok"] is True
     assert r["steps"] == 3 and r["dry_run"] is True
+
+
+def _flow_worker(rank, world, port, out):
+    """The control flow of bench.py's `scatter_gather` leg at toy size on gloo: rank 0 owns the
+    array, block scatter, scalar norm exchange + local ABS tolerance, one record per rank (here:
+    the oracle's quantized integers of the slab as bytes -- the GPU leg puts mgh_compress there),
+    payload gather, ONE container assembled on rank 0."""
+    import torch
+    import torch.distributed as dist
+    import oracle
+    from mgard_amd import distributed as mdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    oracle.set_num_threads(1)
+    shape = (18, 9, 10)
+    u = smooth_field(shape, np.float64)
+    full = torch.from_numpy(u.copy()) if rank == 0 else None
+    slab = mdist.scatter_slabs(full, shape, src=0, dtype=torch.float64)
+    lo, hi = mdist.split_slowest(shape, world, rank)
+    same_view = rank != 0 or slab.data_ptr() == full[lo:hi].data_ptr()   # rank 0 keeps a view, no copy
+    sub = np.ascontiguousarray(slab.numpy())
+    g = mdist.global_norm(oracle.norm(sub, np.float64(np.inf), normalize_coordinates=False), float("inf"), u.size)
+    atol = mdist.local_abs_tol(mdist.REL, g, 1e-3, float("inf"), world)
+    h = oracle.Hierarchy(sub.shape, np.float64)
+    # (plain integers, no dictionary: the record then needs no outlier list)
+    q, oi, ov, n = h.quantize(h.decompose(sub), oracle.ABS, np.float64(atol), np.float64(np.inf), np.float64(1),
+                              prep_huffman=False)
+    record = torch.from_numpy(np.frombuffer(q.tobytes(), dtype=np.uint8).copy())
+    payloads = mdist.gather_payloads(record, dst=0)
+    ok, info = True, None
+    if rank == 0:
+        header = b"HEADER-OF-THE-WHOLE-DOMAIN"
+        cont = mdist.assemble_container(header, payloads).numpy().tobytes()
+        ok = cont == header + mdist.frame_payloads([p.numpy().tobytes() for p in payloads])
+        # the records decode to slabs that meet the GLOBAL relative bound
+        at = len(header)
+        errs = []
+        for r in range(world):
+            size = int(np.frombuffer(cont[at:at + 8], dtype="<u8")[0])
+            a, b = mdist.split_slowest(shape, world, r)
+            qq = np.frombuffer(cont[at + 8:at + 8 + size], dtype=np.int64).reshape((b - a,) + shape[1:])
+            hr = oracle.Hierarchy(qq.shape, np.float64)
+            back = hr.recompose(hr.dequantize(qq.copy(), oracle.ABS, np.float64(atol), np.float64(np.inf), np.float64(1),
+                                              prep_huffman=False))
+            errs.append(float(np.max(np.abs(back - u[a:b]))))
+            at += 8 + size
+        ok = ok and at == len(cont)
+        info = (max(errs), 1e-3 * g)
+    out.put((rank, bool(ok and same_view), info, g))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scatter_compress_gather_flow_two_ranks():
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flow_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict((r[0], r) for r in (out.get(timeout=180) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1]
+    assert res[0][3] == res[1][3] == float(np.max(np.abs(smooth_field((18, 9, 10), np.float64))))
+    err, bound = res[0][2]
+    assert err <= bound
