@@ -206,6 +206,9 @@ struct mgh_lossless_ctx {
   const uint64_t *d_oidx = nullptr;
   const int64_t *d_oval = nullptr;
   bool on_host = false;  // Huffman_Zstd: the whole record is in `host`
+  // the encoder wrote the code units straight into the caller's record (lossless_compress:
+  // `direct`): record_write() does not move them again
+  bool units_in_place = false;
   size_t record_size() const { return overflow ? ~(size_t)0 : (on_host ? host.size() : lay.total); }
 };
 
@@ -263,7 +266,7 @@ int record_write(mgh_lossless_ctx *c, void *dst, hipStream_t st) {
   }
   const PayloadLayout &L = c->lay;
   HL_HIP(hipMemcpyAsync(d, c->head.data(), c->head.size(), hipMemcpyDefault, st));
-  if (c->n_units)
+  if (c->n_units && !c->units_in_place)
     HL_TRY(copy_any(d + L.ddata, c->units.p, c->n_units * 8, st));
   // (the count travels from a member that outlives the asynchronous copy)
   HL_HIP(hipMemcpyAsync(d + L.outlier_count, &c->n_outliers, 8, hipMemcpyDefault, st));
@@ -281,7 +284,13 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
                       uint64_t chunk, int lossless, int zstd_level, const uint64_t *d_oidx,
                       const int64_t *d_oval, uint64_t ocount, hipStream_t st,
                       const uint64_t *d_ocount = nullptr, uint64_t ocap = ~(uint64_t)0,
-                      uint64_t cap_units = 0, bool sym16 = false) {
+                      uint64_t cap_units = 0, bool sym16 = false, uint8_t *direct = nullptr,
+                      size_t direct_cap = 0) {
+  // direct (device memory, 8-byte aligned, direct_cap bytes): where record_write() will be asked
+  // to put this record. The single-pass encoder then writes the code units there itself -- the
+  // offset of the units inside a record does not depend on the counts -- instead of into a
+  // buffer of the context from which record_write() copies them (512^3 f32: 150 MB moved twice).
+  c->units_in_place = false;
   // sym16: d_q points to uint16_t symbols (mgh_decompose_quantize_sym16) -- only with the
   // single-pass encoder (lossless_sym16_ok)
   if (lossless != MGH_LOSSLESS_HUFFMAN && lossless != MGH_LOSSLESS_HUFFMAN_ZSTD)
@@ -354,8 +363,18 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
     // one pass: bit counts, unit offsets (decoupled look-back) and packing in the same kernel.
     // The stream is written into a buffer of cap_units; more than that means "not compressible".
     const unsigned long long worst = n + nchunk;  // a code is shorter than a unit
-    const unsigned long long cap = cap_units ? std::min<unsigned long long>(cap_units, worst) : worst;
-    HL_TRY(c->units.ensure(std::max<size_t>(cap, 1) * 8 + 8));
+    unsigned long long cap = cap_units ? std::min<unsigned long long>(cap_units, worst) : worst;
+    unsigned long long *units_dst = nullptr;
+    if (direct && lossless == MGH_LOSSLESS_HUFFMAN && ((uintptr_t)(direct + L.ddata) & 7) == 0 &&
+        direct_cap > L.ddata + 64) {
+      // (what does not fit behind the units -- outlier lists -- is the caller's capacity check)
+      cap = std::min<unsigned long long>(cap, (direct_cap - L.ddata - 8) / 8);
+      units_dst = (unsigned long long *)(direct + L.ddata);
+      c->units_in_place = true;
+    } else {
+      HL_TRY(c->units.ensure(std::max<size_t>(cap, 1) * 8 + 8));
+      units_dst = (unsigned long long *)c->units.p;
+    }
     HL_TRY(c->state.ensure((3 + nchunk) * 8));
     HL_HIP(hipMemsetAsync(c->state.p, 0, (3 + nchunk) * 8, st));
     static std::atomic<uint64_t> once{0};
@@ -377,7 +396,7 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
       huff::k_encode_chain<SYM, CODE><<<(unsigned)nchunk, huff::kEncThreads, enc_lds, st>>>(
           (const SYM *)d_q, n, (int)chunk, (int)dict, nchunk, (const CODE *)c->code.p,
           (unsigned long long *)c->state.p, (unsigned long long *)c->bits.p,
-          (unsigned long long *)c->entry.p, (unsigned long long *)c->units.p, cap);
+          (unsigned long long *)c->entry.p, units_dst, cap);
     };
     if (sym16 && short_codes) enc(uint16_t(), uint32_t());
     else if (sym16) enc(uint16_t(), uint64_t());
@@ -1281,6 +1300,7 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
   // the norm of a non-decomposed REL run, whose encoding has a fixed length (a non-zero double)
   fmt::Header hdr;
   header_from(dd, dtype, ebtype, tol_d, s_d, ebtype == MGH_REL ? (dd.decomposed ? (double)norm : 1.0) : 0.0, cptr, cfg, hdr);
+  std::vector<uint8_t> meta;  // (outlives the asynchronous copy of the header below)
   const size_t meta_size = fmt::serialize_metadata(hdr).size();
   if (meta_size > cap) return cleanup(hl_fail(MGH_ERR_OUTPUT_TOO_LARGE, "output buffer too small for the header"));
   size_t byte_offset = meta_size;
@@ -1337,7 +1357,9 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
         rc = lossless_compress(g_cache.ll, q_enc, n, cfg.huff_dict_size,
                                cfg.huff_block_size, cfg.lossless, cfg.zstd_compress_level,
                                (const uint64_t *)g_cache.oidx.p, (const int64_t *)g_cache.oval.p, 0, st,
-                               (const uint64_t *)g_cache.ocount.p, ocap_now, n * elem / 8 + 1, sym16);
+                               (const uint64_t *)g_cache.ocount.p, ocap_now, n * elem / 8 + 1, sym16,
+                               out_dev && cap - byte_offset > 8 ? (uint8_t *)*compressed + byte_offset + 8 : nullptr,
+                               out_dev && cap - byte_offset > 8 ? cap - byte_offset - 8 : 0);
       if (rc != kOutlierOverflow) break;
       // estimate_outlier_ratio was too optimistic: grow the lists to what this subdomain needs
       // and quantize again
@@ -1373,22 +1395,25 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
         rc = record_write(g_cache.ll, dst, st);
       }
     }
+    if (id + 1 == dd.num && rc == MGH_SUCCESS) {
+      // header (with the norm the pipeline computed for a non-decomposed REL run): it travels on the
+      // last record's stream, in front of the synchronisation that record needs anyway
+      header_from(dd, dtype, ebtype, tol_d, s_d, ebtype == MGH_REL ? (double)norm : 0.0, cptr, cfg, hdr);
+      meta = fmt::serialize_metadata(hdr);
+      if (meta.size() != meta_size) return cleanup(hl_fail(MGH_ERR_FORMAT, "metadata size changed"));
+      if (out_dev) {
+        if (hipMemcpyAsync(*compressed, meta.data(), meta.size(), hipMemcpyHostToDevice, st) != hipSuccess)
+          rc = MGH_ERR_DEVICE;
+      } else {
+        std::memcpy(*compressed, meta.data(), meta.size());
+      }
+    }
     if (rc == MGH_SUCCESS && hipStreamSynchronize(st) != hipSuccess) rc = MGH_ERR_DEVICE;
     if (rc != MGH_SUCCESS) return cleanup(hl_fail(rc, "writing the subdomain record"));
     hl_debug("compress: record written");
     byte_offset += 8 + csize;
     buf = nb;
     qi = nq;
-  }
-  // header (with the norm the pipeline computed for a non-decomposed REL run)
-  header_from(dd, dtype, ebtype, tol_d, s_d, ebtype == MGH_REL ? (double)norm : 0.0, cptr, cfg, hdr);
-  const std::vector<uint8_t> meta = fmt::serialize_metadata(hdr);
-  if (meta.size() != meta_size) return cleanup(hl_fail(MGH_ERR_FORMAT, "metadata size changed"));
-  if (out_dev) {
-    if (hipMemcpy(*compressed, meta.data(), meta.size(), hipMemcpyHostToDevice) != hipSuccess)
-      return cleanup(hl_fail(MGH_ERR_DEVICE, "writing the header"));
-  } else {
-    std::memcpy(*compressed, meta.data(), meta.size());
   }
   *compressed_size = byte_offset;
   return cleanup(MGH_SUCCESS);
