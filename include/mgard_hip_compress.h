@@ -94,7 +94,12 @@ int mgh_decompress(const void *compressed_data, size_t compressed_size,
 
 /* One process, several devices (the reference's MGARD_ENABLE_MULTI_DEVICE switch is dead code,
  * include/mgard-x/RuntimeX/RuntimeX.h:53; its multi-GPU example runs one rank per GPU:
- * examples/mgard-x/CompressXgcData/TestXGCAbsoluteError.cpp:36-252). HOST buffers only. The domain
+ * examples/mgard-x/CompressXgcData/TestXGCAbsoluteError.cpp:36-252). mgh_compress_multi takes a
+ * HOST buffer (container in host memory) or a volume resident on ONE device (GPUPipelines.hpp:69-207
+ * takes device pointers: the slabs of other devices travel there once, device to device --
+ * hipMemcpyPeerAsync over xGMI --, the slabs of the source device are compressed where they are,
+ * and the container comes back in device memory of the source device); a pre-allocated output
+ * must be of the same kind as the input. mgh_decompress_multi: host buffers only. The domain
  * is cut into slabs of the slowest dimension, slab id runs on device dev_ids[id % num_dev] (one
  * host thread, stream set and cache per device; an id may be listed more than once); a REL
  * bound uses the norm of the WHOLE domain (slab norms combined on the host,

@@ -23,6 +23,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <condition_variable>
 #include <thread>
 #include <vector>
 
@@ -1782,6 +1783,18 @@ int compress_multi_impl(int ndev, const int *devs, int D, int dtype, const uint6
       coords[d].assign(c, c + shape[d]);
     }
   }
+  // Device-resident input (GPUPipelines.hpp:69-207 takes device pointers): the volume lives on ONE
+  // device; a slab that runs elsewhere travels there ONCE, device to device (hipMemcpyPeerAsync:
+  // xGMI), into a buffer of the worker that serves both the norm and the compression; slabs of
+  // the source device are compressed where they are. The container is assembled in device
+  // memory of the source device (same memory space as the input, like mgh_compress).
+  const bool in_dev = is_device_pointer(original);
+  int src_dev = -1;
+  if (in_dev) {
+    hipPointerAttribute_t a;
+    HL_HIP(hipPointerGetAttributes(&a, original));
+    src_dev = a.device;
+  }
   const uint64_t num = dd.num;
   const int nthr = (int)std::min<uint64_t>(num, (uint64_t)ndev);
   auto slab_ptr = [&](uint64_t id) { return (const char *)original + dd.linear_offset(id) * elem; };
@@ -1793,85 +1806,126 @@ int compress_multi_impl(int ndev, const int *devs, int D, int dtype, const uint6
     return (const void *const *)out.data();
   };
   MultiErr err;
-  // ---- phase 1 (REL): slab norms on their devices, combined on the host --------------------
-  T norm = 1;
-  if (ebtype == MGH_REL) {
-    std::vector<double> ln(num, 0.0);
-    std::vector<std::thread> th;
-    for (int k = 0; k < nthr; k++)
-      th.emplace_back([&, k] {
-        try {
-        mgh_config c = cfg0;
-        c.dev_id = devs[k];
-        if (hipSetDevice(c.dev_id) != hipSuccess || cache_prepare(c.dev_id) != MGH_SUCCESS) {
-          err.set(hl_fail(MGH_ERR_DEVICE, "device of a worker thread"));
-          return;
-        }
-        for (uint64_t id = k; id < num && err.rc == MGH_SUCCESS; id += nthr) {
-          const auto sshape = dd.subdomain_shape(id);
-          uint64_t cnt = 1;
-          for (uint64_t e : sshape) cnt *= e;
-          mgh_hierarchy *h = nullptr;
-          bool owned = false;
-          int rc = get_hierarchy(&h, &owned, dtype, sshape, nullptr, dd.subdomain_offset(id), c);
-          if (rc == MGH_SUCCESS) rc = g_cache.in[0].ensure(cnt * elem);
-          if (rc == MGH_SUCCESS) rc = copy_any(g_cache.in[0].p, slab_ptr(id), cnt * elem, g_cache.streams[0]);
-          if (rc == MGH_SUCCESS) rc = mgh_norm(h, g_cache.in[0].p, s_d, &ln[id], g_cache.streams[0]);
-          if (owned) mgh_hierarchy_destroy(h);
-          if (rc != MGH_SUCCESS) err.set(rc);
-        }
-        worker_thread_teardown();
-        } catch (const std::exception &e) {
-          // (an exception must not leave a worker thread: std::terminate)
-          err.set(hl_fail(MGH_ERR_OUT_OF_MEMORY, std::string("worker thread: ") + e.what()));
-        }
-      });
-    for (auto &t : th) t.join();
-    if (err.rc != MGH_SUCCESS) {
-      mgh_set_last_error_(err.msg.c_str());
-      return err.rc;
-    }
-    double acc = 0;
-    for (uint64_t id = 0; id < num; id++) {
-      uint64_t cnt = inner * dd.subdomain_shape(id)[0];
-      if (s == std::numeric_limits<T>::infinity()) acc = std::max(acc, ln[id]);
-      else acc += ln[id] * ln[id] * (cfg0.normalize_coordinates ? (double)cnt : 1.0);
-    }
-    if (s == std::numeric_limits<T>::infinity()) norm = (T)acc;
-    else norm = (T)(cfg0.normalize_coordinates ? std::sqrt(acc / (double)total) : std::sqrt(acc));
-  }
-  const T local_tol = local_abs_tol<T>(ebtype, norm, tol, s, num);
-  // ---- phase 2: every slab as a stand-alone ABS compression on its device -------------------
+  // One worker thread per device for the whole call: (REL) norms of its slabs -> rendezvous, where
+  // the last worker to arrive combines them on the host (ErrorToleranceCalculator.hpp:69-89) ->
+  // every slab as a stand-alone ABS compression (calc_local_abs_tol).
+  std::vector<double> ln(num, 0.0);
   std::vector<void *> part(num, nullptr);
   std::vector<size_t> part_size(num, 0);
+  std::mutex rv_m;
+  std::condition_variable rv_cv;
+  int rv_arrived = 0;
+  T norm = 1, local_tol = 0;
+  auto rendezvous = [&] {
+    std::unique_lock<std::mutex> lk(rv_m);
+    if (++rv_arrived == nthr) {
+      if (ebtype == MGH_REL && err.rc == MGH_SUCCESS) {
+        double acc = 0;
+        for (uint64_t id = 0; id < num; id++) {
+          const uint64_t cnt = inner * dd.subdomain_shape(id)[0];
+          if (s == std::numeric_limits<T>::infinity()) acc = std::max(acc, ln[id]);
+          else acc += ln[id] * ln[id] * (cfg0.normalize_coordinates ? (double)cnt : 1.0);
+        }
+        if (s == std::numeric_limits<T>::infinity()) norm = (T)acc;
+        else norm = (T)(cfg0.normalize_coordinates ? std::sqrt(acc / (double)total) : std::sqrt(acc));
+      }
+      local_tol = local_abs_tol<T>(ebtype, norm, tol, s, num);
+      rv_cv.notify_all();
+    } else {
+      rv_cv.wait(lk, [&] { return rv_arrived == nthr; });
+    }
+  };
   {
     std::vector<std::thread> th;
     for (int k = 0; k < nthr; k++)
       th.emplace_back([&, k] {
+        bool arrived = false;
         try {
-        mgh_config c = cfg0;
-        c.dev_id = devs[k];
-        c.domain_decomposition = MGH_DD_MAXDIM;  // (a slab that does not fit is split further)
-        for (uint64_t id = k; id < num && err.rc == MGH_SUCCESS; id += nthr) {
-          const auto sshape = dd.subdomain_shape(id);
-          std::vector<const void *> cs;
-          const void *const *cp = slab_coords(id, cs);
-          size_t sz = 0;
-          const int rc = mgh_compress(D, dtype, sshape.data(), (double)local_tol, s_d, MGH_ABS,
-                                      slab_ptr(id), &part[id], &sz, cp, &c, 0);
-          part_size[id] = sz;
-          if (rc != MGH_SUCCESS) err.set(rc);
-        }
-        worker_thread_teardown();
+          mgh_config c = cfg0;
+          c.dev_id = devs[k];
+          c.domain_decomposition = MGH_DD_MAXDIM;  // (a slab that does not fit is split further)
+          bool ok = hipSetDevice(c.dev_id) == hipSuccess && cache_prepare(c.dev_id) == MGH_SUCCESS;
+          if (!ok) err.set(hl_fail(MGH_ERR_DEVICE, "device of a worker thread"));
+          // slabs of this worker; a device-resident slab of another device is brought over once
+          // and kept when it is the worker's only one (the usual case: one slab per device)
+          std::vector<uint64_t> mine;
+          for (uint64_t id = k; id < num; id += nthr) mine.push_back(id);
+          DevBuf peer;  // the worker's copy of a remote slab
+          uint64_t peer_id = ~(uint64_t)0;
+          auto local_ptr = [&](uint64_t id, const void **out) -> int {
+            // where this worker reads slab id from: host memory, the source device itself, or `peer`
+            // (MGH_MULTI_FORCE_PEER=1: take the peer copy also when the slab is already on the
+            // worker's device -- the one-GPU test of that path)
+            static const bool force_peer = env_get("MGH_MULTI_FORCE_PEER", 0) != 0;
+            if (!in_dev || (c.dev_id == src_dev && !force_peer)) {
+              *out = slab_ptr(id);
+              return MGH_SUCCESS;
+            }
+            const size_t bytes = inner * dd.subdomain_shape(id)[0] * elem;
+            if (peer_id != id) {
+              HL_TRY(peer.ensure(bytes));
+              HL_HIP(hipMemcpyPeerAsync(peer.p, c.dev_id, slab_ptr(id), src_dev, bytes, g_cache.streams[0]));
+              HL_HIP(hipStreamSynchronize(g_cache.streams[0]));
+              peer_id = id;
+            }
+            *out = peer.p;
+            return MGH_SUCCESS;
+          };
+          if (ok && ebtype == MGH_REL) {
+            for (uint64_t id : mine) {
+              if (err.rc != MGH_SUCCESS) break;
+              const auto sshape = dd.subdomain_shape(id);
+              uint64_t cnt = 1;
+              for (uint64_t e : sshape) cnt *= e;
+              mgh_hierarchy *h = nullptr;
+              bool owned = false;
+              int rc = get_hierarchy(&h, &owned, dtype, sshape, nullptr, dd.subdomain_offset(id), c);
+              const void *src = nullptr;
+              if (rc == MGH_SUCCESS && in_dev) rc = local_ptr(id, &src);
+              if (rc == MGH_SUCCESS && !in_dev) {
+                rc = g_cache.in[0].ensure(cnt * elem);
+                if (rc == MGH_SUCCESS) rc = copy_any(g_cache.in[0].p, slab_ptr(id), cnt * elem, g_cache.streams[0]);
+                src = g_cache.in[0].p;
+              }
+              if (rc == MGH_SUCCESS) rc = mgh_norm(h, src, s_d, &ln[id], g_cache.streams[0]);
+              if (owned) mgh_hierarchy_destroy(h);
+              if (rc != MGH_SUCCESS) err.set(rc);
+            }
+          }
+          rendezvous();
+          arrived = true;
+          if (ok && err.rc == MGH_SUCCESS) {
+            for (uint64_t id : mine) {
+              if (err.rc != MGH_SUCCESS) break;
+              const auto sshape = dd.subdomain_shape(id);
+              std::vector<const void *> cs;
+              const void *const *cp = slab_coords(id, cs);
+              const void *src = nullptr;
+              int rc = local_ptr(id, &src);
+              size_t sz = 0;
+              if (rc == MGH_SUCCESS)
+                rc = mgh_compress(D, dtype, sshape.data(), (double)local_tol, s_d, MGH_ABS, src, &part[id], &sz,
+                                  cp, &c, 0);
+              part_size[id] = sz;
+              if (rc != MGH_SUCCESS) err.set(rc);
+            }
+          }
+          peer.release();
+          worker_thread_teardown();
         } catch (const std::exception &e) {
           // (an exception must not leave a worker thread: std::terminate)
           err.set(hl_fail(MGH_ERR_OUT_OF_MEMORY, std::string("worker thread: ") + e.what()));
+          if (!arrived) rendezvous();  // the others must not wait for this thread for ever
         }
       });
     for (auto &t : th) t.join();
   }
+  // (parts are host memory for a host input, device memory of their worker's device otherwise)
   auto free_parts = [&] {
-    for (void *p : part) std::free(p);
+    for (void *p : part) {
+      if (!p) continue;
+      if (in_dev) (void)hipFree(p); else std::free(p);
+    }
   };
   if (err.rc != MGH_SUCCESS) {
     free_parts();
@@ -1899,24 +1953,42 @@ int compress_multi_impl(int ndev, const int *devs, int D, int dtype, const uint6
     body_len[id] = part_size[id] - ms;
     need += body_len[id];
   }
+  if (in_dev && hipSetDevice(src_dev) != hipSuccess) {
+    free_parts();
+    return hl_fail(MGH_ERR_DEVICE, "hipSetDevice");
+  }
   if (!prealloc) {
-    if (!(*compressed = std::malloc(need))) {
+    const bool ok = in_dev ? hipMalloc(compressed, need) == hipSuccess : (*compressed = std::malloc(need)) != nullptr;
+    if (!ok) {
       free_parts();
-      return hl_fail(MGH_ERR_OUT_OF_MEMORY, "malloc");
+      return hl_fail(MGH_ERR_OUT_OF_MEMORY, in_dev ? "hipMalloc" : "malloc");
     }
   } else if (*compressed_size < need) {
     free_parts();
     return hl_fail(MGH_ERR_OUTPUT_TOO_LARGE, "output buffer too small");
   }
   char *o = (char *)*compressed;
-  std::memcpy(o, meta.data(), meta.size());
+  const bool any_dev = in_dev || is_device_pointer(o);
+  bool copied = true;
+  auto put = [&](size_t at, const void *src, size_t len) {
+    if (!any_dev) std::memcpy(o + at, src, len);
+    else copied = copied && hipMemcpy(o + at, src, len, hipMemcpyDefault) == hipSuccess;
+  };
+  put(0, meta.data(), meta.size());
   size_t at = meta.size();
   for (uint64_t id = 0; id < num; id++) {
-    std::memcpy(o + at, (const char *)part[id] + body_off[id], body_len[id]);
+    put(at, (const char *)part[id] + body_off[id], body_len[id]);
     at += body_len[id];
   }
-  *compressed_size = at;
   free_parts();
+  if (!copied) {
+    if (!prealloc) {
+      if (in_dev) (void)hipFree(*compressed); else std::free(*compressed);
+      *compressed = nullptr;
+    }
+    return hl_fail(MGH_ERR_DEVICE, "assembling the container");
+  }
+  *compressed_size = at;
   return MGH_SUCCESS;
 }
 
@@ -2044,8 +2116,10 @@ int mgh_compress_multi(int num_dev, const int *dev_ids, int D, int dtype, const 
   if (output_pre_allocated && !*compressed_data) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "pre-allocated output is NULL");
   HL_TRY(check_devs(num_dev, dev_ids));
   HL_TRY(check_config(config));
-  if (is_device_pointer(original_data) || (output_pre_allocated && is_device_pointer(*compressed_data)))
-    return hl_fail(MGH_ERR_INVALID_ARGUMENT, "mgh_compress_multi: host buffers only (the slabs travel to their devices inside)");
+  // host input -> host container; device-resident input (on any one device) -> container in device
+  // memory of that device. A pre-allocated output must be of the same kind.
+  if (output_pre_allocated && is_device_pointer(original_data) != is_device_pointer(*compressed_data))
+    return hl_fail(MGH_ERR_INVALID_ARGUMENT, "mgh_compress_multi: input and pre-allocated output must both be host or both be device memory");
   try {
     if (dtype == MGH_FLOAT)
       return compress_multi_impl<float>(num_dev, dev_ids, D, dtype, shape, tol, s, ebtype, original_data,

@@ -287,29 +287,43 @@ def decompress(buf, config=None, out=None):
 
 
 def compress_multi(data, tol, s=INF, mode=REL, devices=(0,), coords=None, config=None):
-    """mgh_compress_multi: host numpy array in, host stream out; slab id of the slowest dimension
-    runs on devices[id % len(devices)] (one host thread per device)."""
+    """mgh_compress_multi: slab id of the slowest dimension runs on devices[id % len(devices)] (one
+    host thread per device). `data`: host numpy array -> host stream (numpy uint8), or a cuda
+    tensor resident on ONE device -> cuda uint8 tensor on that device (slabs of other devices travel
+    device to device)."""
+    import torch
     L = _hl()
     cfg = config if config is not None else Config()
-    data = np.ascontiguousarray(data)
-    dt = {np.dtype(np.float32): FLOAT, np.dtype(np.float64): DOUBLE}[data.dtype]
-    D = data.ndim
-    shp = (C.c_uint64 * D)(*data.shape)
+    on_device = isinstance(data, torch.Tensor) and data.is_cuda
+    if on_device:
+        data = data.contiguous()
+        np_dt = np.dtype(np.float32) if data.dtype == torch.float32 else np.dtype(np.float64)
+        shape, nbytes, dptr = tuple(data.shape), data.numel() * data.element_size(), data.data_ptr()
+    else:
+        data = np.ascontiguousarray(data)
+        np_dt, shape, nbytes, dptr = data.dtype, data.shape, data.nbytes, data.ctypes.data
+    dt = {np.dtype(np.float32): FLOAT, np.dtype(np.float64): DOUBLE}[np_dt]
+    D = len(shape)
+    shp = (C.c_uint64 * D)(*shape)
     cptr, ckeep = None, []
     if coords is not None:
         arr = (C.c_void_p * D)()
         for d in range(D):
-            c = np.ascontiguousarray(coords[d], dtype=data.dtype)
+            c = np.ascontiguousarray(coords[d], dtype=np_dt)
             ckeep.append(c)
             arr[d] = c.ctypes.data
         cptr = arr
     devs = (C.c_int * len(devices))(*devices)
-    cap = data.nbytes + 1000000
-    out = np.empty(cap, dtype=np.uint8)
-    optr = C.c_void_p(out.ctypes.data)
+    cap = nbytes + 1000000
+    if on_device:
+        out = torch.empty(cap, dtype=torch.uint8, device=data.device)
+        optr = C.c_void_p(out.data_ptr())
+    else:
+        out = np.empty(cap, dtype=np.uint8)
+        optr = C.c_void_p(out.ctypes.data)
     size = C.c_size_t(cap)
     _check(L.mgh_compress_multi(len(devices), devs, D, dt, shp, float(tol), float(s), int(mode),
-                                C.c_void_p(data.ctypes.data), C.byref(optr), C.byref(size), cptr,
+                                C.c_void_p(dptr), C.byref(optr), C.byref(size), cptr,
                                 C.byref(cfg), 1))
     return out[:size.value]
 

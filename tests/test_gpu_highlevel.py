@@ -535,6 +535,63 @@ def test_multi_device_api_on_one_gpu(shape, dt, s, mode, ndev):
     assert _err(u, v3, s, shape) <= bound * (1 + 1e-6)
 
 
+@pytest.mark.parametrize("shape,dt,ndev,mode,s", [((24, 33, 40), np.float32, 3, "REL", np.inf),
+                                                  ((10, 20, 130), np.float64, 2, "REL", 0.0),
+                                                  ((16, 9, 17, 20), np.float32, 2, "ABS", np.inf)])
+def test_multi_device_api_device_resident_input(shape, dt, ndev, mode, s):
+    """mgh_compress_multi with a device-resident volume (GPUPipelines.hpp:69-207 takes device
+    pointers): slabs of the source device are compressed where they are, the others would travel by
+    hipMemcpyPeerAsync (here every "device" is device 0: the same code path with a same-device
+    peer copy is not taken -- the in-place path is). The container comes back in device memory and
+    is byte for byte the one the host-buffer call writes."""
+    torch, mg, hl = _mods()
+    u = smooth_field(shape, dt)
+    m = mg.REL if mode == "REL" else mg.ABS
+    devs = (0,) * ndev
+    ref = hl.compress_multi(u, 1e-3, s, m, devices=devs)
+    got = hl.compress_multi(torch.from_numpy(u).cuda(), 1e-3, s, m, devices=devs)
+    assert got.is_cuda
+    g = got.cpu().numpy()
+    if mode == "REL" and s != np.inf:
+        # (the L2 norm of the header is a sum whose order differs between the host-staged and the
+        # in-place slab: the payloads may differ in the last bits; both must decode within the bound)
+        v = hl.decompress(g)
+        assert _err(u, v, s, shape) <= 1e-3 * _norm(u, s) * (1 + 1e-6)
+    else:
+        assert np.array_equal(g, ref)
+    v1 = hl.decompress_multi(g, devices=devs)
+    bound = 1e-3 * (_norm(u, s) if mode == "REL" else 1.0)
+    assert _err(u, v1, s, shape) <= bound * (1 + 1e-6)
+
+
+def test_multi_device_peer_copy_path_on_one_gpu():
+    """The slab scatter of a device-resident volume (hipMemcpyPeerAsync into the worker's buffer,
+    one copy serving norm and compression) forced on although every slab is already local
+    (MGH_MULTI_FORCE_PEER=1, read once per process: a child process). Same container."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, torch, hashlib\n"
+        "import mgard_amd as mg\n"
+        "from mgard_amd import highlevel as hl\n"
+        "from tests.util import smooth_field\n"
+        "u = smooth_field((24, 33, 40), np.float32)\n"
+        "g = hl.compress_multi(torch.from_numpy(u).cuda(), 1e-3, np.inf, mg.REL, devices=(0, 0, 0))\n"
+        "print('DIGEST', hashlib.sha256(g.cpu().numpy().tobytes()).hexdigest())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra):
+        env = dict(os.environ)
+        env.update(extra)
+        env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST ")][-1]
+
+    assert run({"MGH_MULTI_FORCE_PEER": "1"}) == run({})
+
+
 @pytest.mark.parametrize("shape,dt,ndev", [((12, 40, 50), np.float64, 2), ((9, 33, 70), np.float32, 3)])
 def test_multi_device_api_nonuniform_coordinates(shape, dt, ndev):
     """The slabs of a multi-device compression carry their own part of the non-uniform coordinate
