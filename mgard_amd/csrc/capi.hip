@@ -6,6 +6,7 @@
 #include "../../include/mgard_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -194,6 +195,25 @@ template <typename F> int launch(mgh_hierarchy *h, const char *name, hipStream_t
   f();
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(b, s));
+  h->prof[name].pending.emplace_back(a, b);
+  return MGH_SUCCESS;
+}
+
+// The same for ONE kernel whose timing is read inside timed regions (the level pass: bench.py
+// keeps HIP events on the dominant kernel during the timed steps): hipExtLaunchKernelGGL stamps
+// the start and stop events from the dispatch itself, where hipEventRecord in front of and behind
+// a launch puts two marker packets into the queue -- a ~6 us bubble each (rocprofv3 timeline: the
+// only two gaps of a step sat on either side of the profiled kernel).
+template <typename K, typename... Args>
+int launch_kernel(mgh_hierarchy *h, const char *name, hipStream_t s, K kernel, dim3 grid, dim3 block,
+                  size_t lds, Args... args) {
+  if (h->debug_sync || !h->profiling || (!h->prof_filter.empty() && h->prof_filter != name))
+    return launch(h, name, s, [&] { hipLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, s, args...); });
+  hipEvent_t a, b;
+  HIP_TRY(hipEventCreate(&a));
+  HIP_TRY(hipEventCreate(&b));
+  hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, s, a, b, 0, args...);
+  HIP_TRY(hipGetLastError());
   h->prof[name].pending.emplace_back(a, b);
   return MGH_SUCCESS;
 }
@@ -776,10 +796,11 @@ int launch_fused2_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int 
   const dim3 grid(G.xcd_ranges ? (ntile + 7) / 8 * 8 : ntile, (unsigned)G.nchunk, 1);
   const bool faces = G.n_ff || G.n_cf;
 #define MGH_F2(RCH)                                                                           \
-  return launch(h, nm, s, [&] {                                                               \
-    if (faces) k_level_fused2<T, OUTK, TC, TF, RCH, true><<<grid, 256, 0, s>>>(A, G, Fused4<T>{});  \
-    else k_level_fused2<T, OUTK, TC, TF, RCH, false><<<grid, 256, 0, s>>>(A, G, Fused4<T>{}); \
-  });
+  if (faces)                                                                                  \
+    return launch_kernel(h, nm, s, k_level_fused2<T, OUTK, TC, TF, RCH, true>, grid, dim3(256), 0, A, G, \
+                         Fused4<T>{});                                                        \
+  return launch_kernel(h, nm, s, k_level_fused2<T, OUTK, TC, TF, RCH, false>, grid, dim3(256), 0, A, G, \
+                       Fused4<T>{});
   MGH_F2(16)
 #undef MGH_F2
 }
@@ -1010,10 +1031,10 @@ int launch_fused4_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Fused4<T> &Q,
 #define MGH_F4(RCH, TMODE, NZ, NAME)                                                          \
   if ((NZ) > 0) {                                                                             \
     const dim3 grid(gx, (unsigned)G.nchunk, (NZ));                                            \
-    TRY(launch(h, NAME, s, [&] {                                                              \
-      if (faces) k_level_fused2<T, OUT, TC, TF, RCH, true, TMODE><<<grid, 256, 0, s>>>(A, G, Q);  \
-      else k_level_fused2<T, OUT, TC, TF, RCH, false, TMODE><<<grid, 256, 0, s>>>(A, G, Q);   \
-    }));                                                                                      \
+    if (faces)                                                                                \
+      TRY(launch_kernel(h, NAME, s, k_level_fused2<T, OUT, TC, TF, RCH, true, TMODE>, grid, dim3(256), 0, A, G, Q));  \
+    else                                                                                      \
+      TRY(launch_kernel(h, NAME, s, k_level_fused2<T, OUT, TC, TF, RCH, false, TMODE>, grid, dim3(256), 0, A, G, Q)); \
   }
     MGH_F4(16, 1, n_even, "level4_even")
     MGH_F4(16, 2, n_odd, "level4_odd")
