@@ -81,6 +81,8 @@ struct mgh_hierarchy {
   // MGH_IPK_DMA: 1 = strided float pencils whose tiles are all resident at once run k_ipk_dma
   // (kernels_ipk_dma.hpp: LDS-DMA front end, everything requested up front; default), 0 = never
   int ipk_dma = 1;
+  long ipk_dma_min_env = -1;
+  size_t ipk_dma_min = 512;  // MGH_IPK_DMA_MIN: fewest tiles of a level for k_ipk_dma (two per CU; set in mgh_hierarchy_create)
   int absmax_warm_mb = 192;  // MGH_ABSMAX_WARM_MB: the norm pass reads all but the last so many MB of the input with nontemporal loads
   // MGH_FUSED_FACES: 1 = face tiles for the remainder columns / rows of a level (default), 0 = off
   int fused_faces = 1;
@@ -498,7 +500,8 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
         const size_t tiles = ((size_t)npencil + 63) / 64;
         // (a level with fewer than two tiles per CU is served better by the LDS-staged kernels, whose
         // four waves per tile stream it in and out: 129^3, 261 tiles, 18.8 vs 16.1 us)
-        if (tiles > per_cu * h->num_cu || tiles < 2 * h->num_cu) return kNotApplicable;
+        // (MGH_IPK_DMA_MIN: that threshold in tiles, 0 in the tests that run this kernel on small shapes)
+        if (tiles > per_cu * h->num_cu || tiles < h->ipk_dma_min) return kNotApplicable;
         const unsigned blocks = (unsigned)((tiles + 7) / 8 * 8);
         uint32_t n_inner;
         size_t outer_stride, stride;
@@ -2054,6 +2057,7 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->fused_v = (int)env_get("MGH_FUSED_V", h->fused_v);
     h->ipk_stream = (int)env_get("MGH_IPK_STREAM", h->ipk_stream);
     h->ipk_dma = (int)env_get("MGH_IPK_DMA", h->ipk_dma);
+    h->ipk_dma_min_env = env_get("MGH_IPK_DMA_MIN", -1);
     h->absmax_warm_mb = (int)env_get("MGH_ABSMAX_WARM_MB", h->absmax_warm_mb);
     h->fused_faces = (int)env_get("MGH_FUSED_FACES", h->fused_faces);
     h->fused_xcd = (int)env_get("MGH_FUSED_XCD", h->fused_xcd);
@@ -2084,6 +2088,7 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
       h->num_cu = (size_t)cus;
   }
+  h->ipk_dma_min = h->ipk_dma_min_env >= 0 ? (size_t)h->ipk_dma_min_env : 2 * h->num_cu;
   h->D = D;
   bool ok;
   if (dtype == MGH_FLOAT) {

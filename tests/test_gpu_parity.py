@@ -843,3 +843,26 @@ def test_4d_long_march_class_with_odd_remainders():
     assert float((back - ud).abs().max().item()) <= 1e-3 * nrm
     g.close()
     h.close()
+
+
+@pytest.mark.parametrize("dt", [np.float32])
+@pytest.mark.parametrize("shape", [(40, 330, 70), (400, 30, 50), (330, 200, 36), (19, 321, 130), (513, 9, 70),
+                                   (12, 320, 9, 33)])
+def test_ipk_dma_on_small_shapes(shape, dt, monkeypatch):
+    """k_ipk_dma (LDS-DMA front end of the strided Thomas solves) normally runs only on levels of
+    512+ tiles; MGH_IPK_DMA_MIN=0 puts every float level whose pencils are long enough (160+
+    elements) on it: LDS parts of 1 ... 97 rows (walked singly / in batches / none), the four-rows-
+    per-instruction DMA with its overlapping tail, tiles that straddle a plane or end the array
+    (one row per instruction), a last tile of a single pencil, AddND (+) and SubtractND (-) fused.
+    Decomposition and recomposition bit-identical to the oracle."""
+    torch, mg = _gpu()
+    monkeypatch.setenv("MGH_IPK_DMA_MIN", "0")
+    u = smooth_field(shape, dt, noise=3e-3)
+    h = mg.Hierarchy(shape, dt)
+    o = oracle.Hierarchy(shape, dt)
+    ref = o.decompose(u)
+    c = h.decompose(torch.from_numpy(u).cuda())
+    assert_bit_equal(c.cpu().numpy(), ref, "decompose")
+    back = h.recompose(c)
+    assert_bit_equal(back.cpu().numpy(), o.recompose(ref), "recompose")
+    h.close()

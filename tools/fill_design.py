@@ -21,13 +21,20 @@ R = {
  "E2ETOL": "%.1e" % e2e["tolerance_abs"],
  "DEC512": "%.2f" % d["decompress"]["ms_per_step"], "HLC": "%.2f" % d["end_to_end"]["compress_ms"], "HLD": "%.2f" % d["end_to_end"]["decompress_ms"],
  "TWO": "%.3f" % d["two_streams"]["ms_per_step"], "CPU": "%.2f" % d["cpu_baseline"]["value"], "CPU1": "%.2f" % d["cpu_baseline"]["serial"]["value"],
+ "KVS": "%.2f" % d["roofline"].get("stream_calibration", {}).get("kernel_vs_stream_time", 0.0),
+ "A1024": "%.0f" % (1000 * k1024["absmax"]),
 }
+vol = oc.get("4d_volume", {})
+if "compress_ms" in vol:
+    R.update({"VOLC": "%.1f" % vol["compress_ms"], "VOLCG": "%.0f" % vol["compress_GBps"], "VOLD": "%.1f" % vol["decompress_ms"],
+              "VOLDG": "%.0f" % vol["decompress_GBps"], "VOLR": "%.2f" % vol["compression_ratio"],
+              "VOLERR": "%.1e" % vol["roundtrip_linf_error"], "VOLTOL": "%.1e" % vol["tolerance_abs"]})
 # kernel table
 sys.path.insert(0, ".")
 alg = {"absmax": 536870912, "level_fused_q": 1610612736}
 rows = ["| kernel | ms/step | what |", "|---|---|---|"]
 names = {"absmax": "norm read (REL bound)", "make_qparams": "quantizer table on the device", "level_fused_q": "top-level pass 512³ → 257³ (dominant)",
-         "ipk_f": "top-level f-solve", "ipk_c": "top-level c-solve", "ipk_r": "r-solves + AddND, levels 9…6",
+         "ipk_f": "top-level f-solve (LDS-staged)", "ipk_c": "top-level c-solve (`k_ipk_dma`)", "ipk_r": "r-solves + AddND, levels 9…6 (top level: `k_ipk_dma`)",
          "level_fused_q_small": "passes of levels 8, 7", "ipk_fc": "f+c solves of levels 8, 7, 6 (one launch each)",
          "level_box_q": "box-kernel passes of levels 6, 5", "tail": "levels 4…1 + head + the solves of level 5, one workgroup"}
 for kk, v in sorted(k.items(), key=lambda kv: -kv[1]):

@@ -26,6 +26,10 @@ tools/trace_step.sh $TAG/tl512
 tools/trace_step.sh $TAG/tl1024 --config 1024f32
 tools/trace_step.sh $TAG/tl4d --config 4d
 tools/trace_step.sh $TAG/tlf64 --config 512f64nu
+# SQ / TCC counters of every kernel of the step (final code)
+tools/chain_counters.sh $TAG/chain > /dev/null 2>&1
+cp $O/chain/chain_counters.json $O/sq_counters_chain.json 2>/dev/null
+cp $O/chain/chain_counters.txt $O/sq_counters_chain.txt 2>/dev/null
 python bench.py > $O/bench_with_traffic.log 2>&1
 python bench.py --config 1024f32 --only-step > $O/bench_1024.log 2>&1
 rm -rf $O/fetch $O/write $O/fetch1024 $O/write1024
