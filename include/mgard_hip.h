@@ -69,6 +69,11 @@ int mgh_level_shape(const mgh_hierarchy *h, int level, uint64_t *out_shape); /* 
 uint64_t mgh_total_num_elems(const mgh_hierarchy *h);           /* ::total_num_elems() */
 /* Device bytes held by the handle (tables + workspace). */
 size_t mgh_device_bytes(const mgh_hierarchy *h);
+/* Device address of the norm (one value of the hierarchy's type) the last fused call with a REL
+ * bound and no host read-back (h_norm_out == NULL) computed and used; valid until the next call on
+ * the handle. Lets a caller fetch the norm with its own asynchronous copy behind later work instead
+ * of paying a synchronisation inside mgh_decompose_quantize*. NULL for a NULL handle. */
+const void *mgh_norm_device_ptr(const mgh_hierarchy *h);
 
 /* Host copies of the per-level tables, for inspection/tests. kind: 0=dist
  * (Hierarchy::dist), 1=ratio (::ratio), 2=am, 3=bm (n+1 entries, ::am/::bm),

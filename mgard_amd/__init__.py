@@ -20,7 +20,7 @@ _lib = None
 
 SYMBOLS = [
     "mgh_last_error", "mgh_device_count", "mgh_hierarchy_create", "mgh_hierarchy_destroy",
-    "mgh_l_target", "mgh_level_shape", "mgh_total_num_elems", "mgh_device_bytes",
+    "mgh_l_target", "mgh_level_shape", "mgh_total_num_elems", "mgh_device_bytes", "mgh_norm_device_ptr",
     "mgh_hierarchy_table", "mgh_norm", "mgh_decompose", "mgh_recompose", "mgh_quantize",
     "mgh_dequantize", "mgh_decompose_quantize", "mgh_dequantize_recompose",
     "mgh_norm_device", "mgh_decompose_quantize_dn", "mgh_decompose_quantize_sym16",

@@ -2146,6 +2146,10 @@ int mgh_level_shape(const mgh_hierarchy *h, int level, uint64_t *out_shape) {
 
 uint64_t mgh_total_num_elems(const mgh_hierarchy *h) { return h ? h->total : 0; }
 size_t mgh_device_bytes(const mgh_hierarchy *h) { return h ? h->device_bytes : 0; }
+const void *mgh_norm_device_ptr(const mgh_hierarchy *h) {
+  if (!h) return nullptr;
+  return h->dtype == MGH_FLOAT ? (const void *)DS<float>(h)->normval : (const void *)DS<double>(h)->normval;
+}
 
 
 int64_t mgh_hierarchy_table(const mgh_hierarchy *h, int kind, int level, int dim, void *h_out,

@@ -130,6 +130,28 @@ struct DevBuf {
   }
 };
 
+// grow-only pinned host buffer: the small host<->device transfers of the lossless stage (histogram,
+// code table, record head, counts) go through it -- out of pageable memory every one of them is a
+// staged, host-synchronous copy of 15-25 us (rocprofv3 timeline of mgh_compress: ten of them in a row)
+struct PinBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return MGH_SUCCESS;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    HL_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    cap = bytes;
+    return MGH_SUCCESS;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
 // ---- Zstd through the system library (libzstd.so.1), resolved at first use -----------------
 struct ZstdApi {
   void *lib = nullptr;
@@ -193,14 +215,17 @@ struct mgh_lossless_ctx {
   int dev = 0;
   DevBuf freq, code, bits, entry, total, units, tables, oidx, oval, state, dtable;
   bool overflow = false;  // the code stream did not fit into cap_units: treat as incompressible
-  std::vector<unsigned> h_freq;  // host copies that keep their storage from call to call
-  std::vector<uint32_t> h_code32;
   huff::Codebook codebook;
   std::vector<uint8_t> host;   // serialized payload (when assembled on the host)
   std::vector<uint8_t> host2;  // zstd scratch
   // the record of the last compress call in pieces: everything before the code units sits in
   // `head`, the units and the outlier lists are still on the device
-  std::vector<uint8_t> head;
+  std::vector<uint8_t> head;   // (decompression: host copy of the leading part of a record)
+  // compression: [8 bytes: the record's size prefix, filled by the caller][head of the record:
+  // lay.ddata bytes][histogram][code table][counts] in ONE pinned allocation
+  PinBuf pin;
+  uint8_t *chead = nullptr;            // = pin.p + 8
+  unsigned long long *pcounts = nullptr;  // [0..2] encoder state, [3] outlier count read back, [4] n_outliers to write
   PayloadLayout lay;
   uint64_t n_units = 0, n_outliers = 0;
   uint64_t outliers_needed = 0;  // set when lossless_compress returns kOutlierOverflow
@@ -259,18 +284,26 @@ inline int dev_to_host(void *dst, const void *src, size_t bytes) {
 
 // Copy the record of the last lossless_compress() to dst (host or device memory, record_size()
 // bytes). Asynchronous on st where the memory kinds allow it.
-int record_write(mgh_lossless_ctx *c, void *dst, hipStream_t st) {
+int record_write(mgh_lossless_ctx *c, void *dst, hipStream_t st, const uint64_t *size_prefix = nullptr) {
+  // size_prefix: the 8 bytes in front of dst get *size_prefix -- for a device-resident record they
+  // travel with the head of the record in ONE copy out of the pinned buffer
   char *d = (char *)dst;
   if (c->on_host) {
+    if (size_prefix) HL_HIP(hipMemcpyAsync(d - 8, size_prefix, 8, hipMemcpyDefault, st));
     HL_HIP(hipMemcpyAsync(d, c->host.data(), c->host.size(), hipMemcpyDefault, st));
     return MGH_SUCCESS;
   }
   const PayloadLayout &L = c->lay;
-  HL_HIP(hipMemcpyAsync(d, c->head.data(), c->head.size(), hipMemcpyDefault, st));
+  if (size_prefix) {
+    std::memcpy(c->chead - 8, size_prefix, 8);
+    HL_HIP(hipMemcpyAsync(d - 8, c->chead - 8, 8 + L.ddata, hipMemcpyDefault, st));
+  } else {
+    HL_HIP(hipMemcpyAsync(d, c->chead, L.ddata, hipMemcpyDefault, st));
+  }
   if (c->n_units && !c->units_in_place)
     HL_TRY(copy_any(d + L.ddata, c->units.p, c->n_units * 8, st));
-  // (the count travels from a member that outlives the asynchronous copy)
-  HL_HIP(hipMemcpyAsync(d + L.outlier_count, &c->n_outliers, 8, hipMemcpyDefault, st));
+  // (the count travels from pinned memory that outlives the asynchronous copy)
+  HL_HIP(hipMemcpyAsync(d + L.outlier_count, &c->pcounts[4], 8, hipMemcpyDefault, st));
   if (c->n_outliers) {
     HL_HIP(hipMemcpyAsync(d + L.outlier_idx, c->d_oidx, c->n_outliers * 8, hipMemcpyDefault, st));
     HL_HIP(hipMemcpyAsync(d + L.outliers, c->d_oval, c->n_outliers * 8, hipMemcpyDefault, st));
@@ -320,14 +353,22 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
     huff::k_histogram<int64_t><<<hblocks, 256, dict * 4, st>>>(d_q, n, (int)dict, (unsigned *)c->freq.p);
   HL_HIP(hipGetLastError());
   hl_debug("lossless_compress: histogram kernel done");
-  std::vector<unsigned> &freq = c->h_freq;
-  freq.resize(dict);
-  HL_HIP(hipMemcpyAsync(freq.data(), c->freq.p, dict * 4, hipMemcpyDeviceToHost, st));
+  // pinned staging of this call (see PinBuf)
+  PayloadLayout &L = c->lay;
+  L.compute(nchunk, dict, 0, 0);  // (the offsets before the code units do not depend on the counts)
+  const size_t o_head = 8, o_freq = (o_head + L.ddata + 15) / 16 * 16, o_code = o_freq + dict * 4,
+               o_cnt = o_code + dict * 8;
+  HL_TRY(c->pin.ensure(o_cnt + 64));
+  uint8_t *const pinp = (uint8_t *)c->pin.p;
+  c->chead = pinp + o_head;
+  c->pcounts = (unsigned long long *)(pinp + o_cnt);
+  unsigned *freq = (unsigned *)(pinp + o_freq);
+  HL_HIP(hipMemcpyAsync(freq, c->freq.p, dict * 4, hipMemcpyDeviceToHost, st));
   HL_HIP(hipStreamSynchronize(st));
   hl_debug("lossless_compress: histogram on the host");
   huff::Codebook &cb = c->codebook;
   try {
-    huff::build_codebook(freq.data(), (int)dict, cb);
+    huff::build_codebook(freq, (int)dict, cb);
   } catch (const std::exception &e) {
     return hl_fail(MGH_ERR_INVALID_ARGUMENT, e.what());
   }
@@ -336,26 +377,24 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
   // always does: half the LDS of the encoder, two workgroups per CU), else 64-bit entries
   const bool short_codes = cb.max_len <= huff::kShortCodeBits;
   if (short_codes) {
-    std::vector<uint32_t> &c32 = c->h_code32;
-    c32.resize(dict);
+    uint32_t *c32 = (uint32_t *)(pinp + o_code);
     for (uint64_t k = 0; k < dict; k++)
       c32[k] = (uint32_t)((cb.code[k] >> huff::kMaxCodeBits) << huff::kShortCodeBits) |
                (uint32_t)(cb.code[k] & (((uint64_t)1 << huff::kShortCodeBits) - 1));
-    HL_HIP(hipMemcpyAsync(c->code.p, c32.data(), dict * 4, hipMemcpyHostToDevice, st));
+    HL_HIP(hipMemcpyAsync(c->code.p, c32, dict * 4, hipMemcpyHostToDevice, st));
   } else {
-    HL_HIP(hipMemcpyAsync(c->code.p, cb.code.data(), dict * 8, hipMemcpyHostToDevice, st));
+    std::memcpy(pinp + o_code, cb.code.data(), dict * 8);
+    HL_HIP(hipMemcpyAsync(c->code.p, pinp + o_code, dict * 8, hipMemcpyHostToDevice, st));
   }
   // ---- serialize (Huffman.hpp:163-239): the small leading part on the host, the code units
   // and the outlier lists stay where they are until record_write() ----
-  PayloadLayout &L = c->lay;
-  L.compute(nchunk, dict, 0, 0);  // (the offsets before the code units do not depend on the counts)
-  std::vector<uint8_t> &out = c->head;
-  out.assign(L.ddata, 0);
+  uint8_t *const out = c->chead;
+  std::memset(out, 0, L.ddata);
   auto fetch_meta = [&]() -> int {  // bits_per_chunk[] and word_entry[] into the head
-    HL_HIP(hipMemcpyAsync(out.data() + L.huffmeta, c->bits.p, nchunk * 8, hipMemcpyDeviceToHost, st));
-    HL_HIP(hipMemcpyAsync(out.data() + L.huffmeta + nchunk * 8, c->entry.p, nchunk * 8,
+    HL_HIP(hipMemcpyAsync(out + L.huffmeta, c->bits.p, nchunk * 8, hipMemcpyDeviceToHost, st));
+    HL_HIP(hipMemcpyAsync(out + L.huffmeta + nchunk * 8, c->entry.p, nchunk * 8,
                           hipMemcpyDeviceToHost, st));
-    if (d_ocount) HL_HIP(hipMemcpyAsync(&ocount, d_ocount, 8, hipMemcpyDeviceToHost, st));
+    if (d_ocount) HL_HIP(hipMemcpyAsync(&c->pcounts[3], d_ocount, 8, hipMemcpyDeviceToHost, st));
     return MGH_SUCCESS;
   };
   unsigned long long units = 0;
@@ -404,10 +443,11 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
     else if (short_codes) enc(int64_t(), uint32_t());
     else enc(int64_t(), uint64_t());
     HL_HIP(hipGetLastError());
-    unsigned long long st3[3] = {0, 0, 0};
+    unsigned long long *st3 = c->pcounts;
     HL_HIP(hipMemcpyAsync(st3, c->state.p, 24, hipMemcpyDeviceToHost, st));
     HL_TRY(fetch_meta());
     HL_HIP(hipStreamSynchronize(st));
+    if (d_ocount) ocount = c->pcounts[3];
     units = st3[1];
     c->overflow = st3[2] != 0;
   } else {
@@ -420,9 +460,11 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
                                              (unsigned long long *)c->entry.p,
                                              (unsigned long long *)c->total.p);
     HL_HIP(hipGetLastError());
-    HL_HIP(hipMemcpyAsync(&units, c->total.p, 8, hipMemcpyDeviceToHost, st));
+    HL_HIP(hipMemcpyAsync(&c->pcounts[1], c->total.p, 8, hipMemcpyDeviceToHost, st));
     HL_TRY(fetch_meta());
     HL_HIP(hipStreamSynchronize(st));
+    units = c->pcounts[1];
+    if (d_ocount) ocount = c->pcounts[3];
     HL_TRY(c->units.ensure(std::max<size_t>(units, 1) * 8 + 8));
     HL_HIP(hipMemsetAsync(c->units.p, 0, units * 8, st));
     huff::k_encode<<<(unsigned)nchunk, 256, 0, st>>>(d_q, n, (int)chunk, (const uint64_t *)c->code.p,
@@ -441,19 +483,20 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
   c->on_host = false;
   if (c->overflow) return MGH_SUCCESS;  // record_size() says "larger than anything"
   L.compute(nchunk, dict, units, ocount);
-  auto put64 = [&](size_t off, uint64_t v) { std::memcpy(out.data() + off, &v, 8); };
-  auto put32 = [&](size_t off, int32_t v) { std::memcpy(out.data() + off, &v, 4); };
+  auto put64 = [&](size_t off, uint64_t v) { std::memcpy(out + off, &v, 8); };
+  auto put32 = [&](size_t off, int32_t v) { std::memcpy(out + off, &v, 4); };
   put64(L.primary_count, n);
   put32(8, (int32_t)dict);
   put32(12, (int32_t)chunk);
   put64(16, 2 * nchunk);
   put64(L.decodebook_size, 8 * (2 * 64) + 8 * dict);
-  std::memcpy(out.data() + L.decodebook, cb.first.data(), 8 * 64);
-  std::memcpy(out.data() + L.decodebook + 8 * 64, cb.entry.data(), 8 * 64);
-  std::memcpy(out.data() + L.decodebook + 8 * 128, cb.keys.data(), 8 * dict);
+  std::memcpy(out + L.decodebook, cb.first.data(), 8 * 64);
+  std::memcpy(out + L.decodebook + 8 * 64, cb.entry.data(), 8 * 64);
+  std::memcpy(out + L.decodebook + 8 * 128, cb.keys.data(), 8 * dict);
   put64(L.ddata_size, units);
   c->n_units = units;
   c->n_outliers = ocount;
+  c->pcounts[4] = ocount;
   c->d_oidx = d_oidx;
   c->d_oval = d_oval;
   if (lossless == MGH_LOSSLESS_HUFFMAN_ZSTD) {
@@ -1049,6 +1092,7 @@ int copy_subdomain(const Decomposer &dd, uint64_t id, size_t elem, void *sub, co
 struct HlCache {
   std::map<std::vector<uint64_t>, mgh_hierarchy *> hier;  // key: dtype, normalize, max_level, shape...
   DevBuf in[2], q, q2, ocount, oidx, oval;  // q2: level-linearised copy (config.reorder == 1)
+  PinBuf hpin;  // pinned staging of mgh_compress: [0, 8) a record's size prefix, [64, ...) the header
   mgh_lossless_ctx *ll = nullptr;
   hipStream_t streams[3] = {nullptr, nullptr, nullptr};
   int dev = -1;
@@ -1062,6 +1106,7 @@ struct HlCache {
     ocount.release();
     oidx.release();
     oval.release();
+    hpin.release();
     if (ll) mgh_lossless_destroy(ll);
     ll = nullptr;
     for (auto &s : streams) {
@@ -1304,6 +1349,8 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
   std::vector<uint8_t> meta;  // (outlives the asynchronous copy of the header below)
   const size_t meta_size = fmt::serialize_metadata(hdr).size();
   if (meta_size > cap) return cleanup(hl_fail(MGH_ERR_OUTPUT_TOO_LARGE, "output buffer too small for the header"));
+  // (sized once, here: an asynchronous copy out of it must never meet a re-allocation)
+  if ((rc = g_cache.hpin.ensure(64 + meta_size)) != MGH_SUCCESS) return cleanup(rc);
   size_t byte_offset = meta_size;
 
   // ---- subdomain pipeline (compress_pipeline_gpu, GPUPipelines.hpp:69-207) ----
@@ -1323,8 +1370,9 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
     if ((rc = get_hierarchy(&h, &owned, dtype, sshape, cptr, dd.subdomain_offset(id), cfg)) != MGH_SUCCESS)
       return cleanup(rc);
     hl_debug("compress: subdomain ready");
-    double norm_out = (double)norm;
     uint64_t ocap_now = ocap_cur;
+    double norm_out = (double)norm;
+    bool norm_deferred = false;
     for (int attempt = 0; attempt < 2; attempt++) {
       rc = hipMemsetAsync(g_cache.ocount.p, 0, 8, st) == hipSuccess ? MGH_SUCCESS : hl_fail(MGH_ERR_DEVICE, "memset");
       // 16-bit symbols straight from the quantizer where the fused kernels run (a quarter of the
@@ -1333,7 +1381,7 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
       if (rc == MGH_SUCCESS && !cfg.reorder && lossless_sym16_ok(cfg.huff_dict_size, cfg.huff_block_size)) {
         const int r16 = mgh_decompose_quantize_sym16(
             h, sub_in(id, buf), local_eb, (double)local_tol, s_d, local_eb == MGH_REL ? 0.0 : (double)norm,
-            local_eb == MGH_REL ? &norm_out : nullptr, cfg.huff_dict_size, (uint16_t *)g_cache.q.p,
+            nullptr /* the norm stays on the device: see below */, cfg.huff_dict_size, (uint16_t *)g_cache.q.p,
             (uint64_t *)g_cache.ocount.p, (uint64_t *)g_cache.oidx.p, (int64_t *)g_cache.oval.p, ocap_now, st);
         if (r16 == MGH_SUCCESS) sym16 = true;
         else if (r16 != MGH_ERR_UNSUPPORTED_DIMENSION) rc = r16;
@@ -1345,7 +1393,20 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
                                     (int64_t *)g_cache.q.p, (uint64_t *)g_cache.ocount.p,
                                     (uint64_t *)g_cache.oidx.p, (int64_t *)g_cache.oval.p, ocap_now, nullptr, st);
       hl_debug("compress: decompose + quantize done");
-      if (rc == MGH_SUCCESS && local_eb == MGH_REL) norm = (T)norm_out;
+      // REL on the fused device path (the 16-bit symbol call: the norm never left the device): it
+      // is fetched behind the quantizer into pinned memory and read when the lossless stage has
+      // synchronised anyway -- a read-back inside the call above would stall the queue in front of
+      // the histogram kernel. Every other path hands the norm back itself (norm_out).
+      norm_deferred = false;
+      if (rc == MGH_SUCCESS && local_eb == MGH_REL) {
+        if (sym16) {
+          norm_deferred = true;
+          if (hipMemcpyAsync((char *)g_cache.hpin.p + 16, mgh_norm_device_ptr(h), sizeof(T), hipMemcpyDeviceToHost, st) != hipSuccess)
+            rc = hl_fail(MGH_ERR_DEVICE, "norm read-back");
+        } else {
+          norm = (T)norm_out;
+        }
+      }
       const int64_t *q_enc = (const int64_t *)g_cache.q.p;
       if (rc == MGH_SUCCESS && cfg.reorder) {
         // config.reorder == 1: the lossless stage sees the integers level by level, outlier
@@ -1372,6 +1433,11 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
       rc = kOutlierOverflow;
     }
     if (rc == kOutlierOverflow) rc = hl_fail(MGH_ERR_DEVICE, "outlier lists overflowed twice");
+    if (rc == MGH_SUCCESS && norm_deferred) {  // (lossless_compress has synchronised st)
+      T nv;
+      std::memcpy(&nv, (const char *)g_cache.hpin.p + 16, sizeof(T));
+      norm = nv;
+    }
     hl_debug("compress: lossless stage done");
     if (owned) mgh_hierarchy_destroy(h);
     if (rc != MGH_SUCCESS) return cleanup(rc);
@@ -1381,9 +1447,11 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
     if (csize > cap - byte_offset || cap - byte_offset - csize < 8)
       return cleanup(hl_fail(MGH_ERR_OUTPUT_TOO_LARGE, "Output too large"));
     char *dst = (char *)*compressed + byte_offset;
-    if (out_dev) {
-      rc = hipMemcpyAsync(dst, &csize, 8, hipMemcpyHostToDevice, st) == hipSuccess ? MGH_SUCCESS : MGH_ERR_DEVICE;
-    } else {
+    const bool prefix_with_record = out_dev && !raw;  // (one copy: size prefix + head of the record)
+    if (out_dev && raw) {
+      std::memcpy(g_cache.hpin.p, &csize, 8);
+      rc = hipMemcpyAsync(dst, g_cache.hpin.p, 8, hipMemcpyHostToDevice, st) == hipSuccess ? MGH_SUCCESS : MGH_ERR_DEVICE;
+    } else if (!out_dev) {
       std::memcpy(dst, &csize, 8);
     }
     dst += 8;
@@ -1393,7 +1461,8 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
         // so the buffer still holds it)
         rc = hipMemcpyAsync(dst, sub_in(id, buf), csize, hipMemcpyDefault, st) == hipSuccess ? MGH_SUCCESS : MGH_ERR_DEVICE;
       } else {
-        rc = record_write(g_cache.ll, dst, st);
+        const uint64_t cs64 = csize;
+        rc = record_write(g_cache.ll, dst, st, prefix_with_record ? &cs64 : nullptr);
       }
     }
     if (id + 1 == dd.num && rc == MGH_SUCCESS) {
@@ -1403,7 +1472,9 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
       meta = fmt::serialize_metadata(hdr);
       if (meta.size() != meta_size) return cleanup(hl_fail(MGH_ERR_FORMAT, "metadata size changed"));
       if (out_dev) {
-        if (hipMemcpyAsync(*compressed, meta.data(), meta.size(), hipMemcpyHostToDevice, st) != hipSuccess)
+        // (out of pinned memory: the copy is queued, not staged synchronously)
+        std::memcpy((char *)g_cache.hpin.p + 64, meta.data(), meta.size());
+        if (hipMemcpyAsync(*compressed, (char *)g_cache.hpin.p + 64, meta.size(), hipMemcpyHostToDevice, st) != hipSuccess)
           rc = MGH_ERR_DEVICE;
       } else {
         std::memcpy(*compressed, meta.data(), meta.size());
@@ -2339,6 +2410,7 @@ void mgh_lossless_destroy(mgh_lossless_ctx *c) {
   (void)hipSetDevice(c->dev);
   for (DevBuf *b : {&c->freq, &c->code, &c->bits, &c->entry, &c->total, &c->units, &c->tables, &c->oidx, &c->oval, &c->state, &c->dtable})
     b->release();
+  c->pin.release();
   delete c;
 }
 
