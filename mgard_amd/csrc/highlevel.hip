@@ -235,6 +235,7 @@ struct mgh_lossless_ctx {
   // the encoder wrote the code units straight into the caller's record (lossless_compress:
   // `direct`): record_write() does not move them again
   bool units_in_place = false;
+  std::vector<uint32_t> h_dtable;  // decompression: two-level decode table (source of an asynchronous upload)
   size_t record_size() const { return overflow ? ~(size_t)0 : (on_host ? host.size() : lay.total); }
 };
 
@@ -618,8 +619,18 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
   HL_HIP(hipMemcpyAsync(c->bits.p, meta_src + L.huffmeta, nchunk * 8, hipMemcpyDefault, st));
   HL_HIP(hipMemcpyAsync(c->entry.p, meta_src + L.huffmeta + nchunk * 8, nchunk * 8, hipMemcpyDefault, st));
   HL_HIP(hipMemcpyAsync(c->tables.p, meta_src + L.decodebook, dbsize, hipMemcpyDefault, st));
-  if (units) HL_HIP(hipMemcpyAsync(c->units.p, p + L.ddata, units * 8, hipMemcpyDefault, st));
-  HL_HIP(hipMemsetAsync((char *)c->units.p + units * 8, 0, 8, st));  // (the decoder peeks one unit ahead)
+  // A device-resident record whose code units start 8-byte aligned is decoded where it is (512^3:
+  // 150 MB not copied). The decoders peek one unit past the stream; in the record that is the
+  // outlier count -- the peeked bits lie beyond the last code of the last chunk and never reach a
+  // symbol (every chunk stops at its bit count).
+  const bool units_in_place = on_dev && units && ((uintptr_t)(p + L.ddata) & 7) == 0;
+  const unsigned long long *d_units = (const unsigned long long *)c->units.p;
+  if (units_in_place) {
+    d_units = (const unsigned long long *)(p + L.ddata);
+  } else {
+    if (units) HL_HIP(hipMemcpyAsync(c->units.p, p + L.ddata, units * 8, hipMemcpyDefault, st));
+    HL_HIP(hipMemsetAsync((char *)c->units.p + units * 8, 0, 8, st));  // (the decoder peeks one unit ahead)
+  }
   if (ocount) {
     HL_HIP(hipMemcpyAsync(c->oidx.p, p + o_oidx, ocount * 8, hipMemcpyDefault, st));
     HL_HIP(hipMemcpyAsync(c->oval.p, p + o_oval, ocount * 8, hipMemcpyDefault, st));
@@ -657,8 +668,9 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
     rtb = std::max(8, std::min(14, (int)env_get("MGH_HUFF_TB", rtb)));  // developer switch
     const size_t lds_cap = 150 * 1024;
     const size_t per_wave = huff::decode_ring_lds(0, 1);
-    const std::vector<uint32_t> dt = huff::build_decode_table(book, book + 64, book + 128, (int)dict, rtb,
-                                                              (lds_cap - 8 * per_wave) / 4);
+    // (kept in the context: the upload below is asynchronous and must not outlive its source)
+    std::vector<uint32_t> &dt = c->h_dtable;
+    dt = huff::build_decode_table(book, book + 64, book + 128, (int)dict, rtb, (lds_cap - 8 * per_wave) / 4);
     const int waves = huff::decode_ring_lds(dt.size(), 16) <= lds_cap ? 16 : 8;
     HL_TRY(c->dtable.ensure(dt.size() * 4));
     HL_HIP(hipMemcpyAsync(c->dtable.p, dt.data(), dt.size() * 4, hipMemcpyHostToDevice, st));
@@ -673,17 +685,16 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
     if (sym16 && *sym16)
       huff::k_decode_ring<uint16_t><<<(unsigned)((nchunk + waves - 1) / waves), 64 * waves,
                                       huff::decode_ring_lds(dt.size(), waves), st>>>(
-          (const unsigned long long *)c->units.p, (const unsigned long long *)c->bits.p,
+          d_units, (const unsigned long long *)c->bits.p,
           (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, rtb, (const unsigned *)c->dtable.p,
           (unsigned)dt.size(), tab, tab + 64, tab + 128, (uint16_t *)d_q);
     else
       huff::k_decode_ring<int64_t><<<(unsigned)((nchunk + waves - 1) / waves), 64 * waves,
                                      huff::decode_ring_lds(dt.size(), waves), st>>>(
-          (const unsigned long long *)c->units.p, (const unsigned long long *)c->bits.p,
+          d_units, (const unsigned long long *)c->bits.p,
           (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, rtb, (const unsigned *)c->dtable.p,
           (unsigned)dt.size(), tab, tab + 64, tab + 128, d_q);
     HL_HIP(hipGetLastError());
-    HL_HIP(hipStreamSynchronize(st));  // (dt goes out of scope)
   } else if (!serial_decode && (size_t)chunk >= 1024) {
     if (sym16) *sym16 = false;
     // parallel decoding inside the chunks (one wave per chunk)
@@ -700,12 +711,12 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
     const size_t lds_par = ((size_t)4 << tb) + ((size_t)dict + 3) / 4 * 8 + huff::kParWaves * 64 * huff::kParBatch * 2;
     huff::k_decode_par<<<(unsigned)((nchunk + huff::kParWaves - 1) / huff::kParWaves),
                          64 * huff::kParWaves, lds_par, st>>>(
-        (const unsigned long long *)c->units.p, (const unsigned long long *)c->bits.p,
+        d_units, (const unsigned long long *)c->bits.p,
         (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, tb, tab, tab + 64, tab + 128, d_q);
   } else {
     if (sym16) *sym16 = false;
     huff::k_decode<<<(unsigned)((nchunk + 63) / 64), 64, lds, st>>>(
-        (const unsigned long long *)c->units.p, (const unsigned long long *)c->bits.p,
+        d_units, (const unsigned long long *)c->bits.p,
         (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, tb, tab, tab + 64, tab + 128, d_q);
   }
   HL_HIP(hipGetLastError());
