@@ -1986,7 +1986,10 @@ int fused_q_entry_device(mgh_hierarchy *h, const T *data, int ebtype, double tol
         k_absmax<T><<<grid, 256, 0, st>>>(data, total, slot, total > warm ? total - warm : 0);
       }));
     else
-      TRY(launch(h, "sqsum", st, [&] { k_sqsum<T><<<grid, 256, 0, st>>>(data, total, (double *)slot); }));
+      TRY(launch(h, "sqsum", st, [&] {
+        const size_t warm = ((size_t)h->absmax_warm_mb << 20) / sizeof(T);
+        k_sqsum<T><<<grid, 256, 0, st>>>(data, total, (double *)slot, total > warm ? total - warm : 0);
+      }));
   }
   auto qparams = [&] {
     QParamArgs<T> P;

@@ -575,12 +575,24 @@ k_stream_mix(const T *__restrict__ in, int64_t *__restrict__ out, T *__restrict_
 
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_sqsum(const T *__restrict__ v, size_t n, double *out) {
+k_sqsum(const T *__restrict__ v, size_t n, double *out, size_t n_cold = 0) {
+  // 16-byte loads over the aligned body like k_absmax (the L2 norm is a sum: its last bits depend
+  // on the order of the additions -- across lanes, waves and the atomicAdd below -- in any case);
+  // the leading n_cold elements with nontemporal loads
+  constexpr int VN = Vec16<T>::N;
+  typedef T NV __attribute__((ext_vector_type(VN)));
   T acc = 0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (size_t)gridDim.x * blockDim.x) {
-    acc += v[i] * v[i];
+  const bool aligned = (reinterpret_cast<uintptr_t>(v) & 15) == 0;
+  const size_t nvec = aligned ? n / VN : 0, nvec_cold = aligned ? n_cold / VN : 0;
+  const NV *vv = reinterpret_cast<const NV *>(v);
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nth = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = tid; i < nvec; i += nth) {
+    const NV x = i < nvec_cold ? __builtin_nontemporal_load(vv + i) : vv[i];
+#pragma unroll
+    for (int u = 0; u < VN; u++) acc += x[u] * x[u];
   }
+  for (size_t i = nvec * VN + tid; i < n; i += nth) acc += v[i] * v[i];
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   __shared__ T sm[4];
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;

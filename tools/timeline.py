@@ -18,6 +18,12 @@ ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
 rows = list(c.execute(f"""select s.kernel_name, d.start, d.end, d.grid_size_x, d.grid_size_y, d.queue_id
     from {kd} d join {ks} s on d.kernel_id = s.id order by d.start"""))
 starts = [i for i, r in enumerate(rows) if a.first in r[0]]
+if len(starts) <= a.steps_back:
+    # (an L2 norm starts the step with k_sqsum instead of k_absmax; a given norm with k_make_qparams)
+    for alt in ("k_sqsum", "k_make_qparams"):
+        starts = [i for i, r in enumerate(rows) if alt in r[0]]
+        if len(starts) > a.steps_back:
+            break
 i0 = starts[-1 - a.steps_back]
 i1 = starts[-a.steps_back] if a.steps_back > 0 else len(rows)
 t0 = rows[i0][1]
