@@ -437,7 +437,7 @@ def config_leg(torch, mgard_amd, name, dev, local_rank, steps=5, end_to_end=Fals
         stream = highlevel.compress(d_u, TOL, S, mgard_amd.REL, out=obuf)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        NE = 3
+        NE = 5
         for _ in range(NE):
             stream = highlevel.compress(d_u, TOL, S, mgard_amd.REL, out=obuf)
         torch.cuda.synchronize()
@@ -930,7 +930,7 @@ def main():
             stream = highlevel.compress(d_u, TOL, S, mgard_amd.REL, coords=hl_coords, out=obuf)
             torch.cuda.synchronize()
             t2 = time.perf_counter()
-            NE = 3
+            NE = 10
             for _ in range(NE):
                 stream = highlevel.compress(d_u, TOL, S, mgard_amd.REL, coords=hl_coords, out=obuf)
             torch.cuda.synchronize()
