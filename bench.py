@@ -574,7 +574,10 @@ def scatter_gather_leg(torch, mgard_amd, dist, dev, local_rank, rank, world, sla
             return float(nrm_t.item())
         nrm = timed("norm_exchange", norm)
         h.close()
-        atol = mdist.local_abs_tol(mdist.REL, nrm, TOL, float("inf"), world)
+        # (in the arithmetic of the data type, like calc_local_abs_tol: the reader recomputes it from
+        # the header as float(tol) * float(norm))
+        atol = float(np.float32(TOL) * np.float32(nrm))
+        assert abs(atol - mdist.local_abs_tol(mdist.REL, nrm, TOL, float("inf"), world)) <= 1e-6 * atol
         stream = timed("compress", lambda: highlevel.compress(slab, atol, float("inf"), mgard_amd.ABS, config=cfg, out=obuf))
         ms = highlevel.metadata_parse(bytes(stream[:8192].cpu().numpy()))["metadata_size"]
         record = stream[ms + 8:]          # the subdomain's record without its own size prefix
