@@ -203,9 +203,10 @@ template <typename F> int launch(mgh_hierarchy *h, const char *name, hipStream_t
 
 // The same for ONE kernel whose timing is read inside timed regions (the level pass: bench.py
 // keeps HIP events on the dominant kernel during the timed steps): hipExtLaunchKernelGGL stamps
-// the start and stop events from the dispatch itself, where hipEventRecord in front of and behind
-// a launch puts two marker packets into the queue -- a ~6 us bubble each (rocprofv3 timeline: the
-// only two gaps of a step sat on either side of the profiled kernel).
+// the start and stop events from the dispatch itself instead of two marker packets around the
+// launch. Cost of the events per 512^3 step (tools/exp_gap.py, 20 steps each, same box): none
+// 0.899-0.905 ms, marker packets +4 us, kernel-attached +1.5 us. (The ~6 us gaps a rocprofv3
+// timeline shows on either side of the profiled kernel are there with both kinds of events.)
 template <typename K, typename... Args>
 int launch_kernel(mgh_hierarchy *h, const char *name, hipStream_t s, K kernel, dim3 grid, dim3 block,
                   size_t lds, Args... args) {

@@ -253,12 +253,30 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
   }
   const Cell halo = make_cell(hcj, hfj);
   // boundary tiles predicate their stores; everywhere else every owned node exists
-  const bool all_on = __syncthreads_and(own.s0 && own.s1 && own.s2 && own.s3) != 0;
+  // store predicates of the four outputs of a lane: (even c, even f) and (odd c, even f) of its
+  // own cell, (even c, odd f) and (odd c, odd f) of the cell to its left
+  bool st_on[4];
+  {
+    const Cell left = make_cell(jc, jf - 1);
+    const bool mine = C0 + jc < c_end && F0 + jf < f_end;
+    st_on[0] = own.s0;
+    st_on[1] = left.m1 && mine;
+    st_on[2] = own.s2;
+    st_on[3] = left.m3 && mine;
+  }
+  const bool all_on = __syncthreads_and(st_on[0] && st_on[1] && st_on[2] && st_on[3]) != 0;
 
   // output offsets of the owned cell relative to the output plane (reordered layout:
   // c index C0+jc / mc+C0+jc, same in f); planes of < 2^29 elements (capi.hip: fused_ok)
   const uint32_t oc0 = (uint32_t)(C0 + jc) * (uint32_t)A.dJ, oc1 = (uint32_t)(mc + C0 + jc) * (uint32_t)A.dJ;
-  const uint32_t of0 = (uint32_t)(F0 + jf), of1 = (uint32_t)(mf + F0 + jf);
+  // The odd-f coefficients a tile stores are those of the cells ONE TO THE LEFT of its own
+  // (cell F0 + jf - 1; the leftmost lane's comes from the halo cell, whose coefficient field the
+  // mass sweeps need anyway): in the reordered layout they start at column mf = 2^k + 1, and with
+  // the own cell's the 512 (f32 / int64: 256 / 512; symbols: 128) bytes a wave writes per row
+  // would start one element past a line boundary -- two partial lines per wave and row, each
+  // written a second time by the neighbouring tile. Measured with the int64 output (one box,
+  // alternating runs): top-level pass of 1024^3 3.55 -> 3.16 ms, step of 512^3 -22 us.
+  const uint32_t of0 = (uint32_t)(F0 + jf), of1 = (uint32_t)(mf + F0 + jf - 1 + (F0 + jf == 0));
   const uint32_t off[4] = {oc0 + of0, oc0 + of1, oc1 + of0, oc1 + of1};
   const uint32_t coarse_off = (uint32_t)(C0 + jc) * (uint32_t)mf + (uint32_t)(F0 + jf);
   const T qz = A.quantizer, qv = A.volume;
@@ -337,10 +355,14 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
     cell_todd(c, raw0, Cs0, pv_o, Xa, Xb, cvo);
   };
 
-  // coefficients of one owned plane to HBM. K0 = 1: even plane (slot 0 is the coarse node,
-  // stored by the caller); oi = index of the output plane in the reordered layout.
-  auto emit = [&](const T(&cv)[4], int oi, int K0) {
+  // coefficients of one plane to HBM: (even c, even f) = c0 and (odd c, even f) = c2 of the own
+  // cell from registers, the odd-f ones of the cell to the left from the coefficient field `cs`
+  // (call it behind the barrier that follows phase A). K0 = 1: even plane (slot 0 is the coarse
+  // node, stored by the caller); oi = index of the output plane in the reordered layout.
+  auto emit = [&](const T *cs, const T c0, const T c2, int oi, int K0) {
     const size_t ob = out_base + (size_t)oi * A.dI;
+    const T cv[4] = {c0, cs[own.i01 - 1], c2, cs[own.i11 - 1]};
+    const bool(&on)[4] = st_on;
     if (OUT == OUT_T) {
       T *o = A.coef + ob;
       if (all_on) {
@@ -348,16 +370,15 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
         for (int k = 0; k < 4; k++)
           if (k >= K0) o[off[k]] = cv[k];
       } else {
-        if (K0 == 0 && own.s0) o[off[0]] = cv[0];
-        if (own.s1) o[off[1]] = cv[1];
-        if (own.s2) o[off[2]] = cv[2];
-        if (own.s3) o[off[3]] = cv[3];
+        if (K0 == 0 && on[0]) o[off[0]] = cv[0];
+        if (on[1]) o[off[1]] = cv[1];
+        if (on[2]) o[off[2]] = cv[2];
+        if (on[3]) o[off[3]] = cv[3];
       }
       return;
     }
     if (OUT != OUT_Q && OUT != OUT_QH) return;
     constexpr bool kFixed = OUT == OUT_QH;
-    const bool on[4] = {own.s0, own.s1, own.s2, own.s3};
     int32_t qs[4];
     bool slow = false;
     if (kFixed || A.prep_huffman) {
@@ -537,22 +558,21 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
   e_prev = c_sweep(t1s1);
   T o_prev = 0;  // c-swept value of the previous odd plane
   // Two barriers per pair. Per pair and thread: A (reads the raw ring, writes Cs) | barrier |
-  // stash of the NEXT pair's raw planes + f-sweep (reads Cs, writes t1s) | barrier | c- and
-  // r-sweep (read t1s) -- and straight on into A of the next pair: the ring was refilled before
+  // stash of the NEXT pair's raw planes + f-sweep (reads Cs, writes t1s) + the pair's coefficients
+  // to HBM (read Cs) | barrier | c- and r-sweep (read t1s) -- and straight on into A of the next pair: the ring was refilled before
   // the last barrier, Cs was last read before it, and t1s is rewritten only behind the next one.
   // Q holds the planes of the pair at p + 2 and is refilled with those of the pair at p + 4.
   auto pair_step = [&](const int p, Pre &Q) {
     MGH_PT_DECL
-    // ---- phase A: coefficient fields of both planes, owned coefficients to HBM ----
+    // ---- phase A: coefficient fields of both planes ----
+    const bool pv_o = p >= 0 && p <= Pmax_r && p != ghost_r;
+    const bool pv_e = p + 1 >= 0 && p + 1 <= Pmax_r && p + 1 != ghost_r;
+    T keep_o0, keep_o2, keep_e0, keep_e2;  // even-f coefficients of the own cell, stored behind the barrier
     {
-      const bool pv_o = p >= 0 && p <= Pmax_r && p != ghost_r;
-      const bool pv_e = p + 1 >= 0 && p + 1 <= Pmax_r && p + 1 != ghost_r;
       const T rr = rrs[p - r_lo];
       T E[4], cve[4], cvo[4];
       if constexpr (TODD) {
         pair_todd(own, pv_o, pv_e, rr, Ga2, Gb2, cvo, cve);
-        if (pv_o && p >= 2 * R0) emit(cvo, mr + (p - 1) / 2, 0);
-        if (pv_e && p + 1 < 2 * R0 + 2 * rch) emit(cve, (p + 1) / 2, 0);
         if (tid < NH) {
           T ho[4], he[4];
           pair_todd(halo, pv_o, pv_e, rr, Gha, Ghb, ho, he);
@@ -563,11 +583,8 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
 #pragma unroll
         for (int k = 0; k < 4; k++) Go[k] = E[k];
         MGH_PT(6);
-        if (pv_o && p >= 2 * R0) emit(cvo, mr + (p - 1) / 2, 0);
-        if (pv_e && p + 1 < 2 * R0 + 2 * rch) {
+        if (pv_e && p + 1 < 2 * R0 + 2 * rch)
           if (all_on || own.s0) A.coarse[(size_t)((p + 1) / 2) * mc * mf + coarse_off] = E[0];
-          emit(cve, (p + 1) / 2, 1);
-        }
         MGH_PT(7);
         if (tid < NH) {
           T Eh[4], ch[4];
@@ -577,6 +594,10 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
           for (int k = 0; k < 4; k++) Gh[k] = Eh[k];
         }
       }
+      keep_o0 = cvo[0];
+      keep_o2 = cvo[2];
+      keep_e0 = cve[0];
+      keep_e2 = cve[2];
     }
     MGH_PT(0);
     __syncthreads();
@@ -588,6 +609,11 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
     MGH_PT(2);
     phase_b(Cs0, t1s0);
     phase_b(Cs1, t1s1);
+    // the planes' coefficients to HBM (odd-f ones from the field: see `of1`). Last in the phase:
+    // in front of the ring refill or between refill and sweeps the top-level pass of 512^3 was
+    // 10 us slower (one box, alternating runs)
+    if (pv_o && p >= 2 * R0) emit(Cs0, keep_o0, keep_o2, mr + (p - 1) / 2, 0);
+    if (pv_e && p + 1 < 2 * R0 + 2 * rch) emit(Cs1, keep_e0, keep_e2, (p + 1) / 2, TODD ? 0 : 1);
     MGH_PT(3);
     __syncthreads();
     MGH_PT(4);
