@@ -51,6 +51,18 @@ inline bool hl_attr_pending(const std::atomic<uint64_t> &done) {
 inline void hl_attr_done(std::atomic<uint64_t> &done) {
   done.fetch_or(hl_device_bit(), std::memory_order_release);
 }
+// compute units of the current device (cached per device ordinal)
+inline int hl_num_cu() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int v = cache[dev & 63].load(std::memory_order_relaxed);
+  if (v <= 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cache[dev & 63].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
 
 
 using namespace mgh;
@@ -346,13 +358,19 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
   if (n >= ((uint64_t)1 << 32))
     return hl_fail(MGH_ERR_INVALID_ARGUMENT, "lossless stage: more than 2^32 - 1 symbols in one record");
   HL_HIP(hipMemsetAsync(c->freq.p, 0, dict * 4, st));
-  const unsigned hblocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+  const unsigned hblocks =
+      (unsigned)std::min<size_t>((n + huff::kHistThreads - 1) / huff::kHistThreads, 2 * (size_t)hl_num_cu());
   if (sym16)
-    huff::k_histogram<uint16_t><<<hblocks, 256, dict * 4, st>>>((const uint16_t *)d_q, n, (int)dict,
-                                                                (unsigned *)c->freq.p);
+    huff::k_histogram<uint16_t><<<hblocks, huff::kHistThreads, dict * 4, st>>>((const uint16_t *)d_q, n, (int)dict,
+                                                                               (unsigned *)c->freq.p);
   else
-    huff::k_histogram<int64_t><<<hblocks, 256, dict * 4, st>>>(d_q, n, (int)dict, (unsigned *)c->freq.p);
+    huff::k_histogram<int64_t><<<hblocks, huff::kHistThreads, dict * 4, st>>>(d_q, n, (int)dict,
+                                                                              (unsigned *)c->freq.p);
   HL_HIP(hipGetLastError());
+  // (the encoder's chunk states are cleared here, behind the histogram kernel, so that nothing but
+  // the code table stands between the code construction on the host and the encoder's launch)
+  HL_TRY(c->state.ensure((3 + nchunk) * 8));
+  HL_HIP(hipMemsetAsync(c->state.p, 0, (3 + nchunk) * 8, st));
   hl_debug("lossless_compress: histogram kernel done");
   // pinned staging of this call (see PinBuf)
   PayloadLayout &L = c->lay;
@@ -416,8 +434,6 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
       HL_TRY(c->units.ensure(std::max<size_t>(cap, 1) * 8 + 8));
       units_dst = (unsigned long long *)c->units.p;
     }
-    HL_TRY(c->state.ensure((3 + nchunk) * 8));
-    HL_HIP(hipMemsetAsync(c->state.p, 0, (3 + nchunk) * 8, st));
     static std::atomic<uint64_t> once{0};
     if (hl_attr_pending(once)) {
       const int lim = 144 * 1024;

@@ -53,94 +53,146 @@ struct Codebook {
   std::vector<uint64_t> first, entry;  // [64]
   std::vector<uint64_t> keys;          // [dict]: symbols in decreasing-frequency / code order
   int max_len = 0;
+  // work arrays of build_codebook (they keep their capacity from call to call: the construction
+  // runs once per subdomain on the critical path of mgh_compress)
+  std::vector<uint64_t> w_asc, w_weight;
+  std::vector<int> w_left, w_right, w_depth, w_len, w_idx;
 };
 
-// Builds into `cb` (its vectors keep their capacity from call to call, as do the thread-local
-// work arrays: the construction runs once per subdomain on the critical path of mgh_compress).
+// Symbols by decreasing frequency, ties by DECREASING symbol -- the order the reference arrives at
+// (GetCodebook.hpp:44-57,125-128: stable ascending sort by frequency over the symbols in
+// increasing order, then the arrays are reversed); code lengths from a two-queue Huffman tree over
+// the leaves in increasing weight; canonical codes longest-first (GenerateCW.hpp:54-83).
+// 8192 used symbols: ~0.03 ms on one core of the GPU box's host.
 inline void build_codebook(const unsigned *freq, int dict, Codebook &cb) {
-  struct Node { uint64_t w; int l, r; };
-  static thread_local std::vector<uint64_t> key, count, first, next;
-  static thread_local std::vector<int> order, len, depth, idx, at;
-  static thread_local std::vector<Node> nodes;
   cb.max_len = 0;
   cb.code.assign(dict, 0);
   cb.first.assign(kUnitBits, ~(uint64_t)0);
   cb.entry.assign(kUnitBits, 0);
   cb.keys.resize(dict);
-  // symbols by decreasing frequency, ties by DECREASING symbol -- the order the reference arrives
-  // at (GetCodebook.hpp:44-57,125-128: stable ascending sort by frequency, then the arrays are
-  // reversed): one integer key per used symbol, (2^32-1 - frequency) above (2^32-1 - symbol)
-  key.clear();
-  key.reserve(dict);
-  for (int i = dict - 1; i >= 0; i--)
-    if (freq[i]) key.push_back(((uint64_t)(0xffffffffu - freq[i]) << 32) | (uint32_t)(0xffffffffu - (uint32_t)i));
-  const int nz = (int)key.size();
-  {  // LSD radix sort on the upper 32 bits (stable: ties stay in decreasing-symbol order)
-    static thread_local std::vector<uint64_t> tmp;
-    tmp.resize(nz);
-    uint64_t *a = key.data(), *b = tmp.data();
-    for (int shift = 32; shift < 64; shift += 8) {
-      int cnt[257] = {0};
-      for (int i = 0; i < nz; i++) cnt[((a[i] >> shift) & 0xff) + 1]++;
-      for (int k = 0; k < 256; k++) cnt[k + 1] += cnt[k];
-      for (int i = 0; i < nz; i++) b[cnt[(a[i] >> shift) & 0xff]++] = a[i];
-      std::swap(a, b);
-    }  // (4 passes: the sorted keys are back in `key`)
+  // used symbols in increasing order as (frequency << 32 | symbol)
+  cb.w_asc.resize(2 * (size_t)dict);
+  uint64_t *a = cb.w_asc.data(), *t = a + dict;
+  constexpr int kDigit = 11, kRadix = 1 << kDigit, kPass = 3;
+  int cnt[kRadix + 1];
+  std::memset(cnt, 0, sizeof(cnt));
+  int nz = 0;
+  unsigned differ = 0, f0 = 0;  // bits in which the used counts differ from the first one
+  for (int i = 0; i < dict; i++) {
+    const unsigned f = freq[i];
+    a[nz] = ((uint64_t)f << 32) | (uint32_t)i;
+    if (f) {
+      if (!nz) f0 = f;
+      differ |= f ^ f0;
+      cnt[(f & (kRadix - 1)) + 1]++;
+      nz++;
+    }
   }
-  order.resize(nz);
-  for (int k = 0; k < nz; k++) order[k] = (int)(0xffffffffu - (uint32_t)(key[k] & 0xffffffffu));
-  // keys[]: the used symbols in code order (filled below), then the unused ones (decreasing
-  // symbol, as the reversed stable sort leaves them)
-  {
+  // the unused ones follow the used ones in keys[], in decreasing symbol order (what the reversed
+  // stable sort leaves)
+  if (nz < dict) {
     int k = nz;
     for (int i = dict - 1; i >= 0; i--)
       if (!freq[i]) cb.keys[k++] = (uint64_t)i;
   }
   if (nz == 0) return;
-  len.assign(nz, 0);
+  {  // stable LSD radix sort by frequency, 11 bits a pass; a digit all counts share is skipped,
+     // and a pass counts the digits of the next one while it scatters
+    uint64_t *src = a, *dst = t;
+    bool counted = true;  // cnt[] holds the digit counts of pass `ps`
+    for (int ps = 0; ps < kPass; ps++) {
+      const int shift = ps * kDigit;
+      if (!((differ >> shift) & (kRadix - 1))) {
+        counted = false;
+        continue;
+      }
+      if (!counted) {
+        std::memset(cnt, 0, sizeof(cnt));
+        for (int i = 0; i < nz; i++) cnt[((src[i] >> (32 + shift)) & (kRadix - 1)) + 1]++;
+      }
+      for (int k = 0; k < kRadix; k++) cnt[k + 1] += cnt[k];
+      const int nshift = shift + kDigit;
+      const bool more = ps + 1 < kPass && ((differ >> nshift) & (kRadix - 1));
+      if (more) {
+        int nxt[kRadix + 1];
+        std::memset(nxt, 0, sizeof(nxt));
+        for (int i = 0; i < nz; i++) {
+          const uint64_t e = src[i];
+          dst[cnt[(e >> (32 + shift)) & (kRadix - 1)]++] = e;
+          nxt[((e >> (32 + nshift)) & (kRadix - 1)) + 1]++;
+        }
+        std::memcpy(cnt, nxt, sizeof(cnt));
+        counted = true;
+      } else {
+        for (int i = 0; i < nz; i++) dst[cnt[(src[i] >> (32 + shift)) & (kRadix - 1)]++] = src[i];
+        counted = false;
+      }
+      std::swap(src, dst);
+    }
+    a = src;  // ascending (frequency, symbol); order[k] of the reference = symbol of a[nz - 1 - k]
+  }
+  cb.w_len.resize(nz);
+  int *len = cb.w_len.data();  // indexed like order[]: k = 0 is the most frequent symbol
   if (nz == 1) {
     len[0] = 1;
   } else {
-    // Huffman tree with two queues over the leaves sorted by increasing weight
-    nodes.clear();
-    nodes.reserve(2 * nz);
-    for (int i = nz - 1; i >= 0; i--) nodes.push_back({freq[order[i]], -1, -1});  // increasing
-    size_t leaf = 0, inner = (size_t)nz, inner_end = (size_t)nz;
-    auto take = [&]() -> int {
-      if (leaf < (size_t)nz && (inner >= inner_end || nodes[leaf].w <= nodes[inner].w)) return (int)leaf++;
-      return (int)inner++;
-    };
+    // Huffman tree with two queues: leaves 0..nz-1 in increasing weight, inner nodes behind them
+    // in the order they are made (their weights are non-decreasing); a leaf wins a tie.
+    // (Branches, not selects: the pattern of takes is regular enough to predict, and a select
+    // chain through the weights just stored measured five times slower.)
+    cb.w_weight.resize(2 * (size_t)nz);
+    cb.w_left.resize(2 * (size_t)nz);
+    cb.w_right.resize(2 * (size_t)nz);
+    cb.w_depth.resize(2 * (size_t)nz);
+    uint64_t *w = cb.w_weight.data();
+    int *lc = cb.w_left.data(), *rc = cb.w_right.data(), *depth = cb.w_depth.data();
+    for (int i = 0; i < nz; i++) w[i] = a[i] >> 32;
+    int leaf = 0, inner = nz, end = nz;
     for (int k = 0; k < nz - 1; k++) {
-      const int a = take(), b = take();
-      nodes.push_back({nodes[a].w + nodes[b].w, a, b});
-      inner_end++;
+      int x, y;
+      if (leaf < nz && (inner >= end || w[leaf] <= w[inner])) x = leaf++; else x = inner++;
+      if (leaf < nz && (inner >= end || w[leaf] <= w[inner])) y = leaf++; else y = inner++;
+      w[end] = w[x] + w[y];
+      lc[end] = x;
+      rc[end] = y;
+      end++;
     }
-    depth.assign(nodes.size(), 0);
-    for (int i = (int)nodes.size() - 1; i >= nz; i--) {
-      depth[nodes[i].l] = depth[i] + 1;
-      depth[nodes[i].r] = depth[i] + 1;
+    depth[end - 1] = 0;
+    for (int i = end - 1; i >= nz; i--) {
+      depth[lc[i]] = depth[i] + 1;
+      depth[rc[i]] = depth[i] + 1;
     }
-    for (int i = 0; i < nz; i++) len[nz - 1 - i] = depth[i];  // leaf i = order[nz-1-i]
+    for (int i = 0; i < nz; i++) len[nz - 1 - i] = depth[i];
   }
-  // lengths are non-decreasing along `order` up to ties in the tree; canonical assignment
-  // needs symbols grouped by length: counting sort of the key order by length (stable)
-  count.assign(kUnitBits + 1, 0);
-  for (int i = 0; i < nz; i++) {
-    if (len[i] > kMaxCodeBits)
-      throw std::runtime_error("Huffman: codeword longer than 56 bits");
-    count[len[i]]++;
-    cb.max_len = std::max(cb.max_len, len[i]);
+  // lengths are non-decreasing along order[] up to ties in the tree; canonical assignment needs the
+  // symbols grouped by length: counting sort of the order by length (stable)
+  // (the lengths come in long runs: the loops below carry a run's counter in a register instead
+  // of incrementing through memory element by element)
+  int count[kUnitBits + 2] = {0}, at[kUnitBits + 2] = {0};
+  for (int i = 0; i < nz;) {
+    const int l = len[i];
+    int j = i + 1;
+    while (j < nz && len[j] == l) j++;
+    if (l > kMaxCodeBits) throw std::runtime_error("Huffman: codeword longer than 56 bits");
+    count[l] += j - i;
+    cb.max_len = l > cb.max_len ? l : cb.max_len;
+    i = j;
   }
-  idx.resize(nz);
-  at.assign(kUnitBits + 2, 0);
-  for (int l = 1; l <= kUnitBits; l++) at[l + 1] = at[l] + (int)count[l];
-  for (int i = 0; i < nz; i++) idx[at[len[i]]++] = i;
-  for (int k = 0; k < nz; k++) cb.keys[k] = (uint64_t)order[idx[k]];
+  cb.w_idx.resize(nz);
+  int *idx = cb.w_idx.data();
+  for (int l = 1; l <= kUnitBits; l++) at[l + 1] = at[l] + count[l];
+  for (int i = 0; i < nz;) {
+    const int l = len[i];
+    int pos = at[l];
+    int j = i;
+    while (j < nz && len[j] == l) idx[pos++] = j++;
+    at[l] = pos;
+    i = j;
+  }
   // first[l]: longest codes start at 0, every shorter length continues above the prefixes of
   // the longer ones: first[l] = ceil((first[l+1] + count[l+1]) / 2)
-  first.assign(kUnitBits + 2, 0);
-  first[cb.max_len] = 0;
-  for (int l = cb.max_len - 1; l >= 1; l--) first[l] = (first[l + 1] + count[l + 1] + 1) / 2;
+  uint64_t first[kUnitBits + 2] = {0};
+  for (int l = cb.max_len - 1; l >= 1; l--) first[l] = (first[l + 1] + (uint64_t)count[l + 1] + 1) / 2;
   // a lone symbol: the reference's canonical code counts up from 0 and is then complemented
   // (GenerateCW.hpp:54-71,209-222), which leaves the one-bit code "1"
   if (nz == 1) first[1] = 1;
@@ -148,13 +200,19 @@ inline void build_codebook(const unsigned *freq, int dict, Codebook &cb) {
   for (int l = 1; l < kUnitBits; l++) {
     cb.entry[l] = e;
     if (l <= cb.max_len && count[l]) cb.first[l] = first[l];
-    e += l <= cb.max_len ? count[l] : 0;
+    e += l <= cb.max_len ? (uint64_t)count[l] : 0;
   }
-  // codes: the j-th symbol of length l (in keys order) gets first[l] + j
-  next = first;
-  for (int k = 0; k < nz; k++) {
-    const int i = idx[k], l = len[i];
-    cb.code[order[i]] = ((uint64_t)l << kMaxCodeBits) | next[l]++;
+  // keys[] in code order; codes: the j-th symbol of length l (in keys order) gets first[l] + j
+  // (keys[] is grouped by length)
+  for (int k = 0; k < nz;) {
+    const int l = len[idx[k]];
+    uint64_t v = ((uint64_t)l << kMaxCodeBits) | first[l];
+    const int k1 = k + count[l];
+    for (; k < k1; k++) {
+      const uint32_t sym = (uint32_t)a[nz - 1 - idx[k]];
+      cb.keys[k] = (uint64_t)sym;
+      cb.code[sym] = v++;
+    }
   }
 }
 
@@ -167,20 +225,23 @@ inline Codebook build_codebook(const std::vector<unsigned> &freq) {
 // ---------------------------------------------------------------------------------------
 // device kernels
 // ---------------------------------------------------------------------------------------
-// Histogram of the symbols (int64 values in [0, dict)); bins privatised in LDS.
+// Histogram of the symbols (int64 values in [0, dict)); bins privatised in LDS. Launch with
+// kHistThreads threads and few workgroups (two per CU): every workgroup ends with one global atomic
+// per used bin, and with 2048 workgroups of 256 those 16 M atomics on 8192 addresses were a third
+// of the kernel's time.
+constexpr int kHistThreads = 512;
 template <typename SYM>  // int64_t (the reference's quantized array) or uint16_t symbols
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kHistThreads)
 k_histogram(const SYM *__restrict__ q, size_t n, int dict, unsigned *__restrict__ freq) {
   extern __shared__ unsigned bins[];
-  for (int i = threadIdx.x; i < dict; i += 256) bins[i] = 0;
+  for (int i = threadIdx.x; i < dict; i += kHistThreads) bins[i] = 0;
   __syncthreads();
-  const size_t nth = (size_t)gridDim.x * 256;
+  const size_t nth = (size_t)gridDim.x * kHistThreads;
   size_t done = 0;
   if (sizeof(SYM) == 2 && (reinterpret_cast<uintptr_t>(q) & 15) == 0) {  // 8 symbols per load
     const size_t nv = n / 8;
     const uint4 *qv = reinterpret_cast<const uint4 *>(q);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += nth) {
-      const uint4 v = qv[i];
+    auto count8 = [&](const uint4 &v) {
       const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -188,15 +249,25 @@ k_histogram(const SYM *__restrict__ q, size_t n, int dict, unsigned *__restrict_
         if (a < (unsigned)dict) atomicAdd(&bins[a], 1u);
         if (b < (unsigned)dict) atomicAdd(&bins[b], 1u);
       }
+    };
+    // four loads in flight per lane
+    size_t i = (size_t)blockIdx.x * kHistThreads + threadIdx.x;
+    for (; i + 3 * nth < nv; i += 4 * nth) {
+      const uint4 v0 = qv[i], v1 = qv[i + nth], v2 = qv[i + 2 * nth], v3 = qv[i + 3 * nth];
+      count8(v0);
+      count8(v1);
+      count8(v2);
+      count8(v3);
     }
+    for (; i < nv; i += nth) count8(qv[i]);
     done = nv * 8;
   }
-  for (size_t i = done + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += nth) {
+  for (size_t i = done + (size_t)blockIdx.x * kHistThreads + threadIdx.x; i < n; i += nth) {
     const uint64_t s = (uint64_t)q[i];
     if (s < (uint64_t)dict) atomicAdd(&bins[s], 1u);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < dict; i += 256)
+  for (int i = threadIdx.x; i < dict; i += kHistThreads)
     if (bins[i]) atomicAdd(&freq[i], bins[i]);
 }
 
