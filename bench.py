@@ -164,14 +164,16 @@ def cpu_baseline(u, tol, s, coords=None):
 
 
 def source_hash():
-    """Hash of the kernel sources: PMC traffic files are only valid for the code they were taken
-    on (tools/make_traffic.py stores the hash of that code)."""
+    """Hash of the sources of the low-level library (capi.hip and every file it includes, directly or
+    not): the kernels of the measured step. PMC traffic files are only valid for the code they were
+    taken on (tools/make_traffic.py stores the hash of that code). The high-level translation unit
+    (highlevel.hip, huffman.hpp, format.hpp) launches none of the step's kernels and is not part of it."""
     import hashlib
+    from mgard_amd import _build
     hsh = hashlib.sha256()
-    d = os.path.join(ROOT, "mgard_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp")):
-            hsh.update(open(os.path.join(d, f), "rb").read())
+    for f in sorted(_build._closure(os.path.join(ROOT, "mgard_amd", "csrc", "capi.hip"))):
+        hsh.update(os.path.basename(f).encode())
+        hsh.update(open(f, "rb").read())
     return hsh.hexdigest()[:16]
 
 
