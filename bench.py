@@ -164,16 +164,20 @@ def cpu_baseline(u, tol, s, coords=None):
 
 
 def source_hash():
-    """Hash of the sources of the low-level library (capi.hip and every file it includes, directly or
-    not): the kernels of the measured step. PMC traffic files are only valid for the code they were
-    taken on (tools/make_traffic.py stores the hash of that code). The high-level translation unit
-    (highlevel.hip, huffman.hpp, format.hpp) launches none of the step's kernels and is not part of it."""
+    """Hash of the kernel sources of the low-level library: capi.hip and the kernels_*.hpp /
+    hierarchy.hpp it includes, directly or not -- the code of the measured step. PMC traffic files
+    are only valid for the code they were taken on (tools/make_traffic.py stores the hash of that
+    code). Not part of it: the list of developer switches (env.hpp), the C header, and the
+    high-level translation unit (highlevel.hip, huffman.hpp, format.hpp), which launches none of the
+    step's kernels."""
     import hashlib
     from mgard_amd import _build
     hsh = hashlib.sha256()
     for f in sorted(_build._closure(os.path.join(ROOT, "mgard_amd", "csrc", "capi.hip"))):
-        hsh.update(os.path.basename(f).encode())
-        hsh.update(open(f, "rb").read())
+        name = os.path.basename(f)
+        if name == "capi.hip" or name == "hierarchy.hpp" or name.startswith("kernels_"):
+            hsh.update(name.encode())
+            hsh.update(open(f, "rb").read())
     return hsh.hexdigest()[:16]
 
 
