@@ -866,3 +866,52 @@ def test_ipk_dma_on_small_shapes(shape, dt, monkeypatch):
     back = h.recompose(c)
     assert_bit_equal(back.cpu().numpy(), o.recompose(ref), "recompose")
     h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,dt", [((130, 129, 257), np.float32), ((66, 131, 260), np.float64),
+                                      ((8, 40, 66, 129), np.float32)])
+def test_outputs_at_odd_offsets_equal_the_aligned_ones(shape, dt):
+    """The level pass lays its stores out for a 128-byte aligned output array (a lane stores the
+    odd-f coefficients of the cell to its left so that a wave's row pieces start on line
+    boundaries); any element-aligned base must give the same integers, coefficients and outlier
+    sets: int64 output at +8 / +504 bytes, float coefficients at +4 / +12 elements, the input at
+    an odd element offset too, and the way back reads the shifted arrays."""
+    torch, mg = _gpu()
+    u = smooth_field(shape, dt)
+    N = u.size
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    ud = torch.from_numpy(u).cuda()
+    h = mg.Hierarchy(shape, dt)
+    nrm = float(np.max(np.abs(u)))
+    cap = N  # (a list that overflows holds an arbitrary subset)
+    q0, oi0, ov0, n0, _ = h.decompose_quantize(ud, mg.REL, 1e-3, np.inf, nrm, outlier_cap=cap)
+    assert n0 <= cap
+    c0 = h.decompose(ud)
+    order0 = torch.argsort(oi0)
+    for q_off, c_off, u_off in ((1, 1, 3), (63, 3, 1)):
+        upool = torch.empty(N + 64, dtype=tdt, device="cuda")
+        uv = upool[u_off:u_off + N].view(shape)
+        uv.copy_(ud)
+        assert h.norm(uv) == h.norm(ud) == nrm
+        qpool = torch.full((N + 128,), -7, dtype=torch.int64, device="cuda")
+        qv = qpool[q_off:q_off + N].view(shape)
+        cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        oi = torch.empty(cap, dtype=torch.int64, device="cuda")
+        ov = torch.empty(cap, dtype=torch.int64, device="cuda")
+        h.decompose_quantize(uv, mg.REL, 1e-3, np.inf, nrm, bufs=(qv, cnt, oi, ov), want_norm=False)
+        torch.cuda.synchronize()
+        assert int(cnt.item()) == n0
+        assert torch.equal(qv, q0), "int64 output at +%d bytes differs" % (8 * q_off)
+        # nothing outside the view was touched
+        assert int((qpool[:q_off] != -7).sum().item()) == 0 and int((qpool[q_off + N:] != -7).sum().item()) == 0
+        order = torch.argsort(oi[:n0])
+        assert torch.equal(oi[:n0][order], oi0[order0]) and torch.equal(ov[:n0][order], ov0[order0])
+        cpool = torch.zeros(N + 64, dtype=tdt, device="cuda")
+        cv = cpool[c_off:c_off + N].view(shape)
+        h.decompose(uv, out=cv)
+        assert_bit_equal(cv.cpu().numpy(), c0.cpu().numpy(), "coefficients at +%d elements" % c_off)
+        back = h.dequantize_recompose(qv, mg.REL, 1e-3, np.inf, nrm, outlier_idx=oi[:n0], outlier_val=ov[:n0])
+        back0 = h.dequantize_recompose(q0.clone(), mg.REL, 1e-3, np.inf, nrm, outlier_idx=oi0, outlier_val=ov0)
+        assert_bit_equal(back.cpu().numpy(), back0.cpu().numpy(), "reconstruction from the shifted integers")
+    h.close()
