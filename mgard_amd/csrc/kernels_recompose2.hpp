@@ -69,7 +69,6 @@ k_level_restore3_q(RecomposeArgs<T> A, Restore3Grid G) {
   const ptrdiff_t to_b = TODD ? A.coarse_b - A.coarse : 0;
   const T rt = TODD ? A.ratio_t[A.tpos - 1] : (T)0;
   using QR = typename QReg<T, QT>::type;
-  struct alignas(2 * sizeof(T)) Pair { T a, b; };
 
   // the four interpolants (node, f, c, fc) of coarse plane R at this column: f innermost, then c
   auto interp4 = [&](const T *cp, T(&Gv)[4]) {
@@ -118,19 +117,30 @@ k_level_restore3_q(RecomposeArgs<T> A, Restore3Grid G) {
     Gv[2] = lerp_ref(v[0], v[2], rc);
     Gv[3] = lerp_ref(g0, g1, rc);
   };
+  // Streaming stores for the reconstructed nodes: the output is not read again by this call, and
+  // lines left dirty in the memory-side cache are written back at the expense of the quantized
+  // integers still streaming in (node restore of all levels 395 -> 366 us at 512^3, one box,
+  // alternating runs; nontemporal LOADS of the integers: slower, 1.07 -> 1.11 ms).
+  auto store_pair = [](T *p, T a, T b) {
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    V2 v;
+    v[0] = a;
+    v[1] = b;
+    __builtin_nontemporal_store(v, reinterpret_cast<V2 *>(p));
+  };
   // one fine plane (real index rp) out: the four node values of the cell
   auto store_plane = [&](int rp, const T(&val)[4]) {
     T *pl = A.fine + (size_t)rp * A.fI;
     T *rowE = pl + outE, *rowO = pl + outO;
     if (vfo && (reinterpret_cast<uintptr_t>(rowE) & (2 * sizeof(T) - 1)) == 0) {
-      *reinterpret_cast<Pair *>(rowE) = Pair{val[0], val[1]};
+      store_pair(rowE, val[0], val[1]);
     } else {
       rowE[0] = val[0];
       if (vfo) rowE[1] = val[1];
     }
     if (vco) {
       if (vfo && (reinterpret_cast<uintptr_t>(rowO) & (2 * sizeof(T) - 1)) == 0) {
-        *reinterpret_cast<Pair *>(rowO) = Pair{val[2], val[3]};
+        store_pair(rowO, val[2], val[3]);
       } else {
         rowO[0] = val[2];
         if (vfo) rowO[1] = val[3];
