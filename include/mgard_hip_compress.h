@@ -186,7 +186,19 @@ int mgh_lossless_compress(mgh_lossless_ctx *ctx, const int64_t *d_quantized, uin
                           const uint64_t *d_outlier_idx, const int64_t *d_outlier_val,
                           uint64_t outlier_count, const uint8_t **h_payload_out,
                           uint64_t *size_out, void *stream);
-/* Inverse: payload (host) -> d_quantized [n], outlier list in device buffers owned by the
+/* The same with the record written into DEVICE memory of the caller (d_record_out, any byte
+ * alignment, `capacity` bytes): what the subdomain pipeline of mgh_compress does with every record
+ * of a device-resident container -- the encoder stores its code units straight into the record
+ * (GPUPipelines.hpp:189-193 lays the records out back to back, so a record starts wherever the
+ * previous one ended). Huffman only (a Zstd frame is assembled on the host).
+ * MGH_ERR_OUTPUT_TOO_LARGE when the record does not fit. */
+int mgh_lossless_compress_device(mgh_lossless_ctx *ctx, const int64_t *d_quantized, uint64_t n,
+                                 uint64_t dict_size, uint64_t chunk_size,
+                                 const uint64_t *d_outlier_idx, const int64_t *d_outlier_val,
+                                 uint64_t outlier_count, void *d_record_out, uint64_t capacity,
+                                 uint64_t *size_out, void *stream);
+/* Inverse: payload (host, or device memory at any byte alignment) -> d_quantized [n], outlier
+ * list in device buffers owned by the
  * context (*d_outlier_idx_out / *d_outlier_val_out, *outlier_count_out entries). */
 int mgh_lossless_decompress(mgh_lossless_ctx *ctx, const uint8_t *h_payload, uint64_t size,
                             int lossless, int64_t *d_quantized, uint64_t n,

@@ -31,6 +31,7 @@ inline const EnvSwitch *env_switches(size_t *count) {
       {"MGH_RESTORE_V", 2, 3},
       {"MGH_IPK_KR16", 0, 1},
       {"MGH_IPK_RANGE_MB", 0, 1 << 20},
+      {"MGH_HL_PIPELINE", 0, 1},
   };
   *count = sizeof(k) / sizeof(k[0]);
   return k;

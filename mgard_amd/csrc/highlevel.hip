@@ -113,6 +113,18 @@ bool is_device_pointer(const void *p) {
   return a.type == hipMemoryTypeDevice;
 }
 
+// device memory OF DEVICE `dev`: the zero-copy paths (encoder writing into the caller's record,
+// decoders reading the code units in place) let KERNELS touch the caller's buffer, which works
+// only on the device the kernels run on; memory of another GPU goes through hipMemcpyAsync
+bool is_device_pointer_on(const void *p, int dev) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return a.type == hipMemoryTypeDevice && a.device == dev;
+}
+
 bool is_registered_host(const void *p) {
   hipPointerAttribute_t a;
   if (hipPointerGetAttributes(&a, p) != hipSuccess) {
@@ -283,6 +295,7 @@ struct HostPrefix {
   }
   ~HostPrefix() { host_prefix().base = nullptr; }
 };
+int aux_read(void *dst, const void *src, size_t bytes);  // (below, with the cache)
 // device -> host copy that is served from the prefix where it can be
 inline int dev_to_host(void *dst, const void *src, size_t bytes) {
   const HostPrefixState &s = host_prefix();
@@ -291,8 +304,7 @@ inline int dev_to_host(void *dst, const void *src, size_t bytes) {
     std::memcpy(dst, s.bytes.data() + (p - s.base), bytes);
     return MGH_SUCCESS;
   }
-  HL_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
-  return MGH_SUCCESS;
+  return aux_read(dst, src, bytes);
 }
 
 // Copy the record of the last lossless_compress() to dst (host or device memory, record_size()
@@ -327,17 +339,29 @@ int record_write(mgh_lossless_ctx *c, void *dst, hipStream_t st, const uint64_t 
 // ocount: number of outliers, or (d_ocount != nullptr) read from the device together with the
 // results of the encoder (one host synchronisation less) and checked against ocap.
 // cap_units: upper bound for the code stream the caller is interested in (0: worst case).
-int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint64_t dict,
-                      uint64_t chunk, int lossless, int zstd_level, const uint64_t *d_oidx,
-                      const int64_t *d_oval, uint64_t ocount, hipStream_t st,
-                      const uint64_t *d_ocount = nullptr, uint64_t ocap = ~(uint64_t)0,
-                      uint64_t cap_units = 0, bool sym16 = false, uint8_t *direct = nullptr,
-                      size_t direct_cap = 0) {
-  // direct (device memory, 8-byte aligned, direct_cap bytes): where record_write() will be asked
-  // to put this record. The single-pass encoder then writes the code units there itself -- the
-  // offset of the units inside a record does not depend on the counts -- instead of into a
-  // buffer of the context from which record_write() copies them (512^3 f32: 150 MB moved twice).
-  c->units_in_place = false;
+// The stage runs in two halves so that the subdomain pipeline can queue the first half of
+// subdomain k+1 (behind its decomposition, on its own stream) before it waits for subdomain k:
+//   lossless_begin():  histogram kernel + its copy to the host, queued on st, no synchronisation;
+//   lossless_finish(): waits for the histogram, builds the code on the host, encodes, reads the
+//                      counts back (second synchronisation) and lays out the head of the record.
+// lossless_compress() = both, for the stand-alone entry point.
+struct LosslessJob {
+  const int64_t *d_q = nullptr;
+  uint64_t n = 0, dict = 0, chunk = 0;
+  int lossless = MGH_LOSSLESS_HUFFMAN, zstd_level = 3;
+  const uint64_t *d_oidx = nullptr;
+  const int64_t *d_oval = nullptr;
+  uint64_t ocount = 0;
+  const uint64_t *d_ocount = nullptr;
+  uint64_t ocap = ~(uint64_t)0, cap_units = 0;
+  bool sym16 = false;
+};
+
+int lossless_begin(mgh_lossless_ctx *c, const LosslessJob &J, hipStream_t st) {
+  const int64_t *d_q = J.d_q;
+  const uint64_t n = J.n, dict = J.dict, chunk = J.chunk;
+  const int lossless = J.lossless;
+  const bool sym16 = J.sym16;
   // sym16: d_q points to uint16_t symbols (mgh_decompose_quantize_sym16) -- only with the
   // single-pass encoder (lossless_sym16_ok)
   if (lossless != MGH_LOSSLESS_HUFFMAN && lossless != MGH_LOSSLESS_HUFFMAN_ZSTD)
@@ -383,6 +407,28 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
   c->pcounts = (unsigned long long *)(pinp + o_cnt);
   unsigned *freq = (unsigned *)(pinp + o_freq);
   HL_HIP(hipMemcpyAsync(freq, c->freq.p, dict * 4, hipMemcpyDeviceToHost, st));
+  return MGH_SUCCESS;
+}
+
+int lossless_finish(mgh_lossless_ctx *c, const LosslessJob &J, hipStream_t st, uint8_t *direct = nullptr,
+                    size_t direct_cap = 0) {
+  const int64_t *d_q = J.d_q;
+  const uint64_t n = J.n, dict = J.dict, chunk = J.chunk, ocap = J.ocap, cap_units = J.cap_units;
+  const int lossless = J.lossless, zstd_level = J.zstd_level;
+  const uint64_t *d_oidx = J.d_oidx, *d_ocount = J.d_ocount;
+  const int64_t *d_oval = J.d_oval;
+  uint64_t ocount = J.ocount;
+  const bool sym16 = J.sym16;
+  // direct (memory of this device, 8-byte aligned, direct_cap bytes): where record_write() will be
+  // asked to put this record. The single-pass encoder then writes the code units there itself --
+  // the offset of the units inside a record does not depend on the counts -- instead of into a
+  // buffer of the context from which record_write() copies them (512^3 f32: 150 MB moved twice).
+  c->units_in_place = false;
+  const size_t nchunk = (n - 1) / chunk + 1;
+  PayloadLayout &L = c->lay;
+  const size_t o_head = 8, o_freq = (o_head + L.ddata + 15) / 16 * 16, o_code = o_freq + dict * 4;
+  uint8_t *const pinp = (uint8_t *)c->pin.p;
+  unsigned *freq = (unsigned *)(pinp + o_freq);
   HL_HIP(hipStreamSynchronize(st));
   hl_debug("lossless_compress: histogram on the host");
   huff::Codebook &cb = c->codebook;
@@ -424,8 +470,9 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
     const unsigned long long worst = n + nchunk;  // a code is shorter than a unit
     unsigned long long cap = cap_units ? std::min<unsigned long long>(cap_units, worst) : worst;
     unsigned long long *units_dst = nullptr;
-    if (direct && lossless == MGH_LOSSLESS_HUFFMAN && ((uintptr_t)(direct + L.ddata) & 7) == 0 &&
-        direct_cap > L.ddata + 64) {
+    // (the record may start at any byte: the encoder stores its units unaligned where it has to)
+    if (direct && lossless == MGH_LOSSLESS_HUFFMAN && direct_cap > L.ddata + 64 &&
+        is_device_pointer_on(direct, c->dev)) {
       // (what does not fit behind the units -- outlier lists -- is the caller's capacity check)
       cap = std::min<unsigned long long>(cap, (direct_cap - L.ddata - 8) / 8);
       units_dst = (unsigned long long *)(direct + L.ddata);
@@ -464,9 +511,26 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
     HL_HIP(hipMemcpyAsync(st3, c->state.p, 24, hipMemcpyDeviceToHost, st));
     HL_TRY(fetch_meta());
     HL_HIP(hipStreamSynchronize(st));
+    if ((st3[2] & 2) && c->units_in_place) {
+      // a chunk needed the path that packs with atomics, which an unaligned destination cannot
+      // take (k_encode_chain): once more into the context's own (aligned) buffer
+      c->units_in_place = false;
+      cap = cap_units ? std::min<unsigned long long>(cap_units, worst) : worst;
+      HL_TRY(c->units.ensure(std::max<size_t>(cap, 1) * 8 + 8));
+      units_dst = (unsigned long long *)c->units.p;
+      HL_HIP(hipMemsetAsync(c->state.p, 0, (3 + nchunk) * 8, st));
+      if (sym16 && short_codes) enc(uint16_t(), uint32_t());
+      else if (sym16) enc(uint16_t(), uint64_t());
+      else if (short_codes) enc(int64_t(), uint32_t());
+      else enc(int64_t(), uint64_t());
+      HL_HIP(hipGetLastError());
+      HL_HIP(hipMemcpyAsync(st3, c->state.p, 24, hipMemcpyDeviceToHost, st));
+      HL_TRY(fetch_meta());
+      HL_HIP(hipStreamSynchronize(st));
+    }
     if (d_ocount) ocount = c->pcounts[3];
     units = st3[1];
-    c->overflow = st3[2] != 0;
+    c->overflow = (st3[2] & 1) != 0;
   } else {
     if (sym16) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "lossless: 16-bit symbols need the single-pass encoder");
     if (short_codes)  // (these kernels read 64-bit entries)
@@ -534,13 +598,27 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
   return MGH_SUCCESS;
 }
 
+int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint64_t dict,
+                      uint64_t chunk, int lossless, int zstd_level, const uint64_t *d_oidx,
+                      const int64_t *d_oval, uint64_t ocount, hipStream_t st,
+                      const uint64_t *d_ocount = nullptr, uint64_t ocap = ~(uint64_t)0,
+                      uint64_t cap_units = 0, bool sym16 = false, uint8_t *direct = nullptr,
+                      size_t direct_cap = 0) {
+  LosslessJob J;
+  J.d_q = d_q; J.n = n; J.dict = dict; J.chunk = chunk; J.lossless = lossless; J.zstd_level = zstd_level;
+  J.d_oidx = d_oidx; J.d_oval = d_oval; J.ocount = ocount; J.d_ocount = d_ocount; J.ocap = ocap;
+  J.cap_units = cap_units; J.sym16 = sym16;
+  HL_TRY(lossless_begin(c, J, st));
+  return lossless_finish(c, J, st, direct, direct_cap);
+}
+
 // `payload` may be host or device memory: only the small leading part of the record is brought
 // to the host, the code units and outlier lists go device-to-device (or host-to-device).
 // sym16: decode to uint16_t symbols at d_q (the ring decoder only; *sym16 is cleared when another
 // decoder had to be used and d_q holds int64 values).
 int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t size, int lossless,
                         int64_t *d_q, uint64_t n, uint64_t *ocount_out, hipStream_t st,
-                        bool *sym16 = nullptr) {
+                        bool *sym16 = nullptr, bool sync_end = true) {
   const uint8_t *p = payload;
   uint64_t psize = size;
   bool on_dev = is_device_pointer(payload);
@@ -635,11 +713,25 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
   HL_HIP(hipMemcpyAsync(c->bits.p, meta_src + L.huffmeta, nchunk * 8, hipMemcpyDefault, st));
   HL_HIP(hipMemcpyAsync(c->entry.p, meta_src + L.huffmeta + nchunk * 8, nchunk * 8, hipMemcpyDefault, st));
   HL_HIP(hipMemcpyAsync(c->tables.p, meta_src + L.decodebook, dbsize, hipMemcpyDefault, st));
-  // A device-resident record whose code units start 8-byte aligned is decoded where it is (512^3:
-  // 150 MB not copied). The decoders peek one unit past the stream; in the record that is the
-  // outlier count -- the peeked bits lie beyond the last code of the last chunk and never reach a
-  // symbol (every chunk stops at its bit count).
-  const bool units_in_place = on_dev && units && ((uintptr_t)(p + L.ddata) & 7) == 0;
+  static const bool serial_decode = env_get("MGH_HUFF_SERIAL_DECODE", 0) != 0;  // cross-check
+  static const bool par_decode = env_get("MGH_HUFF_PAR_DECODE", 0) != 0;           // cross-check
+  int book_max_len = 0;  // longest code of the decodebook (unused lengths carry first = 2^64-1)
+  {
+    const uint64_t *first = reinterpret_cast<const uint64_t *>(head.data() + L.decodebook);
+    for (int l = 1; l < 64; l++)
+      if (first[l] != ~(uint64_t)0) book_max_len = l;
+  }
+  // (the ring decoder keeps more than 32 bits in its bit buffer: codes of up to 32 bits)
+  const bool ring_decode = !serial_decode && !par_decode && (size_t)chunk >= 1024 && (size_t)chunk <= (1u << 24) &&
+                           dict <= 65536 && book_max_len <= 32;
+  // A device-resident record is decoded where it is (512^3: 150 MB not copied) -- by the ring
+  // decoder wherever its code units start (load_unit), by the others when they start 8-byte
+  // aligned. The decoders peek one unit past the stream; in the record that is the outlier count
+  // -- the peeked bits lie beyond the last code of the last chunk and never reach a symbol (every
+  // chunk stops at its bit count).
+  // (only memory of the device the decoder runs on: a record on another GPU is copied over)
+  const bool units_in_place = on_dev && units && (ring_decode || ((uintptr_t)(p + L.ddata) & 7) == 0) &&
+                              is_device_pointer_on(p, c->dev);
   const unsigned long long *d_units = (const unsigned long long *)c->units.p;
   if (units_in_place) {
     d_units = (const unsigned long long *)(p + L.ddata);
@@ -665,18 +757,8 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
                                hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     hl_attr_done(once);
   }
-  static const bool serial_decode = env_get("MGH_HUFF_SERIAL_DECODE", 0) != 0;  // cross-check
   hl_debug("lossless_decompress: uploads done (units, tables, outliers)");
-  static const bool par_decode = env_get("MGH_HUFF_PAR_DECODE", 0) != 0;           // cross-check
-  int book_max_len = 0;  // longest code of the decodebook (unused lengths carry first = 2^64-1)
-  {
-    const uint64_t *first = reinterpret_cast<const uint64_t *>(head.data() + L.decodebook);
-    for (int l = 1; l < 64; l++)
-      if (first[l] != ~(uint64_t)0) book_max_len = l;
-  }
-  // (the ring decoder keeps more than 32 bits in its bit buffer: codes of up to 32 bits)
-  if (!serial_decode && !par_decode && (size_t)chunk >= 1024 && (size_t)chunk <= (1u << 24) && dict <= 65536 &&
-      book_max_len <= 32) {
+  if (ring_decode) {
     // parallel decoding inside the chunks: two-level table from the decodebook (host, microseconds),
     // code units through per-lane LDS rings. 16 waves per workgroup when the table leaves room.
     const uint64_t *book = reinterpret_cast<const uint64_t *>(head.data() + L.decodebook);
@@ -737,8 +819,9 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
   }
   HL_HIP(hipGetLastError());
   hl_debug("lossless_decompress: decode launched");
-  // the host payload may go away when we return
-  HL_HIP(hipStreamSynchronize(st));
+  // the host payload may go away when we return (the subdomain pipeline keeps it, and the context's
+  // host-side sources, alive until the lane has drained: sync_end = false)
+  if (sync_end) HL_HIP(hipStreamSynchronize(st));
   *ocount_out = ocount;
   return MGH_SUCCESS;
 }
@@ -1116,29 +1199,62 @@ int copy_subdomain(const Decomposer &dd, uint64_t id, size_t elem, void *sub, co
 
 // ---- per-thread cache: hierarchies, device buffers, lossless context
 // (CompressorCache, CompressionLowLevel/CompressorCache.hpp:139-142) -------------------------
-struct HlCache {
-  std::map<std::vector<uint64_t>, mgh_hierarchy *> hier;  // key: dtype, normalize, max_level, shape...
-  DevBuf in[2], q, q2, ocount, oidx, oval;  // q2: level-linearised copy (config.reorder == 1)
-  PinBuf hpin;  // pinned staging of mgh_compress: [0, 8) a record's size prefix, [64, ...) the header
+// One compute lane of the subdomain pipeline: a stream with everything a subdomain needs between
+// its decomposition and its record (quantized symbols, outlier lists, lossless context, pinned
+// scratch). Two lanes: while subdomain k is in histogram -> code construction (host) -> encoder
+// -> record on one lane, subdomain k+1 is decomposed and quantized on the other
+// (GPUPipelines.hpp:88-207 runs 2 buffers x 3 queues the same way).
+struct Lane {
+  hipStream_t st = nullptr;
+  DevBuf q, q2, ocount, oidx, oval;  // q2: level-linearised copy (config.reorder == 1)
+  DevBuf sub;                        // decompression: the dense subdomain when the output is not written in place
+  PinBuf pin;                        // [0, 8) size prefix of a raw record, [16, 24) norm read-back
   mgh_lossless_ctx *ll = nullptr;
-  hipStream_t streams[3] = {nullptr, nullptr, nullptr};
-  int dev = -1;
+  uint64_t ocap = 0;                 // elements oidx / oval hold
   void release() {
-    for (auto &kv : hier) mgh_hierarchy_destroy(kv.second);
-    hier.clear();
-    in[0].release();
-    in[1].release();
     q.release();
     q2.release();
     ocount.release();
     oidx.release();
     oval.release();
-    hpin.release();
+    sub.release();
+    pin.release();
     if (ll) mgh_lossless_destroy(ll);
     ll = nullptr;
-    for (auto &s : streams) {
-      if (s) (void)hipStreamDestroy(s);
-      s = nullptr;
+    ocap = 0;
+    if (st) (void)hipStreamDestroy(st);
+    st = nullptr;
+  }
+};
+constexpr int kLanes = 2;
+constexpr int kInBufs = 3;  // subdomain k in its record phase, k+1 being decomposed, k+2 arriving
+
+struct HlCache {
+  std::map<std::vector<uint64_t>, mgh_hierarchy *> hier;  // key: lane, dtype, normalize, max_level, shape...
+  DevBuf in[kInBufs];
+  hipEvent_t in_ready[kInBufs] = {nullptr, nullptr, nullptr};  // the copy into in[b] has landed
+  hipEvent_t in_free[kInBufs] = {nullptr, nullptr, nullptr};   // the last reader of in[b] is done (norm phase)
+  PinBuf hpin;  // pinned staging of mgh_compress: [64, ...) the header
+  Lane lane[kLanes];
+  hipStream_t copy_st = nullptr;  // prefetch of the next subdomains (compression), strided write-back (decompression)
+  hipStream_t aux_st = nullptr;   // small device -> host reads that must not wait for the lanes
+  PinBuf aux_pin;
+  int dev = -1;
+  void release() {
+    for (auto &kv : hier) mgh_hierarchy_destroy(kv.second);
+    hier.clear();
+    for (auto &b : in) b.release();
+    for (auto *arr : {in_ready, in_free})
+      for (int b = 0; b < kInBufs; b++) {
+        if (arr[b]) (void)hipEventDestroy(arr[b]);
+        arr[b] = nullptr;
+      }
+    hpin.release();
+    aux_pin.release();
+    for (auto &l : lane) l.release();
+    for (hipStream_t *s : {&copy_st, &aux_st}) {
+      if (*s) (void)hipStreamDestroy(*s);
+      *s = nullptr;
     }
     dev = -1;
   }
@@ -1154,6 +1270,24 @@ inline HlCache &hl_cache() {
 }
 #define g_cache (hl_cache())
 
+// Small synchronous device -> host read (record sizes, record heads). On the cache's own stream
+// and through its pinned buffer: hipMemcpy() would run on the NULL stream and with it wait for
+// everything the lanes have queued. Stand-alone calls that never prepared a cache use hipMemcpy.
+int aux_read(void *dst, const void *src, size_t bytes) {
+  HlCache *c = g_cache_ptr;
+  if (!c || !c->aux_st || !c->aux_pin.p) {
+    HL_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return MGH_SUCCESS;
+  }
+  for (size_t off = 0; off < bytes; off += c->aux_pin.cap) {
+    const size_t nb = std::min(c->aux_pin.cap, bytes - off);
+    HL_HIP(hipMemcpyAsync(c->aux_pin.p, (const char *)src + off, nb, hipMemcpyDeviceToHost, c->aux_st));
+    HL_HIP(hipStreamSynchronize(c->aux_st));
+    std::memcpy((char *)dst + off, c->aux_pin.p, nb);
+  }
+  return MGH_SUCCESS;
+}
+
 int cache_prepare(int dev) {
   if (g_cache.dev != dev) {
     g_cache.release();
@@ -1164,8 +1298,15 @@ int cache_prepare(int dev) {
     // before the first pipeline stage reads it, and work the caller queues on the NULL stream
     // afterwards waits for the pipeline. Inputs produced on OTHER non-blocking streams must be
     // synchronised by the caller (include/mgard_hip_compress.h).
-    for (auto &s : g_cache.streams) HL_HIP(hipStreamCreate(&s));
-    HL_TRY(mgh_lossless_create(&g_cache.ll, dev));
+    for (auto &l : g_cache.lane) {
+      HL_HIP(hipStreamCreate(&l.st));
+      HL_TRY(mgh_lossless_create(&l.ll, dev));
+    }
+    HL_HIP(hipStreamCreate(&g_cache.copy_st));
+    HL_HIP(hipStreamCreate(&g_cache.aux_st));
+    for (auto &e : g_cache.in_ready) HL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : g_cache.in_free) HL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HL_TRY(g_cache.aux_pin.ensure(512 * 1024));
     g_cache.dev = dev;
   }
   return MGH_SUCCESS;
@@ -1173,12 +1314,24 @@ int cache_prepare(int dev) {
 
 // Hierarchy of a subdomain (DomainDecomposer::subdomain_hierarchy, :265-301). Uniform ones
 // are cached by shape (at most 4 alive); non-uniform ones are built per subdomain.
+constexpr size_t kHierCacheMax = 8 * kLanes;  // (a Block decomposition of a 3-D array has up to 8 subdomain shapes)
+// start of a high-level call (nothing in flight): make room when the cache is full
+int trim_hierarchy_cache() {
+  if (g_cache.hier.size() < kHierCacheMax) return MGH_SUCCESS;
+  for (auto &kv : g_cache.hier) mgh_hierarchy_destroy(kv.second);
+  g_cache.hier.clear();
+  return MGH_SUCCESS;
+}
+
+// A hierarchy owns the workspace of the subdomain that runs on it, so the two lanes of the
+// pipeline keep separate ones (`lane` is part of the key).
 int get_hierarchy(mgh_hierarchy **out, bool *owned, int dtype, const std::vector<uint64_t> &shape,
                   const std::vector<std::vector<double>> *coords, const std::vector<uint64_t> &off,
-                  const mgh_config &cfg) {
+                  const mgh_config &cfg, int lane = 0) {
   const int D = (int)shape.size();
   if (!coords) {
-    std::vector<uint64_t> key = {(uint64_t)dtype, (uint64_t)cfg.normalize_coordinates, cfg.max_larget_level};
+    std::vector<uint64_t> key = {(uint64_t)lane, (uint64_t)dtype, (uint64_t)cfg.normalize_coordinates,
+                                 cfg.max_larget_level};
     key.insert(key.end(), shape.begin(), shape.end());
     auto it = g_cache.hier.find(key);
     if (it != g_cache.hier.end()) {
@@ -1186,16 +1339,15 @@ int get_hierarchy(mgh_hierarchy **out, bool *owned, int dtype, const std::vector
       *owned = false;
       return MGH_SUCCESS;
     }
-    if (g_cache.hier.size() >= 4) {
-      for (auto &kv : g_cache.hier) mgh_hierarchy_destroy(kv.second);
-      g_cache.hier.clear();
-    }
     mgh_hierarchy *h = nullptr;
     HL_TRY(mgh_hierarchy_create(&h, D, shape.data(), dtype, nullptr, cfg.normalize_coordinates,
                                 cfg.max_larget_level, cfg.dev_id));
-    g_cache.hier[key] = h;
     *out = h;
-    *owned = false;
+    // A full cache is emptied between calls only (trim_hierarchy_cache): inside a call a cached
+    // hierarchy may be at work on the other lane. A shape that does not fit any more is built for
+    // its subdomain alone.
+    *owned = g_cache.hier.size() >= kHierCacheMax;
+    if (!*owned) g_cache.hier[key] = h;
     return MGH_SUCCESS;
   }
   // slice of the coordinate arrays, converted to the data type
@@ -1262,6 +1414,7 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
                   const void *original, void **compressed, size_t *compressed_size,
                   const void *const *coords_in, const mgh_config &cfg, bool prealloc) {
   HL_TRY(cache_prepare(cfg.dev_id));
+  HL_TRY(trim_hierarchy_cache());
   const T tol = (T)tol_d, s = (T)s_d;
   size_t total = 1;
   for (int d = 0; d < D; d++) total *= shape[d];
@@ -1296,7 +1449,19 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
     else
       (void)hipGetLastError();
   }
+  // MGH_HL_PIPELINE=0: every subdomain runs start to end before the next one is queued (cross-check;
+  // same container byte for byte up to the order of the outlier lists)
+  const bool pipelined = env_get("MGH_HL_PIPELINE", 1) != 0;
+  const int nlanes = dd.num > 1 && pipelined ? kLanes : 1;
+  auto drain = [&] {  // nothing of this call may be in flight when it returns
+    for (int l = 0; l < kLanes; l++) (void)hipStreamSynchronize(g_cache.lane[l].st);
+    (void)hipStreamSynchronize(g_cache.copy_st);
+  };
+  std::vector<mgh_hierarchy *> owned_alive;  // per-subdomain hierarchies (non-uniform grids) not yet destroyed
   auto cleanup = [&](int rc) {
+    if (rc != MGH_SUCCESS) drain();
+    for (mgh_hierarchy *h : owned_alive) mgh_hierarchy_destroy(h);
+    owned_alive.clear();
     if (pinned_here) (void)hipHostUnregister(const_cast<void *>(original));
     if (rc != MGH_SUCCESS && !prealloc) {
       if (in_dev) (void)hipFree(*compressed); else std::free(*compressed);
@@ -1306,28 +1471,34 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
   };
   const uint64_t max_elems = dd.max_subdomain_elems();
   const uint64_t ocap = std::max<uint64_t>(1, (uint64_t)(cfg.estimate_outlier_ratio * (double)max_elems));
-  uint64_t ocap_cur = ocap;  // grows when a subdomain has more outliers than estimated
   // device-resident input whose subdomains are contiguous slabs: compress them where they are
   const bool zero_copy = in_dev && dd.all_contiguous();
-  auto sub_in = [&](uint64_t id, int buf) -> const void * {
+  const int nbufs = zero_copy ? 0 : (int)std::min<uint64_t>(dd.num, nlanes > 1 ? kInBufs : 2);
+  auto sub_in = [&](uint64_t id) -> const void * {
     return zero_copy ? (const void *)((const char *)original + dd.linear_offset(id) * elem)
-                     : (const void *)g_cache.in[buf].p;
+                     : (const void *)g_cache.in[id % nbufs].p;
   };
-  auto fetch_sub = [&](uint64_t id, int buf, hipStream_t stream) -> int {
+  // subdomain id into its input buffer on the copy stream; in_ready[buffer] fires when it has landed
+  auto fetch_sub = [&](uint64_t id) -> int {
     if (zero_copy) return MGH_SUCCESS;
-    return copy_subdomain(dd, id, elem, g_cache.in[buf].p, original, nullptr, true, stream);
+    const int b = (int)(id % nbufs);
+    HL_TRY(copy_subdomain(dd, id, elem, g_cache.in[b].p, original, nullptr, true, g_cache.copy_st));
+    HL_HIP(hipEventRecord(g_cache.in_ready[b], g_cache.copy_st));
+    return MGH_SUCCESS;
   };
   int rc;
   auto ensure_all = [&]() -> int {
-    if (!zero_copy) {
-      HL_TRY(g_cache.in[0].ensure(max_elems * elem));
-      if (dd.num > 1) HL_TRY(g_cache.in[1].ensure(max_elems * elem));
+    for (int b = 0; b < nbufs; b++) HL_TRY(g_cache.in[b].ensure(max_elems * elem));
+    for (int l = 0; l < nlanes; l++) {
+      Lane &L = g_cache.lane[l];
+      HL_TRY(L.q.ensure(max_elems * 8));
+      if (cfg.reorder) HL_TRY(L.q2.ensure(max_elems * 8));
+      HL_TRY(L.ocount.ensure(8));
+      HL_TRY(L.oidx.ensure(ocap * 8));
+      HL_TRY(L.oval.ensure(ocap * 8));
+      L.ocap = std::max(L.ocap, ocap);  // (grow-only buffers: an earlier call may have left more)
+      HL_TRY(L.pin.ensure(64));
     }
-    HL_TRY(g_cache.q.ensure(max_elems * 8));
-    if (cfg.reorder) HL_TRY(g_cache.q2.ensure(max_elems * 8));
-    HL_TRY(g_cache.ocount.ensure(8));
-    HL_TRY(g_cache.oidx.ensure(ocap * 8));
-    HL_TRY(g_cache.oval.ensure(ocap * 8));
     return MGH_SUCCESS;
   };
   if ((rc = ensure_all()) != MGH_SUCCESS) return cleanup(rc);
@@ -1338,29 +1509,45 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
   int local_eb = ebtype;
   if (dd.decomposed) {
     if (ebtype == MGH_REL) {
-      double acc = 0;
-      int buf = 0;
-      if ((rc = fetch_sub(0, 0, g_cache.streams[0])) != MGH_SUCCESS)
+      // every subdomain's norm is left on the device (one slot each) and all of them come back in
+      // one copy: no host round trip between the reductions
+      hipStream_t st = g_cache.lane[0].st;
+      DevBuf &slots = g_cache.lane[0].q;  // (free until the pipeline starts)
+      if ((rc = g_cache.aux_pin.ensure(std::max<size_t>(512 * 1024, dd.num * sizeof(T)))) != MGH_SUCCESS)
         return cleanup(rc);
+      if ((rc = slots.ensure(dd.num * sizeof(T))) != MGH_SUCCESS) return cleanup(rc);
       for (uint64_t id = 0; id < dd.num; id++) {
-        const int nb = (buf + 1) % 2;
-        if (id + 1 < dd.num && (rc = fetch_sub(id + 1, nb, g_cache.streams[1])) != MGH_SUCCESS)
-          return cleanup(rc);
+        if (!zero_copy) {
+          // (the buffers in turn: the copy of id waits for the reduction that read id - nbufs)
+          if (id >= (uint64_t)nbufs && hipStreamWaitEvent(g_cache.copy_st, g_cache.in_free[id % nbufs], 0) != hipSuccess)
+            return cleanup(hl_fail(MGH_ERR_DEVICE, "hipStreamWaitEvent"));
+          if ((rc = fetch_sub(id)) != MGH_SUCCESS) return cleanup(rc);
+          if (hipStreamWaitEvent(st, g_cache.in_ready[id % nbufs], 0) != hipSuccess)
+            return cleanup(hl_fail(MGH_ERR_DEVICE, "hipStreamWaitEvent"));
+        }
         mgh_hierarchy *h = nullptr;
         bool owned = false;
         const auto sshape = dd.subdomain_shape(id);
-        if ((rc = get_hierarchy(&h, &owned, dtype, sshape, nullptr, dd.subdomain_offset(id), cfg)) != MGH_SUCCESS)
+        if ((rc = get_hierarchy(&h, &owned, dtype, sshape, nullptr, dd.subdomain_offset(id), cfg, 0)) != MGH_SUCCESS)
           return cleanup(rc);
-        double ln = 0;
-        rc = mgh_norm(h, sub_in(id, buf), s_d, &ln, g_cache.streams[0]);
+        if (owned) owned_alive.push_back(h);
+        rc = mgh_norm_device(h, sub_in(id), s_d, (char *)slots.p + id * sizeof(T), st);
         if (rc != MGH_SUCCESS) return cleanup(rc);
+        if (!zero_copy && hipEventRecord(g_cache.in_free[id % nbufs], st) != hipSuccess)
+          return cleanup(hl_fail(MGH_ERR_DEVICE, "hipEventRecord"));
+      }
+      if (hipMemcpyAsync(g_cache.aux_pin.p, slots.p, dd.num * sizeof(T), hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipStreamSynchronize(st) != hipSuccess)
+        return cleanup(hl_fail(MGH_ERR_DEVICE, "norms of the subdomains"));
+      for (mgh_hierarchy *h : owned_alive) mgh_hierarchy_destroy(h);
+      owned_alive.clear();
+      double acc = 0;
+      for (uint64_t id = 0; id < dd.num; id++) {
+        const double ln = (double)((const T *)g_cache.aux_pin.p)[id];
         uint64_t cnt = 1;
-        for (uint64_t e : sshape) cnt *= e;
+        for (uint64_t e : dd.subdomain_shape(id)) cnt *= e;
         if (s == std::numeric_limits<T>::infinity()) acc = std::max(acc, ln);
         else acc += ln * ln * (cfg.normalize_coordinates ? (double)cnt : 1.0);  // un-normalised square
-        // mgh_norm returned a host value, so streams[0] is idle; the prefetch must have landed
-        if (hipStreamSynchronize(g_cache.streams[1]) != hipSuccess) return cleanup(hl_fail(MGH_ERR_DEVICE, "sync"));
-        buf = nb;
       }
       if (s == std::numeric_limits<T>::infinity()) norm = (T)acc;
       else norm = (T)(cfg.normalize_coordinates ? std::sqrt(acc / (double)total) : std::sqrt(acc));
@@ -1381,138 +1568,180 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
   size_t byte_offset = meta_size;
 
   // ---- subdomain pipeline (compress_pipeline_gpu, GPUPipelines.hpp:69-207) ----
-  int buf = 0, qi = 0;
-  if ((rc = fetch_sub(0, 0, g_cache.streams[0])) != MGH_SUCCESS)
-    return cleanup(rc);
-  for (uint64_t id = 0; id < dd.num; id++) {
-    const int nb = (buf + 1) % 2, nq = (qi + 1) % 3;
-    hipStream_t st = g_cache.streams[qi];
-    if (id + 1 < dd.num && (rc = fetch_sub(id + 1, nb, g_cache.streams[nq])) != MGH_SUCCESS)
-      return cleanup(rc);
-    const auto sshape = dd.subdomain_shape(id);
-    uint64_t n = 1;
-    for (uint64_t e : sshape) n *= e;
+  // issue(k): decomposition + quantizer + histogram of subdomain k queued on lane k % nlanes, no
+  // host synchronisation; finish(k): code construction, encoder, record -- the host waits for lane
+  // k % nlanes only. With two lanes issue(k + 1) is queued BEFORE finish(k), so the device has the
+  // next subdomain's level passes and solves to run while this one's histogram travels to the
+  // host and its encoder runs; the input of k + 2 arrives on the copy stream meanwhile.
+  struct SubJob {
+    uint64_t id = 0, n = 0;
+    int lane = 0;
     mgh_hierarchy *h = nullptr;
-    bool owned = false;
-    if ((rc = get_hierarchy(&h, &owned, dtype, sshape, cptr, dd.subdomain_offset(id), cfg)) != MGH_SUCCESS)
-      return cleanup(rc);
+    bool owned = false, sym16 = false, norm_deferred = false;
+    double norm_out = 0;
+    LosslessJob lj;
+  };
+  auto issue = [&](SubJob &J, uint64_t id) -> int {
+    J = SubJob();
+    J.id = id;
+    J.lane = (int)(id % nlanes);
+    Lane &L = g_cache.lane[J.lane];
+    hipStream_t st = L.st;
+    const auto sshape = dd.subdomain_shape(id);
+    J.n = 1;
+    for (uint64_t e : sshape) J.n *= e;
+    if (!zero_copy) HL_HIP(hipStreamWaitEvent(st, g_cache.in_ready[id % nbufs], 0));
+    HL_TRY(get_hierarchy(&J.h, &J.owned, dtype, sshape, cptr, dd.subdomain_offset(id), cfg, J.lane));
+    if (J.owned) owned_alive.push_back(J.h);
     hl_debug("compress: subdomain ready");
-    uint64_t ocap_now = ocap_cur;
-    double norm_out = (double)norm;
-    bool norm_deferred = false;
-    for (int attempt = 0; attempt < 2; attempt++) {
-      rc = hipMemsetAsync(g_cache.ocount.p, 0, 8, st) == hipSuccess ? MGH_SUCCESS : hl_fail(MGH_ERR_DEVICE, "memset");
-      // 16-bit symbols straight from the quantizer where the fused kernels run (a quarter of the
-      // bytes written by the quantizer and read twice by the lossless stage); int64 otherwise
-      bool sym16 = false;
-      if (rc == MGH_SUCCESS && !cfg.reorder && lossless_sym16_ok(cfg.huff_dict_size, cfg.huff_block_size)) {
-        const int r16 = mgh_decompose_quantize_sym16(
-            h, sub_in(id, buf), local_eb, (double)local_tol, s_d, local_eb == MGH_REL ? 0.0 : (double)norm,
-            nullptr /* the norm stays on the device: see below */, cfg.huff_dict_size, (uint16_t *)g_cache.q.p,
-            (uint64_t *)g_cache.ocount.p, (uint64_t *)g_cache.oidx.p, (int64_t *)g_cache.oval.p, ocap_now, st);
-        if (r16 == MGH_SUCCESS) sym16 = true;
-        else if (r16 != MGH_ERR_UNSUPPORTED_DIMENSION) rc = r16;
-      }
-      if (rc == MGH_SUCCESS && !sym16)
-        rc = mgh_decompose_quantize(h, sub_in(id, buf), local_eb, (double)local_tol, s_d,
-                                    local_eb == MGH_REL ? 0.0 : (double)norm,
-                                    local_eb == MGH_REL ? &norm_out : nullptr, cfg.huff_dict_size, 1,
-                                    (int64_t *)g_cache.q.p, (uint64_t *)g_cache.ocount.p,
-                                    (uint64_t *)g_cache.oidx.p, (int64_t *)g_cache.oval.p, ocap_now, nullptr, st);
-      hl_debug("compress: decompose + quantize done");
-      // REL on the fused device path (the 16-bit symbol call: the norm never left the device): it
-      // is fetched behind the quantizer into pinned memory and read when the lossless stage has
-      // synchronised anyway -- a read-back inside the call above would stall the queue in front of
-      // the histogram kernel. Every other path hands the norm back itself (norm_out).
-      norm_deferred = false;
-      if (rc == MGH_SUCCESS && local_eb == MGH_REL) {
-        if (sym16) {
-          norm_deferred = true;
-          if (hipMemcpyAsync((char *)g_cache.hpin.p + 16, mgh_norm_device_ptr(h), sizeof(T), hipMemcpyDeviceToHost, st) != hipSuccess)
-            rc = hl_fail(MGH_ERR_DEVICE, "norm read-back");
-        } else {
-          norm = (T)norm_out;
-        }
-      }
-      const int64_t *q_enc = (const int64_t *)g_cache.q.p;
-      if (rc == MGH_SUCCESS && cfg.reorder) {
-        // config.reorder == 1: the lossless stage sees the integers level by level, outlier
-        // indices are positions in that array (LinearQuantization.hpp:226-232, 588-605)
-        rc = mgh_level_linearize(h, (const int64_t *)g_cache.q.p, (int64_t *)g_cache.q2.p, 0,
-                                 (uint64_t *)g_cache.oidx.p, (const uint64_t *)g_cache.ocount.p, 0, ocap_now, st);
-        q_enc = (const int64_t *)g_cache.q2.p;
-      }
-      if (rc == MGH_SUCCESS)  // (the outlier count is read back together with the encoder's results)
-        rc = lossless_compress(g_cache.ll, q_enc, n, cfg.huff_dict_size,
-                               cfg.huff_block_size, cfg.lossless, cfg.zstd_compress_level,
-                               (const uint64_t *)g_cache.oidx.p, (const int64_t *)g_cache.oval.p, 0, st,
-                               (const uint64_t *)g_cache.ocount.p, ocap_now, n * elem / 8 + 1, sym16,
-                               out_dev && cap - byte_offset > 8 ? (uint8_t *)*compressed + byte_offset + 8 : nullptr,
-                               out_dev && cap - byte_offset > 8 ? cap - byte_offset - 8 : 0);
-      if (rc != kOutlierOverflow) break;
-      // estimate_outlier_ratio was too optimistic: grow the lists to what this subdomain needs
-      // and quantize again
-      ocap_now = g_cache.ll->outliers_needed;
-      rc = g_cache.oidx.ensure(ocap_now * 8);
-      if (rc == MGH_SUCCESS) rc = g_cache.oval.ensure(ocap_now * 8);
-      if (rc != MGH_SUCCESS) break;
-      ocap_cur = ocap_now;
-      rc = kOutlierOverflow;
+    HL_HIP(hipMemsetAsync(L.ocount.p, 0, 8, st));
+    J.norm_out = (double)norm;
+    // 16-bit symbols straight from the quantizer where the fused kernels run (a quarter of the
+    // bytes written by the quantizer and read twice by the lossless stage); int64 otherwise
+    if (!cfg.reorder && lossless_sym16_ok(cfg.huff_dict_size, cfg.huff_block_size)) {
+      const int r16 = mgh_decompose_quantize_sym16(
+          J.h, sub_in(id), local_eb, (double)local_tol, s_d, local_eb == MGH_REL ? 0.0 : (double)norm,
+          nullptr /* the norm stays on the device: see below */, cfg.huff_dict_size, (uint16_t *)L.q.p,
+          (uint64_t *)L.ocount.p, (uint64_t *)L.oidx.p, (int64_t *)L.oval.p, L.ocap, st);
+      if (r16 == MGH_SUCCESS) J.sym16 = true;
+      else if (r16 != MGH_ERR_UNSUPPORTED_DIMENSION) return r16;
     }
-    if (rc == kOutlierOverflow) rc = hl_fail(MGH_ERR_DEVICE, "outlier lists overflowed twice");
-    if (rc == MGH_SUCCESS && norm_deferred) {  // (lossless_compress has synchronised st)
+    if (!J.sym16)
+      HL_TRY(mgh_decompose_quantize(J.h, sub_in(id), local_eb, (double)local_tol, s_d,
+                                    local_eb == MGH_REL ? 0.0 : (double)norm,
+                                    local_eb == MGH_REL ? &J.norm_out : nullptr, cfg.huff_dict_size, 1,
+                                    (int64_t *)L.q.p, (uint64_t *)L.ocount.p, (uint64_t *)L.oidx.p,
+                                    (int64_t *)L.oval.p, L.ocap, nullptr, st));
+    hl_debug("compress: decompose + quantize done");
+    // REL on the fused device path (the 16-bit symbol call: the norm never left the device): it
+    // is fetched behind the quantizer into pinned memory and read when the lossless stage has
+    // synchronised anyway -- a read-back inside the call above would stall the queue in front of
+    // the histogram kernel. Every other path hands the norm back itself (norm_out).
+    if (local_eb == MGH_REL && J.sym16) {
+      J.norm_deferred = true;
+      HL_HIP(hipMemcpyAsync((char *)L.pin.p + 16, mgh_norm_device_ptr(J.h), sizeof(T), hipMemcpyDeviceToHost, st));
+    }
+    const int64_t *q_enc = (const int64_t *)L.q.p;
+    if (cfg.reorder) {
+      // config.reorder == 1: the lossless stage sees the integers level by level, outlier
+      // indices are positions in that array (LinearQuantization.hpp:226-232, 588-605)
+      HL_TRY(mgh_level_linearize(J.h, (const int64_t *)L.q.p, (int64_t *)L.q2.p, 0, (uint64_t *)L.oidx.p,
+                                 (const uint64_t *)L.ocount.p, 0, L.ocap, st));
+      q_enc = (const int64_t *)L.q2.p;
+    }
+    LosslessJob &lj = J.lj;
+    lj.d_q = q_enc;
+    lj.n = J.n;
+    lj.dict = cfg.huff_dict_size;
+    lj.chunk = cfg.huff_block_size;
+    lj.lossless = cfg.lossless;
+    lj.zstd_level = cfg.zstd_compress_level;
+    lj.d_oidx = (const uint64_t *)L.oidx.p;
+    lj.d_oval = (const int64_t *)L.oval.p;
+    lj.ocount = 0;  // (read back together with the encoder's results)
+    lj.d_ocount = (const uint64_t *)L.ocount.p;
+    lj.ocap = L.ocap;
+    lj.cap_units = J.n * elem / 8 + 1;
+    lj.sym16 = J.sym16;
+    return lossless_begin(L.ll, lj, st);
+  };
+  auto finish = [&](SubJob &J) -> int {
+    Lane &L = g_cache.lane[J.lane];
+    hipStream_t st = L.st;
+    const uint64_t id = J.id, n = J.n;
+    int frc = MGH_SUCCESS;
+    for (int attempt = 0; attempt < 2; attempt++) {
+      const bool direct_ok = out_dev && cap - byte_offset > 8;
+      frc = lossless_finish(L.ll, J.lj, st, direct_ok ? (uint8_t *)*compressed + byte_offset + 8 : nullptr,
+                            direct_ok ? cap - byte_offset - 8 : 0);
+      if (frc != kOutlierOverflow) break;
+      if (attempt == 1) return hl_fail(MGH_ERR_DEVICE, "outlier lists overflowed twice");
+      // estimate_outlier_ratio was too optimistic: grow this lane's lists to what the subdomain
+      // needs and quantize it again (LinearQuantization.hpp:621-676 re-launches the same way)
+      const uint64_t need = L.ll->outliers_needed;
+      HL_TRY(L.oidx.ensure(need * 8));
+      HL_TRY(L.oval.ensure(need * 8));
+      L.ocap = need;
+      mgh_hierarchy *h = J.h;
+      const bool owned = J.owned;
+      SubJob again;
+      // (the hierarchy of the first attempt serves the second; issue() looks it up again)
+      if (owned) {
+        owned_alive.erase(std::remove(owned_alive.begin(), owned_alive.end(), h), owned_alive.end());
+        mgh_hierarchy_destroy(h);
+      }
+      HL_TRY(issue(again, id));
+      J = again;
+    }
+    HL_TRY(frc);
+    if (J.norm_deferred) {  // (lossless_finish has synchronised the lane)
       T nv;
-      std::memcpy(&nv, (const char *)g_cache.hpin.p + 16, sizeof(T));
+      std::memcpy(&nv, (const char *)L.pin.p + 16, sizeof(T));
       norm = nv;
+    } else if (local_eb == MGH_REL) {
+      norm = (T)J.norm_out;
     }
     hl_debug("compress: lossless stage done");
-    if (owned) mgh_hierarchy_destroy(h);
-    if (rc != MGH_SUCCESS) return cleanup(rc);
-    uint64_t csize = g_cache.ll->record_size();
+    uint64_t csize = L.ll->record_size();
     const bool raw = (double)(n * elem) / (double)csize < 1.0;  // GPUPipelines.hpp:136-155
     if (raw) csize = n * elem;
     if (csize > cap - byte_offset || cap - byte_offset - csize < 8)
-      return cleanup(hl_fail(MGH_ERR_OUTPUT_TOO_LARGE, "Output too large"));
+      return hl_fail(MGH_ERR_OUTPUT_TOO_LARGE, "Output too large");
     char *dst = (char *)*compressed + byte_offset;
     const bool prefix_with_record = out_dev && !raw;  // (one copy: size prefix + head of the record)
     if (out_dev && raw) {
-      std::memcpy(g_cache.hpin.p, &csize, 8);
-      rc = hipMemcpyAsync(dst, g_cache.hpin.p, 8, hipMemcpyHostToDevice, st) == hipSuccess ? MGH_SUCCESS : MGH_ERR_DEVICE;
+      std::memcpy(L.pin.p, &csize, 8);
+      HL_HIP(hipMemcpyAsync(dst, L.pin.p, 8, hipMemcpyHostToDevice, st));
     } else if (!out_dev) {
       std::memcpy(dst, &csize, 8);
     }
     dst += 8;
-    if (rc == MGH_SUCCESS) {
-      if (raw) {
-        // the dense subdomain itself (re-fetched: decompose_quantize does not modify its input,
-        // so the buffer still holds it)
-        rc = hipMemcpyAsync(dst, sub_in(id, buf), csize, hipMemcpyDefault, st) == hipSuccess ? MGH_SUCCESS : MGH_ERR_DEVICE;
-      } else {
-        const uint64_t cs64 = csize;
-        rc = record_write(g_cache.ll, dst, st, prefix_with_record ? &cs64 : nullptr);
-      }
+    if (raw) {
+      // the dense subdomain itself (decompose_quantize does not modify its input, so the buffer
+      // still holds it)
+      HL_HIP(hipMemcpyAsync(dst, sub_in(id), csize, hipMemcpyDefault, st));
+    } else {
+      const uint64_t cs64 = csize;
+      HL_TRY(record_write(L.ll, dst, st, prefix_with_record ? &cs64 : nullptr));
     }
-    if (id + 1 == dd.num && rc == MGH_SUCCESS) {
+    if (id + 1 == dd.num) {
       // header (with the norm the pipeline computed for a non-decomposed REL run): it travels on the
       // last record's stream, in front of the synchronisation that record needs anyway
       header_from(dd, dtype, ebtype, tol_d, s_d, ebtype == MGH_REL ? (double)norm : 0.0, cptr, cfg, hdr);
       meta = fmt::serialize_metadata(hdr);
-      if (meta.size() != meta_size) return cleanup(hl_fail(MGH_ERR_FORMAT, "metadata size changed"));
+      if (meta.size() != meta_size) return hl_fail(MGH_ERR_FORMAT, "metadata size changed");
       if (out_dev) {
         // (out of pinned memory: the copy is queued, not staged synchronously)
         std::memcpy((char *)g_cache.hpin.p + 64, meta.data(), meta.size());
-        if (hipMemcpyAsync(*compressed, (char *)g_cache.hpin.p + 64, meta.size(), hipMemcpyHostToDevice, st) != hipSuccess)
-          rc = MGH_ERR_DEVICE;
+        HL_HIP(hipMemcpyAsync(*compressed, (char *)g_cache.hpin.p + 64, meta.size(), hipMemcpyHostToDevice, st));
       } else {
         std::memcpy(*compressed, meta.data(), meta.size());
       }
     }
-    if (rc == MGH_SUCCESS && hipStreamSynchronize(st) != hipSuccess) rc = MGH_ERR_DEVICE;
-    if (rc != MGH_SUCCESS) return cleanup(hl_fail(rc, "writing the subdomain record"));
+    if (hipStreamSynchronize(st) != hipSuccess) return hl_fail(MGH_ERR_DEVICE, "writing the subdomain record");
     hl_debug("compress: record written");
+    if (J.owned) {
+      owned_alive.erase(std::remove(owned_alive.begin(), owned_alive.end(), J.h), owned_alive.end());
+      mgh_hierarchy_destroy(J.h);
+    }
     byte_offset += 8 + csize;
-    buf = nb;
-    qi = nq;
+    return MGH_SUCCESS;
+  };
+
+  // Inputs: P = nbufs - 1 subdomains are fetched ahead of the one whose record is being written.
+  // At the start of iteration id the buffer of subdomain id + P is the one subdomain id - 1 used,
+  // and finish(id - 1) ended with a synchronisation of its lane.
+  const uint64_t P = nbufs > 0 ? (uint64_t)(nbufs - 1) : 0;
+  for (uint64_t id = 0; id < std::max<uint64_t>(P, 1) && id < dd.num; id++)
+    if ((rc = fetch_sub(id)) != MGH_SUCCESS) return cleanup(rc);
+  SubJob jobs[kLanes];
+  if ((rc = issue(jobs[0], 0)) != MGH_SUCCESS) return cleanup(rc);
+  for (uint64_t id = 0; id < dd.num; id++) {
+    if (P > 0 && id + P < dd.num && (rc = fetch_sub(id + P)) != MGH_SUCCESS) return cleanup(rc);
+    if (nlanes > 1 && id + 1 < dd.num && (rc = issue(jobs[(id + 1) % nlanes], id + 1)) != MGH_SUCCESS)
+      return cleanup(rc);
+    if ((rc = finish(jobs[id % nlanes])) != MGH_SUCCESS) return cleanup(rc);
+    if (nlanes == 1 && id + 1 < dd.num && (rc = issue(jobs[0], id + 1)) != MGH_SUCCESS) return cleanup(rc);
   }
   *compressed_size = byte_offset;
   return cleanup(MGH_SUCCESS);
@@ -1582,6 +1811,7 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
                     void **out, const mgh_config &cfg_in, bool prealloc) {
   mgh_config cfg = cfg_in;
   HL_TRY(cache_prepare(cfg.dev_id));
+  HL_TRY(trim_hierarchy_cache());
   const int dtype = hd.is_double ? MGH_DOUBLE : MGH_FLOAT;
   const size_t elem = sizeof(T);
   size_t total = 1;
@@ -1601,7 +1831,15 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
     if (in_dev) HL_HIP(hipMalloc(out, total * elem));
     else if (!(*out = std::malloc(total * elem))) return hl_fail(MGH_ERR_OUT_OF_MEMORY, "malloc");
   }
+  const bool pipelined = env_get("MGH_HL_PIPELINE", 1) != 0;
+  const int nlanes = dd.num > 1 && pipelined ? kLanes : 1;
+  mgh_hierarchy *owned_h[kLanes] = {nullptr, nullptr};  // per-subdomain hierarchy (non-uniform grid) of the lane's last job
   auto cleanup = [&](int rc) {
+    for (int l = 0; l < kLanes; l++) {
+      if (rc != MGH_SUCCESS || owned_h[l]) (void)hipStreamSynchronize(g_cache.lane[l].st);
+      if (owned_h[l]) mgh_hierarchy_destroy(owned_h[l]);
+      owned_h[l] = nullptr;
+    }
     if (rc != MGH_SUCCESS && !prealloc) {
       if (in_dev) (void)hipFree(*out); else std::free(*out);
       *out = nullptr;
@@ -1613,9 +1851,12 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
   // device-resident output whose subdomains are contiguous slabs: reconstruct them in place
   const bool zero_copy = is_device_pointer(*out) && dd.all_contiguous();
   auto ensure_all = [&]() -> int {
-    if (!zero_copy) HL_TRY(g_cache.in[0].ensure(max_elems * elem));
-    HL_TRY(g_cache.q.ensure(max_elems * 8));
-    if (hd.reorder) HL_TRY(g_cache.q2.ensure(max_elems * 8));
+    for (int l = 0; l < nlanes; l++) {
+      Lane &L = g_cache.lane[l];
+      if (!zero_copy) HL_TRY(L.sub.ensure(max_elems * elem));
+      HL_TRY(L.q.ensure(max_elems * 8));
+      if (hd.reorder) HL_TRY(L.q2.ensure(max_elems * 8));
+    }
     return MGH_SUCCESS;
   };
   if ((rc = ensure_all()) != MGH_SUCCESS) return cleanup(rc);
@@ -1638,74 +1879,83 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
       for (double &x : c) x = (double)(float)x;
     cptr = &coords_f32;
   }
+  // ---- subdomain pipeline (decompress_pipeline_gpu, GPUPipelines.hpp:330-520) ----
+  // issue(k): everything of subdomain k up to the reconstructed dense subdomain, queued on lane
+  // k % nlanes without a host synchronisation (the decoder of k + 1 runs beside the recomposition
+  // of k); finish(k): the dense subdomain into its box of the output when it was not reconstructed
+  // in place (for a pageable host output that copy occupies the host).
   size_t byte_offset = meta_size;
-  hipStream_t st = g_cache.streams[0];
-  for (uint64_t id = 0; id < dd.num; id++) {
-    if (csize_total - byte_offset < 8) return cleanup(hl_fail(MGH_ERR_FORMAT, "subdomain record truncated"));
+  auto issue = [&](uint64_t id) -> int {
+    const int lane = (int)(id % nlanes);
+    Lane &L = g_cache.lane[lane];
+    hipStream_t st = L.st;
+    // what the lane's previous subdomain read from the host (decode tables, record head) and its
+    // hierarchy are free again once the lane has drained
+    HL_HIP(hipStreamSynchronize(st));
+    if (owned_h[lane]) mgh_hierarchy_destroy(owned_h[lane]);
+    owned_h[lane] = nullptr;
+    if (csize_total - byte_offset < 8) return hl_fail(MGH_ERR_FORMAT, "subdomain record truncated");
     std::vector<uint8_t> sz;
-    if ((rc = fetch_host((const char *)compressed + byte_offset, 8, 8, sz)) != MGH_SUCCESS) return cleanup(rc);
+    HL_TRY(fetch_host((const char *)compressed + byte_offset, 8, 8, sz));
     uint64_t csize = 0;
     std::memcpy(&csize, sz.data(), 8);
     byte_offset += 8;
-    if (csize > csize_total - byte_offset) return cleanup(hl_fail(MGH_ERR_FORMAT, "subdomain record truncated"));
+    if (csize > csize_total - byte_offset) return hl_fail(MGH_ERR_FORMAT, "subdomain record truncated");
     const auto sshape = dd.subdomain_shape(id);
     uint64_t n = 1;
     for (uint64_t e : sshape) n *= e;
     const char *rec = (const char *)compressed + byte_offset;
-    void *sub = zero_copy ? (void *)((char *)*out + dd.linear_offset(id) * elem) : g_cache.in[0].p;
-    if ((double)(n * elem) / (double)csize > 1.0) {  // GPUPipelines.hpp:414-417
-      const uint8_t *payload = (const uint8_t *)rec;
-      uint64_t ocount = 0;
-      mgh_hierarchy *h = nullptr;
-      bool owned = false;
-      if ((rc = get_hierarchy(&h, &owned, dtype, sshape, cptr, dd.subdomain_offset(id), cfg)) != MGH_SUCCESS)
-        return cleanup(rc);
-      // 16-bit symbols between decoder and dequantizer: measured SLOWER than int64 on this side
-      // (3.0 vs 2.9 ms at 512^3: decoder and node restore are instruction-bound, not
-      // bandwidth-bound, and the outlier look-ups of the coarse levels cost more than the
-      // outlier-restore pass they replace) -- opt-in, MGH_SYM16_DECODE=1
-      static const bool sym16_decode = env_get("MGH_SYM16_DECODE", 0) != 0;
-      bool sym16 = sym16_decode && !hd.reorder && mgh_sym16_supported(h) && hd.huff_dict_size <= 65536;
-      rc = lossless_decompress(g_cache.ll, payload, csize, lossless, (int64_t *)g_cache.q.p, n, &ocount, st,
-                               &sym16);
-      if (rc == MGH_SUCCESS) {
-        if (sym16)
-          rc = mgh_dequantize_recompose_sym16(h, (const uint16_t *)g_cache.q.p, local_eb, (double)local_tol,
-                                              (double)s, (double)norm, hd.huff_dict_size,
-                                              (const uint64_t *)g_cache.ll->oidx.p,
-                                              (const int64_t *)g_cache.ll->oval.p, ocount, sub, st);
-        else if (hd.reorder) {
-          // level-linearised integers: outliers back at their linearised positions, the
-          // permutation undone, then the ordinary path with nothing left to restore
-          rc = mgh_outlier_restore((int64_t *)g_cache.q.p, n, (const uint64_t *)g_cache.ll->oidx.p,
-                                   (const int64_t *)g_cache.ll->oval.p, ocount, st);
-          if (rc == MGH_SUCCESS)
-            rc = mgh_level_linearize(h, (const int64_t *)g_cache.q.p, (int64_t *)g_cache.q2.p, 1, nullptr,
-                                     nullptr, 0, 0, st);
-          if (rc == MGH_SUCCESS)
-            rc = mgh_dequantize_recompose(h, (int64_t *)g_cache.q2.p, local_eb, (double)local_tol, (double)s,
-                                          (double)norm, hd.huff_dict_size, 1, nullptr, nullptr, 0, sub, st);
-        } else
-          rc = mgh_dequantize_recompose(h, (int64_t *)g_cache.q.p, local_eb, (double)local_tol, (double)s,
-                                        (double)norm, hd.huff_dict_size, 1,
-                                        (const uint64_t *)g_cache.ll->oidx.p,
-                                        (const int64_t *)g_cache.ll->oval.p, ocount, sub, st);
-      }
-      if (owned) {
-        (void)hipStreamSynchronize(st);
-        mgh_hierarchy_destroy(h);
-      }
-      if (rc != MGH_SUCCESS) return cleanup(rc);
-    } else {
-      if (csize != n * elem) return cleanup(hl_fail(MGH_ERR_FORMAT, "raw subdomain record has the wrong size"));
-      if (hipMemcpyAsync(sub, rec, csize, hipMemcpyDefault, st) != hipSuccess)
-        return cleanup(hl_fail(MGH_ERR_DEVICE, "reading the raw subdomain"));
-    }
-    if (!zero_copy && (rc = copy_subdomain(dd, id, elem, sub, nullptr, *out, false, st)) != MGH_SUCCESS)
-      return cleanup(rc);
-    if (hipStreamSynchronize(st) != hipSuccess) return cleanup(hl_fail(MGH_ERR_DEVICE, "sync"));
+    void *sub = zero_copy ? (void *)((char *)*out + dd.linear_offset(id) * elem) : L.sub.p;
     byte_offset += csize;
+    if (!((double)(n * elem) / (double)csize > 1.0)) {  // GPUPipelines.hpp:414-417
+      if (csize != n * elem) return hl_fail(MGH_ERR_FORMAT, "raw subdomain record has the wrong size");
+      HL_HIP(hipMemcpyAsync(sub, rec, csize, hipMemcpyDefault, st));
+      return MGH_SUCCESS;
+    }
+    const uint8_t *payload = (const uint8_t *)rec;
+    uint64_t ocount = 0;
+    mgh_hierarchy *h = nullptr;
+    bool owned = false;
+    HL_TRY(get_hierarchy(&h, &owned, dtype, sshape, cptr, dd.subdomain_offset(id), cfg, lane));
+    if (owned) owned_h[lane] = h;
+    // 16-bit symbols between decoder and dequantizer: measured SLOWER than int64 on this side
+    // (3.0 vs 2.9 ms at 512^3: decoder and node restore are instruction-bound, not
+    // bandwidth-bound, and the outlier look-ups of the coarse levels cost more than the
+    // outlier-restore pass they replace) -- opt-in, MGH_SYM16_DECODE=1
+    static const bool sym16_decode = env_get("MGH_SYM16_DECODE", 0) != 0;
+    bool sym16 = sym16_decode && !hd.reorder && mgh_sym16_supported(h) && hd.huff_dict_size <= 65536;
+    HL_TRY(lossless_decompress(L.ll, payload, csize, lossless, (int64_t *)L.q.p, n, &ocount, st, &sym16,
+                               /*sync_end=*/false));
+    if (sym16)
+      return mgh_dequantize_recompose_sym16(h, (const uint16_t *)L.q.p, local_eb, (double)local_tol, (double)s,
+                                            (double)norm, hd.huff_dict_size, (const uint64_t *)L.ll->oidx.p,
+                                            (const int64_t *)L.ll->oval.p, ocount, sub, st);
+    if (hd.reorder) {
+      // level-linearised integers: outliers back at their linearised positions, the
+      // permutation undone, then the ordinary path with nothing left to restore
+      HL_TRY(mgh_outlier_restore((int64_t *)L.q.p, n, (const uint64_t *)L.ll->oidx.p,
+                                 (const int64_t *)L.ll->oval.p, ocount, st));
+      HL_TRY(mgh_level_linearize(h, (const int64_t *)L.q.p, (int64_t *)L.q2.p, 1, nullptr, nullptr, 0, 0, st));
+      return mgh_dequantize_recompose(h, (int64_t *)L.q2.p, local_eb, (double)local_tol, (double)s, (double)norm,
+                                      hd.huff_dict_size, 1, nullptr, nullptr, 0, sub, st);
+    }
+    return mgh_dequantize_recompose(h, (int64_t *)L.q.p, local_eb, (double)local_tol, (double)s, (double)norm,
+                                    hd.huff_dict_size, 1, (const uint64_t *)L.ll->oidx.p,
+                                    (const int64_t *)L.ll->oval.p, ocount, sub, st);
+  };
+  auto finish = [&](uint64_t id) -> int {
+    if (zero_copy) return MGH_SUCCESS;
+    Lane &L = g_cache.lane[id % nlanes];
+    return copy_subdomain(dd, id, elem, L.sub.p, nullptr, *out, false, L.st);
+  };
+  if ((rc = issue(0)) != MGH_SUCCESS) return cleanup(rc);
+  for (uint64_t id = 0; id < dd.num; id++) {
+    if (nlanes > 1 && id + 1 < dd.num && (rc = issue(id + 1)) != MGH_SUCCESS) return cleanup(rc);
+    if ((rc = finish(id)) != MGH_SUCCESS) return cleanup(rc);
+    if (nlanes == 1 && id + 1 < dd.num && (rc = issue(id + 1)) != MGH_SUCCESS) return cleanup(rc);
   }
+  for (int l = 0; l < nlanes; l++)
+    if (hipStreamSynchronize(g_cache.lane[l].st) != hipSuccess) return cleanup(hl_fail(MGH_ERR_DEVICE, "sync"));
   return cleanup(MGH_SUCCESS);
 }
 
@@ -1962,8 +2212,8 @@ int compress_multi_impl(int ndev, const int *devs, int D, int dtype, const uint6
             const size_t bytes = inner * dd.subdomain_shape(id)[0] * elem;
             if (peer_id != id) {
               HL_TRY(peer.ensure(bytes));
-              HL_HIP(hipMemcpyPeerAsync(peer.p, c.dev_id, slab_ptr(id), src_dev, bytes, g_cache.streams[0]));
-              HL_HIP(hipStreamSynchronize(g_cache.streams[0]));
+              HL_HIP(hipMemcpyPeerAsync(peer.p, c.dev_id, slab_ptr(id), src_dev, bytes, g_cache.lane[0].st));
+              HL_HIP(hipStreamSynchronize(g_cache.lane[0].st));
               peer_id = id;
             }
             *out = peer.p;
@@ -1982,10 +2232,10 @@ int compress_multi_impl(int ndev, const int *devs, int D, int dtype, const uint6
               if (rc == MGH_SUCCESS && in_dev) rc = local_ptr(id, &src);
               if (rc == MGH_SUCCESS && !in_dev) {
                 rc = g_cache.in[0].ensure(cnt * elem);
-                if (rc == MGH_SUCCESS) rc = copy_any(g_cache.in[0].p, slab_ptr(id), cnt * elem, g_cache.streams[0]);
+                if (rc == MGH_SUCCESS) rc = copy_any(g_cache.in[0].p, slab_ptr(id), cnt * elem, g_cache.lane[0].st);
                 src = g_cache.in[0].p;
               }
-              if (rc == MGH_SUCCESS) rc = mgh_norm(h, src, s_d, &ln[id], g_cache.streams[0]);
+              if (rc == MGH_SUCCESS) rc = mgh_norm(h, src, s_d, &ln[id], g_cache.lane[0].st);
               if (owned) mgh_hierarchy_destroy(h);
               if (rc != MGH_SUCCESS) err.set(rc);
             }
@@ -2460,6 +2710,28 @@ int mgh_lossless_compress(mgh_lossless_ctx *ctx, const int64_t *d_q, uint64_t n,
   }
   *payload_out = ctx->host.data();
   *size_out = ctx->host.size();
+  return MGH_SUCCESS;
+}
+
+int mgh_lossless_compress_device(mgh_lossless_ctx *ctx, const int64_t *d_q, uint64_t n, uint64_t dict,
+                                 uint64_t chunk, const uint64_t *d_oidx, const int64_t *d_oval,
+                                 uint64_t ocount, void *d_record_out, uint64_t capacity, uint64_t *size_out,
+                                 void *stream) {
+  if (!ctx || !d_q || !d_record_out || !size_out) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (hipSetDevice(ctx->dev) != hipSuccess) return hl_fail(MGH_ERR_DEVICE, "hipSetDevice");
+  if (!is_device_pointer(d_record_out)) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "d_record_out must be device memory");
+  try {
+    HL_TRY(lossless_compress(ctx, d_q, n, dict, chunk, MGH_LOSSLESS_HUFFMAN, 0, d_oidx, d_oval, ocount,
+                             (hipStream_t)stream, nullptr, ~(uint64_t)0, 0, false, (uint8_t *)d_record_out,
+                             (size_t)capacity));
+  } catch (const std::exception &e) {
+    return hl_fail(MGH_ERR_DEVICE, e.what());
+  }
+  if (ctx->overflow || ctx->record_size() > capacity)
+    return hl_fail(MGH_ERR_OUTPUT_TOO_LARGE, "record does not fit the buffer");
+  HL_TRY(record_write(ctx, d_record_out, (hipStream_t)stream));
+  HL_HIP(hipStreamSynchronize((hipStream_t)stream));
+  *size_out = ctx->record_size();
   return MGH_SUCCESS;
 }
 

@@ -398,6 +398,18 @@ template <> struct CodeEntry<uint64_t> { static constexpr int shift = kMaxCodeBi
 template <> struct CodeEntry<uint32_t> { static constexpr int shift = 27; };
 constexpr int kShortCodeBits = 27;
 
+// Code units at an address that need not be 8-byte aligned: a record inside a container starts
+// wherever the header and the records before it end, and the encoder / decoder work on the units
+// where they lie (gfx950 serves unaligned global dwordx2 accesses; atomics need alignment).
+__device__ __forceinline__ unsigned long long load_unit(const unsigned long long *p, size_t i) {
+  unsigned long long v;
+  __builtin_memcpy(&v, reinterpret_cast<const unsigned char *>(p) + 8 * i, 8);
+  return v;
+}
+__device__ __forceinline__ void store_unit(unsigned long long *p, size_t i, unsigned long long v) {
+  __builtin_memcpy(reinterpret_cast<unsigned char *>(p) + 8 * i, &v, 8);
+}
+
 template <typename SYM, typename CODE>
 __global__ void __launch_bounds__(kEncThreads)
 k_encode_chain(const SYM *__restrict__ q, size_t n, int chunk, int dict, size_t nchunk,
@@ -495,7 +507,7 @@ k_encode_chain(const SYM *__restrict__ q, size_t n, int chunk, int dict, size_t 
       bits[id] = chunk_bits;
       entry[id] = excl;
       if (id == nchunk - 1) state[1] = excl + my_units;
-      if (excl + my_units > cap_units) atomicExch(&state[2], 1ull);
+      if (excl + my_units > cap_units) atomicOr(&state[2], 1ull);
       sh_entry = excl;
     }
   }
@@ -558,8 +570,14 @@ k_encode_chain(const SYM *__restrict__ q, size_t n, int chunk, int dict, size_t 
     __syncthreads();
     if (active) pack(obuf);
     __syncthreads();
-    for (size_t i = threadIdx.x; i < my_units; i += kEncThreads) dst[i] = obuf[i];
+    for (size_t i = threadIdx.x; i < my_units; i += kEncThreads) store_unit(dst, i, obuf[i]);
   } else {
+    // (atomics on the destination: an unaligned one cannot take this path -- state[2] bit 1 asks
+    // the host to run the encoder again into an aligned buffer; rare: more than 16 bits per symbol)
+    if (reinterpret_cast<uintptr_t>(out) & 7) {
+      if (threadIdx.x == 0) atomicOr(&state[2], 2ull);
+      return;
+    }
     for (size_t i = threadIdx.x; i < my_units; i += kEncThreads) dst[i] = 0;
     __syncthreads();
     if (active) pack(dst);
@@ -1053,7 +1071,7 @@ k_decode_ring(const unsigned long long *__restrict__ units, const unsigned long 
     unsigned hi = cw0;
 #pragma unroll
     for (int r = 0; r < kRingUnits; r++)  // initial fill of the ring
-      ring[((cw0 + r) % kRingUnits) * 64 + lane] = src[min(cw0 + r, nun)];
+      ring[((cw0 + r) % kRingUnits) * 64 + lane] = load_unit(src, min(cw0 + r, nun));
     hi = cw0 + kRingUnits;
     unsigned long long win;
     unsigned avail, wnext;
@@ -1083,7 +1101,7 @@ k_decode_ring(const unsigned long long *__restrict__ units, const unsigned long 
       for (int rep = 0; rep < kRingBatch / kRingStep; rep++) {
         if (live && !pending) {  // request the next units; they are committed kRingStep symbols later
 #pragma unroll
-          for (int j = 0; j < kRingFetch; j++) pf[j] = src[min(hi + j, nun)];
+          for (int j = 0; j < kRingFetch; j++) pf[j] = load_unit(src, min(hi + j, nun));
           pending = true;
         }
         for (int k = 0; k < kRingStep; k++) {

@@ -20,7 +20,7 @@ HL_SYMBOLS = [
     "mgh_config_default", "mgh_compress", "mgh_decompress", "mgh_infer_shape",
     "mgh_infer_data_type", "mgh_free_device", "mgh_release_cache", "mgh_metadata_serialize",
     "mgh_metadata_parse", "mgh_lossless_create", "mgh_lossless_destroy", "mgh_lossless_compress",
-    "mgh_lossless_decompress", "mgh_memcpy", "mgh_huffman_codebook",
+    "mgh_lossless_decompress", "mgh_lossless_compress_device", "mgh_memcpy", "mgh_huffman_codebook",
     "mgh_compress_multi", "mgh_decompress_multi", "mgh_pin_memory", "mgh_check_memory_pinned",
     "mgh_unpin_memory",
 ]
@@ -123,6 +123,7 @@ def _hl():
     L.mgh_lossless_destroy.restype = None
     L.mgh_lossless_compress.argtypes = [vp, vp, u64, u64, u64, C.c_int, C.c_int, vp, vp, u64,
                                         C.POINTER(vp), C.POINTER(u64), vp]
+    L.mgh_lossless_compress_device.argtypes = [vp, vp, u64, u64, u64, vp, vp, u64, vp, u64, C.POINTER(u64), vp]
     L.mgh_lossless_decompress.argtypes = [vp, vp, u64, C.c_int, vp, u64, C.POINTER(vp), C.POINTER(vp),
                                           C.POINTER(u64), vp]
     L.mgh_memcpy.argtypes = [vp, vp, C.c_size_t]
@@ -389,11 +390,28 @@ class Lossless:
             C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return C.string_at(pay, size.value)
 
+    def compress_device(self, q, out, dict_size=8192, chunk_size=20480, outlier_idx=None, outlier_val=None):
+        """The record written into `out` (cuda uint8 tensor or a view of one: any byte alignment).
+        Returns the record as a view of `out`."""
+        import torch
+        n_out = 0 if outlier_idx is None else int(outlier_idx.numel())
+        size = C.c_uint64()
+        _check(_hl().mgh_lossless_compress_device(
+            self._c, C.c_void_p(q.data_ptr()), q.numel(), dict_size, chunk_size,
+            C.c_void_p(outlier_idx.data_ptr()) if n_out else None,
+            C.c_void_p(outlier_val.data_ptr()) if n_out else None, n_out, C.c_void_p(out.data_ptr()),
+            out.numel(), C.byref(size), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out[:size.value]
+
     def decompress(self, payload, n, lossless=HUFFMAN):
-        """Returns (q, outlier_idx, outlier_val) as cuda tensors."""
+        """payload: bytes, or a cuda uint8 tensor (decoded where it lies). Returns (q, outlier_idx,
+        outlier_val) as cuda tensors."""
         import torch
         q = torch.empty(n, dtype=torch.int64, device="cuda")
-        raw = (C.c_uint8 * len(payload)).from_buffer_copy(payload)
+        if isinstance(payload, torch.Tensor):
+            raw = C.c_void_p(payload.data_ptr())
+        else:
+            raw = (C.c_uint8 * len(payload)).from_buffer_copy(payload)
         oi, ov, cnt = C.c_void_p(), C.c_void_p(), C.c_uint64()
         _check(_hl().mgh_lossless_decompress(
             self._c, raw, len(payload), lossless, C.c_void_p(q.data_ptr()), n, C.byref(oi), C.byref(ov),

@@ -859,3 +859,122 @@ def test_mirror_reference_coord_cast_switch():
     hf.close()
     assert np.array_equal(exact, want_exact.cpu().numpy())
     assert np.array_equal(cast, want_cast.cpu().numpy())
+
+
+def _canonical_records(hl, buf):
+    """The container as (header bytes, [record with its outlier list sorted by index]): what must not
+    depend on how the subdomains were scheduled (the outlier list of a record is in atomic order)."""
+    b = bytes(buf)
+    m = hl.metadata_parse(b)
+    out = []
+    for r in pl.split_container(b, m["metadata_size"]):
+        if m["lossless"] == hl.HUFFMAN_ZSTD and len(r) >= 8:
+            # [u64 size of the Huffman record][zstd frame] (Zstd.hpp:69-90)
+            import ctypes
+            z = ctypes.CDLL("libzstd.so.1")
+            z.ZSTD_decompress.restype = ctypes.c_size_t
+            z.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+            raw_size = int(np.frombuffer(r[:8], dtype="<u8")[0])
+            if raw_size < (1 << 32):
+                dst = ctypes.create_string_buffer(max(raw_size, 1))
+                got = z.ZSTD_decompress(dst, raw_size, r[8:], len(r) - 8)
+                if got == raw_size:
+                    r = dst.raw[:raw_size]
+        try:
+            p = pl.parse_huffman_record(r)
+        except Exception:  # (a raw subdomain: GPUPipelines.hpp:136-155)
+            out.append(("raw", r))
+            continue
+        n = len(p["outlier_idx"])
+        head = r[:len(r) - 16 * n]
+        order = np.argsort(p["outlier_idx"], kind="stable")
+        out.append(("huffman", head, p["outlier_idx"][order].tobytes(), p["outliers"][order].tobytes()))
+    return b[:m["metadata_size"]], out
+
+
+from struct import error as struct_error  # noqa: E402
+
+
+@pytest.mark.parametrize("where", ["host", "device"])
+@pytest.mark.parametrize("kind,dt,s", [("block", np.float32, np.inf), ("variable", np.float32, 0.0),
+                                       ("maxdim_auto", np.float64, np.inf), ("variable_nonuniform", np.float32, np.inf),
+                                       ("block_zstd", np.float32, np.inf), ("variable_dim0", np.float32, np.inf)])
+def test_pipelined_and_sequential_schedules_write_the_same_container(kind, dt, s, where, monkeypatch):
+    """The two-lane subdomain pipeline (subdomain k + 1 decomposed while k is encoded;
+    GPUPipelines.hpp:88-207) against MGH_HL_PIPELINE=0, every subdomain start to end before the next
+    is queued: the same container byte for byte (outlier lists of a record compared sorted), and each
+    of the two schedules of mgh_decompress reconstructs the same values from it."""
+    torch, mg, hl = _mods()
+    shape = (66, 120, 80)
+    u = smooth_field(shape, dt, noise=1e-3)
+    coords = None
+    if kind == "maxdim_auto":
+        cfg = hl.Config(max_memory_footprint=40 * u.size)
+    elif kind in ("block", "block_zstd"):
+        cfg = hl.Config(domain_decomposition=hl.DD_BLOCK, block_size=40,
+                        lossless=hl.HUFFMAN_ZSTD if kind == "block_zstd" else hl.HUFFMAN)
+    elif kind == "variable_dim0":  # contiguous slabs: compressed / reconstructed in place
+        cfg = hl.Config(domain_decomposition=hl.DD_VARIABLE, domain_decomposition_dim=0,
+                        domain_decomposition_sizes=[10, 20, 9, 27])
+    else:
+        cfg = hl.Config(domain_decomposition=hl.DD_VARIABLE, domain_decomposition_dim=1,
+                        domain_decomposition_sizes=[40, 30, 50])
+        if kind == "variable_nonuniform":
+            from tests.util import nonuniform_coords
+            coords = nonuniform_coords(shape, dt)
+    src = torch.from_numpy(u).cuda() if where == "device" else u
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MGH_HL_PIPELINE", mode)
+        buf = hl.compress(src, 1e-3, s, mg.REL, config=cfg, coords=coords)
+        host = buf.cpu().numpy() if hasattr(buf, "cpu") else np.asarray(buf)
+        got[mode] = (_canonical_records(hl, host), buf)
+    assert got["1"][0][0] == got["0"][0][0]
+    assert len(got["1"][0][1]) == len(got["0"][0][1]) > 1
+    for a, b in zip(got["1"][0][1], got["0"][0][1]):
+        assert a == b
+    back = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MGH_HL_PIPELINE", mode)
+        v = hl.decompress(got["1"][1], config=cfg)
+        back[mode] = v.cpu().numpy() if hasattr(v, "cpu") else np.asarray(v)
+    assert np.array_equal(back["1"], back["0"])
+    nrm = _norm(u, s)
+    assert _err(u, back["1"], s, shape) <= 1e-3 * nrm * (1 + 1e-6)
+
+
+@pytest.mark.parametrize("shift", [0, 3, 4])
+def test_records_in_device_memory_at_any_byte_offset(shift):
+    """Behind a header of arbitrary length the records of a device-resident container start at any
+    byte offset. The encoder writes its code units straight into such a record and the ring
+    decoder reads them where they are (unaligned 8-byte accesses); a chunk of more than 16 bits per
+    symbol -- the encoder's path with atomics on the destination -- makes the host run the encoder
+    again into an aligned buffer. Same record as through the host path, byte for byte."""
+    torch, mg, hl = _mods()
+    fib = [1, 1]
+    while len(fib) < 31:
+        fib.append(fib[-1] + fib[-2])
+    # rarest symbols first: the leading chunks consist of the longest codes (~20 bits / symbol)
+    ordered = np.concatenate([np.full(f, 100 + k, np.int64) for k, f in enumerate(fib)])
+    mixed = np.random.default_rng(5).permutation(ordered)
+    ctx = hl.Lossless()
+    for q, chunk in ((ordered, 2048), (mixed, 2048), (_symbols(700_001, seed=9), 20480)):
+        d_q = torch.from_numpy(q).cuda()
+        oi = torch.tensor([5, 77, 12345], dtype=torch.int64, device="cuda")
+        ov = torch.tensor([-9, 1 << 40, 3], dtype=torch.int64, device="cuda")
+        want = ctx.compress(d_q, 8192, chunk, outlier_idx=oi, outlier_val=ov)
+        pool = torch.zeros(len(want) + 4096, dtype=torch.uint8, device="cuda")
+        base = (-pool.data_ptr()) % 256 + shift   # 256-byte aligned + shift
+        rec = ctx.compress_device(d_q, pool[base:], 8192, chunk, outlier_idx=oi, outlier_val=ov)
+        assert rec.data_ptr() % 8 == shift % 8
+        assert bytes(rec.cpu().numpy()) == want
+        assert not pool[:base].any() and not pool[base + rec.numel():].any()
+        back, bi, bv = ctx.decompress(rec, q.size)
+        assert np.array_equal(back.cpu().numpy(), q)
+        assert torch.equal(bi, oi) and torch.equal(bv, ov)
+    if shift:
+        r = pl.parse_huffman_record(want)
+        assert r  # (parsed: the layout is the reference's)
+    with pytest.raises(mg.MgardHipError):
+        ctx.compress_device(d_q, torch.zeros(1000, dtype=torch.uint8, device="cuda"), 8192, 20480)
+    ctx.close()
