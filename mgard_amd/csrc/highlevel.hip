@@ -440,13 +440,29 @@ int lossless_finish(mgh_lossless_ctx *c, const LosslessJob &J, hipStream_t st, u
   hl_debug("lossless_compress: histogram + codebook done");
   // code table for the kernels: 32-bit entries when every code fits 27 bits (it practically
   // always does: half the LDS of the encoder, two workgroups per CU), else 64-bit entries
-  const bool short_codes = cb.max_len <= huff::kShortCodeBits;
+  // (codes longer than 27 bits -- the rarest symbols of a large subdomain -- become escape entries
+  // into a list of 64-bit entries behind the table)
+  size_t nlong = 0;
+  if (cb.max_len > huff::kShortCodeBits)
+    for (uint64_t k = 0; k < dict; k++) nlong += (cb.code[k] >> huff::kMaxCodeBits) > (uint64_t)huff::kShortCodeBits;
+  const size_t o_long = (dict * 4 + 7) / 8 * 8;  // offset of the escape list behind the 32-bit table
+  const bool short_codes = o_long + nlong * 8 <= dict * 8;  // (table + list fit the buffers sized for 64-bit entries)
+  if (!short_codes) nlong = 0;
   if (short_codes) {
     uint32_t *c32 = (uint32_t *)(pinp + o_code);
-    for (uint64_t k = 0; k < dict; k++)
-      c32[k] = (uint32_t)((cb.code[k] >> huff::kMaxCodeBits) << huff::kShortCodeBits) |
-               (uint32_t)(cb.code[k] & (((uint64_t)1 << huff::kShortCodeBits) - 1));
-    HL_HIP(hipMemcpyAsync(c->code.p, c32, dict * 4, hipMemcpyHostToDevice, st));
+    uint64_t *lg = (uint64_t *)(pinp + o_code + o_long);
+    size_t j = 0;
+    for (uint64_t k = 0; k < dict; k++) {
+      const uint64_t len = cb.code[k] >> huff::kMaxCodeBits;
+      if (len <= (uint64_t)huff::kShortCodeBits) {
+        c32[k] = (uint32_t)(len << huff::kShortCodeBits) |
+                 (uint32_t)(cb.code[k] & (((uint64_t)1 << huff::kShortCodeBits) - 1));
+      } else {
+        c32[k] = (huff::kEscapeLen << huff::kShortCodeBits) | (uint32_t)j;
+        lg[j++] = cb.code[k];
+      }
+    }
+    HL_HIP(hipMemcpyAsync(c->code.p, c32, o_long + nlong * 8, hipMemcpyHostToDevice, st));
   } else {
     std::memcpy(pinp + o_code, cb.code.data(), dict * 8);
     HL_HIP(hipMemcpyAsync(c->code.p, pinp + o_code, dict * 8, hipMemcpyHostToDevice, st));
@@ -463,7 +479,7 @@ int lossless_finish(mgh_lossless_ctx *c, const LosslessJob &J, hipStream_t st, u
     return MGH_SUCCESS;
   };
   unsigned long long units = 0;
-  const size_t enc_lds = (dict * (short_codes ? 4 : 8) + 15) / 16 * 16 + chunk * 2;
+  const size_t enc_lds = huff::encode_chain_lds(dict, short_codes ? 4 : 8, chunk);
   if (lossless_sym16_ok(dict, chunk) && chunk <= (1u << 24)) {
     // one pass: bit counts, unit offsets (decoupled look-back) and packing in the same kernel.
     // The stream is written into a buffer of cap_units; more than that means "not compressible".
@@ -500,7 +516,7 @@ int lossless_finish(mgh_lossless_ctx *c, const LosslessJob &J, hipStream_t st, u
       huff::k_encode_chain<SYM, CODE><<<(unsigned)nchunk, huff::kEncThreads, enc_lds, st>>>(
           (const SYM *)d_q, n, (int)chunk, (int)dict, nchunk, (const CODE *)c->code.p,
           (unsigned long long *)c->state.p, (unsigned long long *)c->bits.p,
-          (unsigned long long *)c->entry.p, units_dst, cap);
+          (unsigned long long *)c->entry.p, units_dst, cap, (int)nlong);
     };
     if (sym16 && short_codes) enc(uint16_t(), uint32_t());
     else if (sym16) enc(uint16_t(), uint64_t());

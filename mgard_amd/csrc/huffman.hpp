@@ -393,10 +393,41 @@ constexpr unsigned long long kStAggregate = 1ull << 62, kStInclusive = 2ull << 6
 
 // CODE: uint64_t entries (length << 56 | value) or, when no code is longer than 27 bits, uint32_t
 // entries (length << 27 | value): half the LDS, two workgroups per CU instead of one.
+// A code longer than 27 bits belongs to one of the rarest symbols; a histogram of 10^9 symbols has
+// a few dozen of them. They do not force the 64-bit table on the kernel: their 32-bit entry is an
+// ESCAPE (length field 31, value = index) into a list of 64-bit entries behind the table.
 template <typename CODE> struct CodeEntry;
 template <> struct CodeEntry<uint64_t> { static constexpr int shift = kMaxCodeBits; };
 template <> struct CodeEntry<uint32_t> { static constexpr int shift = 27; };
 constexpr int kShortCodeBits = 27;
+constexpr unsigned kEscapeLen = 31;  // length field of an escape entry
+
+// (length, value) of a table entry; escapes resolved through `slong` (32-bit tables only)
+template <typename CODE>
+__device__ __forceinline__ void entry_decode(CODE c, const unsigned long long *slong, int &len,
+                                             unsigned long long &val) {
+  constexpr int SH = CodeEntry<CODE>::shift;
+  len = (int)(c >> SH);
+  val = (unsigned long long)(c & (((CODE)1 << SH) - 1));
+  if (sizeof(CODE) == 4 && len == (int)kEscapeLen) {
+    const unsigned long long e = slong[val];
+    len = (int)(e >> kMaxCodeBits);
+    val = e & (((unsigned long long)1 << kMaxCodeBits) - 1);
+  }
+}
+template <typename CODE>
+__device__ __forceinline__ unsigned entry_len(CODE c, const unsigned long long *slong) {
+  constexpr int SH = CodeEntry<CODE>::shift;
+  unsigned len = (unsigned)(c >> SH);
+  if (sizeof(CODE) == 4 && len == kEscapeLen)
+    len = (unsigned)(slong[c & (((CODE)1 << SH) - 1)] >> kMaxCodeBits);
+  return len;
+}
+
+// dynamic LDS of k_encode_chain (bytes)
+inline size_t encode_chain_lds(size_t dict, size_t entry_bytes, size_t chunk) {
+  return (dict * entry_bytes + 15) / 16 * 16 + chunk * 2;
+}
 
 // Code units at an address that need not be 8-byte aligned: a record inside a container starts
 // wherever the header and the records before it end, and the encoder / decoder work on the units
@@ -415,12 +446,17 @@ __global__ void __launch_bounds__(kEncThreads)
 k_encode_chain(const SYM *__restrict__ q, size_t n, int chunk, int dict, size_t nchunk,
                const CODE *__restrict__ code, unsigned long long *__restrict__ state,
                unsigned long long *__restrict__ bits, unsigned long long *__restrict__ entry,
-               unsigned long long *__restrict__ out, unsigned long long cap_units) {
-  constexpr int SH = CodeEntry<CODE>::shift;
+               unsigned long long *__restrict__ out, unsigned long long cap_units, int nlong) {
+  // LDS: code table [dict] | symbols of the chunk (encode_chain_lds() is the host's copy of this
+  // layout). The escape list stays in global memory behind the table (8-byte aligned): its entries
+  // belong to symbols that occur a handful of times in the whole subdomain.
   extern __shared__ unsigned long long enc_lds[];
   CODE *scode = reinterpret_cast<CODE *>(enc_lds);
   unsigned short *ssym = reinterpret_cast<unsigned short *>(
       reinterpret_cast<unsigned char *>(enc_lds) + ((size_t)dict * sizeof(CODE) + 15) / 16 * 16);
+  const unsigned long long *slong = reinterpret_cast<const unsigned long long *>(
+      reinterpret_cast<const unsigned char *>(code) + ((size_t)dict * sizeof(CODE) + 7) / 8 * 8);
+  (void)nlong;
   __shared__ unsigned sc[kEncThreads];   // bit offset of every thread's run in the chunk
   __shared__ unsigned swave[kEncThreads / 64];
   __shared__ unsigned long long sh_id, sh_entry;
@@ -454,10 +490,10 @@ k_encode_chain(const SYM *__restrict__ q, size_t n, int chunk, int dict, size_t 
 #pragma unroll
     for (int k = 0; k < RR; k++) {
       cc[k] = lo + k < hi ? scode[ssym[lo + k]] : (CODE)0;  // (a zero entry packs nothing)
-      s += (unsigned)(cc[k] >> SH);
+      s += entry_len(cc[k], slong);
     }
   } else {
-    for (size_t i = lo; i < hi; i++) s += (unsigned)(scode[ssym[i]] >> SH);
+    for (size_t i = lo; i < hi; i++) s += entry_len(scode[ssym[i]], slong);
   }
   // exclusive scan of the per-thread bit counts: inside the waves with shuffles, across them
   // through swave[] (a chunk holds fewer than 2^32 bits: the host limits the chunk size)
@@ -530,8 +566,9 @@ k_encode_chain(const SYM *__restrict__ q, size_t n, int chunk, int dict, size_t 
       first_unit = false;
     };
     auto put = [&](CODE c) {
-      const int len = (int)(c >> SH);
-      const unsigned long long val = (unsigned long long)(c & (((CODE)1 << SH) - 1));
+      int len;
+      unsigned long long val;
+      entry_decode(c, slong, len, val);
       if (len <= room) {
         room -= len;
         acc |= val << room;

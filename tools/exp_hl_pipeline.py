@@ -38,8 +38,9 @@ def run(mode, label=True):
 
 
 if once:
-    run("1", False)
-    run("1")
+    m = "0" if "--seq" in sys.argv else "1"
+    run(m, False)
+    run(m)
     sys.exit(0)
 run("1", False); run("0", False)
 for _ in range(reps):
