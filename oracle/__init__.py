@@ -67,6 +67,13 @@ def _declare(L):
             g = getattr(L, name + sfx)
             g.argtypes = [C.c_void_p, rp]
             g.restype = C.c_int
+        for name in ("mgxo_op_lerp", "mgxo_op_mass_trans"):
+            g = getattr(L, name + sfx)
+            g.argtypes = [C.c_void_p, C.c_int, C.c_int, rp, rp]
+            g.restype = C.c_int
+        g = getattr(L, "mgxo_op_thomas" + sfx)
+        g.argtypes = [C.c_void_p, C.c_int, C.c_int, rp]
+        g.restype = C.c_int
         g = getattr(L, "mgxo_calc_quantizers" + sfx)
         g.argtypes = [C.c_void_p, C.c_int, ct, ct, ct, C.c_int, rp]
         g.restype = None
@@ -177,6 +184,32 @@ class Hierarchy:
             raise NotImplementedError("oracle recompose: D=%d unsupported" % self.D)
         return v
 
+    # ---- the line operators on their own (test hooks; odd level sizes) ----
+    def op_lerp(self, l, d, fine):
+        """Interpolants at the odd nodes of level l along dimension d (GridProcessingKernel3D.hpp:614-617)."""
+        f = np.ascontiguousarray(fine, dtype=self.dtype)
+        n = self.level_shape(l)[d]
+        assert f.shape == (n,)
+        out = np.zeros(n // 2, dtype=self.dtype)
+        assert getattr(lib(), "mgxo_op_lerp" + self.sfx)(self._h, l, d, self._rp(f), self._rp(out)) == 0
+        return out
+
+    def op_mass_trans(self, l, d, fine):
+        """Restriction of the level-l mass matrix applied to `fine`, on the nodes of level l - 1
+        (LPKFunctor.h:77-93 through one Lpk line)."""
+        f = np.ascontiguousarray(fine, dtype=self.dtype)
+        assert f.shape == (self.level_shape(l)[d],)
+        out = np.zeros(self.level_shape(l - 1)[d], dtype=self.dtype)
+        assert getattr(lib(), "mgxo_op_mass_trans" + self.sfx)(self._h, l, d, self._rp(f), self._rp(out)) == 0
+        return out
+
+    def op_thomas(self, l, d, rhs):
+        """Solution of the level-l mass system along dimension d (IPKFunctor.h:111-149)."""
+        x = np.array(rhs, dtype=self.dtype, order="C", copy=True)
+        assert x.shape == (self.level_shape(l)[d],)
+        assert getattr(lib(), "mgxo_op_thomas" + self.sfx)(self._h, l, d, self._rp(x)) == 0
+        return x
+
     def quantizers(self, ebtype, tol, s, norm, reciprocal):
         out = np.zeros(self.l_target + 1, dtype=self.dtype)
         getattr(lib(), "mgxo_calc_quantizers" + self.sfx)(self._h, ebtype, tol, s, norm,
@@ -239,7 +272,7 @@ def norm(data, s, normalize_coordinates=True):
 
 
 def dyadic_natural_to_reordered(a):
-    """Permute an array given in natural node order on a dyadic grid (every dim 2^L+1, same L)
+    """Permute an array given in natural node order on a dyadic grid (every dim 2^k+1)
     into MGARD-X's in-place reordered layout (coarse corner first, level by level). A node's
     level is the max over dims of its per-dim level, and ALL its coordinates are laid out by
     that level's split (coarse index p/2 for even p, n_coarse + (p-1)/2 for odd p), which is why
@@ -258,22 +291,28 @@ def dyadic_reordered_to_natural(a):
 
 
 def _dyadic_maps(shape):
-    n = shape[0]
-    L = (n - 1).bit_length() - 1
-    assert all(s == (1 << L) + 1 for s in shape) and n >= 2, "dyadic cubes only"
+    """Every dim 2^k + 1 (k may differ between the dims; the hierarchy has L = min k levels)."""
+    ks = [(n - 1).bit_length() - 1 for n in shape]
+    assert all(n == (1 << k) + 1 and n >= 2 for n, k in zip(shape, ks)), "dyadic sizes only"
+    L = min(ks)
     nat = np.indices(shape)  # natural coordinates of every node
-    # per-dim level of coordinate p: smallest l with p % 2^(L-l) == 0 (0 for the end points)
-    lev1 = np.zeros(n, dtype=np.int64)
-    for p in range(n):
-        l = 0
-        while p % (1 << (L - l)) != 0:
-            l += 1
-        lev1[p] = l
-    level = np.max(lev1[nat], axis=0)
-    pl = nat >> (L - level)          # coordinate on the node's own level grid
-    ncoarse = np.where(level > 0, (1 << np.maximum(level - 1, 0)) + 1, 0)
-    reo = np.where(level == 0, pl, np.where(pl % 2 == 0, pl // 2, ncoarse + (pl - 1) // 2))
-    return tuple(reo)
+    # per-dim level of coordinate p: smallest l with p % 2^(L-l) == 0
+    lev = []
+    for n in shape:
+        lev1 = np.zeros(n, dtype=np.int64)
+        for p in range(n):
+            l = 0
+            while p % (1 << (L - l)) != 0:
+                l += 1
+            lev1[p] = l
+        lev.append(lev1)
+    level = np.max(np.stack([lev[d][nat[d]] for d in range(len(shape))]), axis=0)
+    out = []
+    for d, n in enumerate(shape):
+        pl = nat[d] >> (L - level)          # coordinate on the node's own level grid
+        ncoarse = np.where(level > 0, ((n - 1) >> (L - np.maximum(level, 1) + 1)) + 1, 0)
+        out.append(np.where(level == 0, pl, np.where(pl % 2 == 0, pl // 2, ncoarse + (pl - 1) // 2)))
+    return tuple(out)
 
 
 # ---- MGARD-CPU (mgard::compress, BASELINE.json configs[0]) restated for one dimension -------

@@ -393,6 +393,38 @@ static inline void FN(thomas_line)(uint64_t n, const REAL *am, const REAL *bm, R
   }
 }
 
+/* ---- test hooks: the three line operators of the decomposition on their own, so that the
+ * operator vectors the reference's tests hold (tests/src/test_TensorMassMatrix.cpp,
+ * test_TensorRestriction.cpp, test_TensorProlongation.cpp: known answers on custom spacing) can
+ * pin the expressions above -- tests/test_oracle_operator_goldens.py. `fine`: the level-l nodes
+ * of dimension d in natural order; odd sizes only (the ghost node of an even size has no
+ * counterpart in MGARD-CPU, whose vectors these are). Return 0, or -1 on a bad argument. ---- */
+int FN(mgxo_op_lerp)(const FN(mgxo_hier) * h, int l, int d, const REAL *fine, REAL *out_odd) {
+  if (l < 1 || l > h->L || d < 0 || d >= h->D) return -1;
+  const uint64_t n = h->lshape[l][d];
+  if (n % 2 == 0) return -1;
+  for (uint64_t p = 1; p + 1 < n; p += 2)  /* GridProcessingKernel3D.hpp:614-617 */
+    out_odd[p / 2] = FN(lerp)(fine[p - 1], fine[p + 1], h->ratio[l][d][p - 1]);
+  return 0;
+}
+int FN(mgxo_op_mass_trans)(const FN(mgxo_hier) * h, int l, int d, const REAL *fine, REAL *coarse_out) {
+  if (l < 1 || l > h->L || d < 0 || d >= h->D) return -1;
+  const uint64_t n = h->lshape[l][d], nc = h->lshape[l - 1][d];
+  if (n % 2 == 0) return -1;
+  REAL *e = (REAL *)malloc(nc * sizeof(REAL)), *o = (REAL *)malloc((n - nc + 1) * sizeof(REAL));
+  for (uint64_t j = 0; j < nc; j++) e[j] = fine[2 * j];
+  for (uint64_t j = 0; j < n - nc; j++) o[j] = fine[2 * j + 1];
+  FN(mass_trans_line)(n, nc, h->dist[l][d], e, 0, o, 1, coarse_out, 1);
+  free(e);
+  free(o);
+  return 0;
+}
+int FN(mgxo_op_thomas)(const FN(mgxo_hier) * h, int l, int d, REAL *x) {
+  if (l < 0 || l > h->L || d < 0 || d >= h->D) return -1;
+  FN(thomas_line)(h->lshape[l][d], h->am[l][d], h->bm[l][d], x, 1);
+  return 0;
+}
+
 /* Correction/CalcCorrection3D.hpp:26-185: LPK1,2,3 then IPK1,2,3 on the
  * reordered coefficient array v (strides ldv1, ldv2); returns a freshly
  * allocated compact (rr,cc,ff) correction. */

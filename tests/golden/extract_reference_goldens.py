@@ -2,6 +2,8 @@
 """Extract the golden input/output VECTORS (data only, no code) that the reference's own unit
 tests hold for the decomposition path, and write them to tests/golden/reference_goldens.json.
 
+Source of the operator vectors ("operators"): <reference>/tests/src/test_TensorMassMatrix.cpp :21-262,
+test_TensorRestriction.cpp :18-221, test_TensorProlongation.cpp :16-106 (dyadic sections).
 Source of the vectors: <reference>/tests/src/test_decompose.cpp
   TEST_CASE("decomposition") :276-457  sections "1D/2D/4D, dyadic, uniform", "1D, dyadic, nonuniform"
   TEST_CASE("recomposition") :549-746  sections "1D/3D/4D, dyadic, uniform"
@@ -60,6 +62,144 @@ def _dtype(sec, name):
     return m.group(1)
 
 
+def _num_list(text):
+    """A C++ brace initializer whose entries are arithmetic on literals (`2.6 / 6 + 6.0 / 6`, `-3`,
+    `1. / 18`) as nested lists of floats: the entries are evaluated, nothing else is."""
+    text = re.sub(r"//[^\n]*", "", text)
+
+    def parse(i):
+        assert text[i] == "{"
+        i += 1
+        items, cur = [], ""
+        while True:
+            c = text[i]
+            if c == "{":
+                sub, i = parse(i)
+                items.append(sub)
+                cur = ""
+            elif c in ",}":
+                if cur.strip():
+                    expr = cur.strip()
+                    assert re.fullmatch(r"[0-9eE.+\-*/ \n\t()]+", expr), expr
+                    items.append(float(eval(expr, {"__builtins__": {}})))
+                cur = ""
+                i += 1
+                if c == "}":
+                    return items, i
+            else:
+                cur += c
+                i += 1
+
+    val, _ = parse(0)
+    while isinstance(val, list) and len(val) == 1 and isinstance(val[0], list):
+        val = val[0]  # std::array's double braces
+    return val
+
+
+def _init(sec, name, nth=0):
+    """The nth initializer `name = {...}` / `name{...}` in sec."""
+    ms = list(re.finditer(r"\b%s\b\s*=?\s*\{" % re.escape(name), sec))
+    m = ms[nth]
+    return _num_list(_braces(sec, m.end() - 1))
+
+
+def _between(text, a, b=None, start=0):
+    i = text.index(a, start)
+    j = text.index(b, i + len(a)) if b else len(text)
+    return text[i:j]
+
+
+def _operators(ref):
+    """Known answers of the MGARD-CPU operators on DYADIC grids (where MGARD-CPU and MGARD-X define the
+    same hierarchy), default and custom spacing. Each entry: the constituent operator applied along
+    `dimension` on the level-`l` nodes of the lines starting at `multiindices`, everything in natural
+    node order. Transformations the test code applies to its literals (a scaling by 1/48, a division
+    of three entries by 12) are applied here and cited."""
+    src = os.path.join(ref, "tests", "src")
+    ops = []
+    # ---- tests/src/test_TensorMassMatrix.cpp ----
+    t = open(os.path.join(src, "test_TensorMassMatrix.cpp")).read()
+    case = _between(t, 'TEST_CASE("constituent mass matrices"', 'TEST_CASE("tensor product mass matrices"')
+    sec = _between(case, 'SECTION("1D and default spacing")', 'SECTION("1D and nondyadic")')
+    u = _init(sec, "u_")
+    e3 = [x / 48 for x in _init(sec, "expected", 0)]          # :38-39 blas::scal(ndof, 1/48, expected)
+    e1 = _init(sec, "expected", 1)
+    for i in range(3):                                         # :54-56 expected.at(4 * i) /= 12
+        e1[4 * i] /= 12
+    ops.append({"op": "mass", "source": "test_TensorMassMatrix.cpp:21-62", "dtype": "float", "shape": [9],
+                "coords": None, "u": u, "l": 3, "dimension": 0, "multiindices": [[0]], "expected": e3})
+    ops.append({"op": "mass", "source": "test_TensorMassMatrix.cpp:21-62", "dtype": "float", "shape": [9],
+                "coords": None, "u": u, "l": 1, "dimension": 0, "multiindices": [[0]], "expected": e1})
+    sec = _between(case, 'SECTION("2D and custom spacing")')
+    coords = _num_list(_braces(sec, sec.index("{5, 5}, {{{") + len("{5, 5}, ")))
+    u = _init(sec, "u_")
+    ops.append({"op": "mass", "source": "test_TensorMassMatrix.cpp:96-150", "dtype": "double", "shape": [5, 5],
+                "coords": coords, "u": u, "l": 2, "dimension": 0, "multiindices": [[0, 0], [0, 3]],
+                "expected": _init(sec, "expected", 0)})
+    ops.append({"op": "mass", "source": "test_TensorMassMatrix.cpp:151-194", "dtype": "double", "shape": [5, 5],
+                "coords": coords, "u": u, "l": 2, "dimension": 1, "multiindices": [[1, 0], [2, 0]],
+                "expected": _init(sec, "expected", 1)})
+    last = _init(sec, "expected", 2)                           # :203-211 only the last row changes
+    ops.append({"op": "mass", "source": "test_TensorMassMatrix.cpp:195-213", "dtype": "double", "shape": [5, 5],
+                "coords": coords, "u": u, "l": 1, "dimension": 1, "multiindices": [[4, 0]],
+                "expected": u[:20] + last})
+    case = _between(t, 'TEST_CASE("tensor product mass matrices"', "namespace {")
+    coords = _num_list(_braces(case, case.index("{3, 3}, {{{") + len("{3, 3}, ")))
+    u = _init(case, "u_")
+    for k, l in ((0, 1), (1, 0)):
+        ops.append({"op": "tensor_mass", "source": "test_TensorMassMatrix.cpp:217-262", "dtype": "double",
+                    "shape": [3, 3], "coords": coords, "u": u, "l": l, "expected": _init(case, "expected", k)})
+    # ---- tests/src/test_TensorRestriction.cpp ----
+    t = open(os.path.join(src, "test_TensorRestriction.cpp")).read()
+    case = _between(t, 'TEST_CASE("constituent restrictions"', "namespace {")
+    sec = _between(case, 'SECTION("1D and default spacing")', 'SECTION("1D and custom spacing and nondyadic")')
+    u, ex = _init(sec, "u_"), _init(sec, "expecteds")
+    for i, l in enumerate((3, 2, 1)):                          # :33-34 l = 3, 2, 1 <-> expecteds[0, 1, 2]
+        ops.append({"op": "restriction", "source": "test_TensorRestriction.cpp:19-47", "dtype": "float", "shape": [9],
+                    "coords": None, "u": u, "l": l, "dimension": 0, "multiindices": [[0]], "expected": ex[i]})
+    sec = _between(case, 'SECTION("2D and custom spacing")')
+    coords = _num_list(_braces(sec, sec.index("{3, 3}, {{{") + len("{3, 3}, ")))
+    u = _init(sec, "u_")
+    ex0, ex1 = _init(sec, "expecteds", 0), _init(sec, "expecteds", 1)
+    for mi, e in zip(([0, 0], [0, 1]), ex0):
+        ops.append({"op": "restriction", "source": "test_TensorRestriction.cpp:78-113", "dtype": "double",
+                    "shape": [3, 3], "coords": coords, "u": u, "l": 1, "dimension": 0, "multiindices": [mi],
+                    "expected": e})
+    for mi, e in zip(([1, 0], [2, 0]), ex1):
+        ops.append({"op": "restriction", "source": "test_TensorRestriction.cpp:114-133", "dtype": "double",
+                    "shape": [3, 3], "coords": coords, "u": u, "l": 1, "dimension": 1, "multiindices": [mi],
+                    "expected": e})
+    case = _between(t, 'TEST_CASE("tensor product restrictions"', "std::default_random_engine generator(445624)")
+    coords = _num_list(_braces(case, case.index("{3, 3}, {{{") + len("{3, 3}, ")))
+    ops.append({"op": "tensor_restriction", "source": "test_TensorRestriction.cpp:200-221", "dtype": "double",
+                "shape": [3, 3], "coords": coords, "u": _init(case, "u_"), "l": 1,
+                "expected": _init(case, "expected")})
+    # ---- tests/src/test_TensorProlongation.cpp ----
+    t = open(os.path.join(src, "test_TensorProlongation.cpp")).read()
+    case = _between(t, 'TEST_CASE("constituent prolongations"', "namespace {")
+    sec = _between(case, 'SECTION("1D and default spacing")', 'SECTION("2D and custom spacing")')
+    u, ex = _init(sec, "u_"), _init(sec, "expecteds")
+    for i, l in enumerate((3, 2, 1)):
+        ops.append({"op": "prolongation_addition", "source": "test_TensorProlongation.cpp:17-48", "dtype": "float",
+                    "shape": [9], "coords": None, "u": u, "l": l, "dimension": 0, "multiindices": [[0]],
+                    "expected": ex[i]})
+    sec = _between(case, 'SECTION("2D and custom spacing")', 'SECTION("2D and nondyadic")')
+    coords = _num_list(_braces(sec, sec.index("{3, 3}, {{{") + len("{3, 3}, ")))
+    u = _init(sec, "u_")
+    ex0, ex1 = _init(sec, "expecteds", 0), _init(sec, "expecteds", 1)
+    for mi, e in zip(([0, 0], [0, 1]), ex0):
+        ops.append({"op": "prolongation_addition", "source": "test_TensorProlongation.cpp:50-83", "dtype": "double",
+                    "shape": [3, 3], "coords": coords, "u": u, "l": 1, "dimension": 0, "multiindices": [mi],
+                    "expected": e})
+    for mi, e in zip(([1, 0], [2, 0]), ex1):
+        ops.append({"op": "prolongation_addition", "source": "test_TensorProlongation.cpp:84-106", "dtype": "double",
+                    "shape": [3, 3], "coords": coords, "u": u, "l": 1, "dimension": 1, "multiindices": [mi],
+                    "expected": e})
+    return {"source": "tests/src/test_Tensor{MassMatrix,Restriction,Prolongation}.cpp (CODARcode/MGARD v1.6.0)",
+            "note": "dyadic grids only (on those MGARD-CPU's hierarchy is MGARD-X's); natural node order",
+            "cases": ops}
+
+
 def main():
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
     path = os.path.join(ref, "tests", "src", "test_decompose.cpp")
@@ -98,6 +238,7 @@ def main():
         "quantize": {"quantum": quantum1, "dtype": "double", "x": xs1, "n": ns1},
         "dequantize": {"quantum": quantum2, "dtype": "float", "n": ns2, "x": xs2},
     }
+    out["operators"] = _operators(ref)
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_goldens.json")
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)

@@ -915,3 +915,28 @@ def test_outputs_at_odd_offsets_equal_the_aligned_ones(shape, dt):
         back0 = h.dequantize_recompose(q0.clone(), mg.REL, 1e-3, np.inf, nrm, outlier_idx=oi0, outlier_val=ov0)
         assert_bit_equal(back.cpu().numpy(), back0.cpu().numpy(), "reconstruction from the shifted integers")
     h.close()
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_decompose_equals_the_operator_built_decomposition_on_nonuniform_grids(dt):
+    """The -m gpu mirror of tests/test_oracle_operator_goldens.py step 3: mgh_decompose against a
+    decomposition assembled from the dense mass / interpolation / restriction matrices that the
+    reference's own operator vectors pin (tests/src/test_TensorMassMatrix.cpp:21-262,
+    test_TensorRestriction.cpp:18-221, test_TensorProlongation.cpp:16-106), on non-uniform dyadic
+    grids in 1-3 D -- the reference's 5 x 5 custom spacing among them. Tolerance: rounding of the
+    data type (the matrices are evaluated in double)."""
+    from tests.test_oracle_operator_goldens import NONUNIFORM_GRIDS, decompose_by_matrices, nonuniform_grid
+    torch, mg = _gpu()
+    tol = 5e-5 if dt == np.float32 else 1e-11
+    for shape, seed in NONUNIFORM_GRIDS:
+        coords = [x.astype(dt) for x in nonuniform_grid(shape, seed)]
+        u = np.random.default_rng(11).normal(size=shape).astype(dt)
+        h = mg.Hierarchy(shape, dt, coords=coords)
+        got = oracle.dyadic_reordered_to_natural(h.decompose(torch.from_numpy(u).cuda()).cpu().numpy())
+        want = decompose_by_matrices([c.astype(np.float64) for c in coords], u.astype(np.float64))
+        assert np.allclose(got.astype(np.float64), want, rtol=tol, atol=tol * np.abs(want).max()), shape
+        # (and bit for bit what the oracle computes: the product and its checker agree on the very
+        # grids the reference's numbers were checked on)
+        o = oracle.Hierarchy(shape, dt, coords=coords)
+        assert_bit_equal(h.decompose(torch.from_numpy(u).cuda()).cpu().numpy(), o.decompose(u), "decompose %r" % (shape,))
+        h.close()
