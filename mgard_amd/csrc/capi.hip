@@ -72,9 +72,6 @@ struct mgh_hierarchy {
   bool force_v1 = false;  // MGH_FORCE_V1=1: run the one-thread-per-element kernels only
   bool force_nd = false;  // MGH_FORCE_ND=1: run the generic N-D kernels also for D <= 3 (cross-check)
   std::string prof_filter;  // empty = every kernel
-  // MGH_FUSED_V: 2 = second-generation fused level kernel (kernels_fused2.hpp, default),
-  // 1 = first generation (kernels_fused.hpp; cross-check)
-  int fused_v = 2;
   // MGH_IPK_STREAM: 1 = streaming Thomas solves (kernels_ipk_stream.hpp) on the levels whose
   // LDS-staged solve needs more than one round of resident workgroups (default), 0 = never
   int ipk_stream = 1;
@@ -94,6 +91,7 @@ struct mgh_hierarchy {
   // the box kernel (kernels_box.hpp: no march, every phase once over a 4 x 4 x 8 box) instead of
   // the marching tile kernel; 0 = none, 1 = class 0 (default), 2 = classes 0-1, 3 = every level
   int box = 1;
+  int sym16_mixed = 1;  // MGH_SYM16_MIXED: 16-bit symbols for the finest level only, int64 below it (default), 0 = 16-bit symbols on every level
   int restore_v = 3;  // MGH_RESTORE_V: 3 = marching node restore (kernels_recompose2.hpp), 2 = one wave per pair of fine rows
   int tail_solves = 1;  // MGH_TAIL_SOLVES: the tail kernel runs the Thomas solves of the level above it
   // (the rest of the developer switches, env.hpp; all read when the hierarchy is created)
@@ -162,6 +160,8 @@ template <typename T> struct DeviceState {
   unsigned long long *oh_key = nullptr;  // outlier table of the 16-bit symbol path (grown on demand)
   long long *oh_val = nullptr;
   size_t oh_slots = 0;
+  int64_t *qbox = nullptr;               // ... and its compact int64 copy of the coarse corner box
+  size_t qbox_elems = 0;
   QuantMeta qmeta;
   size_t full_I = 0, full_J = 0;   // strides of the full array in the 3-D view
 };
@@ -414,6 +414,7 @@ template <typename T> void destroy_state(mgh_hierarchy *h) {
     (void)hipFree(ds->normval);
     (void)hipFree(ds->oh_key);
     (void)hipFree(ds->oh_val);
+    (void)hipFree(ds->qbox);
     delete ds;
   }
   delete HH<T>(h);
@@ -834,7 +835,7 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
   const size_t fI = ds->full_I, fJ = ds->full_J;
   const T *src = data;
   size_t sI = fI, sJ = fJ;
-  constexpr int TC = 8, TF = 32;
+
   FusedArgs<T> A{};
   A.coef = coeff;
   A.dI = fI;
@@ -882,15 +883,14 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
       A.quantizer = qp->qz[l];
       A.volume = qp->vol[l];
     }
-    const unsigned gx = (b.m[2] + TF - 1) / TF, gy = (b.m[1] + TC - 1) / TC;
     const int cls = level_class(h, b);
     {
       if (l == L) TRY(after_first());
-      // long marches (RCH = 16: 9% r-halo) when there are plenty of tiles, short ones
-      // (RCH = 4) on the small levels where the march length is pure latency
-      // second generation: needs the dictionary test in 32 bits
-      const bool v2 = h->fused_v == 2 && (OUT != OUT_Q || (qp->dict_size >= 0 && qp->dict_size <= ((int64_t)1 << 30)));
-      if (h->fused_v == 2 && cls < h->box) {
+      // (the level kernels test the dictionary range in 32 bits: the entry points send larger
+      // dictionaries through decompose + quantize)
+      if (OUT == OUT_Q && !(qp->dict_size >= 0 && qp->dict_size <= ((int64_t)1 << 30)))
+        return fail(MGH_ERR_INVALID_ARGUMENT, "fused path: dict_size must be at most 2^30");
+      if (cls < h->box) {
         // small level: no march (kernels_box.hpp)
         constexpr int BR = 4, BC = 4, BF = 8;
         const int bx = ((int)b.m[2] + BF - 1) / BF, by = ((int)b.m[1] + BC - 1) / BC,
@@ -898,29 +898,15 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
         TRY(launch(h, OUT == OUT_Q ? "level_box_q" : "level_box", s, [&] {
           k_level_box<T, OUT, BR, BC, BF><<<(unsigned)(bx * by * bz), 256, 0, s>>>(A, bx, by);
         }));
-      } else if (v2) {
+      } else {
+        // long marches (RCH = 16: 9% r-halo) when there are plenty of tiles, short ones
+        // (RCH = 4) on the small levels where the march length is pure latency
         const char *nm = cls == 2 ? (OUT == OUT_Q ? "level_fused_q" : "level_fused")
                                   : (OUT == OUT_Q ? "level_fused_q_small" : "level_fused_small");
         if (OUT == OUT_Q && A.prep_huffman && !A.q16 && h->fused_fixed)
           TRY((launch_fused2<T, OUT == OUT_Q ? OUT_QH : OUT>(h, A, b, cls, nm, s)));
         else
           TRY((launch_fused2<T, OUT>(h, A, b, cls, nm, s)));
-      } else if (cls == 2) {
-        const dim3 grid(gx, gy, (b.m[0] + 15) / 16);
-        TRY(launch(h, OUT == OUT_Q ? "level_fused_q" : "level_fused", s, [&] {
-          k_level_fused<T, OUT, TC, TF, 16, false><<<grid, 256, 0, s>>>(A);
-        }));
-      } else if (cls == 1) {
-        const dim3 grid(gx, gy, (b.m[0] + 3) / 4);
-        TRY(launch(h, OUT == OUT_Q ? "level_fused_q_small" : "level_fused_small", s, [&] {
-          k_level_fused<T, OUT, TC, TF, 4, false><<<grid, 256, 0, s>>>(A);
-        }));
-      } else {
-        // few tiles: the march length is the whole cost -> one coarse plane per block
-        const dim3 grid(gx, gy, b.m[0]);
-        TRY(launch(h, OUT == OUT_Q ? "level_fused_q_small" : "level_fused_small", s, [&] {
-          k_level_fused<T, OUT, TC, TF, 1, true><<<grid, 256, 0, s>>>(A);
-        }));
       }
     }
     // (the level right above the tail leaves its three solves to the tail kernel, which needs the
@@ -1426,13 +1412,13 @@ int decompose_impl(mgh_hierarchy *h, const T *data, T *coeff, hipStream_t s) {
 }
 
 
-template <typename T, typename QT>
+template <typename T, typename QT, typename QTL = QT>
 int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> &level_qv, T *data,
-                     hipStream_t st);
+                     hipStream_t st, const RecomposeArgs<T> *AL = nullptr);
 
-template <typename T, typename QT>
+template <typename T, typename QT, typename QTL = QT>
 int recompose_levels4(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> &level_qv, T *data,
-                      hipStream_t st);
+                      hipStream_t st, const RecomposeArgs<T> *AL = nullptr, size_t A_sT = 0);
 inline bool fused4_ok(const mgh_hierarchy *h);
 
 template <typename T>
@@ -1552,9 +1538,12 @@ int launch_loadvec(mgh_hierarchy *h, const RecomposeArgs<T> &A, const Box3 &b, h
   });
 }
 
-template <typename T, typename QT>
+// QTL / AL: coefficient source of the FINEST level when it differs from that of the levels below
+// (16-bit symbols for the finest level, int64 of the coarse corner box for the rest:
+// dequantize_recompose_fused16); AL == nullptr: one source for all levels.
+template <typename T, typename QT, typename QTL>
 int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> &level_qv, T *data,
-                     hipStream_t st) {
+                     hipStream_t st, const RecomposeArgs<T> *AL) {
   auto *ds = DS<T>(h);
   const int L = h->L;
   // levels 1 .. l_head run inside ONE single-workgroup kernel (their working set fits in LDS);
@@ -1562,7 +1551,7 @@ int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> 
   const bool no_head = h->no_head;
   int l_head = 0;
   if (!no_head) {
-    for (int l = 1; l <= std::min(L, kTailMaxLevels); l++) {
+    for (int l = 1; l <= std::min(AL ? L - 1 : L, kTailMaxLevels); l++) {
       if ((head_lds_elems(ds->lt[l].box) + ds->lt_end[l]) * sizeof(T) > 150 * 1024) break;
       l_head = l;
     }
@@ -1603,22 +1592,26 @@ int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> 
   for (int l = l_head + 1; l <= L; l++) {
     const LevelTables<T> &t = ds->lt[l];
     const Box3 &b = t.box;
+    const bool top = AL && l == L;
+    RecomposeArgs<T> B = top ? *AL : A;
     for (int k = 0; k < 3; k++) {
-      A.n[k] = (int)b.n[k];
-      A.m[k] = (int)b.m[k];
-      A.ratio[k] = t.ratio[k];
-      A.mass[k] = t.mass[k];
+      B.n[k] = (int)b.n[k];
+      B.m[k] = (int)b.m[k];
+      B.ratio[k] = t.ratio[k];
+      B.mass[k] = t.mass[k];
     }
-    A.qv = level_qv[l];
-    A.load = ds->t3;
-    A.coarse = ds->nodal[l - 1];
-    TRY((launch_loadvec<T, QT>(h, A, b, st)));
+    B.qv = level_qv[l];
+    B.load = ds->t3;
+    B.coarse = ds->nodal[l - 1];
+    if (top) TRY((launch_loadvec<T, QTL>(h, B, b, st)));
+    else TRY((launch_loadvec<T, QT>(h, B, b, st)));
     TRY(ipk_fc_launch<T>(h, b.m, ds->t3, t.thomas[2], t.thomas[1], st));
     TRY(ipk_launch<T>(h, 0, b.m, ds->t3, t.thomas[0], ds->nodal[l - 1], -1, st));
-    A.fine = (l == L) ? data : ds->nodal[l];
-    A.fJ = (l == L) ? ds->full_J : b.n[2];
-    A.fI = (l == L) ? ds->full_I : (size_t)b.n[1] * b.n[2];
-    TRY((launch_restore<T, QT, false>(h, A, b, "restore_q", st)));
+    B.fine = (l == L) ? data : ds->nodal[l];
+    B.fJ = (l == L) ? ds->full_J : b.n[2];
+    B.fI = (l == L) ? ds->full_I : (size_t)b.n[1] * b.n[2];
+    if (top) TRY((launch_restore<T, QTL, false>(h, B, b, "restore_q", st)));
+    else TRY((launch_restore<T, QT, false>(h, B, b, "restore_q", st)));
   }
   return MGH_SUCCESS;
 }
@@ -1627,9 +1620,11 @@ int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> 
 // t-slice with the 3-D kernel (odd slices: every node is a coefficient), the t-sweep, four Thomas
 // solves subtracting the correction from the coarse nodes, then the node restore slice by slice
 // (odd slices interpolate across t between the two neighbouring coarse slices).
-template <typename T, typename QT>
-int recompose_levels4(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> &level_qv, T *data,
-                      hipStream_t st) {
+// A_sT: element stride between two t-slices of A's source (0: the full array's). AL / QTL as in
+// recompose_levels (the finest level's source has the full array's strides).
+template <typename T, typename QT, typename QTL>
+int recompose_levels4(mgh_hierarchy *h, RecomposeArgs<T> A0, const std::vector<T> &level_qv, T *data,
+                      hipStream_t st, const RecomposeArgs<T> *AL, size_t A_sT) {
   auto *ds = DS<T>(h);
   auto *hh = HH<T>(h);
   const int L = h->L;
@@ -1637,18 +1632,28 @@ int recompose_levels4(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T>
   const size_t full[4] = {(size_t)sh[L][1] * sh[L][2] * sh[L][3], (size_t)sh[L][2] * sh[L][3],
                           (size_t)sh[L][3], 1};
   TRY(ensure_state4<T>(h));
-  A.dI = full[1];
-  A.dJ = full[2];
+  if (!A_sT) {
+    A_sT = full[0];
+    A0.dI = full[1];
+    A0.dJ = full[2];
+  }
   {
     const auto &M0 = sh[0];
     const size_t tot = (size_t)M0[0] * M0[1] * M0[2] * M0[3];
-    A.qv = level_qv[0];
+    A0.qv = level_qv[0];
     TRY(launch(h, "head_in", st, [&] {
       k_head_in4_q<T, QT><<<(unsigned)std::min<size_t>((tot + 255) / 256, 1024), 256, 0, st>>>(
-          (int)M0[0], (int)M0[1], (int)M0[2], (int)M0[3], A, full[0], ds->nodal4[0]);
+          (int)M0[0], (int)M0[1], (int)M0[2], (int)M0[3], A0, A_sT, ds->nodal4[0]);
     }));
   }
   for (int l = 1; l <= L; l++) {
+    const bool top = AL && l == L;
+    RecomposeArgs<T> A = top ? *AL : A0;
+    const size_t sT = top ? full[0] : A_sT;
+    if (top) {
+      A.dI = full[1];
+      A.dJ = full[2];
+    }
     const auto &N = sh[l], &Mc = sh[l - 1];
     Box3 b;
     for (int k = 0; k < 3; k++) {
@@ -1670,9 +1675,10 @@ int recompose_levels4(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T>
         continue;
       }
       A.allcoef = P & 1;
-      A.lin_base = (size_t)((P & 1) ? m_t + (P - 1) / 2 : P / 2) * full[0];
+      A.lin_base = (size_t)((P & 1) ? m_t + (P - 1) / 2 : P / 2) * sT;
       A.load = ds->load4 + (size_t)P * M;
-      TRY((launch_loadvec<T, QT>(h, A, b, st)));
+      if (top) TRY((launch_loadvec<T, QTL>(h, A, b, st)));
+      else TRY((launch_loadvec<T, QT>(h, A, b, st)));
     }
     A.allcoef = 0;
     // ---- t-sweep, Thomas solves f, c, r, t; the last one subtracts from the coarse nodes
@@ -1695,18 +1701,19 @@ int recompose_levels4(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T>
       if (!(tp & 1) || last_even) {
         const int zi = last_even ? m_t - 1 : tp / 2;
         A.coarse = ds->nodal4[l - 1] + (size_t)zi * M;
-        A.lin_base = (size_t)zi * full[0];
-        TRY((launch_restore<T, QT, false>(h, A, b, "restore_q", st)));
+        A.lin_base = (size_t)zi * sT;
+        if (top) TRY((launch_restore<T, QTL, false>(h, A, b, "restore_q", st)));
+        else TRY((launch_restore<T, QT, false>(h, A, b, "restore_q", st)));
       } else {
         const int zi = (tp - 1) / 2;
         A.coarse = ds->nodal4[l - 1] + (size_t)zi * M;
         A.coarse_b = ds->nodal4[l - 1] + (size_t)(zi + 1) * M;
         A.tpos = tp;
-        A.lin_base = (size_t)(m_t + zi) * full[0];
-        TRY((launch_restore<T, QT, true>(h, A, b, "restore_q_odd", st)));
+        A.lin_base = (size_t)(m_t + zi) * sT;
+        if (top) TRY((launch_restore<T, QTL, true>(h, A, b, "restore_q_odd", st)));
+        else TRY((launch_restore<T, QT, true>(h, A, b, "restore_q_odd", st)));
       }
     }
-    A.lin_base = 0;
   }
   return MGH_SUCCESS;
 }
@@ -1780,6 +1787,46 @@ int dequantize_recompose_fused16(mgh_hierarchy *h, const uint16_t *sym, int ebty
   A.half = (int64_t)(dict_size / 2);
   std::vector<T> level_qv(L + 1);
   for (int l = 0; l <= L; l++) level_qv[l] = qz[l] * (calc_vol ? hh->level_volume(l, true) : (T)1);
+  // Symbol width PER LEVEL: only the finest level -- 7/8 (D = 3) or 15/16 (D = 4) of the array,
+  // where out-of-dictionary values are rare -- is read as 16-bit symbols with the table look-up
+  // behind symbol 0. The levels below hold nearly all the outliers, and a look-up there is a
+  // dependent global load inside latency-bound kernels (measured: slower than the int64 path
+  // at 256^3). Their symbols -- the coarse corner box of the reordered layout, 1/8 resp. 1/16 of
+  // the array -- are widened to int64 in a compact box with the outliers written over them, and
+  // those levels run the int64 kernels on it.
+  if (h->sym16_mixed && L >= 2 && h->total >= ((uint64_t)1 << 18)) {
+    const auto &Mc = hh->level_shape[L - 1];
+    const auto &N = hh->level_shape[L];
+    BoxMap bm{};
+    for (int k = 0; k < 4; k++) bm.m[k] = bm.n[k] = 1;
+    for (int d = 0; d < h->D; d++) {
+      bm.m[4 - h->D + d] = (uint32_t)Mc[d];
+      bm.n[4 - h->D + d] = (uint32_t)N[d];
+    }
+    const size_t box = (size_t)bm.m[0] * bm.m[1] * bm.m[2] * bm.m[3];
+    if (box > ds->qbox_elems) {
+      (void)hipFree(ds->qbox);
+      ds->qbox = nullptr;
+      ds->qbox_elems = 0;
+      HIP_TRY(hipMalloc(&ds->qbox, box * sizeof(int64_t)));
+      ds->qbox_elems = box;
+    }
+    TRY(launch(h, "widen_box", st, [&] {
+      k_widen_box<<<(unsigned)std::min<size_t>((box + 255) / 256, 256 * 16), 256, 0, st>>>(sym, ds->qbox, bm, box);
+    }));
+    if (ocount)
+      TRY(launch(h, "outlier_restore", st, [&] {
+        k_outlier_restore_box<<<(unsigned)((ocount + 255) / 256), 256, 0, st>>>(ds->qbox, bm, oidx, oval, ocount);
+      }));
+    RecomposeArgs<T> A64{};
+    A64.q = ds->qbox;
+    A64.dJ = bm.m[3];
+    A64.dI = (size_t)bm.m[2] * bm.m[3];
+    A64.half = A.half;
+    if (h->D == 4)
+      return recompose_levels4<T, int64_t, uint16_t>(h, A64, level_qv, data, st, &A, (size_t)bm.m[1] * bm.m[2] * bm.m[3]);
+    return recompose_levels<T, int64_t, uint16_t>(h, A64, level_qv, data, st, &A);
+  }
   if (h->D == 4) return recompose_levels4<T, uint16_t>(h, A, level_qv, data, st);
   return recompose_levels<T, uint16_t>(h, A, level_qv, data, st);
 }
@@ -2058,7 +2105,6 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
   {
     h->force_v1 = env_get("MGH_FORCE_V1", 0) != 0;
     h->force_nd = env_get("MGH_FORCE_ND", 0) != 0;
-    h->fused_v = (int)env_get("MGH_FUSED_V", h->fused_v);
     h->ipk_stream = (int)env_get("MGH_IPK_STREAM", h->ipk_stream);
     h->ipk_dma = (int)env_get("MGH_IPK_DMA", h->ipk_dma);
     h->ipk_dma_min_env = env_get("MGH_IPK_DMA_MIN", -1);
@@ -2070,6 +2116,7 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->fused4 = (int)env_get("MGH_FUSED4", h->fused4);
     h->box = (int)env_get("MGH_BOX", h->box);
     h->restore_v = (int)env_get("MGH_RESTORE_V", h->restore_v);
+    h->sym16_mixed = (int)env_get("MGH_SYM16_MIXED", h->sym16_mixed);
     h->tail_solves = (int)env_get("MGH_TAIL_SOLVES", h->tail_solves);
     h->cls1 = (size_t)env_get("MGH_CLS1", (long)h->cls1);
     h->cls2 = (size_t)env_get("MGH_CLS2", (long)h->cls2);
@@ -2289,7 +2336,8 @@ int mgh_decompose_quantize(mgh_hierarchy *h, const void *d_data, int error_bound
                            uint64_t outlier_capacity, void *d_coeff_opt, void *stream) {
   if (!h || !d_data || !d_quantized) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
   HIP_TRY(hipSetDevice(h->device));
-  const bool fused = !d_coeff_opt && fusedc_ok(h) && !h->force_v1;
+  // (the fused level kernels test the dictionary range in 32 bits: larger dictionaries are staged)
+  const bool fused = !d_coeff_opt && fusedc_ok(h) && !h->force_v1 && dict_size <= ((uint64_t)1 << 30);
   if (fused && error_bound_type == MGH_REL && !(norm > 0)) {
     // the norm and the quantizers stay on the device: no host round trip inside the call
     if (prep_huffman && (!d_outlier_count || (outlier_capacity && (!d_outlier_idx || !d_outlier_val))))
@@ -2309,7 +2357,7 @@ int mgh_decompose_quantize(mgh_hierarchy *h, const void *d_data, int error_bound
     if (rc != MGH_SUCCESS) return rc;
   }
   if (h_norm_out) *h_norm_out = norm;
-  if (!d_coeff_opt && fusedc_ok(h) && !h->force_v1) {
+  if (fused) {
     if (prep_huffman && (!d_outlier_count || (outlier_capacity && (!d_outlier_idx || !d_outlier_val))))
       return fail(MGH_ERR_INVALID_ARGUMENT, "outlier buffers required with prep_huffman");
     if (d_outlier_count) HIP_TRY(hipMemsetAsync(d_outlier_count, 0, sizeof(uint64_t), (hipStream_t)stream));

@@ -1934,11 +1934,15 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
     bool owned = false;
     HL_TRY(get_hierarchy(&h, &owned, dtype, sshape, cptr, dd.subdomain_offset(id), cfg, lane));
     if (owned) owned_h[lane] = h;
-    // 16-bit symbols between decoder and dequantizer: measured SLOWER than int64 on this side
-    // (3.0 vs 2.9 ms at 512^3: decoder and node restore are instruction-bound, not
-    // bandwidth-bound, and the outlier look-ups of the coarse levels cost more than the
-    // outlier-restore pass they replace) -- opt-in, MGH_SYM16_DECODE=1
-    static const bool sym16_decode = env_get("MGH_SYM16_DECODE", 0) != 0;
+    // 16-bit symbols between decoder and dequantizer (a quarter of the bytes the decoder writes and
+    // the two passes over the finest level read). The symbol width is chosen PER LEVEL inside
+    // mgh_dequantize_recompose_sym16: the finest level reads the symbols, the levels below --
+    // where the out-of-dictionary values live -- an int64 copy of the coarse corner box.
+    // Subdomains below 2^25 elements keep int64: the box copy and the outlier table are three more
+    // launches in a latency-bound chain (256^3: 0.86 ms with int64, 0.89 ms with symbols; 512^3: 2.16
+    // vs 2.03 ms). MGH_SYM16_DECODE=0 / 1: never / always (cross-checks).
+    static const long sym16_env = env_get("MGH_SYM16_DECODE", -1);
+    const bool sym16_decode = sym16_env < 0 ? n >= ((uint64_t)1 << 25) : sym16_env != 0;
     bool sym16 = sym16_decode && !hd.reorder && mgh_sym16_supported(h) && hd.huff_dict_size <= 65536;
     HL_TRY(lossless_decompress(L.ll, payload, csize, lossless, (int64_t *)L.q.p, n, &ocount, st, &sym16,
                                /*sync_end=*/false));

@@ -421,6 +421,42 @@ k_outlier_restore(int64_t *__restrict__ q, uint64_t total, const uint64_t *__res
   if (t < count && idx[t] < total) q[idx[t]] = val[t];
 }
 
+// The coarse corner box of the reordered layout -- what every level below the finest reads --
+// as a compact int64 array: 16-bit symbols widened (k_widen_box), then the outliers that lie
+// inside the box written over them (k_outlier_restore_box). Up to four dimensions, leading 1s.
+struct BoxMap {
+  uint32_t n[4];  // the full array
+  uint32_t m[4];  // the box [0, m0) x [0, m1) x [0, m2) x [0, m3)
+};
+__global__ void __launch_bounds__(256)
+k_widen_box(const uint16_t *__restrict__ sym, int64_t *__restrict__ box, BoxMap B, size_t count) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t f = (uint32_t)(e % B.m[3]);
+    size_t r = e / B.m[3];
+    const uint32_t c = (uint32_t)(r % B.m[2]);
+    r /= B.m[2];
+    const uint32_t i = (uint32_t)(r % B.m[1]), t = (uint32_t)(r / B.m[1]);
+    box[e] = (int64_t)sym[(((size_t)t * B.n[1] + i) * B.n[2] + c) * B.n[3] + f];
+  }
+}
+__global__ void __launch_bounds__(256)
+k_outlier_restore_box(int64_t *__restrict__ box, BoxMap B, const uint64_t *__restrict__ idx,
+                      const int64_t *__restrict__ val, uint64_t count) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  uint64_t lin = idx[k];
+  const uint32_t f = (uint32_t)(lin % B.n[3]);
+  lin /= B.n[3];
+  const uint32_t c = (uint32_t)(lin % B.n[2]);
+  lin /= B.n[2];
+  const uint32_t i = (uint32_t)(lin % B.n[1]);
+  const uint64_t t = lin / B.n[1];
+  // (outside the box: an outlier of the finest level, found through the table; an index outside the
+  // array can only come from a damaged stream and falls outside the box as well)
+  if (t < B.m[0] && i < B.m[1] && c < B.m[2] && f < B.m[3])
+    box[(((size_t)t * B.m[1] + i) * B.m[2] + c) * B.m[3] + f] = val[k];
+}
+
 // ---------------------------------------------------------------------------
 // config.reorder == 1: the quantized array level by level ("level linearised",
 // Quantization/LinearQuantization.hpp:46-146 calc_level_offset + :588-605 slot of a level).

@@ -414,11 +414,14 @@ def test_alternative_kernels_give_the_same_result():
     ref = run({})
     assert run({"MGH_RESTORE_ROWS": "1", "MGH_NO_RECOMPOSE_HEAD": "1", "MGH_HUFF_PAR_DECODE": "1"}) == ref
     assert run({"MGH_SYM16_DECODE": "1", "MGH_HUFF_SERIAL_DECODE": "1"}) == ref
+    # int64 between decoder and dequantizer / 16-bit symbols on every level (not only the finest)
+    assert run({"MGH_SYM16_DECODE": "0"}) == ref
+    assert run({"MGH_SYM16_MIXED": "0"}) == ref
     assert run({"MGH_FORCE_V1": "1"}) == ref
     # the round-2 level kernel's tile shapes / chunk lengths / variants and the Thomas solvers
     assert run({"MGH_FUSED_WIDE": "0", "MGH_FUSED_FIXED": "0", "MGH_RCH": "2,3,8"}) == ref
     assert run({"MGH_FUSED_WIDE": "2", "MGH_FUSED_XCD": "0", "MGH_FUSED_FACES": "0", "MGH_IPK_STREAM": "0"}) == ref
-    assert run({"MGH_FUSED_V": "1", "MGH_FUSED4": "0", "MGH_IPK_W": "32"}) == ref
+    assert run({"MGH_FUSED_WIDE": "0", "MGH_FUSED4": "0", "MGH_IPK_W": "32"}) == ref
     # round 3: no box kernel / box kernel on every level, tail kernel without the solves of the
     # level above it, other residency plans of the streaming Thomas solves
     assert run({"MGH_BOX": "0", "MGH_TAIL_SOLVES": "0", "MGH_RESTORE_V": "2", "MGH_IPK_CONTIG": "2"}) == ref

@@ -679,11 +679,16 @@ def test_round3_schedules_bit_exact(shape, mode, s, dict_size, env, dt, monkeypa
     ((65, 70, 129), np.float32, "REL", 1e-3, np.inf, 8192), ((33, 40, 36), np.float64, "ABS", 1e-4, 0.0, 8192),
     ((129, 129, 129), np.float32, "REL", 1e-4, np.inf, 64), ((20, 17, 300), np.float32, "REL", 1e-2, 1.0, 65536),
     ((8, 66, 70, 129), np.float32, "REL", 1e-3, np.inf, 8192), ((7, 33, 40, 65), np.float64, "ABS", 1e-5, np.inf, 64)])
-def test_sym16_output_equals_the_int64_output(shape, dt, mode, tol, s, dict_size):
+@pytest.mark.parametrize("mixed", ["1", "0"])
+def test_sym16_output_equals_the_int64_output(shape, dt, mode, tol, s, dict_size, mixed, monkeypatch):
     """mgh_decompose_quantize_sym16 = mgh_decompose_quantize(prep_huffman=1) narrowed to 16 bits,
-    same outlier list (the small dictionary forces many outliers)."""
+    same outlier list (the small dictionary forces many outliers). The way back with the symbol
+    width chosen per level (finest level: 16-bit symbols + outlier table, below: int64 copy of the
+    coarse corner box; the default from 2^18 elements on) and with 16-bit symbols on every level
+    (MGH_SYM16_MIXED=0; read when the hierarchy is created)."""
     import torch
     import mgard_amd as mg
+    monkeypatch.setenv("MGH_SYM16_MIXED", mixed)
     u = smooth_field(shape, dt)
     d = torch.from_numpy(u).cuda()
     h = mg.Hierarchy(shape, dt)

@@ -5,7 +5,7 @@ sys.path.insert(0, '/root/repo')
 import mgard_amd as mg
 from mgard_amd import highlevel as hl
 from tests.util import smooth_field
-for n, tol in ((256, 1e-3), (256, 1e-5), (256, 1e-7), (512, 1e-5)):
+for n, tol in ((256, 1e-3), (256, 1e-5), (256, 1e-7), (512, 1e-3), (512, 1e-5)):
     u = smooth_field((n, n, n), np.float32); ud = torch.from_numpy(u).cuda()
     s = hl.compress(ud, tol, np.inf, mg.REL)
     out = torch.empty_like(ud)
