@@ -412,6 +412,30 @@ def config_leg(torch, mgard_amd, name, dev, local_rank, steps=5, end_to_end=Fals
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
+    if dist is not None:
+        # First step with every rank-local call guarded: all ranks agree (MIN all-reduce) that a phase
+        # went through before anyone enters the collective behind it, so a rank that cannot run the
+        # step (out of memory, an unsupported shape) does not leave its peers inside an all-reduce
+        # until the RCCL time-out. The timed steps below are the plain ones.
+        def agree(err):
+            okt = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            return bool(okt.item())
+        for phase in ("norm", "decompose_quantize"):
+            err = None
+            try:
+                if phase == "norm":
+                    h.norm_device(d_u, S, out=nrm_t)
+                else:
+                    h.decompose_quantize_dn(d_u, mgard_amd.REL, TOL, S, nrm_t, world, bufs)
+                torch.cuda.synchronize()
+            except (mgard_amd.MgardHipError, RuntimeError) as e:
+                err = str(e)[:200]
+            if not agree(err):
+                h.close()
+                return {"error": "%s failed on some rank: %s" % (phase, err)}
+            if phase == "norm":
+                dist.all_reduce(nrm_t, op=dist.ReduceOp.MAX)
     for _ in range(2):
         step()
     barrier()
@@ -569,30 +593,57 @@ def scatter_gather_leg(torch, mgard_amd, dist, dev, local_rank, rank, world, sla
         times[name] = float(t.item())
         return out
 
+    class PhaseError(Exception):
+        pass
+
+    def local(fn):
+        """Rank-local work of a phase. Every rank learns whether ALL ranks got through it BEFORE anyone
+        enters the next collective: a rank that failed must not leave its peers inside an all-reduce or
+        a receive until the RCCL time-out."""
+        res, err = None, None
+        try:
+            res = fn()
+        except (mgard_amd.MgardHipError, RuntimeError, AssertionError, ValueError) as e:
+            err = "%s: %s" % (type(e).__name__, str(e)[:200])
+        if not agree(err is None):
+            raise PhaseError(err or "a peer rank failed")
+        return res
+
     def round_trip():
         slab = timed("scatter", lambda: mdist.scatter_slabs(vol, shape, src=0, device=dev, dtype=torch.float32))
-        h = mgard_amd.Hierarchy(slab_shape, np.float32, device=local_rank)
         nrm_t = torch.zeros(1, dtype=torch.float32, device=dev)
 
         def norm():
-            h.norm_device(slab, float("inf"), out=nrm_t)
+            def mine():
+                h = mgard_amd.Hierarchy(slab_shape, np.float32, device=local_rank)
+                h.norm_device(slab, float("inf"), out=nrm_t)
+                h.close()
+            local(mine)
             dist.all_reduce(nrm_t, op=dist.ReduceOp.MAX)
             return float(nrm_t.item())
         nrm = timed("norm_exchange", norm)
-        h.close()
         # (in the arithmetic of the data type, like calc_local_abs_tol: the reader recomputes it from
         # the header as float(tol) * float(norm))
         atol = float(np.float32(TOL) * np.float32(nrm))
-        assert abs(atol - mdist.local_abs_tol(mdist.REL, nrm, TOL, float("inf"), world)) <= 1e-6 * atol
-        stream = timed("compress", lambda: highlevel.compress(slab, atol, float("inf"), mgard_amd.ABS, config=cfg, out=obuf))
-        ms = highlevel.metadata_parse(bytes(stream[:8192].cpu().numpy()))["metadata_size"]
-        record = stream[ms + 8:]          # the subdomain's record without its own size prefix
+
+        def compress():
+            assert abs(atol - mdist.local_abs_tol(mdist.REL, nrm, TOL, float("inf"), world)) <= 1e-6 * atol
+            stream = highlevel.compress(slab, atol, float("inf"), mgard_amd.ABS, config=cfg, out=obuf)
+            ms = highlevel.metadata_parse(bytes(stream[:8192].cpu().numpy()))["metadata_size"]
+            return stream[ms + 8:]        # the subdomain's record without its own size prefix
+        record = timed("compress", lambda: local(compress))
         payloads = timed("gather", lambda: mdist.gather_payloads(record, dst=0))
         return slab, nrm, payloads
 
-    slab, nrm, payloads = round_trip()     # warm-up: allocations, hierarchies, RCCL channels
-    del slab, payloads
-    slab, nrm, payloads = round_trip()
+    try:
+        slab, nrm, payloads = round_trip()     # warm-up: allocations, hierarchies, RCCL channels
+        del slab, payloads
+        slab, nrm, payloads = round_trip()
+    except PhaseError as e:
+        del vol, obuf
+        highlevel.release_cache()
+        torch.cuda.empty_cache()
+        return {"error": "a phase failed on some rank: %s" % e}
     out = {"workload": "4D %dx512x512x512 float32 device-resident on rank 0: RCCL block scatter -> norm all-reduce "
                        "-> mgh_compress per slab -> RCCL payload gather -> one container" % shape[0],
            "ranks": world, "volume_GB": round(world * slab_bytes / 1e9, 2)}
@@ -989,7 +1040,12 @@ def main():
         else:
             # N > 1: configs[3] as it is meant -- the 64 x 512^3 volume split on dim 0, one
             # 8 x 512^3 slab per rank (weak scaling), scalar norm all-reduce over RCCL
-            oc["4d"] = config_leg(torch, mgard_amd, "4d", dev, local_rank, dist=dist, world=world, rank=rank)
+            try:
+                oc["4d"] = config_leg(torch, mgard_amd, "4d", dev, local_rank, dist=dist, world=world, rank=rank)
+            except (mgard_amd.MgardHipError, RuntimeError, AssertionError) as e:
+                # (a failure every rank sees alike, e.g. the outlier assertion; rank-local ones are agreed
+                # on inside the leg before any collective)
+                oc["4d"] = {"error": str(e)[:300]}
             # ... and with the block scatter / payload gather north_star names, timed phase by phase
             try:
                 oc["scatter_gather"] = scatter_gather_leg(torch, mgard_amd, dist, dev, local_rank, rank, world,

@@ -138,6 +138,9 @@ bool is_registered_host(const void *p) {
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
   int ensure(size_t bytes) {
     if (bytes <= cap) return MGH_SUCCESS;
     if (p) (void)hipFree(p);
@@ -314,7 +317,11 @@ int record_write(mgh_lossless_ctx *c, void *dst, hipStream_t st, const uint64_t 
   // travel with the head of the record in ONE copy out of the pinned buffer
   char *d = (char *)dst;
   if (c->on_host) {
-    if (size_prefix) HL_HIP(hipMemcpyAsync(d - 8, size_prefix, 8, hipMemcpyDefault, st));
+    if (size_prefix) {
+      // (through the context's pinned buffer: the caller's variable may be gone before the queued copy runs)
+      std::memcpy(c->chead - 8, size_prefix, 8);
+      HL_HIP(hipMemcpyAsync(d - 8, c->chead - 8, 8, hipMemcpyDefault, st));
+    }
     HL_HIP(hipMemcpyAsync(d, c->host.data(), c->host.size(), hipMemcpyDefault, st));
     return MGH_SUCCESS;
   }
@@ -1314,12 +1321,22 @@ int cache_prepare(int dev) {
     // before the first pipeline stage reads it, and work the caller queues on the NULL stream
     // afterwards waits for the pipeline. Inputs produced on OTHER non-blocking streams must be
     // synchronised by the caller (include/mgard_hip_compress.h).
-    for (auto &l : g_cache.lane) {
-      HL_HIP(hipStreamCreate(&l.st));
-      HL_TRY(mgh_lossless_create(&l.ll, dev));
+    // The two lanes must sit on DIFFERENT hardware queues, or the pipeline is a sequence again. The
+    // runtime multiplexes all streams of one priority over a few hardware queues (GPU_MAX_HW_QUEUES,
+    // 4 by default) by use count: in a process that already holds many streams -- torch keeps a pool
+    // of 32 -- two freshly created ones can share a queue (seen in bench.py: both lanes on one queue,
+    // 64 x 512^3 decompression 97 instead of 86 ms). Queues are pooled PER PRIORITY, so the lanes get
+    // different priorities (they swap roles with every subdomain, neither is favoured for long), and
+    // the copy / small-read streams the third level, away from both.
+    int prio_least = 0, prio_greatest = 0;
+    HL_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    const bool three = prio_least > 0 && prio_greatest < 0;
+    for (int l = 0; l < kLanes; l++) {
+      HL_HIP(hipStreamCreateWithPriority(&g_cache.lane[l].st, hipStreamDefault, l == 0 ? 0 : prio_greatest));
+      HL_TRY(mgh_lossless_create(&g_cache.lane[l].ll, dev));
     }
-    HL_HIP(hipStreamCreate(&g_cache.copy_st));
-    HL_HIP(hipStreamCreate(&g_cache.aux_st));
+    HL_HIP(hipStreamCreateWithPriority(&g_cache.copy_st, hipStreamDefault, three ? prio_least : 0));
+    HL_HIP(hipStreamCreateWithPriority(&g_cache.aux_st, hipStreamDefault, three ? prio_least : 0));
     for (auto &e : g_cache.in_ready) HL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : g_cache.in_free) HL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HL_TRY(g_cache.aux_pin.ensure(512 * 1024));
@@ -2218,10 +2235,19 @@ int compress_multi_impl(int ndev, const int *devs, int D, int dtype, const uint6
           // and kept when it is the worker's only one (the usual case: one slab per device)
           std::vector<uint64_t> mine;
           for (uint64_t id = k; id < num; id += nthr) mine.push_back(id);
-          DevBuf peer;  // the worker's copy of a remote slab
-          uint64_t peer_id = ~(uint64_t)0;
+          // the worker's copies of its remote slabs: every one travels ONCE and serves both the
+          // norm and the compression; if they do not all fit the device, the oldest ones are
+          // dropped and fetched again when their turn comes
+          std::vector<std::pair<uint64_t, std::unique_ptr<DevBuf>>> peers;
+          struct PeerGuard {  // (released on every way out of the worker, exceptions included)
+            std::vector<std::pair<uint64_t, std::unique_ptr<DevBuf>>> &v;
+            ~PeerGuard() {
+              for (auto &kv : v) kv.second->release();
+              v.clear();
+            }
+          } peer_guard{peers};
           auto local_ptr = [&](uint64_t id, const void **out) -> int {
-            // where this worker reads slab id from: host memory, the source device itself, or `peer`
+            // where this worker reads slab id from: host memory, the source device itself, or a peer copy
             // (MGH_MULTI_FORCE_PEER=1: take the peer copy also when the slab is already on the
             // worker's device -- the one-GPU test of that path)
             static const bool force_peer = env_get("MGH_MULTI_FORCE_PEER", 0) != 0;
@@ -2229,14 +2255,22 @@ int compress_multi_impl(int ndev, const int *devs, int D, int dtype, const uint6
               *out = slab_ptr(id);
               return MGH_SUCCESS;
             }
+            for (auto &kv : peers)
+              if (kv.first == id) {
+                *out = kv.second->p;
+                return MGH_SUCCESS;
+              }
             const size_t bytes = inner * dd.subdomain_shape(id)[0] * elem;
-            if (peer_id != id) {
-              HL_TRY(peer.ensure(bytes));
-              HL_HIP(hipMemcpyPeerAsync(peer.p, c.dev_id, slab_ptr(id), src_dev, bytes, g_cache.lane[0].st));
-              HL_HIP(hipStreamSynchronize(g_cache.lane[0].st));
-              peer_id = id;
+            std::unique_ptr<DevBuf> nb(new DevBuf());
+            while (nb->ensure(bytes) != MGH_SUCCESS) {
+              if (peers.empty()) return hl_fail(MGH_ERR_OUT_OF_MEMORY, "peer copy of a slab");
+              peers.front().second->release();
+              peers.erase(peers.begin());
             }
-            *out = peer.p;
+            HL_HIP(hipMemcpyPeerAsync(nb->p, c.dev_id, slab_ptr(id), src_dev, bytes, g_cache.lane[0].st));
+            HL_HIP(hipStreamSynchronize(g_cache.lane[0].st));
+            *out = nb->p;
+            peers.emplace_back(id, std::move(nb));
             return MGH_SUCCESS;
           };
           if (ok && ebtype == MGH_REL) {
@@ -2275,10 +2309,15 @@ int compress_multi_impl(int ndev, const int *devs, int D, int dtype, const uint6
                 rc = mgh_compress(D, dtype, sshape.data(), (double)local_tol, s_d, MGH_ABS, src, &part[id], &sz,
                                   cp, &c, 0);
               part_size[id] = sz;
+              for (size_t k = 0; k < peers.size(); k++)  // (this slab's copy has served its purpose)
+                if (peers[k].first == id) {
+                  peers[k].second->release();
+                  peers.erase(peers.begin() + k);
+                  break;
+                }
               if (rc != MGH_SUCCESS) err.set(rc);
             }
           }
-          peer.release();
           worker_thread_teardown();
         } catch (const std::exception &e) {
           // (an exception must not leave a worker thread: std::terminate)

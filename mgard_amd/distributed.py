@@ -52,13 +52,16 @@ def split_slowest(shape, world_size, rank):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def scatter_slabs(full, shape, src=0, group=None, device=None, dtype=None):
+def scatter_slabs(full, shape, src=0, group=None, device=None, dtype=None, copy=False):
     """Block scatter of the domain decomposition (reference: DomainDecomposer::copy_subdomain,
     DomainDecomposer.hpp:649-845, across devices): rank `src` holds the whole array `full`
     (shape `shape`, C order) and sends every other rank its contiguous slab along the slowest
     dimension with point-to-point sends (RCCL send/recv over xGMI with backend "nccl"; there is
     no halo, subdomains share no nodes). Returns this rank's slab. `full` is only read on `src`;
-    the other ranks pass None and must give `dtype`."""
+    the other ranks pass None and must give `dtype`.
+    ALIASING: on `src` the returned slab is a VIEW of `full` (nothing is copied there): changing or
+    freeing `full` afterwards changes the slab. Pass copy=True for a slab of its own. `full` must be
+    C-contiguous (ValueError otherwise)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
@@ -70,7 +73,8 @@ def scatter_slabs(full, shape, src=0, group=None, device=None, dtype=None):
     if rank == src:
         # slabs of the slowest dimension are contiguous views: every send streams straight out of
         # `full` (no staging copy), all of them in flight at once -- one xGMI link per peer
-        assert full.is_contiguous(), "the array to scatter must be C-contiguous"
+        if not full.is_contiguous():
+            raise ValueError("scatter_slabs: the array to scatter must be C-contiguous")
         reqs = []
         for r in range(world):
             if r == src:
@@ -79,7 +83,7 @@ def scatter_slabs(full, shape, src=0, group=None, device=None, dtype=None):
             reqs.append(dist.isend(full[a:b], dst=g(r), group=group))
         for q in reqs:
             q.wait()
-        return full[lo:hi]  # (a view: the caller's own slab is not copied either)
+        return full[lo:hi].clone() if copy else full[lo:hi]  # (a view unless asked otherwise)
     mine = torch.empty((hi - lo,) + tuple(shape[1:]), dtype=dtype, device=device)
     dist.recv(mine, src=g(src), group=group)
     return mine
