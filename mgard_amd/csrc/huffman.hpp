@@ -447,6 +447,7 @@ k_encode_chain(const SYM *__restrict__ q, size_t n, int chunk, int dict, size_t 
                const CODE *__restrict__ code, unsigned long long *__restrict__ state,
                unsigned long long *__restrict__ bits, unsigned long long *__restrict__ entry,
                unsigned long long *__restrict__ out, unsigned long long cap_units, int nlong) {
+  constexpr int SH = CodeEntry<CODE>::shift;
   // LDS: code table [dict] | symbols of the chunk (encode_chain_lds() is the host's copy of this
   // layout). The escape list stays in global memory behind the table (8-byte aligned): its entries
   // belong to symbols that occur a handful of times in the whole subdomain.
@@ -486,7 +487,40 @@ k_encode_chain(const SYM *__restrict__ q, size_t n, int chunk, int dict, size_t 
   CODE cc[RR];
   const bool in_regs = run <= (size_t)RR;
   unsigned s = 0;
-  if (in_regs) {
+  // Fast path: a full chunk of the default size with a 32-bit table (every thread has exactly RR
+  // symbols). The generic loop below tests `lo + k < hi` per symbol, which puts every look-up into
+  // a basic block of its own -- symbol load, wait, table load, wait, 40 times in a row. Here the
+  // thread's 80 bytes of symbols arrive as five 16-byte LDS reads (lane stride 80 bytes = 20 banks:
+  // conflict-free) and the 40 table look-ups are issued back to back. Escape entries (codes longer
+  // than 27 bits: the rarest symbols) only raise a flag; a thread that holds one recounts and packs
+  // on the generic path.
+  const bool fast = sizeof(CODE) == 4 && cnt == (size_t)RR * kEncThreads;
+  bool esc = false;
+  if (fast) {
+    const uint4 *sp = reinterpret_cast<const uint4 *>(ssym + (size_t)threadIdx.x * RR);
+    unsigned wv[RR / 2];
+#pragma unroll
+    for (int j = 0; j < RR / 8; j++) {
+      const uint4 t4 = sp[j];
+      wv[4 * j + 0] = t4.x;
+      wv[4 * j + 1] = t4.y;
+      wv[4 * j + 2] = t4.z;
+      wv[4 * j + 3] = t4.w;
+    }
+#pragma unroll
+    for (int k = 0; k < RR; k++) cc[k] = scode[(k & 1) ? (wv[k / 2] >> 16) : (wv[k / 2] & 0xffffu)];
+#pragma unroll
+    for (int k = 0; k < RR; k++) {
+      const unsigned l = (unsigned)(cc[k] >> SH);
+      esc |= l == kEscapeLen;
+      s += l;
+    }
+    if (esc) {  // (unrolled: a loop would index cc[] dynamically and send the array to scratch)
+      s = 0;
+#pragma unroll
+      for (int k = 0; k < RR; k++) s += entry_len(cc[k], slong);
+    }
+  } else if (in_regs) {
 #pragma unroll
     for (int k = 0; k < RR; k++) {
       cc[k] = lo + k < hi ? scode[ssym[lo + k]] : (CODE)0;  // (a zero entry packs nothing)
@@ -605,7 +639,32 @@ k_encode_chain(const SYM *__restrict__ q, size_t n, int chunk, int dict, size_t 
     unsigned long long *obuf = reinterpret_cast<unsigned long long *>(ssym);
     for (size_t i = threadIdx.x; i < my_units; i += kEncThreads) obuf[i] = 0;
     __syncthreads();
-    if (active) pack(obuf);
+    if (fast && !esc) {
+      // Branch-light packing in 32-bit words: codes of at most 27 bits are appended to a 64-bit
+      // accumulator that never holds 32 or more bits between two symbols (31 + 27 < 64), a full
+      // upper half is OR-ed into the stream (word w of the MSB-first stream is the 32-bit half
+      // w ^ 1 of the little-endian 64-bit units). Every word goes out by ds_or, so the words a
+      // run shares with its neighbours need no special case.
+      unsigned *o32 = reinterpret_cast<unsigned *>(obuf);
+      unsigned wi = pos >> 5, fill = pos & 31;
+      unsigned long long acc = 0;
+#pragma unroll
+      for (int k = 0; k < RR; k++) {
+        const unsigned len = (unsigned)(cc[k] >> SH);
+        const unsigned long long val = (unsigned long long)(cc[k] & (((CODE)1 << SH) - 1));
+        acc |= val << (64 - fill - len);
+        fill += len;
+        if (fill >= 32) {
+          atomicOr(&o32[wi ^ 1], (unsigned)(acc >> 32));
+          acc <<= 32;
+          fill -= 32;
+          wi++;
+        }
+      }
+      if (fill) atomicOr(&o32[wi ^ 1], (unsigned)(acc >> 32));
+    } else if (active) {
+      pack(obuf);
+    }
     __syncthreads();
     for (size_t i = threadIdx.x; i < my_units; i += kEncThreads) store_unit(dst, i, obuf[i]);
   } else {
