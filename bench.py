@@ -97,6 +97,29 @@ def algorithmic_bytes_per_step(h, esz):
     return out
 
 
+TRAFFIC_FILES = {"512f32": "traffic_512cube_f32.json", "1024f32": "traffic_1024cube_f32.json",
+                 "512f64nu": "traffic_512cube_f64nu.json", "4d": "traffic_4d_slab_f32.json"}
+
+
+def pmc_traffic(config_name, kernel):
+    """(bytes per launch or None, note) of `kernel` from the committed rocprofv3 PMC passes of this
+    configuration (profiles/traffic_*.json, tools/make_traffic.py). A file taken on other kernel
+    sources than the ones this run loads is refused."""
+    tname = TRAFFIC_FILES.get(config_name)
+    tpath = os.path.join(ROOT, "profiles", tname or "none")
+    if not tname or not os.path.exists(tpath):
+        return None, "no PMC traffic file for this configuration"
+    tj = json.load(open(tpath))
+    if tj.get("source_hash") != source_hash():
+        return None, "profiles/%s was taken on other kernel sources (hash %s, now %s): refused" % (
+            tname, tj.get("source_hash"), source_hash())
+    t = tj.get(kernel)
+    if not t:
+        return None, "profiles/%s has no entry for %s" % (tname, kernel)
+    return (int((t["fetch_kib"] * t["read_correction"] + t["write_kib"]) * 1024),
+            "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on these kernel sources, per launch")
+
+
 def _oracle_step(o, oracle, u, tol, s):
     import numpy as np
     t0 = time.perf_counter()
@@ -439,11 +462,24 @@ def config_leg(torch, mgard_amd, name, dev, local_rank, steps=5, end_to_end=Fals
     for _ in range(2):
         step()
     barrier()
+    # per-kernel breakdown (HIP events on every launch, untimed), then the timed steps with events
+    # on the dominant kernel's launches only -- like the metric's leg
+    NPROF = 2
+    h.profile(True)
+    for _ in range(NPROF):
+        step()
+    torch.cuda.synchronize()
+    prof = h.profile_read(reset=True)
+    dominant = max(prof.items(), key=lambda kv: kv[1][0])[0]
+    h.profile(True, only=dominant)
+    barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     barrier()
     el = time.perf_counter() - t0
+    dom_ms, dom_launches = h.profile_read(reset=True)[dominant]
+    h.profile(False)
     if dist is not None:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -456,6 +492,15 @@ def config_leg(torch, mgard_amd, name, dev, local_rank, steps=5, end_to_end=Fals
            "hbm_frac_whole_step": round((np_dt.itemsize + 8.0) * N / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
            "outliers_per_step": int(cnt.item()),
            "data": "synthetic, generated on the device (same recipe as the metric's field)"}
+    alg = algorithmic_bytes_per_step(h, np_dt.itemsize)
+    achieved = alg.get(dominant, 0) * steps / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    traffic, traffic_note = pmc_traffic(name, dominant)
+    out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                       "traffic_source": traffic_note,
+                       "avg_launch_ms": round(dom_ms / max(dom_launches, 1), 5), "launches": dom_launches,
+                       "algorithmic_bytes_per_step": alg.get(dominant, 0),
+                       "kernel_ms_per_step_all": {k: round(v[0] / NPROF, 4) for k, v in sorted(prof.items())}}
     assert out["outliers_per_step"] <= cap
     if end_to_end:
         # configs[4]: compress + decompress round trip through the container, error against the
@@ -815,19 +860,8 @@ def main():
 
     # HBM traffic of the dominant kernel from the committed PMC passes (same workload only)
     # (a file taken on other kernel sources than the ones this run loads is refused)
-    traffic = None
-    traffic_note = "no PMC traffic file for this configuration"
-    tname = {"512f32": "traffic_512cube_f32.json", "1024f32": "traffic_1024cube_f32.json"}.get(args.config)
-    tpath = os.path.join(ROOT, "profiles", tname or "none")
-    if tname and not args.shape and os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        t = tj.get(dominant)
-        if tj.get("source_hash") != source_hash():
-            traffic_note = "profiles/%s was taken on other kernel sources (hash %s, now %s): refused" % (
-                tname, tj.get("source_hash"), source_hash())
-        elif t:
-            traffic = int((t["fetch_kib"] * t["read_correction"] + t["write_kib"]) * 1024)
-            traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on these kernel sources, per launch"
+    traffic, traffic_note = (None, "no PMC traffic file for this configuration") if args.shape else \
+        pmc_traffic(args.config, dominant)
     in_bytes = N * esz
     value = in_bytes * args.steps * world / elapsed / 1e9
     alg = algorithmic_bytes_per_step(h, esz)

@@ -1856,7 +1856,7 @@ int quantize_impl(mgh_hierarchy *h, const T *coeff, int ebtype, double tol, doub
   TRY(upload_quantizers<T>(h, ebtype, tol, s, norm, true, st));
   if (ocount) HIP_TRY(hipMemsetAsync(ocount, 0, sizeof(uint64_t), st));
   const size_t total = h->total;
-  const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 32);
+  const unsigned grid = (unsigned)std::min<size_t>((total + kQuantPerRound - 1) / kQuantPerRound, 256 * 32);
   TRY(launch(h, "quantize", st, [&] {
     k_quantize<T><<<grid, 256, 0, st>>>(ds->qmeta, total, coeff, ds->marks, ds->qz,
                                         ds->qz + (h->L + 1), (int64_t)dict_size, prep_huffman, q,

@@ -981,3 +981,31 @@ def test_records_in_device_memory_at_any_byte_offset(shift):
     with pytest.raises(mg.MgardHipError):
         ctx.compress_device(d_q, torch.zeros(1000, dtype=torch.uint8, device="cuda"), 8192, 20480)
     ctx.close()
+
+
+@pytest.mark.parametrize("lossless", ["HUFFMAN_LZ4", "CPU_LOSSLESS"])
+def test_unsupported_lossless_types_are_refused_with_a_fixed_status(lossless):
+    """lossless_type::Huffman_LZ4 (needs nvcomp upstream, Lossless/LZ4.hpp) and CPU_Lossless (the
+    legacy MGARD-CPU Huffman + zstd stream, Lossless/CPU.hpp) are not built here.
+    What a caller gets is pinned: the writer refuses the config with MGH_ERR_INVALID_ARGUMENT (-1) and
+    a message that names the two supported types, the reader refuses a stream whose header carries
+    such a type with MGH_ERR_FORMAT (-8) -- never a crash, never a silently different stream."""
+    torch, mg, hl = _mods()
+    kind = getattr(hl, lossless)
+    u = smooth_field((33, 40, 65), np.float32)
+    with pytest.raises(mg.MgardHipError, match=r"-1.*only Huffman and Huffman_Zstd"):
+        hl.compress(u, 1e-3, np.inf, mg.REL, config=hl.Config(lossless=kind))
+    with pytest.raises(mg.MgardHipError, match=r"-1.*only Huffman and Huffman_Zstd"):
+        hl.compress(torch.from_numpy(u).cuda(), 1e-3, np.inf, mg.REL, config=hl.Config(lossless=kind))
+    # a stock stream of that type: its header in front of some payload bytes
+    good = hl.compress(u, 1e-3, np.inf, mg.REL)
+    m = hl.metadata_parse(bytes(good))
+    head = hl.metadata_serialize(mg.FLOAT, list(u.shape), mg.REL, 1e-3, float("inf"), norm=m["norm"], lossless=kind)
+    assert hl.metadata_parse(head)["lossless"] == kind
+    stream = np.frombuffer(head + bytes(good)[m["metadata_size"]:], dtype=np.uint8).copy()
+    with pytest.raises(mg.MgardHipError, match=r"-8.*not supported"):
+        hl.decompress(stream)
+    with pytest.raises(mg.MgardHipError, match=r"-8.*not supported"):
+        hl.decompress(torch.from_numpy(stream).cuda())
+    # the library is fine afterwards
+    assert np.array_equal(hl.decompress(good), hl.decompress(hl.compress(u, 1e-3, np.inf, mg.REL)))

@@ -1,0 +1,23 @@
+"""Per-kernel times of the 5-D step (8 x 8 x 64^3 f32). Dev tool."""
+import sys, os, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mgard_amd
+from tests.util import smooth_field
+shape = tuple(int(x) for x in sys.argv[1].split("x")) if len(sys.argv) > 1 else (8, 8, 64, 64, 64)
+u = smooth_field(shape, np.float32)
+d = torch.from_numpy(u).cuda()
+h = mgard_amd.Hierarchy(shape, np.float32)
+N = u.size
+q = torch.empty(shape, dtype=torch.int64, device='cuda'); cnt = torch.zeros(1, dtype=torch.int64, device='cuda')
+oi = torch.empty(N, dtype=torch.int64, device='cuda'); ov = torch.empty(N, dtype=torch.int64, device='cuda')
+f = lambda: h.decompose_quantize(d, mgard_amd.REL, 1e-3, float('inf'), 0.0, bufs=(q, cnt, oi, ov), want_norm=False)
+for _ in range(2): f()
+torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(5): f()
+torch.cuda.synchronize(); ms = (time.perf_counter() - t) / 5 * 1e3
+print(shape, "%.3f ms  %.1f GB/s" % (ms, u.nbytes / ms / 1e6), "L =", h.l_target)
+h.profile(True)
+for _ in range(3): f()
+torch.cuda.synchronize()
+for k, v in sorted(h.profile_read(reset=True).items(), key=lambda kv: -kv[1][0]):
+    print("  %-22s %8.1f us/step  %4d launches/step" % (k, v[0] / 3 * 1e3, v[1] // 3))

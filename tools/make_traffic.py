@@ -56,13 +56,35 @@ def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {"_about": __doc__.strip(), "source_hash": source_hash()}
-    for label, needle, corr in (("level_fused_q", "k_level_fused2", 2.0), ("absmax", "k_absmax", 2.0)):
-        f, nf = biggest(fetch, needle)
-        w, nw = biggest(write, needle)
+    for label, needle, corr in (("level_fused_q", "k_level_fused2", 2.0), ("absmax", "k_absmax", 2.0),
+                                ("sqsum", "k_sqsum", 2.0)):
+        pick = (lambda st: {k: v for k, v in st.items() if "ELi0EEEv" in k[0]}) if needle == "k_level_fused2" else (lambda st: st)
+        f, nf = biggest(pick(fetch), needle)
+        w, nw = biggest(pick(write), needle)
         if f is None or w is None:
             continue
         out[label] = {"fetch_kib": round(f, 1), "write_kib": round(w, 1), "read_correction": corr,
                       "dispatches": [nf, nw]}
+    # D = 4: the level kernel under the names the library profiles it with, per t-slice parity
+    # (template argument TMODE = 1 / 2 at the end of the symbol; absent from a 3-D run)
+    for label, tmode in (("level4_even", 1), ("level4_odd", 2)):
+        sub_f = {k: v for k, v in fetch.items() if "k_level_fused2" in k[0] and ("ELi%dEEEv" % tmode) in k[0]}
+        sub_w = {k: v for k, v in write.items() if "k_level_fused2" in k[0] and ("ELi%dEEEv" % tmode) in k[0]}
+        f, nf = biggest(sub_f, "k_level_fused2")
+        w, nw = biggest(sub_w, "k_level_fused2")
+        if f is not None and w is not None:
+            out[label] = {"fetch_kib": round(f, 1), "write_kib": round(w, 1), "read_correction": 2.0,
+                          "dispatches": [nf, nw]}
+    # the Thomas solves: ALL k_ipk* launches of one step together (the kernels and their launch
+    # counts differ between configurations: LDS-staged, streaming, LDS-DMA, plane-fused, ranges of
+    # r-planes at 1024^3), against ipk_f + ipk_c + ipk_r of bench.py:algorithmic_bytes_per_step
+    steps_f = max(len(v) for k, v in fetch.items() if "k_make_qparams" in k[0]) if any("k_make_qparams" in k[0] for k in fetch) else 1
+    steps_w = max(len(v) for k, v in write.items() if "k_make_qparams" in k[0]) if any("k_make_qparams" in k[0] for k in write) else 1
+    tf = sum(sum(v) for k, v in fetch.items() if "k_ipk" in k[0] or "k_tsolve" in k[0]) / steps_f
+    tw = sum(sum(v) for k, v in write.items() if "k_ipk" in k[0] or "k_tsolve" in k[0]) / steps_w
+    out["ipk_all_per_step"] = {"fetch_kib": round(tf, 1), "write_kib": round(tw, 1), "read_correction": 2.0,
+                               "steps": [steps_f, steps_w],
+                               "what": "every Thomas-solve launch of one step, summed"}
     name = sys.argv[4] if len(sys.argv) > 4 else "traffic_512cube_f32.json"
     json.dump(out, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
     if len(sys.argv) > 3:
