@@ -1414,11 +1414,11 @@ int decompose_impl(mgh_hierarchy *h, const T *data, T *coeff, hipStream_t s) {
 
 template <typename T, typename QT, typename QTL = QT>
 int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> &level_qv, T *data,
-                     hipStream_t st, const RecomposeArgs<T> *AL = nullptr);
+                     hipStream_t st, const RecomposeArgs<T> *AL = nullptr, int ntop = 1);
 
 template <typename T, typename QT, typename QTL = QT>
 int recompose_levels4(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> &level_qv, T *data,
-                      hipStream_t st, const RecomposeArgs<T> *AL = nullptr, size_t A_sT = 0);
+                      hipStream_t st, const RecomposeArgs<T> *AL = nullptr, size_t A_sT = 0, int ntop = 1);
 inline bool fused4_ok(const mgh_hierarchy *h);
 
 template <typename T>
@@ -1538,12 +1538,12 @@ int launch_loadvec(mgh_hierarchy *h, const RecomposeArgs<T> &A, const Box3 &b, h
   });
 }
 
-// QTL / AL: coefficient source of the FINEST level when it differs from that of the levels below
-// (16-bit symbols for the finest level, int64 of the coarse corner box for the rest:
+// QTL / AL: coefficient source of the `ntop` FINEST levels when it differs from that of the levels
+// below (16-bit symbols for the finest levels, int64 of the coarse corner box for the rest:
 // dequantize_recompose_fused16); AL == nullptr: one source for all levels.
 template <typename T, typename QT, typename QTL>
 int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> &level_qv, T *data,
-                     hipStream_t st, const RecomposeArgs<T> *AL) {
+                     hipStream_t st, const RecomposeArgs<T> *AL, int ntop) {
   auto *ds = DS<T>(h);
   const int L = h->L;
   // levels 1 .. l_head run inside ONE single-workgroup kernel (their working set fits in LDS);
@@ -1551,7 +1551,7 @@ int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> 
   const bool no_head = h->no_head;
   int l_head = 0;
   if (!no_head) {
-    for (int l = 1; l <= std::min(AL ? L - 1 : L, kTailMaxLevels); l++) {
+    for (int l = 1; l <= std::min(AL ? L - ntop : L, kTailMaxLevels); l++) {
       if ((head_lds_elems(ds->lt[l].box) + ds->lt_end[l]) * sizeof(T) > 150 * 1024) break;
       l_head = l;
     }
@@ -1592,7 +1592,7 @@ int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> 
   for (int l = l_head + 1; l <= L; l++) {
     const LevelTables<T> &t = ds->lt[l];
     const Box3 &b = t.box;
-    const bool top = AL && l == L;
+    const bool top = AL && l > L - ntop;
     RecomposeArgs<T> B = top ? *AL : A;
     for (int k = 0; k < 3; k++) {
       B.n[k] = (int)b.n[k];
@@ -1624,7 +1624,7 @@ int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> 
 // recompose_levels (the finest level's source has the full array's strides).
 template <typename T, typename QT, typename QTL>
 int recompose_levels4(mgh_hierarchy *h, RecomposeArgs<T> A0, const std::vector<T> &level_qv, T *data,
-                      hipStream_t st, const RecomposeArgs<T> *AL, size_t A_sT) {
+                      hipStream_t st, const RecomposeArgs<T> *AL, size_t A_sT, int ntop) {
   auto *ds = DS<T>(h);
   auto *hh = HH<T>(h);
   const int L = h->L;
@@ -1647,7 +1647,7 @@ int recompose_levels4(mgh_hierarchy *h, RecomposeArgs<T> A0, const std::vector<T
     }));
   }
   for (int l = 1; l <= L; l++) {
-    const bool top = AL && l == L;
+    const bool top = AL && l > L - ntop;
     RecomposeArgs<T> A = top ? *AL : A0;
     const size_t sT = top ? full[0] : A_sT;
     if (top) {
@@ -1787,15 +1787,17 @@ int dequantize_recompose_fused16(mgh_hierarchy *h, const uint16_t *sym, int ebty
   A.half = (int64_t)(dict_size / 2);
   std::vector<T> level_qv(L + 1);
   for (int l = 0; l <= L; l++) level_qv[l] = qz[l] * (calc_vol ? hh->level_volume(l, true) : (T)1);
-  // Symbol width PER LEVEL: only the finest level -- 7/8 (D = 3) or 15/16 (D = 4) of the array,
-  // where out-of-dictionary values are rare -- is read as 16-bit symbols with the table look-up
-  // behind symbol 0. The levels below hold nearly all the outliers, and a look-up there is a
-  // dependent global load inside latency-bound kernels (measured: slower than the int64 path
-  // at 256^3). Their symbols -- the coarse corner box of the reordered layout, 1/8 resp. 1/16 of
-  // the array -- are widened to int64 in a compact box with the outliers written over them, and
-  // those levels run the int64 kernels on it.
+  // Symbol width PER LEVEL: the finest levels -- where out-of-dictionary values are rare -- are
+  // read as 16-bit symbols with the table look-up behind symbol 0. The levels below hold nearly
+  // all the outliers, and a look-up there is a dependent global load inside latency-bound
+  // kernels (measured: slower than the int64 path at 256^3). Their symbols -- the coarse corner
+  // box of the reordered layout -- are widened to int64 in a compact box with the outliers
+  // written over them, and those levels run the int64 kernels on it. Two levels stay on symbols
+  // where the hierarchy is deep enough: the box is then 1/64 (D = 3) of the array instead of 1/8
+  // (512^3: widening the 257^3 box cost 51 us, almost all of it the 136 MB of int64 stores).
   if (h->sym16_mixed && L >= 2 && h->total >= ((uint64_t)1 << 18)) {
-    const auto &Mc = hh->level_shape[L - 1];
+    const int ntop = L >= 4 ? 2 : 1;
+    const auto &Mc = hh->level_shape[L - ntop];
     const auto &N = hh->level_shape[L];
     BoxMap bm{};
     for (int k = 0; k < 4; k++) bm.m[k] = bm.n[k] = 1;
@@ -1811,8 +1813,10 @@ int dequantize_recompose_fused16(mgh_hierarchy *h, const uint16_t *sym, int ebty
       HIP_TRY(hipMalloc(&ds->qbox, box * sizeof(int64_t)));
       ds->qbox_elems = box;
     }
+    const size_t rows = box / bm.m[3];
+    if (rows >= ((size_t)1 << 32)) return fail(MGH_ERR_INVALID_ARGUMENT, "coarse box too large");
     TRY(launch(h, "widen_box", st, [&] {
-      k_widen_box<<<(unsigned)std::min<size_t>((box + 255) / 256, 256 * 16), 256, 0, st>>>(sym, ds->qbox, bm, box);
+      k_widen_box<<<(unsigned)std::min<size_t>((rows + 3) / 4, 256 * 32), 256, 0, st>>>(sym, ds->qbox, bm, (uint32_t)rows);
     }));
     if (ocount)
       TRY(launch(h, "outlier_restore", st, [&] {
@@ -1824,8 +1828,8 @@ int dequantize_recompose_fused16(mgh_hierarchy *h, const uint16_t *sym, int ebty
     A64.dI = (size_t)bm.m[2] * bm.m[3];
     A64.half = A.half;
     if (h->D == 4)
-      return recompose_levels4<T, int64_t, uint16_t>(h, A64, level_qv, data, st, &A, (size_t)bm.m[1] * bm.m[2] * bm.m[3]);
-    return recompose_levels<T, int64_t, uint16_t>(h, A64, level_qv, data, st, &A);
+      return recompose_levels4<T, int64_t, uint16_t>(h, A64, level_qv, data, st, &A, (size_t)bm.m[1] * bm.m[2] * bm.m[3], ntop);
+    return recompose_levels<T, int64_t, uint16_t>(h, A64, level_qv, data, st, &A, ntop);
   }
   if (h->D == 4) return recompose_levels4<T, uint16_t>(h, A, level_qv, data, st);
   return recompose_levels<T, uint16_t>(h, A, level_qv, data, st);

@@ -464,15 +464,16 @@ struct BoxMap {
   uint32_t n[4];  // the full array
   uint32_t m[4];  // the box [0, m0) x [0, m1) x [0, m2) x [0, m3)
 };
+// (one wave per row of the box: the row's position is scalar arithmetic, the lanes stream it)
 __global__ void __launch_bounds__(256)
-k_widen_box(const uint16_t *__restrict__ sym, int64_t *__restrict__ box, BoxMap B, size_t count) {
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) {
-    const uint32_t f = (uint32_t)(e % B.m[3]);
-    size_t r = e / B.m[3];
-    const uint32_t c = (uint32_t)(r % B.m[2]);
-    r /= B.m[2];
-    const uint32_t i = (uint32_t)(r % B.m[1]), t = (uint32_t)(r / B.m[1]);
-    box[e] = (int64_t)sym[(((size_t)t * B.n[1] + i) * B.n[2] + c) * B.n[3] + f];
+k_widen_box(const uint16_t *__restrict__ sym, int64_t *__restrict__ box, BoxMap B, uint32_t rows) {
+  const int lane = threadIdx.x & 63;
+  for (uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+    const uint32_t c = row % B.m[2], ti = row / B.m[2];
+    const uint32_t i = ti % B.m[1], t = ti / B.m[1];
+    const uint16_t *src = sym + (((size_t)t * B.n[1] + i) * B.n[2] + c) * B.n[3];
+    int64_t *dst = box + (size_t)row * B.m[3];
+    for (uint32_t f = lane; f < B.m[3]; f += 64) dst[f] = (int64_t)src[f];
   }
 }
 __global__ void __launch_bounds__(256)
