@@ -18,10 +18,17 @@
  * Also pinned (tests/test_oracle_goldens.py): one EVEN-size case (the ghost-node
  * rule) derived from the 1-D golden through the even = odd embedding, and the
  * scalar quantizer's known answers (tests/src/test_LinearQuantizer.cpp:94-111).
+ * NON-UNIFORM spacing and the operators themselves (tests/test_oracle_operator_goldens.py):
+ * the known answers of the reference's mass-matrix / restriction / prolongation tests on
+ * default and custom spacing (tests/src/test_TensorMassMatrix.cpp:21-262,
+ * test_TensorRestriction.cpp:18-221, test_TensorProlongation.cpp:16-106) pin dense-matrix forms
+ * of the three operators; the line operators below (test hooks mgxo_op_*) equal those matrices,
+ * and a decomposition assembled from them equals mgxo_decompose on non-uniform dyadic grids.
  * The MGARD-X SERIAL backend itself cannot be built under this repo's rules
  * (it needs the cmake-generated MGARDXConfig.h and zstd headers that are not on
- * the system include path), so for general NON-dyadic 2-D / 3-D shapes and for
- * the level-dependent quantizers (s != infinity) parity is "unpinned": it rests
+ * the system include path), so for general NON-dyadic 2-D / 3-D shapes (the
+ * ghost-node rule beyond that one case) and for the level-dependent quantizers
+ * (s != infinity) parity is "unpinned": it rests
  * on the code reading cited in mgx_oracle_impl.h plus structural property tests
  * (tests/test_oracle_properties.py).
  *

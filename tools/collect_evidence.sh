@@ -21,13 +21,18 @@ for c in 512:tl512 1024:tl1024 4d:tl4d f64:tlf64; do
   cp $O/$d/timeline.txt $P/${TAG}_timeline_$n.txt
   cp $O/$d/kernel_times.csv $P/${TAG}_step_only_kernel_times_$n.csv
 done
-cp $O/traffic_512cube_f32.json $O/traffic_1024cube_f32.json $P/
+cp $O/traffic_512cube_f32.json $O/traffic_1024cube_f32.json $O/traffic_512cube_f64nu.json $O/traffic_4d_slab_f32.json $P/
+cp $O/pmc_raw_f64nu.json $P/${TAG}_pmc_counters_512cube_f64nu.json
+cp $O/pmc_raw_4d.json $P/${TAG}_pmc_counters_4d_slab_f32.json
+for f in hl_pipeline_lanes hl_pipeline_sequential hl_pipeline_ab recompose_profile 5d_profile e2e_512 grid_barrier; do
+  [ -f $O/$f.txt ] && grep -v "amdgpu.ids" $O/$f.txt > $P/${TAG}_$f.txt
+done
 python - <<PY
 import json, sys
 sys.path.insert(0, '.')
 import bench
 h = bench.source_hash()
-for f in ("traffic_512cube_f32.json", "traffic_1024cube_f32.json"):
+for f in ("traffic_512cube_f32.json", "traffic_1024cube_f32.json", "traffic_512cube_f64nu.json", "traffic_4d_slab_f32.json"):
     t = json.load(open("profiles/" + f))
     print(f, "source_hash", t.get("source_hash"), "matches" if t.get("source_hash") == h else "DOES NOT MATCH", h)
 PY

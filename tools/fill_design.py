@@ -24,6 +24,9 @@ R = {
  "KVS": "%.2f" % d["roofline"].get("stream_calibration", {}).get("kernel_vs_stream_time", 0.0),
  "A1024": "%.0f" % (1000 * k1024["absmax"]),
 }
+rf = oc["512f64nu"].get("roofline", {})
+R["F64FR"] = "%.1f" % (100 * rf.get("frac", 0))
+R["F64TR"] = "%.2f" % ((rf.get("traffic") or 0) / max(rf.get("algorithmic_bytes_per_step", 1), 1))
 vol = oc.get("4d_volume", {})
 if "compress_ms" in vol:
     R.update({"VOLC": "%.1f" % vol["compress_ms"], "VOLCG": "%.0f" % vol["compress_GBps"], "VOLD": "%.1f" % vol["decompress_ms"],

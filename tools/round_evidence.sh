@@ -17,10 +17,30 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -- python3 $R/bench.py --s
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -- python3 $R/bench.py --steps 3 --warmup 1 --only-step > $O/write.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch1024 -- python3 $R/bench.py --config 1024f32 --steps 3 --warmup 1 --only-step > $O/fetch1024.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write1024 -- python3 $R/bench.py --config 1024f32 --steps 3 --warmup 1 --only-step > $O/write1024.log 2>&1
+for c in 512f64nu:f64nu 4d:4d; do
+  cfg=${c%%:*}; d=${c##*:}
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch_$d -- python3 $R/bench.py --config $cfg --steps 3 --warmup 1 --only-step > $O/fetch_$d.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write_$d -- python3 $R/bench.py --config $cfg --steps 3 --warmup 1 --only-step > $O/write_$d.log 2>&1
+done
+# the two-lane subdomain pipeline of mgh_compress / mgh_decompress on the 64 x 512^3 volume: which
+# queue runs what, pipelined and sequential (MGH_HL_PIPELINE=0)
+rocprofv3 --kernel-trace -d $O/lanes1 -- python3 $R/tools/exp_hl_pipeline.py 64 1 --once > $O/lanes1.log 2>&1
+rocprofv3 --kernel-trace -d $O/lanes0 -- python3 $R/tools/exp_hl_pipeline.py 64 1 --once --seq > $O/lanes0.log 2>&1
 cd $R
+python3 tools/lanes_timeline.py $(ls $O/lanes1/*/*.db | head -1) --window-ms 170 --min-us 250 > $O/hl_pipeline_lanes.txt 2>&1
+python3 tools/lanes_timeline.py $(ls $O/lanes0/*/*.db | head -1) --window-ms 185 --min-us 250 > $O/hl_pipeline_sequential.txt 2>&1
+python3 tools/exp_hl_pipeline.py 64 3 > $O/hl_pipeline_ab.txt 2>&1
+python3 tools/exp_recompose_profile.py > $O/recompose_profile.txt 2>&1
+python3 tools/exp_5d_profile.py > $O/5d_profile.txt 2>&1
+python3 tools/exp_e2e_out.py > $O/e2e_512.txt 2>&1
+[ -x tools/micro/grid_barrier ] && ./tools/micro/grid_barrier > $O/grid_barrier.txt 2>&1
+rm -rf $O/lanes1 $O/lanes0
+python tools/make_traffic.py $(ls $O/fetch_f64nu/*/*.db | head -1) $(ls $O/write_f64nu/*/*.db | head -1) $O/pmc_raw_f64nu.json traffic_512cube_f64nu.json > $O/traffic_f64nu.txt 2>&1
+python tools/make_traffic.py $(ls $O/fetch_4d/*/*.db | head -1) $(ls $O/write_4d/*/*.db | head -1) $O/pmc_raw_4d.json traffic_4d_slab_f32.json > $O/traffic_4d.txt 2>&1
+rm -rf $O/fetch_f64nu $O/write_f64nu $O/fetch_4d $O/write_4d
 python tools/make_traffic.py $(ls $O/fetch/*/*.db | head -1) $(ls $O/write/*/*.db | head -1) $O/pmc_raw.json > $O/traffic.txt 2>&1
 python tools/make_traffic.py $(ls $O/fetch1024/*/*.db | head -1) $(ls $O/write1024/*/*.db | head -1) $O/pmc_raw_1024.json traffic_1024cube_f32.json > $O/traffic1024.txt 2>&1
-cp profiles/traffic_512cube_f32.json profiles/traffic_1024cube_f32.json $O/
+cp profiles/traffic_512cube_f32.json profiles/traffic_1024cube_f32.json profiles/traffic_512cube_f64nu.json profiles/traffic_4d_slab_f32.json $O/
 # timelines of one step (kernel trace, no counters)
 tools/trace_step.sh $TAG/tl512
 tools/trace_step.sh $TAG/tl1024 --config 1024f32
