@@ -1009,3 +1009,49 @@ def test_unsupported_lossless_types_are_refused_with_a_fixed_status(lossless):
         hl.decompress(torch.from_numpy(stream).cuda())
     # the library is fine afterwards
     assert np.array_equal(hl.decompress(good), hl.decompress(hl.compress(u, 1e-3, np.inf, mg.REL)))
+
+
+@pytest.mark.parametrize("pipeline", ["1", "0"])
+def test_outlier_estimate_too_small_is_retried_inside_the_subdomain_pipeline(pipeline, monkeypatch):
+    """The same re-launch (LinearQuantization.hpp:621-676) when the domain is decomposed: a subdomain
+    whose outliers do not fit its lane's lists is quantized again on that lane while the next
+    subdomain is already queued on the other one; every lane grows its own lists. The stream equals
+    the one written with generously sized lists."""
+    torch, mg, hl = _mods()
+    monkeypatch.setenv("MGH_HL_PIPELINE", pipeline)
+    rng = np.random.default_rng(7)
+    shape = (48, 65, 66)
+    u = smooth_field(shape, np.float32)
+    u[8:40] += (rng.normal(0, 30.0, (32, 65, 66)).astype(np.float32) * (rng.random((32, 65, 66)) < 0.02))
+    dd = dict(domain_decomposition=hl.DD_VARIABLE, domain_decomposition_dim=0, domain_decomposition_sizes=[8, 16, 16, 8])
+    small = hl.Config(estimate_outlier_ratio=1e-5, huff_dict_size=64, **dd)
+    big = hl.Config(estimate_outlier_ratio=1.0, huff_dict_size=64, **dd)
+    for src in (u, torch.from_numpy(u).cuda()):
+        sa = hl.compress(src, 1e-4, np.inf, mg.REL, config=small)
+        sb = hl.compress(src, 1e-4, np.inf, mg.REL, config=big)
+        ha = sa.cpu().numpy() if hasattr(sa, "cpu") else np.asarray(sa)
+        hb = sb.cpu().numpy() if hasattr(sb, "cpu") else np.asarray(sb)
+        assert _canonical_records(hl, ha) == _canonical_records(hl, hb)
+        a = hl.decompress(sa, config=small)
+        a = a if isinstance(a, np.ndarray) else a.cpu().numpy()
+        assert float(np.max(np.abs(a - u))) <= 1e-4 * float(np.max(np.abs(u))) * (1 + 1e-6)
+
+
+def test_more_subdomain_shapes_than_the_hierarchy_cache_holds():
+    """A 4-D Block decomposition with a remainder in every dimension has 16 subdomain shapes, times two
+    lanes: more hierarchies than the per-thread cache keeps (8 per lane). The ones that do not fit are
+    built for their subdomain alone and destroyed behind it; nothing cached is evicted while the other
+    lane may still be running on it. Round trip within the bound, twice in a row (the second call
+    finds a full cache)."""
+    torch, mg, hl = _mods()
+    shape = (21, 21, 21, 21)
+    u = smooth_field(shape, np.float32)
+    cfg = hl.Config(domain_decomposition=hl.DD_BLOCK, block_size=9)
+    nrm = float(np.max(np.abs(u)))
+    for _ in range(2):
+        buf = hl.compress(torch.from_numpy(u).cuda(), 1e-3, np.inf, mg.REL, config=cfg)
+        m = hl.metadata_parse(bytes(buf[:8192].cpu().numpy()))
+        assert m["domain_decomposed"] and m["dd_method"] == hl.DD_BLOCK
+        v = hl.decompress(buf, config=cfg).cpu().numpy()
+        assert float(np.max(np.abs(v - u))) <= 1e-3 * nrm * (1 + 1e-6)
+    hl.release_cache()
