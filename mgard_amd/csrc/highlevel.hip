@@ -251,6 +251,7 @@ struct mgh_lossless_ctx {
   // compression: [8 bytes: the record's size prefix, filled by the caller][head of the record:
   // lay.ddata bytes][histogram][code table][counts] in ONE pinned allocation
   PinBuf pin;
+  PinBuf dpin;                         // decompression: pinned copy of the decode table (source of its upload)
   uint8_t *chead = nullptr;            // = pin.p + 8
   unsigned long long *pcounts = nullptr;  // [0..2] encoder state, [3] outlier count read back, [4] n_outliers to write
   PayloadLayout lay;
@@ -794,7 +795,10 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
     dt = huff::build_decode_table(book, book + 64, book + 128, (int)dict, rtb, (lds_cap - 8 * per_wave) / 4);
     const int waves = huff::decode_ring_lds(dt.size(), 16) <= lds_cap ? 16 : 8;
     HL_TRY(c->dtable.ensure(dt.size() * 4));
-    HL_HIP(hipMemcpyAsync(c->dtable.p, dt.data(), dt.size() * 4, hipMemcpyHostToDevice, st));
+    // (out of pinned memory: a copy from pageable memory is staged synchronously, ~15 us)
+    HL_TRY(c->dpin.ensure(dt.size() * 4));
+    std::memcpy(c->dpin.p, dt.data(), dt.size() * 4);
+    HL_HIP(hipMemcpyAsync(c->dtable.p, c->dpin.p, dt.size() * 4, hipMemcpyHostToDevice, st));
     static std::atomic<uint64_t> once3{0};
     if (hl_attr_pending(once3)) {
       HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_decode_ring<int64_t>),
@@ -1163,13 +1167,74 @@ int copy_any(void *dst, const void *src, size_t bytes, hipStream_t st) {
   return MGH_SUCCESS;
 }
 
+// A box of an array <-> a dense buffer, both in memory of the current device: one launch whatever
+// the dimension (the reference copies subdomains with its own N-D kernels too:
+// DomainDecomposer.hpp:649-845). One wave per row of the box; W = 4- or 8-byte words.
+struct BoxCopy {
+  uint32_t ext[MGH_MAX_DIM];      // extents of the box, leading 1s
+  uint64_t fstride[MGH_MAX_DIM];  // element strides of the full array for those dims
+  uint64_t rows;                  // product of all extents but the last
+};
+template <typename W>
+__global__ void __launch_bounds__(256)
+k_copy_box(W *__restrict__ dense, W *__restrict__ full, BoxCopy B, int to_dense) {
+  const int lane = threadIdx.x & 63;
+  for (uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < B.rows; row += (uint64_t)gridDim.x * 4) {
+    uint64_t r = row, fo = 0;
+#pragma unroll
+    for (int d = MGH_MAX_DIM - 2; d >= 0; d--) {
+      const uint64_t q = r / B.ext[d];
+      fo += (r - q * B.ext[d]) * B.fstride[d];
+      r = q;
+    }
+    W *f = full + fo;
+    W *s = dense + row * B.ext[MGH_MAX_DIM - 1];
+    if (to_dense)
+      for (uint32_t k = lane; k < B.ext[MGH_MAX_DIM - 1]; k += 64) s[k] = f[k];
+    else
+      for (uint32_t k = lane; k < B.ext[MGH_MAX_DIM - 1]; k += 64) f[k] = s[k];
+  }
+}
+
 // copy_subdomain (DomainDecomposer.hpp:649-845): dense subdomain buffer <-> its box inside the
-// full array (host or device), as few strided copies as the box allows.
+// full array (host or device). Device to device on one GPU: ONE kernel launch. Otherwise as few
+// strided copies as the box allows -- one hipMemcpy3DAsync per 3-D sub-box (round 5; a 2-D copy per
+// r-plane was 129 calls of ~5 us for a 129^3 block, more than the block's compression).
 int copy_subdomain(const Decomposer &dd, uint64_t id, size_t elem, void *sub, const void *full_c,
                    void *full_m, bool to_sub, hipStream_t st) {
   hl_debug(to_sub ? "copy_subdomain: to subdomain" : "copy_subdomain: to original");
   const int D = dd.D;
   const auto ext = dd.subdomain_shape(id), off = dd.subdomain_offset(id);
+  {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const void *full_any = to_sub ? full_c : (const void *)full_m;
+    if ((elem == 4 || elem == 8) && is_device_pointer_on(full_any, dev) && is_device_pointer_on(sub, dev)) {
+      BoxCopy B{};
+      uint64_t fs = 1, first = 0;
+      std::vector<uint64_t> fstr(D);
+      for (int d = D - 1; d >= 0; d--) {
+        fstr[d] = fs;
+        fs *= dd.shape[d];
+      }
+      B.rows = 1;
+      for (int k = 0; k < MGH_MAX_DIM; k++) {
+        const int d = k - (MGH_MAX_DIM - D);
+        B.ext[k] = d >= 0 ? (uint32_t)ext[d] : 1u;
+        B.fstride[k] = d >= 0 ? fstr[d] : 0;
+        if (d >= 0) first += off[d] * fstr[d];
+        if (k < MGH_MAX_DIM - 1) B.rows *= B.ext[k];
+      }
+      const unsigned grid = (unsigned)std::min<uint64_t>((B.rows + 3) / 4, 256 * 32);
+      char *fp = (char *)const_cast<void *>(full_any) + first * elem;
+      if (elem == 4)
+        k_copy_box<uint32_t><<<grid, 256, 0, st>>>((uint32_t *)sub, (uint32_t *)fp, B, to_sub ? 1 : 0);
+      else
+        k_copy_box<uint64_t><<<grid, 256, 0, st>>>((uint64_t *)sub, (uint64_t *)fp, B, to_sub ? 1 : 0);
+      HL_HIP(hipGetLastError());
+      return MGH_SUCCESS;
+    }
+  }
   // merge trailing dimensions the box spans completely
   int k = D - 1;
   while (k > 0 && ext[k] == dd.shape[k]) k--;
@@ -1195,21 +1260,36 @@ int copy_subdomain(const Decomposer &dd, uint64_t id, size_t elem, void *sub, co
     return copy_any((char *)full_m + fo * elem, sub, width, st);
   }
   size_t sub_off = 0;
-  const size_t sub_block = rows * width;
+  // slabs of dim k-2 travel in one 3-D copy each (depth = ext[k-2]; the full array's slice pitch is
+  // a whole number of its rows); the loop runs over the dims in front of it
+  const bool use3d = k >= 2;
+  const size_t depth = use3d ? ext[k - 2] : 1;
+  const size_t sub_block = rows * width * depth;
+  const int outer = use3d ? k - 2 : k - 1;  // dims 0 .. outer-1 are looped over
   for (;;) {
     size_t fo = off[k] * fstride[k];
     if (k >= 1) fo += off[k - 1] * fstride[k - 1];
-    for (int d = 0; d < k - 1; d++) fo += (off[d] + idx[d]) * fstride[d];
+    if (use3d) fo += off[k - 2] * fstride[k - 2];
+    for (int d = 0; d < outer; d++) fo += (off[d] + idx[d]) * fstride[d];
     char *sp = (char *)sub + sub_off;
-    if (to_sub) {
-      const char *fp = (const char *)full_c + fo * elem;
+    char *fp = (char *)const_cast<void *>(to_sub ? full_c : (const void *)full_m) + fo * elem;
+    if (use3d) {
+      hipMemcpy3DParms pr{};
+      // (pitched pointers: pitch in bytes, then the allocation's width in bytes and height in rows)
+      const hipPitchedPtr dense = make_hipPitchedPtr(sp, width, width, rows);
+      const hipPitchedPtr whole = make_hipPitchedPtr(fp, full_pitch, full_pitch, dd.shape[k - 1]);
+      pr.srcPtr = to_sub ? whole : dense;
+      pr.dstPtr = to_sub ? dense : whole;
+      pr.extent = make_hipExtent(width, rows, depth);
+      pr.kind = hipMemcpyDefault;
+      HL_HIP(hipMemcpy3DAsync(&pr, st));
+    } else if (to_sub) {
       HL_HIP(hipMemcpy2DAsync(sp, width, fp, full_pitch, width, rows, hipMemcpyDefault, st));
     } else {
-      char *fp = (char *)full_m + fo * elem;
       HL_HIP(hipMemcpy2DAsync(fp, full_pitch, sp, width, width, rows, hipMemcpyDefault, st));
     }
     sub_off += sub_block;
-    int d = k - 2;
+    int d = outer - 1;
     while (d >= 0) {
       if (++idx[d] < ext[d]) break;
       idx[d] = 0;
@@ -1928,6 +2008,24 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
     if (owned_h[lane]) mgh_hierarchy_destroy(owned_h[lane]);
     owned_h[lane] = nullptr;
     if (csize_total - byte_offset < 8) return hl_fail(MGH_ERR_FORMAT, "subdomain record truncated");
+    if (in_dev) {
+      // ONE device -> host read per subdomain: the size prefix and what the lossless stage will want
+      // of the record's head (chunk table for the largest subdomain, decodebook) -- every further
+      // read of this subdomain is served from it (dev_to_host). A read is a queued copy plus a
+      // synchronisation, ~25 us: three per subdomain were more than the decoder of a 65^3 block.
+      HostPrefixState &hp = host_prefix();
+      const uint8_t *at = (const uint8_t *)compressed + byte_offset;
+      const bool covered = hp.base && at >= hp.base && (size_t)(at - hp.base) + 8 <= hp.bytes.size();
+      if (!covered) {
+        const size_t want = std::min<size_t>(csize_total - byte_offset,
+                                             8 + 24 + 16 * ((max_elems - 1) / std::max<uint64_t>(hd.huff_block_size, 1) + 1) +
+                                                 16 + 8 * 128 + 8 * (size_t)hd.huff_dict_size + 16);
+        hp.base = nullptr;
+        hp.bytes.resize(want);
+        HL_TRY(aux_read(hp.bytes.data(), at, want));
+        hp.base = at;
+      }
+    }
     std::vector<uint8_t> sz;
     HL_TRY(fetch_host((const char *)compressed + byte_offset, 8, 8, sz));
     uint64_t csize = 0;
@@ -2747,6 +2845,7 @@ void mgh_lossless_destroy(mgh_lossless_ctx *c) {
   for (DevBuf *b : {&c->freq, &c->code, &c->bits, &c->entry, &c->total, &c->units, &c->tables, &c->oidx, &c->oval, &c->state, &c->dtable})
     b->release();
   c->pin.release();
+  c->dpin.release();
   delete c;
 }
 
