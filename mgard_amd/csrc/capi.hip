@@ -25,6 +25,7 @@
 #include "kernels_v1.hpp"
 #include "kernels_ipk.hpp"
 #include "kernels_ipk_stream.hpp"
+#include "kernels_ipk_spec.hpp"
 #include "kernels_ipk_dma.hpp"
 #include "kernels_fused.hpp"
 #include "kernels_fused2.hpp"
@@ -91,6 +92,8 @@ struct mgh_hierarchy {
   // the box kernel (kernels_box.hpp: no march, every phase once over a 4 x 4 x 8 box) instead of
   // the marching tile kernel; 0 = none, 1 = class 0 (default), 2 = classes 0-1, 3 = every level
   int box = 1;
+  int ipk_spec = 1;     // MGH_IPK_SPEC: few long contiguous pencils (1-D arrays) are solved in chunks, each verified against the sequential sweep (kernels_ipk_spec.hpp); 0 = one lane per pencil
+  int ipk_spec_k = 0;   // MGH_IPK_SPEC_K: warm-up length of a chunk (0 = 64 floats / 128 doubles; tiny values make the verification fail and exercise the repair)
   int sym16_mixed = 1;  // MGH_SYM16_MIXED: 16-bit symbols for the finest level only, int64 below it (default), 0 = 16-bit symbols on every level
   int restore_v = 3;  // MGH_RESTORE_V: 3 = marching node restore (kernels_recompose2.hpp), 2 = one wave per pair of fine rows
   int tail_solves = 1;  // MGH_TAIL_SOLVES: the tail kernel runs the Thomas solves of the level above it
@@ -162,6 +165,10 @@ template <typename T> struct DeviceState {
   size_t oh_slots = 0;
   int64_t *qbox = nullptr;               // ... and its compact int64 copy of the coarse corner box
   size_t qbox_elems = 0;
+  // chunked Thomas solves of few long pencils (kernels_ipk_spec.hpp): forward results, chunk-edge values
+  T *spec_y = nullptr, *spec_a = nullptr, *spec_b = nullptr;
+  size_t spec_y_elems = 0, spec_edge_elems = 0;
+  unsigned long long *spec_fixed = nullptr;  // chunks that had to be recomputed (diagnostics)
   QuantMeta qmeta;
   size_t full_I = 0, full_J = 0;   // strides of the full array in the 3-D view
 };
@@ -415,6 +422,10 @@ template <typename T> void destroy_state(mgh_hierarchy *h) {
     (void)hipFree(ds->oh_key);
     (void)hipFree(ds->oh_val);
     (void)hipFree(ds->qbox);
+    (void)hipFree(ds->spec_y);
+    (void)hipFree(ds->spec_a);
+    (void)hipFree(ds->spec_b);
+    (void)hipFree(ds->spec_fixed);
     delete ds;
   }
   delete HH<T>(h);
@@ -459,6 +470,54 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
   // widths take the one that needs the fewest "rounds" of resident workgroups
   const size_t pencil_bytes = (size_t)(n + (axis == 2 && n % 2 == 0 ? 1 : 0)) * sizeof(T);
   const uint32_t npencil = axis == 2 ? m[0] * m[1] : (axis == 1 ? m[0] * m[2] : nbatch * m[1] * m[2]);
+  // Few long contiguous pencils (a 1-D array: ONE pencil per level): parallel inside the pencil,
+  // every chunk verified against the sequential sweep (kernels_ipk_spec.hpp)
+  if (axis == 2 && nbatch == 1 && h->ipk_spec && npencil <= 64 && n >= 2048) {
+    auto *ds = DS<T>(h);
+    const uint32_t K = h->ipk_spec_k > 0 ? (uint32_t)h->ipk_spec_k : (sizeof(T) == 4 ? 64u : 128u);
+    uint32_t S = std::max<uint32_t>(128, std::min<uint32_t>(1024, n / 16384));
+    S = (S + 7) / 8 * 8;
+    const uint32_t nchunk = (n + S - 1) / S;
+    const size_t total = (size_t)npencil * n, edges = (size_t)npencil * nchunk;
+    if (total > ds->spec_y_elems) {
+      (void)hipFree(ds->spec_y);
+      ds->spec_y = nullptr;
+      ds->spec_y_elems = 0;
+      HIP_TRY(hipMalloc(&ds->spec_y, total * sizeof(T)));
+      ds->spec_y_elems = total;
+    }
+    if (edges > ds->spec_edge_elems) {
+      (void)hipFree(ds->spec_a);
+      (void)hipFree(ds->spec_b);
+      ds->spec_a = ds->spec_b = nullptr;
+      ds->spec_edge_elems = 0;
+      HIP_TRY(hipMalloc(&ds->spec_a, edges * sizeof(T)));
+      HIP_TRY(hipMalloc(&ds->spec_b, edges * sizeof(T)));
+      ds->spec_edge_elems = edges;
+    }
+    if (!ds->spec_fixed) {  // [0]: chunks repaired so far, [1]: mismatch flags of the two sweeps of a call
+      HIP_TRY(hipMalloc(&ds->spec_fixed, 16));
+      HIP_TRY(hipMemsetAsync(ds->spec_fixed, 0, 16, s));
+    }
+    const dim3 grid((nchunk + 63) / 64, npencil, 1);
+    const unsigned pgrid = (npencil + 63) / 64;
+    T *y = ds->spec_y, *ea = ds->spec_a, *eb = ds->spec_b;
+    unsigned long long *fx = ds->spec_fixed;
+    unsigned *mm = reinterpret_cast<unsigned *>(ds->spec_fixed + 1);
+    const unsigned cgrid = (unsigned)((edges + 255) / 256);
+    HIP_TRY(hipMemsetAsync(mm, 0, 8, s));
+    TRY(launch(h, name, s, [&] {
+      k_ipk_spec_fwd<T><<<grid, 64, 0, s>>>(n, S, K, nchunk, x, y, tt, ea, eb);
+      k_ipk_spec_check<T><<<cgrid, 256, 0, s>>>(nchunk, npencil, ea, eb, +1, mm);
+      k_ipk_spec_fix<T><<<pgrid, 64, 0, s>>>(n, S, nchunk, npencil, x, y, tt, ea, eb, +1, fx, mm);
+      k_ipk_spec_bwd<T><<<grid, 64, 0, s>>>(n, S, K, nchunk, y, x, tt, ea, eb);
+      k_ipk_spec_check<T><<<cgrid, 256, 0, s>>>(nchunk, npencil, ea, eb, -1, mm + 1);
+      k_ipk_spec_fix<T><<<pgrid, 64, 0, s>>>(n, S, nchunk, npencil, y, x, tt, ea, eb, -1, fx, mm + 1);
+      if (add_to)
+        k_ipk_spec_apply<T><<<(unsigned)std::min<size_t>((total + 255) / 256, 4096), 256, 0, s>>>(total, add_to, x, sign);
+    }));
+    return MGH_SUCCESS;
+  }
   int best_w = 0;
   size_t best_rounds = ~(size_t)0;
   for (int w : {64, 48, 32, 16}) {
@@ -2121,6 +2180,8 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->box = (int)env_get("MGH_BOX", h->box);
     h->restore_v = (int)env_get("MGH_RESTORE_V", h->restore_v);
     h->sym16_mixed = (int)env_get("MGH_SYM16_MIXED", h->sym16_mixed);
+    h->ipk_spec = (int)env_get("MGH_IPK_SPEC", h->ipk_spec);
+    h->ipk_spec_k = (int)env_get("MGH_IPK_SPEC_K", h->ipk_spec_k);
     h->tail_solves = (int)env_get("MGH_TAIL_SOLVES", h->tail_solves);
     h->cls1 = (size_t)env_get("MGH_CLS1", (long)h->cls1);
     h->cls2 = (size_t)env_get("MGH_CLS2", (long)h->cls2);

@@ -33,6 +33,8 @@ inline const EnvSwitch *env_switches(size_t *count) {
       {"MGH_IPK_RANGE_MB", 0, 1 << 20},
       {"MGH_HL_PIPELINE", 0, 1},
       {"MGH_SYM16_MIXED", 0, 1},
+      {"MGH_IPK_SPEC", 0, 1},
+      {"MGH_IPK_SPEC_K", 0, 4096},
   };
   *count = sizeof(k) / sizeof(k[0]);
   return k;

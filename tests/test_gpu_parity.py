@@ -945,3 +945,29 @@ def test_decompose_equals_the_operator_built_decomposition_on_nonuniform_grids(d
         o = oracle.Hierarchy(shape, dt, coords=coords)
         assert_bit_equal(h.decompose(torch.from_numpy(u).cuda()).cpu().numpy(), o.decompose(u), "decompose %r" % (shape,))
         h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"MGH_IPK_SPEC_K": "2"}, {"MGH_IPK_SPEC_K": "9"}, {"MGH_IPK_SPEC": "0"}])
+@pytest.mark.parametrize("shape,dt,nonuniform", [((1 << 20,), np.float32, False), ((300001,), np.float64, True),
+                                                 ((3, 40000), np.float32, False), ((70001,), np.float32, True)])
+def test_long_contiguous_pencils_are_solved_in_verified_chunks(shape, dt, nonuniform, env, monkeypatch):
+    """Few long contiguous pencils (a 1-D array is one pencil per level) are solved in chunks that start
+    from a wrong state a warm-up length in front of their first element; every chunk's start is then
+    compared bit for bit with the end of the chunk before it and recomputed where they differ
+    (kernels_ipk_spec.hpp). The result must be the sequential sweep's (IPKFunctor.h:111-149) whatever the
+    warm-up length: default, 2 and 9 (nearly every chunk fails the comparison and is repaired), and with
+    the one-lane-per-pencil kernel (MGH_IPK_SPEC=0)."""
+    torch, mg = _gpu()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    coords = nonuniform_coords(shape, dt) if nonuniform else None
+    u = smooth_field(shape, dt, noise=1e-2)
+    h = mg.Hierarchy(shape, dt, coords=coords)
+    o = oracle.Hierarchy(shape, dt, coords=coords)
+    ud = torch.from_numpy(u).cuda()
+    c = h.decompose(ud)
+    ref = o.decompose(u)
+    assert_bit_equal(c.cpu().numpy(), ref, "decompose %r %r" % (shape, env))
+    assert_bit_equal(h.recompose(c).cpu().numpy(), o.recompose(ref), "recompose %r %r" % (shape, env))
+    h.close()
