@@ -93,6 +93,9 @@ struct mgh_hierarchy {
   // the marching tile kernel; 0 = none, 1 = class 0 (default), 2 = classes 0-1, 3 = every level
   int box = 1;
   int ipk_spec = 1;     // MGH_IPK_SPEC: few long contiguous pencils (1-D arrays) are solved in chunks, each verified against the sequential sweep (kernels_ipk_spec.hpp); 0 = one lane per pencil
+  int ipk_chunk = 1;    // MGH_IPK_CHUNK: the LDS-staged solve of contiguous pencils shares a tile's sweeps between the four waves (thomas_chunked: chunks verified against the sequential sweep)
+  int ipk_chunk_k = 0;  // MGH_IPK_CHUNK_K: warm-up length of a chunk (0 = from the tables, chunk_warmup_need; small values make the verification fail and exercise the fall-back)
+  int ipk_chunk_need = 0;  // warm-up length that the Thomas tables of this hierarchy need (set with the tables)
   int ipk_spec_k = 0;   // MGH_IPK_SPEC_K: warm-up length of a chunk (0 = 64 floats / 128 doubles; tiny values make the verification fail and exercise the repair)
   int sym16_mixed = 1;  // MGH_SYM16_MIXED: 16-bit symbols for the finest level only, int64 below it (default), 0 = 16-bit symbols on every level
   int restore_v = 3;  // MGH_RESTORE_V: 3 = marching node restore (kernels_recompose2.hpp), 2 = one wave per pair of fine rows
@@ -121,6 +124,37 @@ struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
 };
+
+// Warm-up length of the chunked sweeps (thomas_chunked) for one Thomas table: a chunk starts
+// from state 0 instead of the true state, an error of the size of the data; after K steps it is
+// that times the product of the K multipliers it passed. For the two runs to MEET (and not
+// only to be close) the error has to fall far below one unit in the last place: the smallest K
+// for which every window of K consecutive multipliers has a product below 2^-(mantissa + 12),
+// rounded up to 8. (A bad guess costs time, not correctness: a chunk that has not met is
+// detected and the tile solved again by one lane per pencil.)
+template <typename T> int chunk_warmup_need(const std::vector<T> &tt) {
+  const size_t n = tt.size() / 3;
+  if (n < 2) return 0;
+  const double target = -((sizeof(T) == 4 ? 24 : 53) + 12);
+  std::vector<double> lf(n), lb(n);
+  for (size_t i = 0; i < n; i++) {
+    const double f = std::fabs((double)tt[i]);
+    const double b = tt[2 * n + i] != 0 ? std::fabs((double)tt[n + i] / (double)tt[2 * n + i]) : 0.0;
+    lf[i] = f > 0 ? std::log2(f) : -64.0;
+    lb[i] = b > 0 ? std::log2(b) : -64.0;
+  }
+  int need = 0;
+  for (const auto *lg : {&lf, &lb}) {
+    for (size_t i = 0; i < n; i++) {  // windows starting at i (either direction: the same products)
+      double acc = 0;
+      size_t k = 0;
+      while (i + k < n && acc > target) acc += (*lg)[i + k++];
+      if (acc > target) break;  // the window ran into the end of the table: shorter ones are exact starts
+      need = std::max(need, (int)k);
+    }
+  }
+  return (need + 7) / 8 * 8;
+}
 
 template <typename T> struct LevelTables {
   // index k = 0,1,2 <-> (r, c, f) of the 3-D view; nullptr for inactive dims
@@ -330,7 +364,9 @@ template <typename T> int build_device_state(mgh_hierarchy *h) {
       t.box.m[k] = (uint32_t)hh->level_shape[l - 1][d];
       offs[l].ratio[k] = push(hh->lv[l][d].ratio);
       offs[l].mass[k] = push(hh->mass_table(l, d));
-      offs[l].thomas[k] = push(hh->thomas_table(l - 1, d));
+      const std::vector<T> tt = hh->thomas_table(l - 1, d);
+      h->ipk_chunk_need = std::max(h->ipk_chunk_need, chunk_warmup_need(tt));
+      offs[l].thomas[k] = push(tt);
     }
   }
   TRY(dev_alloc(h, &ds->tables, arena.size()));
@@ -440,19 +476,20 @@ template <typename T> int ensure_scratch(mgh_hierarchy *h) {
 // LDS budget for the IPK tiles: whole pencils of 64 (or 32) lanes must fit.
 constexpr size_t kLdsPerCU = 160 * 1024;
 
-template <typename K> int allow_big_lds(K kernel) {
+// (`bytes`: the dynamic part; a kernel with static LDS of its own asks for that much less)
+template <typename K> int allow_big_lds(K kernel, size_t bytes = kLdsPerCU) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCU));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   return MGH_SUCCESS;
 }
 // ... once per DEVICE (the attribute belongs to the function on the current device) and safe
 // from several host threads: `done` holds one bit per device ordinal.
-template <typename K> int allow_big_lds_once(K kernel, std::atomic<uint64_t> &done) {
+template <typename K> int allow_big_lds_once(K kernel, std::atomic<uint64_t> &done, size_t bytes = kLdsPerCU) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   const uint64_t bit = (uint64_t)1 << (dev & 63);
   if (done.load(std::memory_order_acquire) & bit) return MGH_SUCCESS;
-  TRY(allow_big_lds(kernel));
+  TRY(allow_big_lds(kernel, bytes));
   done.fetch_or(bit, std::memory_order_release);
   return MGH_SUCCESS;
 }
@@ -529,6 +566,24 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
     if (rounds < best_rounds) {
       best_rounds = rounds;
       best_w = w;
+    }
+  }
+  // Contiguous pencils, LDS-staged tiles whose sweeps are shared by the four waves (thomas_chunked;
+  // warm-up length from the tables, ipk_chunk_need), ahead of the streaming kernels: 512^3 f32 top
+  // level 53 -> 44 us, f64 120 -> 109 us, 1024^3 554 -> 543 us. (The same for strided pencils and
+  // for the plane kernel of the small levels was measured and dropped: profiles/NOTES.md.)
+  if (h->ipk_chunk && axis == 2 && best_w && n >= 64 && best_w * pencil_bytes + 8192 <= kLdsPerCU) {
+    const uint32_t K = h->ipk_chunk_k > 0 ? (uint32_t)h->ipk_chunk_k : (uint32_t)h->ipk_chunk_need;
+    if (K > 0 && K <= n / 2) {
+      const uint32_t pad = (n % 2 == 0) ? 1u : 0u;
+      const uint32_t magic = (uint32_t)((((uint64_t)1 << 32) + n - 1) / n);
+      const uint32_t P = (uint32_t)best_w;
+      static std::atomic<uint64_t> once{0};
+      TRY(allow_big_lds_once(k_ipk_lds_contig<T, true>, once, kLdsPerCU - 8192));
+      return launch(h, name, s, [&] {
+        k_ipk_lds_contig<T, true><<<(npencil + P - 1) / P, 256, P * pencil_bytes, s>>>(
+            npencil, n, pad, magic, P, x, tt, add_to, sign, K);
+      });
     }
   }
   // Streaming solves: every wave a solver, forward results parked in registers + LDS +
@@ -668,7 +723,7 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
     const uint32_t P = (uint32_t)best_w;
     return launch(h, name, s, [&] {
       k_ipk_lds_contig<T><<<(npencil + P - 1) / P, 256, P * pencil_bytes, s>>>(
-          npencil, n, pad, magic, P, x, tt, add_to, sign);
+          npencil, n, pad, magic, P, x, tt, add_to, sign, 0u);
     });
   }
   if (axis != 2 && best_w) {
@@ -2182,6 +2237,8 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->sym16_mixed = (int)env_get("MGH_SYM16_MIXED", h->sym16_mixed);
     h->ipk_spec = (int)env_get("MGH_IPK_SPEC", h->ipk_spec);
     h->ipk_spec_k = (int)env_get("MGH_IPK_SPEC_K", h->ipk_spec_k);
+    h->ipk_chunk = (int)env_get("MGH_IPK_CHUNK", h->ipk_chunk);
+    h->ipk_chunk_k = (int)env_get("MGH_IPK_CHUNK_K", h->ipk_chunk_k);
     h->tail_solves = (int)env_get("MGH_TAIL_SOLVES", h->tail_solves);
     h->cls1 = (size_t)env_get("MGH_CLS1", (long)h->cls1);
     h->cls2 = (size_t)env_get("MGH_CLS2", (long)h->cls2);

@@ -35,6 +35,8 @@ inline const EnvSwitch *env_switches(size_t *count) {
       {"MGH_SYM16_MIXED", 0, 1},
       {"MGH_IPK_SPEC", 0, 1},
       {"MGH_IPK_SPEC_K", 0, 4096},
+      {"MGH_IPK_CHUNK", 0, 1},
+      {"MGH_IPK_CHUNK_K", 0, 64},
   };
   *count = sizeof(k) / sizeof(k[0]);
   return k;

@@ -134,6 +134,97 @@ __device__ __forceinline__ void thomas_lds(T *s, uint32_t stride, uint32_t n,
   }
 }
 
+__device__ __forceinline__ bool same_bits(float a, float b) { return __float_as_uint(a) == __float_as_uint(b); }
+__device__ __forceinline__ bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
+
+// The two sweeps of a pencil cut into NCH chunks, one lane per chunk, every chunk VERIFIED
+// against the sequential sweep (the idea of kernels_ipk_spec.hpp inside a tile that sits in
+// LDS): with one lane per pencil a 64-pencil tile keeps one wave busy for 2 n dependent steps
+// (the backward step is a division) while the workgroup's other waves wait at a barrier.
+// Here lane (c, j) sweeps chunk c of pencil j: it starts the recurrence from state 0 K elements
+// in front of its chunk -- the multipliers are below 0.5, the state it arrives with at its first
+// element has in practice met the sequential run -- and the value it computed for the element
+// in front of its chunk must equal, BIT FOR BIT, the last value of chunk c - 1 (exact by
+// induction: chunk 0 starts where the sequential sweep starts; two runs of one floating-point
+// recurrence that agree in one value agree in all later ones). The function returns true if any
+// lane of the workgroup saw a mismatch: the tile's content is then undefined and the caller
+// reloads it and runs the one-lane sweep (thomas_lds). Results are therefore those of
+// thomas_lds in every bit, by construction. The sweeps are in place: all warm-ups (reads only)
+// run before a barrier, the chunks' own sweeps (in place) behind it.
+// Must be called by ALL threads of the workgroup (barriers); c < NCH and j < 64 for live lanes;
+// edge: 2 * NCH * 64 values of LDS.
+template <typename T, int NCH>
+__device__ __forceinline__ bool thomas_chunked(T *s, uint32_t stride, uint32_t n,
+                                               const T *__restrict__ tt, uint32_t K, uint32_t c,
+                                               uint32_t j, bool live, T *edge) {
+  const uint32_t CS = (n + NCH - 1) / NCH;
+  const uint32_t start = min(n, c * CS), end = min(n, start + CS);
+  const T *am = tt + n, *bm = tt + 2 * n;
+  uint32_t zero = 0;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+  T *spec = edge + c * 64 + j, *last = edge + (NCH + c) * 64 + j;
+  T prev = 0;
+  // ---- forward: x[i] -= x[i-1] * w[i]. Warm-up (reads only), barrier, the chunk in place.
+  if (live) {
+    uint32_t i = start > K ? start - K : 0;
+    for (; i + 8 <= start; i += 8) {
+      T a[8], w[8];
+      table_load<T, 8, true>(tt + i, zero, w);
+#pragma unroll
+      for (int u = 0; u < 8; u++) a[u] = s[(i + u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; u++) prev = a[u] - prev * w[u];
+    }
+    for (; i < start; i++) prev = s[i * stride] - prev * tt[i];
+    *spec = prev;
+  }
+  __syncthreads();
+  if (live) {
+    uint32_t i = start;
+    for (; i + 8 <= end; i += 8) thomas_fwd<T, 8, true>(s, stride, i, tt, zero, prev);
+    for (; i < end; i++) {
+      T a = s[i * stride];
+      a = a - prev * tt[i];
+      s[i * stride] = a;
+      prev = a;
+    }
+    *last = prev;
+  }
+  __syncthreads();
+  bool bad = live && c >= 1 && !same_bits(*spec, edge[(NCH + c - 1) * 64 + j]);
+  // ---- backward: x[k] = (x[k] - am[k] * x[k+1]) / bm[k]
+  prev = 0;
+  if (live) {
+    int64_t k = (int64_t)min((uint64_t)n, (uint64_t)end + K) - 1;
+    for (; k - 7 >= (int64_t)end; k -= 8) {
+      T a[8], ca[8], cb[8];
+      table_load<T, 8, true>(am + (k - 7), zero, ca);
+      table_load<T, 8, true>(bm + (k - 7), zero, cb);
+#pragma unroll
+      for (int u = 0; u < 8; u++) a[u] = s[(k - u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; u++) prev = (a[u] - ca[7 - u] * prev) / cb[7 - u];
+    }
+    for (; k >= (int64_t)end; k--) prev = (s[k * stride] - am[k] * prev) / bm[k];
+  }
+  if (__syncthreads_or(bad)) return true;  // (forward results of all chunks final, nobody has written yet)
+  if (live) {
+    *spec = prev;
+    int64_t k = (int64_t)end - 1;
+    for (; k - 7 >= (int64_t)start; k -= 8) thomas_bwd<T, 8, true>(s, stride, (uint32_t)k, am, bm, zero, prev);
+    for (; k >= (int64_t)start; k--) {
+      T a = s[k * stride];
+      a = (a - am[k] * prev) / bm[k];
+      s[k * stride] = a;
+      prev = a;
+    }
+    *last = prev;  // (the value at `start`)
+  }
+  __syncthreads();
+  bad = live && c + 1 < NCH && !same_bits(*spec, edge[(NCH + c + 1) * 64 + j]);
+  return __syncthreads_or(bad);
+}
+
 // Pencils contiguous in memory (solve along the fastest dim): x is an
 // [npencil][n] matrix, so a tile of P pencils is one contiguous chunk. All four
 // waves of the block stream the chunk into LDS with 16-byte loads, UV of them in
@@ -142,12 +233,15 @@ __device__ __forceinline__ void thomas_lds(T *s, uint32_t stride, uint32_t n,
 // the P sweeps, all waves stream the result out. LDS rows are padded by `pad` (0 for
 // odd n, 1 for even n) so that lane t walking row t is bank-conflict free;
 // row = e / n is computed as umulhi(e, magic).
-template <typename T>
-__global__ void __launch_bounds__(256)
+// CH and K > 0: the solve of a tile is shared by the four waves (thomas_chunked, warm-up K, P <= 64).
+template <typename T, bool CH = false>
+__global__ void __launch_bounds__(256, CH ? 3 : 1)
 k_ipk_lds_contig(uint32_t npencil, uint32_t n, uint32_t pad, uint32_t magic, uint32_t P,
-                 T *__restrict__ x, const T *__restrict__ tt, T *__restrict__ add_to, int sign) {
+                 T *__restrict__ x, const T *__restrict__ tt, T *__restrict__ add_to, int sign,
+                 uint32_t K) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T *sm = reinterpret_cast<T *>(smem_raw);
+  __shared__ T edge[CH ? 2 * 4 * 64 : 1];
   using VU = typename VecU<T>::type;
   using VA = typename VecU<T>::aligned_type;
   constexpr int VN = VecU<T>::N;
@@ -177,21 +271,31 @@ k_ipk_lds_contig(uint32_t npencil, uint32_t n, uint32_t pad, uint32_t magic, uin
     }
     return v;
   };
-  for (uint32_t q = tid; (MGH_IPK_PHASES & 1) && q < nvec; q += UV * 256) {
-    VA v[UV];
+  // attempt 0 (K > 0 only): chunked solve; attempt 1: one lane per pencil, after a chunked solve
+  // that did not verify (x still holds the right-hand sides: the result is written at the end)
+  for (int attempt = CH && K > 0 ? 0 : 1; attempt < 2; attempt++) {
+    for (uint32_t q = tid; (MGH_IPK_PHASES & 1) && q < nvec; q += UV * 256) {
+      VA v[UV];
 #pragma unroll
-    for (int u = 0; u < UV; u++) {
-      const uint32_t qq = min(q + u * 256, nvec - 1);
-      v[u] = *reinterpret_cast<const VU *>(g + (size_t)qq * VN);
+      for (int u = 0; u < UV; u++) {
+        const uint32_t qq = min(q + u * 256, nvec - 1);
+        v[u] = *reinterpret_cast<const VU *>(g + (size_t)qq * VN);
+      }
+#pragma unroll
+      for (int u = 0; u < UV; u++)
+        if (q + u * 256 < nvec) lds_put((q + u * 256) * VN, v[u]);
     }
-#pragma unroll
-    for (int u = 0; u < UV; u++)
-      if (q + u * 256 < nvec) lds_put((q + u * 256) * VN, v[u]);
+    for (uint32_t e = nvec * VN + tid; e < total; e += 256)
+      sm[e + (pad ? __umulhi(e, magic) : 0u)] = g[e];
+    __syncthreads();
+    if (CH && attempt == 0) {
+      const uint32_t c = __builtin_amdgcn_readfirstlane(tid >> 6), j = tid & 63;
+      if (!thomas_chunked<T, 4>(sm + j * (n + pad), 1, n, tt, K, c, j, j < cnt, edge)) break;
+      continue;
+    }
+    // (the chunked variant's second pass is rare: small batches keep its registers out of the budget)
+    if ((MGH_IPK_PHASES & 2) && tid < cnt) thomas_lds<T, !CH>(sm + tid * (n + pad), 1, n, tt);
   }
-  for (uint32_t e = nvec * VN + tid; e < total; e += 256)
-    sm[e + (pad ? __umulhi(e, magic) : 0u)] = g[e];
-  __syncthreads();
-  if ((MGH_IPK_PHASES & 2) && tid < cnt) thomas_lds<T>(sm + tid * (n + pad), 1, n, tt);
   __syncthreads();
   T *o = (add_to ? add_to : x) + base;
   if (!(MGH_IPK_PHASES & 4)) return;

@@ -21,11 +21,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "kernels_ipk.hpp"  // same_bits
 
 namespace mgh {
-
-__device__ __forceinline__ bool same_bits(float a, float b) { return __float_as_uint(a) == __float_as_uint(b); }
-__device__ __forceinline__ bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
 
 // forward sweep of the chunks: x -> y (out of place: a chunk's warm-up reads the right-hand side
 // of the chunk in front of it). spec[c] = value at index start_c - 1 as this chunk computed it,

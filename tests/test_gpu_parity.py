@@ -971,3 +971,35 @@ def test_long_contiguous_pencils_are_solved_in_verified_chunks(shape, dt, nonuni
     assert_bit_equal(c.cpu().numpy(), ref, "decompose %r %r" % (shape, env))
     assert_bit_equal(h.recompose(c).cpu().numpy(), o.recompose(ref), "recompose %r %r" % (shape, env))
     h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"MGH_IPK_CHUNK": "1"}, {"MGH_IPK_CHUNK": "1", "MGH_IPK_CHUNK_K": "3"},
+                                 {"MGH_IPK_CHUNK": "1", "MGH_IPK_CHUNK_K": "12"}, {"MGH_IPK_CHUNK": "0"},
+                                 {"MGH_IPK_CHUNK": "1", "MGH_FORCE_V1": "1"},
+                                 {"MGH_IPK_CHUNK": "1", "MGH_IPK_CHUNK_K": "5", "MGH_FORCE_V1": "1"}])
+@pytest.mark.parametrize("shape,dt,nonuniform", [((129, 129, 257), np.float32, False), ((130, 67, 200), np.float64, True),
+                                                 ((257, 140, 131), np.float32, True), ((96, 300, 128), np.float64, False),
+                                                 ((5, 70, 66, 129), np.float32, False)])
+def test_tiles_in_lds_are_solved_in_verified_chunks(shape, dt, nonuniform, env, monkeypatch):
+    """The LDS-staged Thomas solve of contiguous pencils shares the two sweeps of a tile between the four
+    waves of the workgroup (kernels_ipk.hpp:thomas_chunked): a lane sweeps one quarter of a pencil from a wrong state a warm-up
+    length in front of it, every quarter's start is compared bit for bit with the end of the quarter
+    before it, and a tile with a mismatch is loaded again and solved by one lane per pencil. The result
+    must be the sequential sweep's (IPKFunctor.h:111-149) whatever the warm-up length: the one derived
+    from the tables, 3, 5 and 12 (most tiles fail the comparison and take the second pass), with the
+    kernels that do not chunk, and on the unfused path (MGH_FORCE_V1: one solve per axis at every level,
+    where the fused path solves f and c of the small levels in one plane kernel)."""
+    torch, mg = _gpu()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    coords = nonuniform_coords(shape, dt) if nonuniform else None
+    u = smooth_field(shape, dt, noise=1e-2)
+    h = mg.Hierarchy(shape, dt, coords=coords)
+    o = oracle.Hierarchy(shape, dt, coords=coords)
+    ud = torch.from_numpy(u).cuda()
+    c = h.decompose(ud)
+    ref = o.decompose(u)
+    assert_bit_equal(c.cpu().numpy(), ref, "decompose %r %r" % (shape, env))
+    assert_bit_equal(h.recompose(c).cpu().numpy(), o.recompose(ref), "recompose %r %r" % (shape, env))
+    h.close()

@@ -47,11 +47,11 @@ int main(int argc, char **argv) {
   };
   for (uint32_t P : {64u, 48u, 32u, 16u})
     timeit(("contig P=" + std::to_string(P)).c_str(), [&] {
-      k_ipk_lds_contig<float><<<(np + P - 1) / P, 256, P * n * 4>>>(np, n, 0, magic, P, x, tt, nullptr, 1); });
+      k_ipk_lds_contig<float><<<(np + P - 1) / P, 256, P * n * 4>>>(np, n, 0, magic, P, x, tt, nullptr, 1, 0); });
   if (MGH_IPK_PHASES == 2)  // solve only: one-wave workgroups (where do the solver waves land?)
     for (uint32_t P : {64u, 48u, 32u})
       timeit(("contig 1-wave P=" + std::to_string(P)).c_str(), [&] {
-        k_ipk_lds_contig<float><<<(np + P - 1) / P, 64, P * n * 4>>>(np, n, 0, magic, P, x, tt, nullptr, 1); });
+        k_ipk_lds_contig<float><<<(np + P - 1) / P, 64, P * n * 4>>>(np, n, 0, magic, P, x, tt, nullptr, 1, 0); });
   timeit("strided<48> c", [&] { k_ipk_lds_strided<float, 48><<<((np + 47) / 48 + 7) / 8 * 8, 256, 48 * n * 4>>>(n, n, (size_t)n * n, n, n, x, tt, nullptr, 1); });
   timeit("strided<64> c", [&] { k_ipk_lds_strided<float, 64><<<((np + 63) / 64 + 7) / 8 * 8, 256, 64 * n * 4>>>(n, n, (size_t)n * n, n, n, x, tt, nullptr, 1); });
   timeit("strided<32> c", [&] { k_ipk_lds_strided<float, 32><<<((np + 31) / 32 + 7) / 8 * 8, 256, 32 * n * 4>>>(n, n, (size_t)n * n, n, n, x, tt, nullptr, 1); });

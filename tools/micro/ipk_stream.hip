@@ -154,7 +154,7 @@ int main(int argc, char **argv) {
   for (int dir : {2, 1, 0}) {
     // reference: the LDS-staged kernels
     if (dir == 2)
-      timeit("lds contig P=48", false, [&] { k_ipk_lds_contig<float><<<(np + 47) / 48, 256, 48 * (n + (n % 2 ? 0 : 1)) * 4>>>(np, n, n % 2 ? 0 : 1, magic, 48, x, tt, nullptr, 1); }, false);
+      timeit("lds contig P=48", false, [&] { k_ipk_lds_contig<float><<<(np + 47) / 48, 256, 48 * (n + (n % 2 ? 0 : 1)) * 4>>>(np, n, n % 2 ? 0 : 1, magic, 48, x, tt, nullptr, 1, 0); }, false);
     if (dir == 1)
       timeit("lds strided<48> c", false, [&] { k_ipk_lds_strided<float, 48><<<((np + 47) / 48 + 7) / 8 * 8, 256, 48 * n * 4>>>(n, n, (size_t)n * n, n, n, x, tt, nullptr, 1); }, false);
     if (dir == 0)
