@@ -93,6 +93,7 @@ struct mgh_hierarchy {
   // the marching tile kernel; 0 = none, 1 = class 0 (default), 2 = classes 0-1, 3 = every level
   int box = 1;
   int ipk_spec = 1;     // MGH_IPK_SPEC: few long contiguous pencils (1-D arrays) are solved in chunks, each verified against the sequential sweep (kernels_ipk_spec.hpp); 0 = one lane per pencil
+  int outlier_agg = 2;  // MGH_OUTLIER_AGG: the level kernel asks for outlier slots once per workgroup and pair step instead of once per wave and plane (kernels_fused2.hpp: OutlierShared): 0 never, 1 always, 2 when the previous call on this hierarchy left more than 0.5 % of its values in the outlier list
   int ipk_chunk = 1;    // MGH_IPK_CHUNK: the LDS-staged solve of contiguous pencils shares a tile's sweeps between the four waves (thomas_chunked: chunks verified against the sequential sweep)
   int ipk_chunk_k = 0;  // MGH_IPK_CHUNK_K: warm-up length of a chunk (0 = from the tables, chunk_warmup_need; small values make the verification fail and exercise the fall-back)
   int ipk_chunk_need = 0;  // warm-up length that the Thomas tables of this hierarchy need (set with the tables)
@@ -203,6 +204,9 @@ template <typename T> struct DeviceState {
   T *spec_y = nullptr, *spec_a = nullptr, *spec_b = nullptr;
   size_t spec_y_elems = 0, spec_edge_elems = 0;
   unsigned long long *spec_fixed = nullptr;  // chunks that had to be recomputed (diagnostics)
+  // outlier count of an earlier call, written by its last kernel into host memory (hipHostMalloc;
+  // the device writes through the same pointer): picks the level kernel's variant, see outlier_agg
+  unsigned long long *outliers_seen = nullptr;
   QuantMeta qmeta;
   size_t full_I = 0, full_J = 0;   // strides of the full array in the 3-D view
 };
@@ -462,6 +466,7 @@ template <typename T> void destroy_state(mgh_hierarchy *h) {
     (void)hipFree(ds->spec_a);
     (void)hipFree(ds->spec_b);
     (void)hipFree(ds->spec_fixed);
+    (void)hipHostFree(ds->outliers_seen);
     delete ds;
   }
   delete HH<T>(h);
@@ -890,7 +895,7 @@ inline int fused_nchunk(int m_r, int rch) { return std::max(1, (m_r - 1 + rch - 
 // (Fused2Grid): a remainder of up to 4 coarse columns / rows beyond the full tiles goes to face
 // tiles, the last r-chunk owns what is left of the planes (one more than the others for sizes
 // 2^k + 1).
-template <typename T, int OUTK, int TC, int TF>
+template <typename T, int OUTK, int TC, int TF, bool AGG = false>
 int launch_fused2_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int cls, const char *nm,
                     hipStream_t s) {
   const int RCHv = fused_rch(h, cls);
@@ -916,9 +921,9 @@ int launch_fused2_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int 
   const bool faces = G.n_ff || G.n_cf;
 #define MGH_F2(RCH)                                                                           \
   if (faces)                                                                                  \
-    return launch_kernel(h, nm, s, k_level_fused2<T, OUTK, TC, TF, RCH, true>, grid, dim3(256), 0, A, G, \
+    return launch_kernel(h, nm, s, k_level_fused2<T, OUTK, TC, TF, RCH, true, 0, AGG>, grid, dim3(256), 0, A, G, \
                          Fused4<T>{});                                                        \
-  return launch_kernel(h, nm, s, k_level_fused2<T, OUTK, TC, TF, RCH, false>, grid, dim3(256), 0, A, G, \
+  return launch_kernel(h, nm, s, k_level_fused2<T, OUTK, TC, TF, RCH, false, 0, AGG>, grid, dim3(256), 0, A, G, \
                        Fused4<T>{});
   MGH_F2(16)
 #undef MGH_F2
@@ -928,12 +933,12 @@ int launch_fused2_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int 
 // writes is 512 contiguous bytes instead of 256, which the memory system rewards more than the
 // larger halo (1.41 x instead of 1.24 x re-read) costs: top level of 512^3 f32 435 -> 383 us, same
 // box, alternating runs. The short marches of the lower levels are a few us faster on 8 x 32.
-template <typename T, int OUTK>
+template <typename T, int OUTK, bool AGG = false>
 int launch_fused2(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int cls, const char *nm,
                   hipStream_t s) {
   if (h->fused_wide >= 2 || (h->fused_wide == 1 && cls == 2))
-    return launch_fused2_t<T, OUTK, 4, 64>(h, A, b, cls, nm, s);
-  return launch_fused2_t<T, OUTK, 8, 32>(h, A, b, cls, nm, s);
+    return launch_fused2_t<T, OUTK, 4, 64, AGG>(h, A, b, cls, nm, s);
+  return launch_fused2_t<T, OUTK, 8, 32, AGG>(h, A, b, cls, nm, s);
 }
 
 template <typename T, int OUT, typename AfterFirst>
@@ -965,6 +970,23 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
     A.outlier_cap = qp->ocap;
     A.qp = qp->d_qp;
     A.nlev = L + 1;
+  }
+  // Which variant of the level kernel: the one that asks for outlier slots per wave and plane (4
+  // waves per SIMD; right when few values leave the dictionary) or per workgroup and pair step
+  // (OutlierShared: 3 waves per SIMD, but the requests no longer queue on the one counter when
+  // many do). The last kernel of every call leaves the call's outlier count in host memory; what
+  // is found there now -- from the previous call or an earlier one, no synchronisation -- decides.
+  bool agg = false;
+  if (OUT == OUT_Q && qp->prep_huffman && qp->ocount) {
+    if (!ds->outliers_seen && h->outlier_agg == 2) {
+      if (hipHostMalloc(&ds->outliers_seen, sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess)
+        *ds->outliers_seen = 0;
+      else
+        ds->outliers_seen = nullptr, (void)hipGetLastError();
+    }
+    const unsigned long long seen =
+        ds->outliers_seen ? *reinterpret_cast<volatile unsigned long long *>(ds->outliers_seen) : 0;
+    agg = h->outlier_agg == 1 || (h->outlier_agg == 2 && seen * 200 > (unsigned long long)h->total);
   }
   // levels whose working set fits in one workgroup's LDS run inside the tail kernel
   constexpr size_t kTailLdsMax = 150 * 1024;
@@ -1017,7 +1039,12 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
         // (RCH = 4) on the small levels where the march length is pure latency
         const char *nm = cls == 2 ? (OUT == OUT_Q ? "level_fused_q" : "level_fused")
                                   : (OUT == OUT_Q ? "level_fused_q_small" : "level_fused_small");
-        if (OUT == OUT_Q && A.prep_huffman && !A.q16 && h->fused_fixed)
+        if (OUT == OUT_Q && agg) {  // (many outliers last time: slot requests per workgroup)
+          if (A.prep_huffman && !A.q16 && h->fused_fixed)
+            TRY((launch_fused2<T, OUT == OUT_Q ? OUT_QH : OUT, OUT == OUT_Q>(h, A, b, cls, nm, s)));
+          else
+            TRY((launch_fused2<T, OUT, OUT == OUT_Q>(h, A, b, cls, nm, s)));
+        } else if (OUT == OUT_Q && A.prep_huffman && !A.q16 && h->fused_fixed)
           TRY((launch_fused2<T, OUT == OUT_Q ? OUT_QH : OUT>(h, A, b, cls, nm, s)));
         else
           TRY((launch_fused2<T, OUT>(h, A, b, cls, nm, s)));
@@ -1080,6 +1107,7 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
       TA.head_volume = qp->vol[0];
     }
     TA.out = A;
+    TA.outliers_seen = OUT == OUT_Q && A.prep_huffman ? ds->outliers_seen : nullptr;
     const size_t tab = ds->lt_end[tail_pre ? l_tail + 1 : l_tail];
     TA.tab_base = ds->tables;
     TA.tab_count = (uint32_t)tab;
@@ -2238,6 +2266,7 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->ipk_spec = (int)env_get("MGH_IPK_SPEC", h->ipk_spec);
     h->ipk_spec_k = (int)env_get("MGH_IPK_SPEC_K", h->ipk_spec_k);
     h->ipk_chunk = (int)env_get("MGH_IPK_CHUNK", h->ipk_chunk);
+    h->outlier_agg = (int)env_get("MGH_OUTLIER_AGG", h->outlier_agg);
     h->ipk_chunk_k = (int)env_get("MGH_IPK_CHUNK_K", h->ipk_chunk_k);
     h->tail_solves = (int)env_get("MGH_TAIL_SOLVES", h->tail_solves);
     h->cls1 = (size_t)env_get("MGH_CLS1", (long)h->cls1);

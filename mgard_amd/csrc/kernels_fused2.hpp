@@ -82,6 +82,27 @@ template <int TC, int TF, int RCH, bool TODD = false> struct Fused2Geom {
                        o_wf = o_wr + (RCH + 1) * 12, o_wc = o_wf + 9 * TF, elems = o_wc + 9 * TC;
 };
 
+// Outlier slots of a pair step, ONE request per workgroup (round 5). The slots of the single outlier
+// list come from one address (~11 ns per atomic once they queue); with one request per wave and
+// plane a field whose values leave the dictionary -- a tolerance below the data's noise -- turned
+// the 0.9 ms step of 512^3 into 1.27 ms at 1.7 % outliers and 7.8 ms from 20 % on. Now a wave that
+// finds up to kOutlierStashOf<T> outliers in a plane only COUNTS them while it stores the plane
+// (cnt[wave * 2 + plane]) and leaves (value, output offset) pairs in LDS; behind the pair's second
+// barrier wave 0 asks for the slots of the whole workgroup, publishes the base through LDS, and
+// every wave writes its entries. More outliers than the stash holds in one wave and plane take
+// the old road, one request for the wave. A pair step without outliers pays one LDS
+// store per wave and plane and two 16-byte LDS loads.
+// entries per wave and plane: floats all 256 values of a wave's plane (the per-wave request never
+// runs), doubles 64 (the tile's LDS leaves room for no more at two workgroups per CU)
+template <typename T> constexpr int kOutlierStashOf = sizeof(T) == 4 ? 256 : 64;
+template <typename T> struct OutlierShared {
+  unsigned *cnt;              // [8]: waves x planes of the pair
+  unsigned long long *base;   // first slot of the workgroup's request
+  unsigned *flag;             // pair sequence number `base` belongs to
+  T *val;                     // [8][kOutlierStashOf<T>]: coefficient values
+  uint32_t *off;              // [8][kOutlierStashOf<T>]: their offsets inside the output plane
+};
+
 // One tile: TC x TF coarse nodes at (C0, F0), marching over the coarse planes [R0, R0 + rch).
 // c_end / f_end: coarse indices from which on the nodes belong to another tile of the launch
 // (face tiles, below); lds: Fused2Geom<TC, TF, RCH, TODD>::elems elements, 16-byte aligned.
@@ -93,12 +114,12 @@ template <int TC, int TF, int RCH, bool TODD = false> struct Fused2Geom {
 // planes (`ua`, `ub`: the same planes of the neighbouring slices), r-lerped on odd planes. The odd
 // planes of the neighbours are never read. `rt` = ratio_t at the left neighbour; out_base =
 // element offset of the slice inside the output array (outlier indices are global).
-template <typename T, int OUT, int TC, int TF, int RCH, bool TODD = false>
+template <typename T, int OUT, int TC, int TF, int RCH, bool TODD = false, bool AGG = false>
 __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const int C0,
                                             const int R0, const int rch, const int c_end,
-                                            const int f_end, T *lds, const T *ua = nullptr,
-                                            const T *ub = nullptr, const T rt = 0,
-                                            const size_t out_base = 0) {
+                                            const int f_end, T *lds, const OutlierShared<T> &OS,
+                                            const T *ua = nullptr, const T *ub = nullptr,
+                                            const T rt = 0, const size_t out_base = 0) {
   using GM = Fused2Geom<TC, TF, RCH, TODD>;
   constexpr int WC = GM::WC;
   constexpr int WF = GM::WF;
@@ -359,7 +380,9 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
   // cell from registers, the odd-f ones of the cell to the left from the coefficient field `cs`
   // (call it behind the barrier that follows phase A). K0 = 1: even plane (slot 0 is the coarse
   // node, stored by the caller); oi = index of the output plane in the reordered layout.
-  auto emit = [&](const T *cs, const T c0, const T c2, int oi, int K0) {
+  constexpr bool kLists = AGG && (OUT == OUT_Q || OUT == OUT_QH);  // workgroup-wide slot requests
+  constexpr int kOutlierStash = kOutlierStashOf<T>;
+  auto emit = [&](const T *cs, const T c0, const T c2, int oi, int K0, int which) {
     const size_t ob = out_base + (size_t)oi * A.dI;
     const T cv[4] = {c0, cs[own.i01 - 1], c2, cs[own.i11 - 1]};
     const bool(&on)[4] = st_on;
@@ -392,9 +415,11 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
         qs[k] = ol[k] ? 0 : (int32_t)s;
         slow |= ol[k];
       }
+      // out-of-dictionary values: counted and stashed here, written behind the pair's second
+      // barrier with slots the whole workgroup asks for at once (flush_outliers;
+      // LinearQuantization.hpp:208-241)
+      unsigned deferred = 0;
       if (__any(slow)) {
-        // out-of-dictionary values: exact 64-bit value into the outlier list, slots of the
-        // whole wave from ONE atomicAdd (LinearQuantization.hpp:208-241)
         unsigned long long masks[4];
         unsigned total = 0;
 #pragma unroll
@@ -402,24 +427,35 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
           masks[k] = k >= K0 ? __ballot(ol[k]) : 0ull;
           total += __popcll(masks[k]);
         }
-        unsigned long long base = 0;
         const int lane = tid & 63;
-        if (lane == 0) base = atomicAdd(A.outlier_count, (unsigned long long)total);
-        base = __shfl(base, 0, 64);
+        const bool stash = kLists && total <= (unsigned)kOutlierStash;
+        unsigned long long base = 0;
+        if (!stash) {  // a wave full of outliers: its own request, as before
+          if (lane == 0) base = atomicAdd(A.outlier_count, (unsigned long long)total);
+          base = __shfl(base, 0, 64);
+        }
+        const int slot0 = ((tid >> 6) * 2 + which) * kOutlierStash;
         unsigned before = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           if (k >= K0 && ol[k]) {
-            const unsigned rank = __popcll(masks[k] & ((1ULL << lane) - 1ULL));
-            const unsigned long long o = base + before + rank;
-            if (o < A.outlier_cap) {
-              A.outlier_idx[o] = ob + off[k];
-              A.outlier_val[o] = quantize_fast(cv[k], qz, qv) + A.dict_size / 2;
+            const unsigned rank = before + __popcll(masks[k] & ((1ULL << lane) - 1ULL));
+            if (kLists && stash) {
+              OS.val[slot0 + rank] = cv[k];
+              OS.off[slot0 + rank] = off[k];
+            } else {
+              const unsigned long long o = base + rank;
+              if (o < A.outlier_cap) {
+                A.outlier_idx[o] = ob + off[k];
+                A.outlier_val[o] = quantize_fast(cv[k], qz, qv) + A.dict_size / 2;
+              }
             }
           }
           before += __popcll(masks[k]);
         }
+        deferred = stash ? total : 0;
       }
+      if (kLists && (tid & 63) == 0) OS.cnt[(tid >> 6) * 2 + which] = deferred;
       if (!kFixed && A.q16) {
         uint16_t *o = A.q16 + ob;
 #pragma unroll
@@ -440,6 +476,7 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
     } else {
       // no dictionary: plain integers; |value| >= 2^31 (the conversion saturated) goes through
       // the 64-bit conversion
+      if (kLists && (tid & 63) == 0) OS.cnt[(tid >> 6) * 2 + which] = 0;
       int64_t *o = A.q + ob;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -457,6 +494,42 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
         for (int k = 0; k < 4; k++)
           if (k >= K0 && (all_on || on[k])) o[off[k]] = (int64_t)qs[k];
       }
+    }
+  };
+
+  // The pair's out-of-dictionary values into the list (behind the pair's second barrier): oi_o / oi_e
+  // = output planes of the pair's odd / even plane, K0e = first value of the even plane that is a
+  // coefficient; seq = the pair's sequence number.
+  auto flush_outliers = [&](int oi_o, int oi_e, unsigned seq) {
+    const uint4 ca = *reinterpret_cast<const uint4 *>(OS.cnt), cb = *reinterpret_cast<const uint4 *>(OS.cnt + 4);
+    const unsigned c[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+    unsigned tot = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) tot += c[k];
+    if (tot == 0) return;  // (the same decision in every wave of the workgroup)
+    const int wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) {
+      *OS.base = atomicAdd(A.outlier_count, (unsigned long long)tot);
+      __hip_atomic_store(OS.flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (lane == 0)
+      while (__hip_atomic_load(OS.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) __builtin_amdgcn_s_sleep(1);
+    unsigned long long o = *OS.base;  // (behind the leader's acquire: uniform in the wave)
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (k < 2 * wave) o += c[k];
+#pragma unroll
+    for (int which = 0; which < 2; which++) {
+      const unsigned n = c[2 * wave + which];
+      for (unsigned r = lane; r < n; r += 64) {
+        const int e = (2 * wave + which) * kOutlierStash + (int)r;
+        const unsigned long long slot = o + r;
+        if (slot < A.outlier_cap) {
+          A.outlier_idx[slot] = out_base + (size_t)(which ? oi_e : oi_o) * A.dI + OS.off[e];
+          A.outlier_val[slot] = quantize_fast(OS.val[e], qz, qv) + A.dict_size / 2;
+        }
+      }
+      o += n;
     }
   };
 
@@ -612,11 +685,15 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
     // the planes' coefficients to HBM (odd-f ones from the field: see `of1`). Last in the phase:
     // in front of the ring refill or between refill and sweeps the top-level pass of 512^3 was
     // 10 us slower (one box, alternating runs)
-    if (pv_o && p >= 2 * R0) emit(Cs0, keep_o0, keep_o2, mr + (p - 1) / 2, 0);
-    if (pv_e && p + 1 < 2 * R0 + 2 * rch) emit(Cs1, keep_e0, keep_e2, (p + 1) / 2, TODD ? 0 : 1);
+    const bool em_o = pv_o && p >= 2 * R0, em_e = pv_e && p + 1 < 2 * R0 + 2 * rch;
+    if (em_o) emit(Cs0, keep_o0, keep_o2, mr + (p - 1) / 2, 0, 0);
+    else if (kLists && (tid & 63) == 0) OS.cnt[(tid >> 6) * 2] = 0;
+    if (em_e) emit(Cs1, keep_e0, keep_e2, (p + 1) / 2, TODD ? 0 : 1, 1);
+    else if (kLists && (tid & 63) == 0) OS.cnt[(tid >> 6) * 2 + 1] = 0;
     MGH_PT(3);
     __syncthreads();
     MGH_PT(4);
+    if constexpr (kLists) flush_outliers(mr + (p - 1) / 2, (p + 1) / 2, (unsigned)(p + 64));
     // ---- phases C, D: c-sweep of both planes, r-sweep of coarse plane R = (p - 1) / 2 ----
     const T vo = c_sweep(t1s0);
     const T ve = c_sweep(t1s1);
@@ -688,7 +765,7 @@ template <typename T> struct Fused4 {
   int n_t, m_t;
 };
 
-template <typename T, int OUT, int TC, int TF, int RCH, bool FACES, int TMODE = 0>
+template <typename T, int OUT, int TC, int TF, int RCH, bool FACES, int TMODE = 0, bool AGG = false>
 __global__ void __launch_bounds__(TC * TF)
 k_level_fused2(FusedArgs<T> A, Fused2Grid G, Fused4<T> Q) {
   static_assert(TC * TF == 256, "face tiles are 64 x 4 and 4 x 64");
@@ -697,6 +774,14 @@ k_level_fused2(FusedArgs<T> A, Fused2Grid G, Fused4<T> Q) {
                 e2 = Fused2Geom<4, 64, RCH, TODD>::elems;
   constexpr int elems = FACES ? (e0 > e1 ? (e0 > e2 ? e0 : e2) : (e1 > e2 ? e1 : e2)) : e0;
   __shared__ __attribute__((aligned(16))) T lds[elems];
+  constexpr bool kLists = AGG && (OUT == OUT_Q || OUT == OUT_QH);
+  __shared__ __attribute__((aligned(16))) unsigned ol_cnt[8];
+  __shared__ unsigned long long ol_base;
+  __shared__ unsigned ol_flag;
+  __shared__ T ol_val[kLists ? 8 * kOutlierStashOf<T> : 1];
+  __shared__ uint32_t ol_off[kLists ? 8 * kOutlierStashOf<T> : 1];
+  if (kLists && threadIdx.x == 0) ol_flag = 0;  // (no pair has sequence number 0; visible behind the tile's first barrier)
+  const OutlierShared<T> OS{ol_cnt, &ol_base, &ol_flag, ol_val, ol_off};
   if ((OUT == OUT_Q || OUT == OUT_QH) && A.qp) {
     A.quantizer = A.qp[A.level];
     A.volume = A.qp[A.nlev + A.level];
@@ -736,14 +821,14 @@ k_level_fused2(FusedArgs<T> A, Fused2Grid G, Fused4<T> Q) {
   }
   const int f_main_end = G.n_ff ? G.ff_F0 : A.m[2], c_main_end = G.n_cf ? G.cf_C0 : A.m[1];
   if (!FACES || b < G.n_main) {
-    level_tile2<T, OUT, TC, TF, RCH, TODD>(A, (b % G.gxm) * TF, (b / G.gxm) * TC, R0, rch,
-                                           c_main_end, f_main_end, lds, ua, ub, rt, out_base);
+    level_tile2<T, OUT, TC, TF, RCH, TODD, AGG>(A, (b % G.gxm) * TF, (b / G.gxm) * TC, R0, rch,
+                                           c_main_end, f_main_end, lds, OS, ua, ub, rt, out_base);
   } else if (b < G.n_main + G.n_ff) {
-    level_tile2<T, OUT, 64, 4, RCH, TODD>(A, G.ff_F0, (b - G.n_main) * 64, R0, rch, A.m[1], A.m[2],
-                                          lds, ua, ub, rt, out_base);
+    level_tile2<T, OUT, 64, 4, RCH, TODD, AGG>(A, G.ff_F0, (b - G.n_main) * 64, R0, rch, A.m[1], A.m[2],
+                                          lds, OS, ua, ub, rt, out_base);
   } else {
-    level_tile2<T, OUT, 4, 64, RCH, TODD>(A, (b - G.n_main - G.n_ff) * 64, G.cf_C0, R0, rch, A.m[1],
-                                          f_main_end, lds, ua, ub, rt, out_base);
+    level_tile2<T, OUT, 4, 64, RCH, TODD, AGG>(A, (b - G.n_main - G.n_ff) * 64, G.cf_C0, R0, rch, A.m[1],
+                                          f_main_end, lds, OS, ua, ub, rt, out_base);
   }
 }
 

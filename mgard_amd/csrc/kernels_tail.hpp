@@ -60,6 +60,10 @@ template <typename T> struct TailArgs {
   uint32_t tab_count;
   T head_quantizer, head_volume;
   FusedArgs<T> out;    // coefficient / quantized output + outlier list
+  // host-visible word (or nullptr) that receives the call's final outlier count: the host reads it
+  // before a LATER call to pick the level kernel's variant (capi.hip: outlier_agg) -- a hint, read
+  // without synchronisation
+  unsigned long long *outliers_seen;
 };
 
 // LDS elements needed for a first tail level with fine box n and coarse box m
@@ -255,6 +259,11 @@ k_tail(TailArgs<T> A) {
         emit_quantized<T, 1>(O, vv, ll, on);
       }
     }
+  }
+  if (OUT != OUT_T && A.outliers_seen && O.outlier_count) {  // (this kernel is the last of the call)
+    __syncthreads();
+    if (tid == 0)
+      *A.outliers_seen = __hip_atomic_load(O.outlier_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   MGH_TT(63);
 }

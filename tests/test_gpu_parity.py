@@ -1003,3 +1003,35 @@ def test_tiles_in_lds_are_solved_in_verified_chunks(shape, dt, nonuniform, env, 
     assert_bit_equal(c.cpu().numpy(), ref, "decompose %r %r" % (shape, env))
     assert_bit_equal(h.recompose(c).cpu().numpy(), o.recompose(ref), "recompose %r %r" % (shape, env))
     h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("agg", ["0", "1", "2"])
+@pytest.mark.parametrize("tol", [1e-3, 1e-5, 1e-7])
+@pytest.mark.parametrize("shape,dt", [((65, 70, 129), np.float32), ((130, 67, 200), np.float64),
+                                      ((129, 129, 257), np.float32), ((3, 40, 66, 65), np.float32)])
+def test_outlier_slots_per_wave_and_per_workgroup_fill_the_same_list(shape, dt, tol, agg, monkeypatch):
+    """The level kernel has two ways of asking for slots in the outlier list: per wave and plane, and
+    (kernels_fused2.hpp: OutlierShared) once per workgroup and pair of planes from a stash in LDS, for
+    fields where most values leave the dictionary. MGH_OUTLIER_AGG = 0 / 1 fixes the variant, 2 (the
+    default) lets the previous call's outlier count decide: the second and third call below run the
+    other variant when the tolerance is tight. Quantized values and the outlier SET must be the
+    oracle's in every case (LinearQuantization.hpp:208-241; the order of the list is not defined)."""
+    torch, mg = _gpu()
+    monkeypatch.setenv("MGH_OUTLIER_AGG", agg)
+    u = smooth_field(shape, dt, noise=1e-2)
+    h = mg.Hierarchy(shape, dt)
+    o = oracle.Hierarchy(shape, dt)
+    ud = torch.from_numpy(u).cuda()
+    nrm = oracle.norm(u, dt(np.inf))
+    rq, roi, rov, rn = o.quantize(o.decompose(u), oracle.REL, dt(tol), dt(np.inf), dt(nrm))
+    ri, rv = _outlier_set(roi, rov)
+    for call in range(3):
+        q, oi, ov, n, got_nrm = h.decompose_quantize(ud, mg.REL, tol, np.inf)
+        torch.cuda.synchronize()
+        assert got_nrm == nrm and n == rn, (call, n, rn)
+        np.testing.assert_array_equal(q.cpu().numpy(), rq)
+        gi, gv = _outlier_set(oi.cpu().numpy(), ov.cpu().numpy())
+        np.testing.assert_array_equal(gi, ri)
+        np.testing.assert_array_equal(gv, rv)
+    h.close()
