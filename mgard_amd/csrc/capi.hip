@@ -941,6 +941,28 @@ int launch_fused2(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int cl
   return launch_fused2_t<T, OUTK, 8, 32, AGG>(h, A, b, cls, nm, s);
 }
 
+// Which variant of the level kernel: the one that asks for outlier slots per wave and plane
+// (right when few values leave the dictionary) or per workgroup and pair step (OutlierShared in
+// kernels_fused2.hpp: more registers and LDS traffic, but the requests no longer queue on the one
+// counter when many do). The last kernel of every call leaves the call's outlier count in host
+// memory; what is found there now -- from the previous call or an earlier one, no synchronisation
+// -- decides.
+template <typename T> bool outlier_agg_now(mgh_hierarchy *h, const QuantParams<T> *qp) {
+  auto *ds = DS<T>(h);
+  if (!qp || !qp->prep_huffman || !qp->ocount) return false;
+  if (!ds->outliers_seen && h->outlier_agg == 2) {
+    if (hipHostMalloc(&ds->outliers_seen, sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess)
+      *ds->outliers_seen = 0;
+    else
+      ds->outliers_seen = nullptr, (void)hipGetLastError();
+  }
+  const unsigned long long seen =
+      ds->outliers_seen ? *reinterpret_cast<volatile unsigned long long *>(ds->outliers_seen) : 0;
+  return h->outlier_agg == 1 || (h->outlier_agg == 2 && seen * 200 > (unsigned long long)h->total);
+}
+
+__global__ void k_publish_count(const unsigned long long *count, unsigned long long *seen) { *seen = *count; }
+
 template <typename T, int OUT, typename AfterFirst>
 int decompose_fused4(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams<T> *qp,
                      hipStream_t s, AfterFirst &&after_first);
@@ -971,23 +993,7 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
     A.qp = qp->d_qp;
     A.nlev = L + 1;
   }
-  // Which variant of the level kernel: the one that asks for outlier slots per wave and plane (4
-  // waves per SIMD; right when few values leave the dictionary) or per workgroup and pair step
-  // (OutlierShared: 3 waves per SIMD, but the requests no longer queue on the one counter when
-  // many do). The last kernel of every call leaves the call's outlier count in host memory; what
-  // is found there now -- from the previous call or an earlier one, no synchronisation -- decides.
-  bool agg = false;
-  if (OUT == OUT_Q && qp->prep_huffman && qp->ocount) {
-    if (!ds->outliers_seen && h->outlier_agg == 2) {
-      if (hipHostMalloc(&ds->outliers_seen, sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess)
-        *ds->outliers_seen = 0;
-      else
-        ds->outliers_seen = nullptr, (void)hipGetLastError();
-    }
-    const unsigned long long seen =
-        ds->outliers_seen ? *reinterpret_cast<volatile unsigned long long *>(ds->outliers_seen) : 0;
-    agg = h->outlier_agg == 1 || (h->outlier_agg == 2 && seen * 200 > (unsigned long long)h->total);
-  }
+  const bool agg = OUT == OUT_Q && outlier_agg_now<T>(h, qp);
   // levels whose working set fits in one workgroup's LDS run inside the tail kernel
   constexpr size_t kTailLdsMax = 150 * 1024;
   int l_tail = 0;  // levels l_tail .. 1 go to the tail (0 = none)
@@ -1124,6 +1130,8 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
     TRY(launch(h, "head_out", s, [&] {
       k_head_out<T, OUT><<<1, 256, 0, s>>>((int)b.m[0], (int)b.m[1], (int)b.m[2], ds->nodal[0], A);
     }));
+    if (OUT == OUT_Q && A.prep_huffman && A.outlier_count && ds->outliers_seen)
+      k_publish_count<<<1, 1, 0, s>>>(A.outlier_count, ds->outliers_seen);
   }
   return MGH_SUCCESS;
 }
@@ -1135,7 +1143,7 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
 // the N/16-sized arrays. Order of every operation as in CalcCoefficientsND.hpp:25-236 and
 // CalcCorrectionND.hpp:25-267 (dims D-1 .. 0): bit-identical to the generic N-D kernels.
 // D = 4: the even and the odd slices of one level (kernels_fused2.hpp, TMODE 1 / 2)
-template <typename T, int OUT, int TC, int TF>
+template <typename T, int OUT, int TC, int TF, bool AGG = false>
 int launch_fused4_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Fused4<T> &Q, const Box3 &b, int cls,
                     int n_t, int m_t, hipStream_t s) {
     const int RCHv = fused_rch(h, cls);
@@ -1164,9 +1172,9 @@ int launch_fused4_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Fused4<T> &Q,
   if ((NZ) > 0) {                                                                             \
     const dim3 grid(gx, (unsigned)G.nchunk, (NZ));                                            \
     if (faces)                                                                                \
-      TRY(launch_kernel(h, NAME, s, k_level_fused2<T, OUT, TC, TF, RCH, true, TMODE>, grid, dim3(256), 0, A, G, Q));  \
+      TRY(launch_kernel(h, NAME, s, k_level_fused2<T, OUT, TC, TF, RCH, true, TMODE, AGG>, grid, dim3(256), 0, A, G, Q));  \
     else                                                                                      \
-      TRY(launch_kernel(h, NAME, s, k_level_fused2<T, OUT, TC, TF, RCH, false, TMODE>, grid, dim3(256), 0, A, G, Q)); \
+      TRY(launch_kernel(h, NAME, s, k_level_fused2<T, OUT, TC, TF, RCH, false, TMODE, AGG>, grid, dim3(256), 0, A, G, Q)); \
   }
     MGH_F4(16, 1, n_even, "level4_even")
     MGH_F4(16, 2, n_odd, "level4_odd")
@@ -1264,6 +1272,7 @@ int decompose_fused4(mgh_hierarchy *h, const T *data, T *coeff, const QuantParam
     A.nlev = L + 1;
   }
   TRY(after_first());
+  const bool agg = OUT == OUT_Q && outlier_agg_now<T>(h, qp);
   const T *src = data;
   size_t sT = full[0], sI = full[1], sJ = full[2];
   for (int l = L; l >= 1; l--) {
@@ -1300,7 +1309,11 @@ int decompose_fused4(mgh_hierarchy *h, const T *data, T *coeff, const QuantParam
     if (n_t % 2 == 0)
       HIP_TRY(hipMemsetAsync(ds->load4 + (size_t)(n_t - 1) * M, 0, M * sizeof(T), s));
     const int cls = level_class(h, b);
-    if (h->fused_wide >= 2 || (h->fused_wide == 1 && cls == 2))
+    const bool wide = h->fused_wide >= 2 || (h->fused_wide == 1 && cls == 2);
+    if (OUT == OUT_Q && agg) {
+      if (wide) TRY((launch_fused4_t<T, OUT, 4, 64, OUT == OUT_Q>(h, A, Q, b, cls, n_t, m_t, s)));
+      else TRY((launch_fused4_t<T, OUT, 8, 32, OUT == OUT_Q>(h, A, Q, b, cls, n_t, m_t, s)));
+    } else if (wide)
       TRY((launch_fused4_t<T, OUT, 4, 64>(h, A, Q, b, cls, n_t, m_t, s)));
     else
       TRY((launch_fused4_t<T, OUT, 8, 32>(h, A, Q, b, cls, n_t, m_t, s)));
@@ -1330,6 +1343,8 @@ int decompose_fused4(mgh_hierarchy *h, const T *data, T *coeff, const QuantParam
       k_head_out4<T, OUT><<<(unsigned)std::min<size_t>((tot + 1023) / 1024, 1024), 1024, 0, s>>>(
           (int)M0[0], (int)M0[1], (int)M0[2], (int)M0[3], ds->nodal4[0], A, full[0]);
     }));
+    if (OUT == OUT_Q && A.prep_huffman && A.outlier_count && ds->outliers_seen)
+      k_publish_count<<<1, 1, 0, s>>>(A.outlier_count, ds->outliers_seen);
   }
   return MGH_SUCCESS;
 }

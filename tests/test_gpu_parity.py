@@ -1009,7 +1009,8 @@ def test_tiles_in_lds_are_solved_in_verified_chunks(shape, dt, nonuniform, env, 
 @pytest.mark.parametrize("agg", ["0", "1", "2"])
 @pytest.mark.parametrize("tol", [1e-3, 1e-5, 1e-7])
 @pytest.mark.parametrize("shape,dt", [((65, 70, 129), np.float32), ((130, 67, 200), np.float64),
-                                      ((129, 129, 257), np.float32), ((3, 40, 66, 65), np.float32)])
+                                      ((129, 129, 257), np.float32), ((3, 40, 66, 65), np.float32),
+                                      ((6, 33, 40, 70), np.float64), ((33, 34),  np.float32)])
 def test_outlier_slots_per_wave_and_per_workgroup_fill_the_same_list(shape, dt, tol, agg, monkeypatch):
     """The level kernel has two ways of asking for slots in the outlier list: per wave and plane, and
     (kernels_fused2.hpp: OutlierShared) once per workgroup and pair of planes from a stash in LDS, for
