@@ -97,6 +97,7 @@ struct mgh_hierarchy {
   int ipk_chunk = 1;    // MGH_IPK_CHUNK: the LDS-staged solve of contiguous pencils shares a tile's sweeps between the four waves (thomas_chunked: chunks verified against the sequential sweep)
   int ipk_chunk_k = 0;  // MGH_IPK_CHUNK_K: warm-up length of a chunk (0 = from the tables, chunk_warmup_need; small values make the verification fail and exercise the fall-back)
   int ipk_chunk_need = 0;  // warm-up length that the Thomas tables of this hierarchy need (set with the tables)
+  uint32_t ipk_spec_max = 16384;  // MGH_IPK_SPEC_MAX: most pencils of a solve whose pencils do not fit LDS that still run in verified chunks
   int ipk_spec_k = 0;   // MGH_IPK_SPEC_K: warm-up length of a chunk (0 = 64 floats / 128 doubles; tiny values make the verification fail and exercise the repair)
   int sym16_mixed = 1;  // MGH_SYM16_MIXED: 16-bit symbols for the finest level only, int64 below it (default), 0 = 16-bit symbols on every level
   int restore_v = 3;  // MGH_RESTORE_V: 3 = marching node restore (kernels_recompose2.hpp), 2 = one wave per pair of fine rows
@@ -512,14 +513,21 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
   // widths take the one that needs the fewest "rounds" of resident workgroups
   const size_t pencil_bytes = (size_t)(n + (axis == 2 && n % 2 == 0 ? 1 : 0)) * sizeof(T);
   const uint32_t npencil = axis == 2 ? m[0] * m[1] : (axis == 1 ? m[0] * m[2] : nbatch * m[1] * m[2]);
-  // Few long contiguous pencils (a 1-D array: ONE pencil per level): parallel inside the pencil,
-  // every chunk verified against the sequential sweep (kernels_ipk_spec.hpp)
-  if (axis == 2 && nbatch == 1 && h->ipk_spec && npencil <= 64 && n >= 2048) {
+  // Few long pencils (a 1-D array: ONE pencil per level): parallel inside the pencil, every chunk
+  // verified against the sequential sweep (kernels_ipk_spec.hpp)
+  auto spec_solve = [&]() -> int {
     auto *ds = DS<T>(h);
-    const uint32_t K = h->ipk_spec_k > 0 ? (uint32_t)h->ipk_spec_k : (sizeof(T) == 4 ? 64u : 128u);
+    SpecGeom G{};
+    G.n = n;
+    G.K = h->ipk_spec_k > 0 ? (uint32_t)h->ipk_spec_k : (sizeof(T) == 4 ? 64u : 128u);
     uint32_t S = std::max<uint32_t>(128, std::min<uint32_t>(1024, n / 16384));
-    S = (S + 7) / 8 * 8;
-    const uint32_t nchunk = (n + S - 1) / S;
+    G.S = (S + 7) / 8 * 8;
+    G.nchunk = (n + G.S - 1) / G.S;
+    G.npencil = npencil;
+    if (axis == 2) { G.n_inner = npencil; G.outer_stride = 0; G.inner_stride = n; G.stride = 1; G.along_p = 0; }
+    else if (axis == 1) { G.n_inner = m[2]; G.outer_stride = (size_t)m[1] * m[2]; G.inner_stride = 1; G.stride = m[2]; G.along_p = 1; }
+    else { G.n_inner = m[1] * m[2]; G.outer_stride = 0; G.inner_stride = 1; G.stride = (size_t)m[1] * m[2]; G.along_p = 1; }
+    const uint32_t nchunk = G.nchunk;
     const size_t total = (size_t)npencil * n, edges = (size_t)npencil * nchunk;
     if (total > ds->spec_y_elems) {
       (void)hipFree(ds->spec_y);
@@ -541,7 +549,7 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
       HIP_TRY(hipMalloc(&ds->spec_fixed, 16));
       HIP_TRY(hipMemsetAsync(ds->spec_fixed, 0, 16, s));
     }
-    const dim3 grid((nchunk + 63) / 64, npencil, 1);
+    const unsigned grid = (unsigned)((edges + 63) / 64);
     const unsigned pgrid = (npencil + 63) / 64;
     T *y = ds->spec_y, *ea = ds->spec_a, *eb = ds->spec_b;
     unsigned long long *fx = ds->spec_fixed;
@@ -549,17 +557,18 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
     const unsigned cgrid = (unsigned)((edges + 255) / 256);
     HIP_TRY(hipMemsetAsync(mm, 0, 8, s));
     TRY(launch(h, name, s, [&] {
-      k_ipk_spec_fwd<T><<<grid, 64, 0, s>>>(n, S, K, nchunk, x, y, tt, ea, eb);
+      k_ipk_spec_fwd<T><<<grid, 64, 0, s>>>(G, x, y, tt, ea, eb);
       k_ipk_spec_check<T><<<cgrid, 256, 0, s>>>(nchunk, npencil, ea, eb, +1, mm);
-      k_ipk_spec_fix<T><<<pgrid, 64, 0, s>>>(n, S, nchunk, npencil, x, y, tt, ea, eb, +1, fx, mm);
-      k_ipk_spec_bwd<T><<<grid, 64, 0, s>>>(n, S, K, nchunk, y, x, tt, ea, eb);
+      k_ipk_spec_fix<T><<<pgrid, 64, 0, s>>>(G, x, y, tt, ea, eb, +1, fx, mm);
+      k_ipk_spec_bwd<T><<<grid, 64, 0, s>>>(G, y, x, tt, ea, eb);
       k_ipk_spec_check<T><<<cgrid, 256, 0, s>>>(nchunk, npencil, ea, eb, -1, mm + 1);
-      k_ipk_spec_fix<T><<<pgrid, 64, 0, s>>>(n, S, nchunk, npencil, y, x, tt, ea, eb, -1, fx, mm + 1);
+      k_ipk_spec_fix<T><<<pgrid, 64, 0, s>>>(G, y, x, tt, ea, eb, -1, fx, mm + 1);
       if (add_to)
         k_ipk_spec_apply<T><<<(unsigned)std::min<size_t>((total + 255) / 256, 4096), 256, 0, s>>>(total, add_to, x, sign);
     }));
     return MGH_SUCCESS;
-  }
+  };
+  if (axis == 2 && nbatch == 1 && h->ipk_spec && npencil <= 64 && n >= 2048) return spec_solve();
   int best_w = 0;
   size_t best_rounds = ~(size_t)0;
   for (int w : {64, 48, 32, 16}) {
@@ -753,7 +762,10 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
     MGH_STRIDED(16)
 #undef MGH_STRIDED
   }
-  // pencils too long for LDS: one thread per pencil straight from global memory
+  // pencils too long for LDS. Not too many of them (a 4194304 x 9 array: 9 strided pencils of
+  // 2^21 elements per level; 100 x 100 x 6000: 2601 contiguous ones of 3001): in verified chunks
+  if (nbatch == 1 && h->ipk_spec && n >= 2048 && npencil <= h->ipk_spec_max) return spec_solve();
+  // ... else one thread per pencil straight from global memory
   if (nbatch > 1) {
     for (uint32_t bi = 0; bi < nbatch; bi++)
       TRY(ipk_launch<T>(h, axis, m, x + (size_t)bi * batch_stride, tt,
@@ -1128,7 +1140,10 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
       A.volume = qp->vol[0];
     }
     TRY(launch(h, "head_out", s, [&] {
-      k_head_out<T, OUT><<<1, 256, 0, s>>>((int)b.m[0], (int)b.m[1], (int)b.m[2], ds->nodal[0], A);
+      // (a hierarchy with one long and two short dimensions has few levels and a long head)
+      const size_t tot = (size_t)b.m[0] * b.m[1] * b.m[2];
+      k_head_out<T, OUT><<<(unsigned)std::min<size_t>((tot + 255) / 256, 1024), 256, 0, s>>>(
+          (int)b.m[0], (int)b.m[1], (int)b.m[2], ds->nodal[0], A);
     }));
     if (OUT == OUT_Q && A.prep_huffman && A.outlier_count && ds->outliers_seen)
       k_publish_count<<<1, 1, 0, s>>>(A.outlier_count, ds->outliers_seen);
@@ -1743,7 +1758,9 @@ int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> 
     const Box3 &b = ds->lt[1].box;
     A.qv = level_qv[0];
     TRY(launch(h, "head_in", st, [&] {
-      k_head_in_q<T, QT><<<1, 256, 0, st>>>((int)b.m[0], (int)b.m[1], (int)b.m[2], A, ds->nodal[0]);
+      const size_t tot = (size_t)b.m[0] * b.m[1] * b.m[2];
+      k_head_in_q<T, QT><<<(unsigned)std::min<size_t>((tot + 255) / 256, 1024), 256, 0, st>>>(
+          (int)b.m[0], (int)b.m[1], (int)b.m[2], A, ds->nodal[0]);
     }));
   }
   for (int l = l_head + 1; l <= L; l++) {
@@ -2280,6 +2297,7 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->sym16_mixed = (int)env_get("MGH_SYM16_MIXED", h->sym16_mixed);
     h->ipk_spec = (int)env_get("MGH_IPK_SPEC", h->ipk_spec);
     h->ipk_spec_k = (int)env_get("MGH_IPK_SPEC_K", h->ipk_spec_k);
+    h->ipk_spec_max = (uint32_t)env_get("MGH_IPK_SPEC_MAX", (long)h->ipk_spec_max);
     h->ipk_chunk = (int)env_get("MGH_IPK_CHUNK", h->ipk_chunk);
     h->outlier_agg = (int)env_get("MGH_OUTLIER_AGG", h->outlier_agg);
     h->ipk_chunk_k = (int)env_get("MGH_IPK_CHUNK_K", h->ipk_chunk_k);

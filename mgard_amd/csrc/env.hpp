@@ -35,6 +35,7 @@ inline const EnvSwitch *env_switches(size_t *count) {
       {"MGH_SYM16_MIXED", 0, 1},
       {"MGH_IPK_SPEC", 0, 1},
       {"MGH_IPK_SPEC_K", 0, 4096},
+      {"MGH_IPK_SPEC_MAX", 0, 1 << 30},
       {"MGH_IPK_CHUNK", 0, 1},
       {"MGH_OUTLIER_AGG", 0, 2},
       {"MGH_IPK_CHUNK_K", 0, 64},

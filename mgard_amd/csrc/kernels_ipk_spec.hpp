@@ -1,5 +1,5 @@
-// Thomas solves of FEW, LONG, contiguous pencils (a 1-D array is ONE pencil per level): parallel
-// INSIDE the pencil and still bit-identical to the sequential sweep.
+// Thomas solves of FEW, LONG pencils (a 1-D array is ONE pencil per level; a 4194304 x 9 array has 9
+// strided ones): parallel INSIDE the pencil and still bit-identical to the sequential sweep.
 //
 // The two sweeps are first-order recurrences,
 //   forward   y[i] = x[i] - y[i-1] * fw[i]                      (IPKFunctor.h:127)
@@ -25,18 +25,43 @@
 
 namespace mgh {
 
+// Where the pencils lie: element i of pencil p at (p / n_inner) * outer_stride + (p % n_inner) *
+// inner_stride + i * stride. Contiguous pencils (stride 1): consecutive lanes take consecutive
+// chunks of one pencil; strided pencils: consecutive lanes take the same chunk of consecutive
+// pencils, which are neighbours in memory.
+struct SpecGeom {
+  uint32_t n, S, K, nchunk, npencil, n_inner;
+  size_t outer_stride, inner_stride, stride;
+  int along_p;
+  __device__ __forceinline__ bool map(size_t e, uint32_t &c, uint32_t &p) const {
+    if (e >= (size_t)nchunk * npencil) return false;
+    if (along_p) {
+      p = (uint32_t)(e % npencil);
+      c = (uint32_t)(e / npencil);
+    } else {
+      c = (uint32_t)(e % nchunk);
+      p = (uint32_t)(e / nchunk);
+    }
+    return true;
+  }
+  __device__ __forceinline__ size_t base(uint32_t p) const {
+    return (size_t)(p / n_inner) * outer_stride + (size_t)(p % n_inner) * inner_stride;
+  }
+};
+
 // forward sweep of the chunks: x -> y (out of place: a chunk's warm-up reads the right-hand side
-// of the chunk in front of it). spec[c] = value at index start_c - 1 as this chunk computed it,
-// last[c] = value at index end_c - 1.
+// of the chunk in front of it). spec[p][c] = value at index start_c - 1 as this chunk computed it,
+// last[p][c] = value at index end_c - 1.
 template <typename T>
 __global__ void __launch_bounds__(64)
-k_ipk_spec_fwd(uint32_t n, uint32_t S, uint32_t K, uint32_t nchunk, const T *__restrict__ x,
-               T *__restrict__ y, const T *__restrict__ tt, T *__restrict__ spec, T *__restrict__ last) {
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= nchunk) return;
-  const size_t pb = (size_t)blockIdx.y * n;
+k_ipk_spec_fwd(SpecGeom G, const T *__restrict__ x, T *__restrict__ y, const T *__restrict__ tt,
+               T *__restrict__ spec, T *__restrict__ last) {
+  uint32_t c, p;
+  if (!G.map((size_t)blockIdx.x * 64 + threadIdx.x, c, p)) return;
+  const size_t pb = G.base(p), st = G.stride;
   const T *xp = x + pb;
   T *yp = y + pb;
+  const uint32_t n = G.n, S = G.S, K = G.K;
   const uint32_t start = c * S, end = min(n, start + S);
   uint32_t i = start > K ? start - K : 0;
   T prev = 0;
@@ -45,19 +70,19 @@ k_ipk_spec_fwd(uint32_t n, uint32_t S, uint32_t K, uint32_t nchunk, const T *__r
     T v[U], m[U];
 #pragma unroll
     for (uint32_t u = 0; u < U; u++) {
-      v[u] = xp[i + u];
+      v[u] = xp[(i + u) * st];
       m[u] = tt[i + u];
     }
 #pragma unroll
     for (uint32_t u = 0; u < U; u++) prev = v[u] - prev * m[u];
   }
-  for (; i < start; i++) prev = xp[i] - prev * tt[i];
-  spec[(size_t)blockIdx.y * nchunk + c] = prev;
+  for (; i < start; i++) prev = xp[i * st] - prev * tt[i];
+  spec[(size_t)p * G.nchunk + c] = prev;
   for (; i + U <= end; i += U) {
     T v[U], m[U];
 #pragma unroll
     for (uint32_t u = 0; u < U; u++) {
-      v[u] = xp[i + u];
+      v[u] = xp[(i + u) * st];
       m[u] = tt[i + u];
     }
 #pragma unroll
@@ -66,26 +91,27 @@ k_ipk_spec_fwd(uint32_t n, uint32_t S, uint32_t K, uint32_t nchunk, const T *__r
       prev = v[u];
     }
 #pragma unroll
-    for (uint32_t u = 0; u < U; u++) yp[i + u] = v[u];
+    for (uint32_t u = 0; u < U; u++) yp[(i + u) * st] = v[u];
   }
   for (; i < end; i++) {
-    prev = xp[i] - prev * tt[i];
-    yp[i] = prev;
+    prev = xp[i * st] - prev * tt[i];
+    yp[i * st] = prev;
   }
-  last[(size_t)blockIdx.y * nchunk + c] = prev;
+  last[(size_t)p * G.nchunk + c] = prev;
 }
 
-// backward sweep of the chunks: y -> z. spec[c] = value at index end_c as this chunk computed it
-// (0 for the last chunk: the sweep starts there), first[c] = value at index start_c.
+// backward sweep of the chunks: y -> z. spec[p][c] = value at index end_c as this chunk computed
+// it (0 for the last chunk: the sweep starts there), first[p][c] = value at index start_c.
 template <typename T>
 __global__ void __launch_bounds__(64)
-k_ipk_spec_bwd(uint32_t n, uint32_t S, uint32_t K, uint32_t nchunk, const T *__restrict__ y,
-               T *__restrict__ z, const T *__restrict__ tt, T *__restrict__ spec, T *__restrict__ first) {
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= nchunk) return;
-  const size_t pb = (size_t)blockIdx.y * n;
+k_ipk_spec_bwd(SpecGeom G, const T *__restrict__ y, T *__restrict__ z, const T *__restrict__ tt,
+               T *__restrict__ spec, T *__restrict__ first) {
+  uint32_t c, p;
+  if (!G.map((size_t)blockIdx.x * 64 + threadIdx.x, c, p)) return;
+  const size_t pb = G.base(p), st = G.stride;
   const T *yp = y + pb;
   T *zp = z + pb;
+  const uint32_t n = G.n, S = G.S, K = G.K;
   const T *am = tt + n, *bm = tt + 2 * (size_t)n;
   const uint32_t start = c * S, end = min(n, start + S);
   int64_t k = (int64_t)min((uint64_t)n, (uint64_t)end + K) - 1;
@@ -95,20 +121,20 @@ k_ipk_spec_bwd(uint32_t n, uint32_t S, uint32_t K, uint32_t nchunk, const T *__r
     T v[U], a[U], b[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      v[u] = yp[k - u];
+      v[u] = yp[(k - u) * st];
       a[u] = am[k - u];
       b[u] = bm[k - u];
     }
 #pragma unroll
     for (int u = 0; u < U; u++) prev = (v[u] - a[u] * prev) / b[u];
   }
-  for (; k >= (int64_t)end; k--) prev = (yp[k] - am[k] * prev) / bm[k];
-  spec[(size_t)blockIdx.y * nchunk + c] = prev;
+  for (; k >= (int64_t)end; k--) prev = (yp[k * st] - am[k] * prev) / bm[k];
+  spec[(size_t)p * G.nchunk + c] = prev;
   for (; k - (U - 1) >= (int64_t)start; k -= U) {
     T v[U], a[U], b[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      v[u] = yp[k - u];
+      v[u] = yp[(k - u) * st];
       a[u] = am[k - u];
       b[u] = bm[k - u];
     }
@@ -118,13 +144,13 @@ k_ipk_spec_bwd(uint32_t n, uint32_t S, uint32_t K, uint32_t nchunk, const T *__r
       prev = v[u];
     }
 #pragma unroll
-    for (int u = 0; u < U; u++) zp[k - u] = v[u];
+    for (int u = 0; u < U; u++) zp[(k - u) * st] = v[u];
   }
   for (; k >= (int64_t)start; k--) {
-    prev = (yp[k] - am[k] * prev) / bm[k];
-    zp[k] = prev;
+    prev = (yp[k * st] - am[k] * prev) / bm[k];
+    zp[k * st] = prev;
   }
-  first[(size_t)blockIdx.y * nchunk + c] = prev;
+  first[(size_t)p * G.nchunk + c] = prev;
 }
 
 // The proof, in parallel: does every chunk's start agree with the end of the chunk before it (in
@@ -147,14 +173,16 @@ k_ipk_spec_check(uint32_t nchunk, uint32_t npencil, const T *__restrict__ spec, 
 // fixed[0] counts the chunks that had to be recomputed (diagnostics / tests).
 template <typename T>
 __global__ void __launch_bounds__(64)
-k_ipk_spec_fix(uint32_t n, uint32_t S, uint32_t nchunk, uint32_t npencil, const T *__restrict__ in,
-               T *__restrict__ out, const T *__restrict__ tt, const T *__restrict__ spec,
-               T *__restrict__ edge, int dir, unsigned long long *fixed, const unsigned *mismatch) {
+k_ipk_spec_fix(SpecGeom G, const T *__restrict__ in, T *__restrict__ out, const T *__restrict__ tt,
+               const T *__restrict__ spec, T *__restrict__ edge, int dir, unsigned long long *fixed,
+               const unsigned *mismatch) {
   if (*mismatch == 0) return;  // (the usual case: every chunk verified)
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= npencil) return;
-  const T *ip = in + (size_t)p * n;
-  T *op = out + (size_t)p * n;
+  if (p >= G.npencil) return;
+  const uint32_t n = G.n, S = G.S, nchunk = G.nchunk;
+  const size_t pb = G.base(p), st = G.stride;
+  const T *ip = in + pb;
+  T *op = out + pb;
   const T *sp = spec + (size_t)p * nchunk;
   T *ep = edge + (size_t)p * nchunk;
   const T *am = tt + n, *bm = tt + 2 * (size_t)n;
@@ -167,9 +195,9 @@ k_ipk_spec_fix(uint32_t n, uint32_t S, uint32_t nchunk, uint32_t npencil, const 
       T prev = ep[c - 1];
       uint32_t i = start;
       for (; i < end; i++) {
-        const T v = ip[i] - prev * tt[i];
-        if (same_bits(v, op[i])) break;  // met the stored run: the rest of the chunk is exact
-        op[i] = v;
+        const T v = ip[i * st] - prev * tt[i];
+        if (same_bits(v, op[i * st])) break;  // met the stored run: the rest of the chunk is exact
+        op[i * st] = v;
         prev = v;
       }
       if (i == end) ep[c] = prev;
@@ -182,9 +210,9 @@ k_ipk_spec_fix(uint32_t n, uint32_t S, uint32_t nchunk, uint32_t npencil, const 
       T prev = ep[c + 1];
       int64_t k = (int64_t)end - 1;
       for (; k >= (int64_t)start; k--) {
-        const T v = (ip[k] - am[k] * prev) / bm[k];
-        if (same_bits(v, op[k])) break;
-        op[k] = v;
+        const T v = (ip[k * st] - am[k] * prev) / bm[k];
+        if (same_bits(v, op[k * st])) break;
+        op[k * st] = v;
         prev = v;
       }
       if (k < (int64_t)start) ep[c] = prev;

@@ -950,9 +950,12 @@ def test_decompose_equals_the_operator_built_decomposition_on_nonuniform_grids(d
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{}, {"MGH_IPK_SPEC_K": "2"}, {"MGH_IPK_SPEC_K": "9"}, {"MGH_IPK_SPEC": "0"}])
 @pytest.mark.parametrize("shape,dt,nonuniform", [((1 << 20,), np.float32, False), ((300001,), np.float64, True),
-                                                 ((3, 40000), np.float32, False), ((70001,), np.float32, True)])
+                                                 ((3, 40000), np.float32, False), ((70001,), np.float32, True),
+                                                 ((40000, 3), np.float32, False), ((20001, 4, 5), np.float64, True),
+                                                 ((6, 9000, 7), np.float32, False), ((70, 9, 5000), np.float32, True)])
 def test_long_contiguous_pencils_are_solved_in_verified_chunks(shape, dt, nonuniform, env, monkeypatch):
-    """Few long contiguous pencils (a 1-D array is one pencil per level) are solved in chunks that start
+    """Few long pencils (a 1-D array is one pencil per level; 40000 x 3 has three strided ones; pencils too
+    long for LDS in general) are solved in chunks that start
     from a wrong state a warm-up length in front of their first element; every chunk's start is then
     compared bit for bit with the end of the chunk before it and recomputed where they differ
     (kernels_ipk_spec.hpp). The result must be the sequential sweep's (IPKFunctor.h:111-149) whatever the

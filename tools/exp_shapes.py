@@ -12,7 +12,10 @@ def t(f, k=3):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / k * 1e3, r
 for shape, dt in (((1 << 24,), np.float32), ((4096, 4096), np.float32), ((8192, 8192), np.float32), ((256, 256, 256), np.float32),
                   ((256, 256, 256), np.float64), ((64, 64, 64, 64), np.float32), ((8, 8, 64, 64, 64), np.float32),
-                  ((300, 311, 322), np.float32)):
+                  ((300, 311, 322), np.float32), ((2048, 2048, 17), np.float32), ((17, 2048, 2048), np.float32),
+                  ((2048, 17, 2048), np.float32), ((100, 100, 6000), np.float32), ((6000, 100, 100), np.float32),
+                  ((1 << 22, 9), np.float32), ((9, 1 << 22), np.float32), ((5, 5, 5, 5, 40000), np.float32),
+                  ((16384, 4097), np.float64), ((3, 3, 1 << 22), np.float32), ((1 << 22, 3, 3), np.float32)):
     u = torch.from_numpy(smooth_field(shape, dt)).cuda()
     nb = u.numel() * u.element_size()
     try:
