@@ -70,7 +70,8 @@ struct mgh_hierarchy {
   void *host = nullptr;  // HostHierarchy<T>*
   void *impl = nullptr;  // DeviceState<T>*
   bool profiling = false;
-  bool force_v1 = false;  // MGH_FORCE_V1=1: run the one-thread-per-element kernels only
+  bool force_v1 = false;  // MGH_FORCE_V1=1: run the one-thread-per-element kernels only (unset: also for thin shapes, see mgh_hierarchy_create; 0: never)
+  int force_v1_env = -1;
   bool force_nd = false;  // MGH_FORCE_ND=1: run the generic N-D kernels also for D <= 3 (cross-check)
   std::string prof_filter;  // empty = every kernel
   // MGH_IPK_STREAM: 1 = streaming Thomas solves (kernels_ipk_stream.hpp) on the levels whose
@@ -2281,7 +2282,8 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
   }
   auto *h = new mgh_hierarchy();
   {
-    h->force_v1 = env_get("MGH_FORCE_V1", 0) != 0;
+    h->force_v1_env = (int)env_get("MGH_FORCE_V1", -1);
+    h->force_v1 = h->force_v1_env == 1;
     h->force_nd = env_get("MGH_FORCE_ND", 0) != 0;
     h->ipk_stream = (int)env_get("MGH_IPK_STREAM", h->ipk_stream);
     h->ipk_dma = (int)env_get("MGH_IPK_DMA", h->ipk_dma);
@@ -2348,6 +2350,16 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
                 "invalid shape: every dimension must have at least 3 nodes");
   }
   h->plane_elems = shape[D - 1] * (D >= 2 ? shape[D - 2] : 1);
+  // Thin arrays (a long slowest dimension over planes of a few nodes: 300000 x 17 x 17): the tiled
+  // level kernels cover the coarse (c, f) plane with tiles of 4 x 64 nodes and march along r; where
+  // the plane fills less than an eighth of its tiles the one-thread-per-element kernels are the
+  // faster ones (4194304 x 3 x 3: 82 -> 12.5 ms per mgh_compress, 300000 x 17 x 17: 16 -> 6.8 ms,
+  // 2048 x 2048 x 17 at 14 %: 5.5 vs 5.3 ms).
+  if (h->force_v1_env < 0 && D == 3) {
+    const uint64_t m1 = shape[1] / 2 + 1, m2 = shape[2] / 2 + 1;
+    const double tiles = (double)((m1 + 3) / 4) * (double)((m2 + 63) / 64);
+    if ((double)(m1 * m2) < 0.125 * tiles * 256.0) h->force_v1 = true;
+  }
   int rc = DISPATCH(h, build_device_state<float>(h), build_device_state<double>(h));
   if (rc != MGH_SUCCESS) {
     mgh_hierarchy_destroy(h);

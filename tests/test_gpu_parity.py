@@ -1039,3 +1039,36 @@ def test_outlier_slots_per_wave_and_per_workgroup_fill_the_same_list(shape, dt, 
         np.testing.assert_array_equal(gi, ri)
         np.testing.assert_array_equal(gv, rv)
     h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("v1", [None, "0", "1"])
+@pytest.mark.parametrize("shape,dt", [((5000, 5, 7), np.float32), ((3000, 17, 17), np.float64), ((40001, 3, 3), np.float32)])
+def test_thin_arrays_take_the_simple_kernels_and_give_the_same_bits(shape, dt, v1, monkeypatch):
+    """A long slowest dimension over planes of a few nodes fills the tiles of the level kernels badly; the
+    hierarchy then selects the one-thread-per-element kernels by itself (mgh_hierarchy_create;
+    MGH_FORCE_V1=0 keeps the tiled kernels, =1 forces the simple ones everywhere). Whatever runs, the
+    integers are the oracle's."""
+    torch, mg = _gpu()
+    if v1 is None:
+        monkeypatch.delenv("MGH_FORCE_V1", raising=False)
+    else:
+        monkeypatch.setenv("MGH_FORCE_V1", v1)
+    u = smooth_field(shape, dt, noise=1e-2)
+    h = mg.Hierarchy(shape, dt)
+    o = oracle.Hierarchy(shape, dt)
+    ud = torch.from_numpy(u).cuda()
+    ref = o.decompose(u)
+    assert_bit_equal(h.decompose(ud).cpu().numpy(), ref, "decompose %r" % (shape,))
+    q, oi, ov, n, nrm = h.decompose_quantize(ud, mg.REL, 1e-3, np.inf)
+    rq, roi, rov, rn = o.quantize(ref, oracle.REL, dt(1e-3), dt(np.inf), dt(nrm))
+    assert n == rn
+    np.testing.assert_array_equal(q.cpu().numpy(), rq)
+    gi, gv = _outlier_set(oi.cpu().numpy(), ov.cpu().numpy())
+    ri, rv = _outlier_set(roi, rov)
+    np.testing.assert_array_equal(gi, ri)
+    np.testing.assert_array_equal(gv, rv)
+    back = h.dequantize_recompose(q, mg.REL, 1e-3, np.inf, nrm, outlier_idx=oi, outlier_val=ov)
+    rback = o.recompose(o.dequantize(rq, oracle.REL, dt(1e-3), dt(np.inf), dt(nrm), outlier_idx=roi, outlier_val=rov))
+    assert_bit_equal(back.cpu().numpy(), rback, "dequantize + recompose %r" % (shape,))
+    h.close()
