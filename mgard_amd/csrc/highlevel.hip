@@ -214,8 +214,15 @@ inline size_t align_up(size_t off, size_t a) { return (off + a - 1) / a * a; }
 struct PayloadLayout {
   size_t primary_count = 0, huffmeta = 0, decodebook_size = 0, decodebook = 0, ddata_size = 0,
          ddata = 0, outlier_count = 0, outlier_idx = 0, outliers = 0, total = 0;
+  // Behind the reference's payload (its reader stops at the outlier lists), optional: the decoder's
+  // synchronisation points (huffman.hpp: k_encode_chain), [u64 kSyncTag][u32 x 64 per chunk]. The
+  // section's size is 8 (mod 16) while the outlier lists' is 0: a reader that knows the record's
+  // size and where the lists start sees from the remainder whether it is there.
+  size_t sync_tag = 0, sync = 0;
+  static constexpr uint64_t kSyncTag = 0x31434e595348474dull;  // "MGHSYNC1"
+  static size_t sync_bytes(size_t nchunk) { return 8 + 4 * (size_t)huff::kSyncLanes * nchunk; }
   // offsets of: primary_count, dict_size, chunk_size, huffmeta_size are fixed (0, 8, 12, 16)
-  void compute(size_t nchunk, size_t dict, size_t units, size_t noutlier) {
+  void compute(size_t nchunk, size_t dict, size_t units, size_t noutlier, bool with_sync = false) {
     size_t off = 0;
     primary_count = off; off += 8;
     off += 4;  // dict_size (int)
@@ -231,6 +238,11 @@ struct PayloadLayout {
     outlier_count = off; off += 8;
     outlier_idx = off; off += 8 * noutlier;
     outliers = off; off += 8 * noutlier;
+    sync_tag = sync = 0;
+    if (with_sync) {
+      sync_tag = off; off += 8;
+      sync = off; off += 4 * (size_t)huff::kSyncLanes * nchunk;
+    }
     total = off;
   }
 };
@@ -240,7 +252,9 @@ struct PayloadLayout {
 // ---- lossless context ----------------------------------------------------------------------
 struct mgh_lossless_ctx {
   int dev = 0;
-  DevBuf freq, code, bits, entry, total, units, tables, oidx, oval, state, dtable;
+  DevBuf freq, code, bits, entry, total, units, tables, oidx, oval, state, dtable, sync;
+  bool use_sync = false;   // the record of the last compress call carries synchronisation points
+  size_t n_chunks = 0;
   bool overflow = false;  // the code stream did not fit into cap_units: treat as incompressible
   huff::Codebook codebook;
   std::vector<uint8_t> host;   // serialized payload (when assembled on the host)
@@ -341,6 +355,8 @@ int record_write(mgh_lossless_ctx *c, void *dst, hipStream_t st, const uint64_t 
     HL_HIP(hipMemcpyAsync(d + L.outlier_idx, c->d_oidx, c->n_outliers * 8, hipMemcpyDefault, st));
     HL_HIP(hipMemcpyAsync(d + L.outliers, c->d_oval, c->n_outliers * 8, hipMemcpyDefault, st));
   }
+  if (c->use_sync)  // (tag + entries as the encoder left them: one piece)
+    HL_TRY(copy_any(d + L.sync_tag, c->sync.p, PayloadLayout::sync_bytes(c->n_chunks), st));
   return MGH_SUCCESS;
 }
 
@@ -475,6 +491,20 @@ int lossless_finish(mgh_lossless_ctx *c, const LosslessJob &J, hipStream_t st, u
     std::memcpy(pinp + o_code, cb.code.data(), dict * 8);
     HL_HIP(hipMemcpyAsync(c->code.p, pinp + o_code, dict * 8, hipMemcpyHostToDevice, st));
   }
+  // Synchronisation points for the decoder behind the record (PayloadLayout): with the single-pass
+  // encoder, chunks of the size it keeps in registers, and streams of 4 bits per symbol or more
+  // -- 256 bytes per chunk are 1.1 % of a chunk of 20 480 nine-bit codes, and the short codes of
+  // a low-entropy stream re-synchronise within a symbol or two anyway. MGH_HUFF_SYNC=0: never.
+  c->use_sync = false;
+  c->n_chunks = nchunk;
+  if (lossless == MGH_LOSSLESS_HUFFMAN && lossless_sym16_ok(dict, chunk) && chunk >= 1024 &&
+      chunk <= (uint64_t)huff::kEncRun * huff::kEncThreads && env_get("MGH_HUFF_SYNC", 1) != 0) {
+    double bits = 0;
+    for (uint64_t k = 0; k < dict; k++) bits += (double)freq[k] * (double)(cb.code[k] >> huff::kMaxCodeBits);
+    c->use_sync = bits >= 4.0 * (double)n;
+    if (c->use_sync) HL_TRY(c->sync.ensure(PayloadLayout::sync_bytes(nchunk)));
+  }
+  const size_t sync_bytes = c->use_sync ? PayloadLayout::sync_bytes(nchunk) : 0;
   // ---- serialize (Huffman.hpp:163-239): the small leading part on the host, the code units
   // and the outlier lists stay where they are until record_write() ----
   uint8_t *const out = c->chead;
@@ -495,10 +525,10 @@ int lossless_finish(mgh_lossless_ctx *c, const LosslessJob &J, hipStream_t st, u
     unsigned long long cap = cap_units ? std::min<unsigned long long>(cap_units, worst) : worst;
     unsigned long long *units_dst = nullptr;
     // (the record may start at any byte: the encoder stores its units unaligned where it has to)
-    if (direct && lossless == MGH_LOSSLESS_HUFFMAN && direct_cap > L.ddata + 64 &&
+    if (direct && lossless == MGH_LOSSLESS_HUFFMAN && direct_cap > L.ddata + 64 + sync_bytes &&
         is_device_pointer_on(direct, c->dev)) {
       // (what does not fit behind the units -- outlier lists -- is the caller's capacity check)
-      cap = std::min<unsigned long long>(cap, (direct_cap - L.ddata - 8) / 8);
+      cap = std::min<unsigned long long>(cap, (direct_cap - L.ddata - 8 - sync_bytes) / 8);
       units_dst = (unsigned long long *)(direct + L.ddata);
       c->units_in_place = true;
     } else {
@@ -524,7 +554,8 @@ int lossless_finish(mgh_lossless_ctx *c, const LosslessJob &J, hipStream_t st, u
       huff::k_encode_chain<SYM, CODE><<<(unsigned)nchunk, huff::kEncThreads, enc_lds, st>>>(
           (const SYM *)d_q, n, (int)chunk, (int)dict, nchunk, (const CODE *)c->code.p,
           (unsigned long long *)c->state.p, (unsigned long long *)c->bits.p,
-          (unsigned long long *)c->entry.p, units_dst, cap, (int)nlong);
+          (unsigned long long *)c->entry.p, units_dst, cap, (int)nlong,
+          c->use_sync ? (unsigned *)c->sync.p + 2 : nullptr, PayloadLayout::kSyncTag);
     };
     if (sym16 && short_codes) enc(uint16_t(), uint32_t());
     else if (sym16) enc(uint16_t(), uint64_t());
@@ -557,6 +588,7 @@ int lossless_finish(mgh_lossless_ctx *c, const LosslessJob &J, hipStream_t st, u
     c->overflow = (st3[2] & 1) != 0;
   } else {
     if (sym16) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "lossless: 16-bit symbols need the single-pass encoder");
+    c->use_sync = false;
     if (short_codes)  // (these kernels read 64-bit entries)
       HL_HIP(hipMemcpyAsync(c->code.p, cb.code.data(), dict * 8, hipMemcpyHostToDevice, st));
     huff::k_chunk_bits<<<(unsigned)nchunk, 256, 0, st>>>(d_q, n, (int)chunk, (const uint64_t *)c->code.p,
@@ -587,7 +619,7 @@ int lossless_finish(mgh_lossless_ctx *c, const LosslessJob &J, hipStream_t st, u
   }
   c->on_host = false;
   if (c->overflow) return MGH_SUCCESS;  // record_size() says "larger than anything"
-  L.compute(nchunk, dict, units, ocount);
+  L.compute(nchunk, dict, units, ocount, c->use_sync);
   auto put64 = [&](size_t off, uint64_t v) { std::memcpy(out + off, &v, 8); };
   auto put32 = [&](size_t off, int32_t v) { std::memcpy(out + off, &v, 4); };
   put64(L.primary_count, n);
@@ -706,16 +738,29 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
   const size_t o_oc = L.ddata + 8 * units;
   if (!need(o_oc, 8)) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
   uint64_t ocount = 0;
+  // Behind the outlier lists: nothing, or the synchronisation points of the decoder (PayloadLayout;
+  // 8 mod 16 bytes where the lists are 0 mod 16).
+  const size_t sync_bytes = PayloadLayout::sync_bytes(nchunk);
+  const size_t rem = psize - o_oc - 8;
+  bool has_sync = rem % 16 == 8 && rem >= sync_bytes;
   if (on_dev) {
-    // the record ends with the two outlier arrays: their length follows from the record size
-    // (saves a synchronous 8-byte copy from the device)
-    if ((psize - o_oc - 8) % 16 != 0) return hl_fail(MGH_ERR_FORMAT, "Huffman record: outlier lists");
-    ocount = (psize - o_oc - 8) / 16;
+    // the record ends with the two outlier arrays (and that section): their length follows from
+    // the record size (saves a synchronous 8-byte copy from the device)
+    if (rem % 16 != 0 && !has_sync) return hl_fail(MGH_ERR_FORMAT, "Huffman record: outlier lists");
+    ocount = (rem - (has_sync ? sync_bytes : 0)) / 16;
   } else {
     std::memcpy(&ocount, p + o_oc, 8);
+    if (has_sync && (ocount > (rem - sync_bytes) / 16 || rem - 16 * ocount != sync_bytes)) has_sync = false;
   }
-  if (ocount > (psize - o_oc - 8) / 16) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
+  if (ocount > rem / 16) return hl_fail(MGH_ERR_FORMAT, "Huffman record truncated");
   const size_t o_oidx = o_oc + 8, o_oval = o_oidx + 8 * ocount;
+  const size_t o_sync = o_oval + 8 * ocount + 8;  // (behind the tag)
+  if (has_sync && !on_dev) {
+    uint64_t tag = 0;
+    std::memcpy(&tag, p + o_sync - 8, 8);
+    if (tag != PayloadLayout::kSyncTag) has_sync = false;
+  }
+  if (env_get("MGH_HUFF_SYNC_DECODE", 1) == 0) has_sync = false;  // cross-check: decode without them
   // the chunk entries must stay inside the unit array (they index it in the decoder)
   {
     const uint64_t *bits = reinterpret_cast<const uint64_t *>(head.data() + L.huffmeta);
@@ -807,18 +852,30 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
       hl_attr_done(once3);
     }
+    // synchronisation points of the encoder, if the record has them: read where they lie in a
+    // record on this device (any alignment), else from a copy
+    const unsigned *d_sync = nullptr;
+    if (has_sync && (size_t)chunk <= 65535) {
+      if (on_dev && is_device_pointer_on(p, c->dev)) {
+        d_sync = (const unsigned *)(p + o_sync);
+      } else {
+        HL_TRY(c->sync.ensure(sync_bytes - 8));
+        HL_HIP(hipMemcpyAsync(c->sync.p, p + o_sync, sync_bytes - 8, hipMemcpyDefault, st));
+        d_sync = (const unsigned *)c->sync.p;
+      }
+    }
     if (sym16 && *sym16)
       huff::k_decode_ring<uint16_t><<<(unsigned)((nchunk + waves - 1) / waves), 64 * waves,
                                       huff::decode_ring_lds(dt.size(), waves), st>>>(
           d_units, (const unsigned long long *)c->bits.p,
           (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, rtb, (const unsigned *)c->dtable.p,
-          (unsigned)dt.size(), tab, tab + 64, tab + 128, (uint16_t *)d_q);
+          (unsigned)dt.size(), tab, tab + 64, tab + 128, (uint16_t *)d_q, d_sync);
     else
       huff::k_decode_ring<int64_t><<<(unsigned)((nchunk + waves - 1) / waves), 64 * waves,
                                      huff::decode_ring_lds(dt.size(), waves), st>>>(
           d_units, (const unsigned long long *)c->bits.p,
           (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, rtb, (const unsigned *)c->dtable.p,
-          (unsigned)dt.size(), tab, tab + 64, tab + 128, d_q);
+          (unsigned)dt.size(), tab, tab + 64, tab + 128, d_q, d_sync);
     HL_HIP(hipGetLastError());
   } else if (!serial_decode && (size_t)chunk >= 1024) {
     if (sym16) *sym16 = false;

@@ -370,6 +370,7 @@ k_encode(const int64_t *__restrict__ q, size_t n, int chunk, const uint64_t *__r
   if (room != kUnitBits) flush(true);
 }
 
+constexpr int kEncRun = 40;      // symbols per thread the single-pass encoder keeps in registers (default chunk: 20480 = 40 x 512)
 constexpr int kEncThreads = 512;  // threads of an encoder workgroup (two workgroups per CU with 32-bit code entries)
 
 
@@ -432,6 +433,12 @@ inline size_t encode_chain_lds(size_t dict, size_t entry_bytes, size_t chunk) {
 // Code units at an address that need not be 8-byte aligned: a record inside a container starts
 // wherever the header and the records before it end, and the encoder / decoder work on the units
 // where they lie (gfx950 serves unaligned global dwordx2 accesses; atomics need alignment).
+constexpr int kSyncLanes = 64;  // synchronisation points per chunk = lanes of the decoder's wave
+__device__ __forceinline__ unsigned load_u32(const unsigned *p, size_t i) {  // (any byte alignment)
+  unsigned v;
+  __builtin_memcpy(&v, reinterpret_cast<const unsigned char *>(p) + 4 * i, 4);
+  return v;
+}
 __device__ __forceinline__ unsigned long long load_unit(const unsigned long long *p, size_t i) {
   unsigned long long v;
   __builtin_memcpy(&v, reinterpret_cast<const unsigned char *>(p) + 8 * i, 8);
@@ -446,7 +453,8 @@ __global__ void __launch_bounds__(kEncThreads)
 k_encode_chain(const SYM *__restrict__ q, size_t n, int chunk, int dict, size_t nchunk,
                const CODE *__restrict__ code, unsigned long long *__restrict__ state,
                unsigned long long *__restrict__ bits, unsigned long long *__restrict__ entry,
-               unsigned long long *__restrict__ out, unsigned long long cap_units, int nlong) {
+               unsigned long long *__restrict__ out, unsigned long long cap_units, int nlong,
+               unsigned *__restrict__ sync, unsigned long long sync_tag) {
   constexpr int SH = CodeEntry<CODE>::shift;
   // LDS: code table [dict] | symbols of the chunk (encode_chain_lds() is the host's copy of this
   // layout). The escape list stays in global memory behind the table (8-byte aligned): its entries
@@ -483,7 +491,7 @@ k_encode_chain(const SYM *__restrict__ q, size_t n, int chunk, int dict, size_t 
   // (default chunk: 40 symbols per thread): the table look-ups of a thread are then independent
   // LDS reads in flight together, and the packing loop runs from registers. Longer runs (bigger
   // chunks) read the table twice.
-  constexpr int RR = 40;
+  constexpr int RR = kEncRun;
   CODE cc[RR];
   const bool in_regs = run <= (size_t)RR;
   unsigned s = 0;
@@ -586,6 +594,42 @@ k_encode_chain(const SYM *__restrict__ q, size_t n, int chunk, int dict, size_t 
   if (e0 + my_units > cap_units) return;
   unsigned long long *dst = out + e0;
   const unsigned pos = sc[threadIdx.x] - s;  // first bit of this thread's run
+  // Synchronisation points for the decoder (kSyncLanes per chunk; not part of the reference's
+  // payload: the caller stores them behind it). The decoder cuts a chunk's stream into 64
+  // subsequences of B = ceil(bits / 64) bits, one per lane; entry k says where the first code
+  // that STARTS at or behind bit k * B begins (delta = its distance from k * B) and which symbol
+  // of the chunk it is. With them a lane decodes its symbols once and straight to their place;
+  // without them it has to find its first code boundary by decoding speculatively, and the
+  // symbols' places by a counting pass (k_decode_ring). A boundary k * B in (start, end] of a
+  // code makes the NEXT symbol the entry of k; entries of subsequences in which no code starts
+  // keep (0, cnt): no symbols.
+  if (sync) {  // (same decision in every thread; in_regs by the host's choice of chunk size)
+    __shared__ unsigned ssync[kSyncLanes];
+    if (threadIdx.x < kSyncLanes) ssync[threadIdx.x] = threadIdx.x ? (unsigned)cnt : 0u;
+    __syncthreads();
+    const unsigned B = (total_bits + kSyncLanes - 1) / kSyncLanes;
+    if (B && in_regs && lo < hi) {
+      unsigned o = pos, kcur = pos / B + 1, nb = kcur * B;
+#pragma unroll
+      for (int k = 0; k < RR; k++) {
+        if (lo + k < hi) {
+          o += entry_len(cc[k], slong);  // end of symbol lo + k = start of symbol lo + k + 1
+          while (o >= nb && kcur < (unsigned)kSyncLanes) {
+            if (lo + k + 1 < cnt) ssync[kcur] = (min(o - nb, 0xffffu) << 16) | (unsigned)(lo + k + 1);
+            kcur++;
+            nb += B;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < kSyncLanes) sync[id * kSyncLanes + threadIdx.x] = ssync[threadIdx.x];
+    // (the section's tag in front of the entries: the caller copies tag + entries in one piece)
+    if (id == 0 && threadIdx.x == 0) {
+      sync[-2] = (unsigned)(sync_tag & 0xffffffffu);
+      sync[-1] = (unsigned)(sync_tag >> 32);
+    }
+  }
   const bool active = lo < hi && s != 0;
   // pack the runs into `buf` (zeroed): whole units are stored, the first and the last unit of a
   // run are shared with the neighbours and OR-ed in
@@ -1091,7 +1135,7 @@ k_decode_ring(const unsigned long long *__restrict__ units, const unsigned long 
               int dict, int tb, const unsigned *__restrict__ g_table, unsigned table_entries,
               const unsigned long long *__restrict__ first,
               const unsigned long long *__restrict__ entry, const unsigned long long *__restrict__ keys,
-              OUT *__restrict__ q) {
+              OUT *__restrict__ q, const unsigned *__restrict__ sync) {
   __shared__ unsigned long long sfirst[64], sentry[64], slim[64];
   __shared__ int smaxlen;
   extern __shared__ unsigned dyn_lds[];
@@ -1289,6 +1333,20 @@ k_decode_ring(const unsigned long long *__restrict__ units, const unsigned long 
   using M1 = std::integral_constant<int, 1>;
   using M2 = std::integral_constant<int, 2>;
 
+  if (sync) {
+    // the encoder's synchronisation points (k_encode_chain): start and place of every lane's
+    // symbols are given, one decoding pass. (Damaged entries decode garbage inside the chunk's
+    // own range of units and symbols at worst: every access below is bounded by total and cap.)
+    const unsigned ent = load_u32(sync, c * kSyncLanes + lane);
+    const unsigned first_sym = lane ? min(ent & 0xffffu, cap) : 0u;
+    unsigned next_sym = __shfl_down(first_sym, 1, 64);
+    if (lane == 63) next_sym = cap;
+    const unsigned s0 = lane ? (unsigned)min((unsigned long long)lane * B + (ent >> 16), (unsigned long long)total) : 0u;
+    const unsigned want = next_sym > first_sym ? next_sym - first_sym : 0u;
+    unsigned c2 = 0;
+    (void)pass(M2{}, s0, &c2, want, first_sym, 0, 0, 0);
+    return;
+  }
   unsigned s = min((unsigned)lane * B, total), cnt = 0;
   unsigned e = pass(M0{}, s, &cnt, 0, 0, 0, 0, 0);
   const unsigned rs = s, re = e, rc = cnt;  // the remembered pass

@@ -33,11 +33,51 @@ def parse_huffman_record(b):
     oc, = struct.unpack_from("<Q", b, off); off += 8
     oidx = np.frombuffer(b, dtype="<u8", count=oc, offset=off); off += 8 * oc
     oval = np.frombuffer(b, dtype="<i8", count=oc, offset=off); off += 8 * oc
-    assert off == len(b), (off, len(b))
     nchunk = hm // 2
+    # behind the reference's payload, optional: the decoder's synchronisation points
+    # ([u64 "MGHSYNC1"][u32 x 64 per chunk], highlevel.hip: PayloadLayout)
+    sync = None
+    if off != len(b):
+        assert len(b) - off == 8 + 256 * nchunk, (off, len(b), nchunk)
+        tag, = struct.unpack_from("<Q", b, off)
+        assert tag == SYNC_TAG, hex(tag)
+        sync = np.frombuffer(b, dtype="<u4", count=64 * nchunk, offset=off + 8).reshape(nchunk, 64)
+        off += 8 + 256 * nchunk
+    assert off == len(b), (off, len(b))
     return dict(primary_count=primary, dict_size=dict_size, chunk_size=chunk, bits=meta[:nchunk],
                 entry=meta[nchunk:], first=first, entry_tab=entry_tab, keys=keys, units=units,
-                outlier_idx=oidx, outliers=oval)
+                outlier_idx=oidx, outliers=oval, sync=sync)
+
+
+SYNC_TAG = int.from_bytes(b"MGHSYNC1", "little")
+
+
+def expected_sync_points(rec, symbols):
+    """What the synchronisation points of a record must be, from the symbols and the decodebook alone:
+    entry k of a chunk = (distance of the first code that starts at or behind bit k * B from that bit)
+    << 16 | index of its symbol in the chunk, B = ceil(bits of the chunk / 64); (0, symbols in the
+    chunk) where no code starts behind k * B; entry 0 = 0."""
+    n, chunk = int(rec["primary_count"]), int(rec["chunk_size"])
+    length = {}
+    first = [int(x) for x in rec["first"]]
+    entry = [int(x) for x in rec["entry_tab"]] + [int(rec["dict_size"])]
+    nxt = int(rec["dict_size"])
+    for l in range(63, 0, -1):            # keys[entry[l] .. next used entry) carry codes of length l
+        if first[l] != 2 ** 64 - 1:
+            for k in range(entry[l], nxt):
+                length[int(rec["keys"][k])] = l
+            nxt = entry[l]
+    out = np.zeros((len(rec["bits"]), 64), dtype=np.uint32)
+    for c in range(len(rec["bits"])):
+        sy = symbols[c * chunk:min(n, (c + 1) * chunk)]
+        starts = np.concatenate([[0], np.cumsum([length[int(x)] for x in sy])]).astype(np.int64)
+        total = int(starts[-1])
+        assert total == int(rec["bits"][c])
+        B = (total + 63) // 64
+        for k in range(1, 64):
+            i = int(np.searchsorted(starts[:-1], k * B, side="left")) if B else len(sy)
+            out[c, k] = ((int(starts[i]) - k * B) << 16 | i) if i < len(sy) else len(sy)
+    return out
 
 
 def decode_huffman_record(rec, max_chunks=None):

@@ -732,8 +732,9 @@ def _outlier_tail(rec):
     p += 8 + u64(p)          # decodebook
     p += 8 + 8 * u64(p)      # code units
     count = u64(p)
-    assert p + 8 + 16 * count == rec.numel()
-    return p + 8
+    # (behind the lists, optional: the decoder's synchronisation points, 8 + 256 bytes per chunk)
+    assert rec.numel() - (p + 8 + 16 * count) in (0, 8 + 256 * (hm // 2))
+    return p + 8, count
 
 
 def _config3_volume(torch, nt=64):
@@ -784,12 +785,12 @@ def test_config3_whole_volume_on_one_gpu():
         # identical integers = identical Huffman part of the record (counts, code book, code
         # stream); the outlier list is in atomic order and is compared as a set
         ra, rb = stream[off:off + size].clone(), alone[aoff:aoff + asize].clone()
-        tail_a, tail_b = _outlier_tail(ra), _outlier_tail(rb)
-        assert tail_a == tail_b
+        (tail_a, na), (tail_b, nb) = _outlier_tail(ra), _outlier_tail(rb)
+        assert tail_a == tail_b and na == nb
         assert torch.equal(ra[:tail_a], rb[:tail_b]), k
-        na = (size - tail_a) // 16
-        ia, va = ra[tail_a:tail_a + 8 * na].view(torch.int64), ra[tail_a + 8 * na:].view(torch.int64)
-        ib, vb = rb[tail_b:tail_b + 8 * na].view(torch.int64), rb[tail_b + 8 * na:].view(torch.int64)
+        assert torch.equal(ra[tail_a + 16 * na:], rb[tail_b + 16 * na:]), k   # synchronisation points
+        ia, va = ra[tail_a:tail_a + 8 * na].view(torch.int64), ra[tail_a + 8 * na:tail_a + 16 * na].view(torch.int64)
+        ib, vb = rb[tail_b:tail_b + 8 * na].view(torch.int64), rb[tail_b + 8 * na:tail_b + 16 * na].view(torch.int64)
         oa, ob = torch.argsort(ia), torch.argsort(ib)
         assert torch.equal(ia[oa], ib[ob]) and torch.equal(va[oa], vb[ob]), k
         del alone, ra, rb
@@ -889,7 +890,8 @@ def _canonical_records(hl, buf):
             out.append(("raw", r))
             continue
         n = len(p["outlier_idx"])
-        head = r[:len(r) - 16 * n]
+        tail = 0 if p["sync"] is None else 8 + 4 * p["sync"].size   # (behind the lists: synchronisation points)
+        head = r[:len(r) - 16 * n - tail] + r[len(r) - tail:]
         order = np.argsort(p["outlier_idx"], kind="stable")
         out.append(("huffman", head, p["outlier_idx"][order].tobytes(), p["outliers"][order].tobytes()))
     return b[:m["metadata_size"]], out
@@ -1055,3 +1057,52 @@ def test_more_subdomain_shapes_than_the_hierarchy_cache_holds():
         v = hl.decompress(buf, config=cfg).cpu().numpy()
         assert float(np.max(np.abs(v - u))) <= 1e-3 * nrm * (1 + 1e-6)
     hl.release_cache()
+
+
+@pytest.mark.parametrize("kind,n,chunk", [("normal60", 3 * 20480 + 777, 20480), ("uniform4096", 50001, 4096),
+                                          ("sorted", 2 * 20480 + 5, 20480), ("narrow", 3 * 20480, 20480),
+                                          ("normal60", 20480 * 2, 1024)])
+def test_synchronisation_points_behind_the_huffman_record(kind, n, chunk, monkeypatch):
+    """Behind the reference's payload the encoder leaves, for streams of 4 bits per symbol or more, 64
+    synchronisation points per chunk: where the first code at or behind bit k * ceil(bits / 64) starts and
+    which symbol it is (huffman.hpp: k_encode_chain). The independent reader recomputes them from the
+    symbols and the decodebook; the library's decoder must return the same symbols with them (one pass)
+    and without them (MGH_HUFF_SYNC_DECODE=0: speculative subsequences + counting pass), also on streams
+    that do not re-synchronise by themselves (sorted symbols: long runs of one code length); a record
+    written with MGH_HUFF_SYNC=0 is the same record without the section."""
+    torch, mg, hl = _mods()
+    rng = np.random.default_rng(11)
+    if kind == "normal60":
+        q = _symbols(n, width=60.0)
+    elif kind == "uniform4096":
+        q = rng.integers(2048, 2048 + 4096, n).astype(np.int64)
+    elif kind == "sorted":
+        q = np.sort(_symbols(n, width=300.0))
+    else:
+        q = _symbols(n, width=0.4)  # ~1.5 bits per symbol: no section
+    oi = np.array([1, n // 3], dtype=np.int64)
+    ov = np.array([-5, 99999], dtype=np.int64)
+    q[oi] = 0
+    ctx = hl.Lossless()
+    qd = torch.from_numpy(q).cuda()
+    args = (8192, chunk, hl.HUFFMAN, 3, torch.from_numpy(oi).cuda(), torch.from_numpy(ov).cuda())
+    monkeypatch.setenv("MGH_HUFF_SYNC", "1")
+    rec = ctx.compress(qd, *args)
+    r = pl.parse_huffman_record(rec)
+    if kind == "narrow":
+        assert r["sync"] is None
+    else:
+        assert r["sync"] is not None
+        np.testing.assert_array_equal(r["sync"], pl.expected_sync_points(r, q))
+    monkeypatch.setenv("MGH_HUFF_SYNC", "0")
+    plain = ctx.compress(qd, *args)
+    assert pl.parse_huffman_record(plain)["sync"] is None
+    assert rec[:len(plain)] == plain
+    for sync_decode in ("1", "0"):
+        monkeypatch.setenv("MGH_HUFF_SYNC_DECODE", sync_decode)
+        for payload in (rec, plain, torch.frombuffer(bytearray(rec), dtype=torch.uint8).cuda(),
+                        torch.frombuffer(bytearray(b"xyz" + rec), dtype=torch.uint8).cuda()[3:]):
+            back, bi, bv = ctx.decompress(payload, n, hl.HUFFMAN)
+            assert np.array_equal(back.cpu().numpy(), q), (kind, sync_decode)
+            assert np.array_equal(bi.cpu().numpy(), oi) and np.array_equal(bv.cpu().numpy(), ov)
+    ctx.close()
