@@ -448,8 +448,9 @@ __device__ __forceinline__ void store_unit(unsigned long long *p, size_t i, unsi
   __builtin_memcpy(reinterpret_cast<unsigned char *>(p) + 8 * i, &v, 8);
 }
 
+// (two workgroups per CU with 32-bit code entries = four waves per SIMD: 128 VGPRs)
 template <typename SYM, typename CODE>
-__global__ void __launch_bounds__(kEncThreads)
+__global__ void __launch_bounds__(kEncThreads, sizeof(CODE) == 4 ? 4 : 2)
 k_encode_chain(const SYM *__restrict__ q, size_t n, int chunk, int dict, size_t nchunk,
                const CODE *__restrict__ code, unsigned long long *__restrict__ state,
                unsigned long long *__restrict__ bits, unsigned long long *__restrict__ entry,
@@ -608,15 +609,31 @@ k_encode_chain(const SYM *__restrict__ q, size_t n, int chunk, int dict, size_t 
     if (threadIdx.x < kSyncLanes) ssync[threadIdx.x] = threadIdx.x ? (unsigned)cnt : 0u;
     __syncthreads();
     const unsigned B = (total_bits + kSyncLanes - 1) / kSyncLanes;
-    if (B && in_regs && lo < hi) {
-      unsigned o = pos, kcur = pos / B + 1, nb = kcur * B;
+    if (B && in_regs && s) {
+      // boundaries in (pos, pos + s]: none for seven threads of eight, one for the others (a run is
+      // much shorter than a subsequence)
+      const unsigned k_lo = pos / B + 1, k_hi = min((pos + s) / B, (unsigned)kSyncLanes - 1);
+      if (fast && !esc && k_lo == k_hi) {
+        // ... and the symbol behind it by straight-line selects over the lengths in registers
+        const unsigned nb = k_lo * B;
+        unsigned o = pos, idx = 0, dl = 0;
+        bool found = false;
 #pragma unroll
-      for (int k = 0; k < RR; k++) {
-        if (lo + k < hi) {
-          o += entry_len(cc[k], slong);  // end of symbol lo + k = start of symbol lo + k + 1
-          while (o >= nb && kcur < (unsigned)kSyncLanes) {
-            if (lo + k + 1 < cnt) ssync[kcur] = (min(o - nb, 0xffffu) << 16) | (unsigned)(lo + k + 1);
-            kcur++;
+        for (int k = 0; k < RR; k++) {
+          o += (unsigned)(cc[k] >> SH);  // end of symbol lo + k = start of symbol lo + k + 1
+          const bool hit = !found && o >= nb;
+          idx = hit ? (unsigned)(k + 1) : idx;
+          dl = hit ? o - nb : dl;
+          found |= hit;
+        }
+        if (found && lo + idx < cnt) ssync[k_lo] = (min(dl, 0xffffu) << 16) | (unsigned)(lo + idx);
+      } else if (k_lo <= k_hi) {  // (several boundaries in one run, a partial chunk, escape entries, 64-bit table: from the LDS copies)
+        unsigned o = pos, kk = k_lo, nb = k_lo * B;
+        for (size_t i = lo; i < hi && kk <= k_hi; i++) {
+          o += entry_len(scode[ssym[i]], slong);
+          while (o >= nb && kk <= k_hi) {
+            if (i + 1 < cnt) ssync[kk] = (min(o - nb, 0xffffu) << 16) | (unsigned)(i + 1);
+            kk++;
             nb += B;
           }
         }
