@@ -325,6 +325,31 @@ inline int dev_to_host(void *dst, const void *src, size_t bytes) {
   return aux_read(dst, src, bytes);
 }
 
+// The small pieces of a device-resident record -- its head out of the context's pinned buffer (which
+// the device reads directly), the outlier count, the two outlier lists, the synchronisation points
+// -- in ONE launch instead of five asynchronous copies of ~7 us of host time each, which all sit
+// between the encoder's result and the caller's return. Any byte alignment on either side.
+struct RecordPieces {
+  const uint8_t *src[5];
+  uint8_t *dst[5];
+  size_t bytes[5];
+  int n;
+};
+__global__ void __launch_bounds__(256) k_record_pieces(RecordPieces P) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+  for (int i = 0; i < P.n; i++) {
+    const uint8_t *sp = P.src[i];
+    uint8_t *dp = P.dst[i];
+    const size_t words = P.bytes[i] / 8;
+    for (size_t w = t; w < words; w += stride) {
+      unsigned long long v;
+      __builtin_memcpy(&v, sp + 8 * w, 8);
+      __builtin_memcpy(dp + 8 * w, &v, 8);
+    }
+    for (size_t b = words * 8 + t; b < P.bytes[i]; b += stride) dp[b] = sp[b];
+  }
+}
+
 // Copy the record of the last lossless_compress() to dst (host or device memory, record_size()
 // bytes). Asynchronous on st where the memory kinds allow it.
 int record_write(mgh_lossless_ctx *c, void *dst, hipStream_t st, const uint64_t *size_prefix = nullptr) {
@@ -341,6 +366,36 @@ int record_write(mgh_lossless_ctx *c, void *dst, hipStream_t st, const uint64_t 
     return MGH_SUCCESS;
   }
   const PayloadLayout &L = c->lay;
+  void *dev_head = nullptr;
+  if (is_device_pointer_on(dst, c->dev) &&
+      hipHostGetDevicePointer(&dev_head, c->chead - 8, 0) == hipSuccess && dev_head) {
+    if (size_prefix) std::memcpy(c->chead - 8, size_prefix, 8);
+    if (c->n_units && !c->units_in_place)
+      HL_TRY(copy_any(d + L.ddata, c->units.p, c->n_units * 8, st));
+    RecordPieces P{};
+    auto piece = [&](const void *src, void *to, size_t bytes) {
+      if (!bytes) return;
+      P.src[P.n] = (const uint8_t *)src;
+      P.dst[P.n] = (uint8_t *)to;
+      P.bytes[P.n] = bytes;
+      P.n++;
+    };
+    const uint8_t *dh = (const uint8_t *)dev_head;
+    if (size_prefix) piece(dh, d - 8, 8 + L.ddata);
+    else piece(dh + 8, d, L.ddata);
+    // (the count out of the pinned buffer too: &c->pcounts[4] lies behind the head in the same allocation)
+    piece(dh + ((const uint8_t *)&c->pcounts[4] - (c->chead - 8)), d + L.outlier_count, 8);
+    piece(c->d_oidx, d + L.outlier_idx, c->n_outliers * 8);
+    piece(c->d_oval, d + L.outliers, c->n_outliers * 8);
+    if (c->use_sync) piece(c->sync.p, d + L.sync_tag, PayloadLayout::sync_bytes(c->n_chunks));
+    size_t total = 0;
+    for (int i = 0; i < P.n; i++) total += P.bytes[i];
+    const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>(total / (256 * 64), 1), 512);
+    k_record_pieces<<<blocks, 256, 0, st>>>(P);
+    HL_HIP(hipGetLastError());
+    return MGH_SUCCESS;
+  }
+  (void)hipGetLastError();
   if (size_prefix) {
     std::memcpy(c->chead - 8, size_prefix, 8);
     HL_HIP(hipMemcpyAsync(d - 8, c->chead - 8, 8 + L.ddata, hipMemcpyDefault, st));
