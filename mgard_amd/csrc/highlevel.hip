@@ -554,9 +554,7 @@ int lossless_finish(mgh_lossless_ctx *c, const LosslessJob &J, hipStream_t st, u
   c->n_chunks = nchunk;
   if (lossless == MGH_LOSSLESS_HUFFMAN && lossless_sym16_ok(dict, chunk) && chunk >= 1024 &&
       chunk <= (uint64_t)huff::kEncRun * huff::kEncThreads && env_get("MGH_HUFF_SYNC", 1) != 0) {
-    double bits = 0;
-    for (uint64_t k = 0; k < dict; k++) bits += (double)freq[k] * (double)(cb.code[k] >> huff::kMaxCodeBits);
-    c->use_sync = bits >= 4.0 * (double)n;
+    c->use_sync = cb.total_bits >= 4 * n;
     if (c->use_sync) HL_TRY(c->sync.ensure(PayloadLayout::sync_bytes(nchunk)));
   }
   const size_t sync_bytes = c->use_sync ? PayloadLayout::sync_bytes(nchunk) : 0;

@@ -53,6 +53,7 @@ struct Codebook {
   std::vector<uint64_t> first, entry;  // [64]
   std::vector<uint64_t> keys;          // [dict]: symbols in decreasing-frequency / code order
   int max_len = 0;
+  uint64_t total_bits = 0;  // length of the code stream without the chunks' padding: sum of frequency x code length
   // work arrays of build_codebook (they keep their capacity from call to call: the construction
   // runs once per subdomain on the critical path of mgh_compress)
   std::vector<uint64_t> w_asc, w_weight;
@@ -66,6 +67,7 @@ struct Codebook {
 // 8192 used symbols: ~0.03 ms on one core of the GPU box's host.
 inline void build_codebook(const unsigned *freq, int dict, Codebook &cb) {
   cb.max_len = 0;
+  cb.total_bits = 0;
   cb.code.assign(dict, 0);
   cb.first.assign(kUnitBits, ~(uint64_t)0);
   cb.entry.assign(kUnitBits, 0);
@@ -212,6 +214,7 @@ inline void build_codebook(const unsigned *freq, int dict, Codebook &cb) {
       const uint32_t sym = (uint32_t)a[nz - 1 - idx[k]];
       cb.keys[k] = (uint64_t)sym;
       cb.code[sym] = v++;
+      cb.total_bits += (uint64_t)l * freq[sym];
     }
   }
 }
