@@ -254,6 +254,7 @@ struct mgh_lossless_ctx {
   int dev = 0;
   DevBuf freq, code, bits, entry, total, units, tables, oidx, oval, state, dtable, sync;
   bool use_sync = false;   // the record of the last compress call carries synchronisation points
+  uint64_t prepared_n = 0, prepared_dict = 0, prepared_chunk = 0;  // lossless_prepare() ran for a record of this size
   size_t n_chunks = 0;
   bool overflow = false;  // the code stream did not fit into cap_units: treat as incompressible
   huff::Codebook codebook;
@@ -436,6 +437,34 @@ struct LosslessJob {
   bool sym16 = false;
 };
 
+// Zeroing of the stage's device state (histogram bins, the encoder's chunk states, optionally a
+// counter of the caller) in ONE launch. Queued by the subdomain pipeline in FRONT of the
+// subdomain's decomposition, where the device is waiting for the host's launches anyway; three
+// memsets between quantizer and encoder were ~15 us of every record's critical path.
+__global__ void __launch_bounds__(256) k_zero_words(unsigned long long *a, size_t na, unsigned long long *b,
+                                                    size_t nb, unsigned long long *c1) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+  for (size_t i = t; i < na; i += stride) a[i] = 0;
+  for (size_t i = t; i < nb; i += stride) b[i] = 0;
+  if (c1 && t == 0) *c1 = 0;
+}
+int lossless_prepare(mgh_lossless_ctx *c, uint64_t n, uint64_t dict, uint64_t chunk, hipStream_t st,
+                     unsigned long long *also_zero = nullptr) {
+  c->prepared_n = 0;
+  if (n == 0 || dict == 0 || dict > 16384 || chunk == 0 || chunk > (1u << 30)) return MGH_SUCCESS;  // (lossless_begin reports it)
+  const size_t nchunk = (n - 1) / chunk + 1;
+  HL_TRY(c->freq.ensure((dict * 4 + 7) / 8 * 8));
+  HL_TRY(c->state.ensure((3 + nchunk) * 8));
+  const size_t words = (dict * 4 + 7) / 8 + 3 + nchunk;
+  k_zero_words<<<(unsigned)std::min<size_t>((words + 255) / 256, 256), 256, 0, st>>>(
+      (unsigned long long *)c->freq.p, (dict * 4 + 7) / 8, (unsigned long long *)c->state.p, 3 + nchunk, also_zero);
+  HL_HIP(hipGetLastError());
+  c->prepared_n = n;
+  c->prepared_dict = dict;
+  c->prepared_chunk = chunk;
+  return MGH_SUCCESS;
+}
+
 int lossless_begin(mgh_lossless_ctx *c, const LosslessJob &J, hipStream_t st) {
   const int64_t *d_q = J.d_q;
   const uint64_t n = J.n, dict = J.dict, chunk = J.chunk;
@@ -450,7 +479,9 @@ int lossless_begin(mgh_lossless_ctx *c, const LosslessJob &J, hipStream_t st) {
   if (lossless == MGH_LOSSLESS_HUFFMAN_ZSTD && !g_zstd.load())
     return hl_fail(MGH_ERR_INVALID_ARGUMENT, "lossless: libzstd.so.1 not found");
   const size_t nchunk = (n - 1) / chunk + 1;
-  HL_TRY(c->freq.ensure(dict * 4));
+  const bool prepared = c->prepared_n == n && c->prepared_dict == dict && c->prepared_chunk == chunk;
+  c->prepared_n = 0;  // (good for one record)
+  HL_TRY(c->freq.ensure((dict * 4 + 7) / 8 * 8));
   HL_TRY(c->code.ensure(dict * 8));
   HL_TRY(c->bits.ensure(nchunk * 8));
   HL_TRY(c->entry.ensure(nchunk * 8));
@@ -460,7 +491,7 @@ int lossless_begin(mgh_lossless_ctx *c, const LosslessJob &J, hipStream_t st) {
   // decomposer never produces one, but the stand-alone entry point could be handed one)
   if (n >= ((uint64_t)1 << 32))
     return hl_fail(MGH_ERR_INVALID_ARGUMENT, "lossless stage: more than 2^32 - 1 symbols in one record");
-  HL_HIP(hipMemsetAsync(c->freq.p, 0, dict * 4, st));
+  if (!prepared) HL_HIP(hipMemsetAsync(c->freq.p, 0, dict * 4, st));
   const unsigned hblocks =
       (unsigned)std::min<size_t>((n + huff::kHistThreads - 1) / huff::kHistThreads, 2 * (size_t)hl_num_cu());
   if (sym16)
@@ -473,7 +504,7 @@ int lossless_begin(mgh_lossless_ctx *c, const LosslessJob &J, hipStream_t st) {
   // (the encoder's chunk states are cleared here, behind the histogram kernel, so that nothing but
   // the code table stands between the code construction on the host and the encoder's launch)
   HL_TRY(c->state.ensure((3 + nchunk) * 8));
-  HL_HIP(hipMemsetAsync(c->state.p, 0, (3 + nchunk) * 8, st));
+  if (!prepared) HL_HIP(hipMemsetAsync(c->state.p, 0, (3 + nchunk) * 8, st));
   hl_debug("lossless_compress: histogram kernel done");
   // pinned staging of this call (see PinBuf)
   PayloadLayout &L = c->lay;
@@ -1817,7 +1848,13 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
     HL_TRY(get_hierarchy(&J.h, &J.owned, dtype, sshape, cptr, dd.subdomain_offset(id), cfg, J.lane));
     if (J.owned) owned_alive.push_back(J.h);
     hl_debug("compress: subdomain ready");
-    HL_HIP(hipMemsetAsync(L.ocount.p, 0, 8, st));
+    // (outlier counter of the lane + the lossless stage's bins and chunk states: one launch, here)
+    if (cfg.reorder || cfg.lossless == MGH_LOSSLESS_HUFFMAN_ZSTD) {
+      HL_HIP(hipMemsetAsync(L.ocount.p, 0, 8, st));
+    } else {
+      HL_TRY(lossless_prepare(L.ll, J.n, cfg.huff_dict_size, cfg.huff_block_size, st, (unsigned long long *)L.ocount.p));
+      if (!L.ll->prepared_n) HL_HIP(hipMemsetAsync(L.ocount.p, 0, 8, st));
+    }
     J.norm_out = (double)norm;
     // 16-bit symbols straight from the quantizer where the fused kernels run (a quarter of the
     // bytes written by the quantizer and read twice by the lossless stage); int64 otherwise
