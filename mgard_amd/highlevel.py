@@ -274,12 +274,15 @@ def decompress(buf, config=None, out=None):
     import torch
     L = _hl()
     cfg = config if config is not None else Config()
-    shape, dt = infer(buf)
     if isinstance(buf, torch.Tensor) and buf.is_cuda:
         if out is None:
+            # (two header reads from device memory, ~60 us: a caller who passes `out` vouches for its
+            # shape and type like the caller of mgard_x::decompress with a pre-allocated buffer does)
+            shape, dt = infer(buf)
             out = torch.empty(shape, dtype=torch.float32 if dt == FLOAT else torch.float64, device=buf.device)
         p, n, optr = C.c_void_p(buf.data_ptr()), buf.numel(), C.c_void_p(out.data_ptr())
     else:
+        shape, dt = infer(buf)
         buf = np.ascontiguousarray(buf)
         out = np.empty(shape, dtype=np.float32 if dt == FLOAT else np.float64)
         p, n, optr = C.c_void_p(buf.ctypes.data), buf.size, C.c_void_p(out.ctypes.data)
