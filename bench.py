@@ -1023,20 +1023,28 @@ def main():
             stream = highlevel.compress(d_u, TOL, S, mgard_amd.REL, coords=hl_coords, out=obuf)
             stream = highlevel.compress(d_u, TOL, S, mgard_amd.REL, coords=hl_coords, out=obuf)
             torch.cuda.synchronize()
-            t2 = time.perf_counter()
             NE = 10
-            for _ in range(NE):
-                stream = highlevel.compress(d_u, TOL, S, mgard_amd.REL, coords=hl_coords, out=obuf)
-            torch.cuda.synchronize()
-            c_ms = (time.perf_counter() - t2) / NE * 1e3
+            # three batches of NE calls each, the best batch reported and all three listed: these
+            # calls are host-latency bound (two host round trips per record), and one evidence run of
+            # round 5 had a single batch at 2.4 ms between runs at 1.30-1.33 ms on either side
+            c_batches, x_batches = [], []
+            for _b in range(3):
+                t2 = time.perf_counter()
+                for _ in range(NE):
+                    stream = highlevel.compress(d_u, TOL, S, mgard_amd.REL, coords=hl_coords, out=obuf)
+                torch.cuda.synchronize()
+                c_batches.append((time.perf_counter() - t2) / NE * 1e3)
+            c_ms = min(c_batches)
             out = torch.empty_like(d_u)
             highlevel.decompress(stream, out=out)
             torch.cuda.synchronize()
-            t3 = time.perf_counter()
-            for _ in range(NE):
-                highlevel.decompress(stream, out=out)
-            torch.cuda.synchronize()
-            x_ms = (time.perf_counter() - t3) / NE * 1e3
+            for _b in range(3):
+                t3 = time.perf_counter()
+                for _ in range(NE):
+                    highlevel.decompress(stream, out=out)
+                torch.cuda.synchronize()
+                x_batches.append((time.perf_counter() - t3) / NE * 1e3)
+            x_ms = min(x_batches)
             e2e_err = float((out - d_u).abs().max().item()) if S == float("inf") else \
                 float(((out - d_u).double() ** 2).mean().sqrt().item())
             result["end_to_end"] = {
@@ -1045,6 +1053,8 @@ def main():
                 "compress_ms": round(c_ms, 3), "compress_GBps": round(in_bytes / c_ms / 1e6, 2),
                 "decompress_ms": round(x_ms, 3), "decompress_GBps": round(in_bytes / x_ms / 1e6, 2),
                 "compression_ratio": round(in_bytes / int(stream.numel()), 3),
+                "compress_ms_batches": [round(v, 3) for v in c_batches],
+                "decompress_ms_batches": [round(v, 3) for v in x_batches],
                 "within_tolerance": bool(e2e_err <= TOL * nrm_host)}
             del out, stream, obuf
             highlevel.release_cache()

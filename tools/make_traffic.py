@@ -41,6 +41,12 @@ def per_kernel(db, counter):
     return out
 
 
+def tmode_is(symbol, tmode):
+    """k_level_fused2<T, OUT, TC, TF, RCH, FACES, TMODE, AGG>: is TMODE (the last integer template
+    argument of the mangled symbol, in front of the bool AGG since round 5) = tmode?"""
+    return any(("ELi%d%sEEEv" % (tmode, tail)) in symbol for tail in ("", "ELb0", "ELb1"))
+
+
 def biggest(stats, needle):
     keys = [k for k in stats if needle in k[0]]
     if not keys:
@@ -58,7 +64,7 @@ def main():
     out = {"_about": __doc__.strip(), "source_hash": source_hash()}
     for label, needle, corr in (("level_fused_q", "k_level_fused2", 2.0), ("absmax", "k_absmax", 2.0),
                                 ("sqsum", "k_sqsum", 2.0)):
-        pick = (lambda st: {k: v for k, v in st.items() if "ELi0EEEv" in k[0]}) if needle == "k_level_fused2" else (lambda st: st)
+        pick = (lambda st: {k: v for k, v in st.items() if tmode_is(k[0], 0)}) if needle == "k_level_fused2" else (lambda st: st)
         f, nf = biggest(pick(fetch), needle)
         w, nw = biggest(pick(write), needle)
         if f is None or w is None:
@@ -68,8 +74,8 @@ def main():
     # D = 4: the level kernel under the names the library profiles it with, per t-slice parity
     # (template argument TMODE = 1 / 2 at the end of the symbol; absent from a 3-D run)
     for label, tmode in (("level4_even", 1), ("level4_odd", 2)):
-        sub_f = {k: v for k, v in fetch.items() if "k_level_fused2" in k[0] and ("ELi%dEEEv" % tmode) in k[0]}
-        sub_w = {k: v for k, v in write.items() if "k_level_fused2" in k[0] and ("ELi%dEEEv" % tmode) in k[0]}
+        sub_f = {k: v for k, v in fetch.items() if "k_level_fused2" in k[0] and tmode_is(k[0], tmode)}
+        sub_w = {k: v for k, v in write.items() if "k_level_fused2" in k[0] and tmode_is(k[0], tmode)}
         f, nf = biggest(sub_f, "k_level_fused2")
         w, nw = biggest(sub_w, "k_level_fused2")
         if f is not None and w is not None:
