@@ -863,9 +863,32 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
   // (a record in device memory: these go device-to-device from the record itself, not back up
   // from the pageable host copy)
   const uint8_t *meta_src = on_dev ? p : head.data();
-  HL_HIP(hipMemcpyAsync(c->bits.p, meta_src + L.huffmeta, nchunk * 8, hipMemcpyDefault, st));
-  HL_HIP(hipMemcpyAsync(c->entry.p, meta_src + L.huffmeta + nchunk * 8, nchunk * 8, hipMemcpyDefault, st));
-  HL_HIP(hipMemcpyAsync(c->tables.p, meta_src + L.decodebook, dbsize, hipMemcpyDefault, st));
+  // (a record on this device: chunk table, decodebook and outlier lists in ONE launch -- five
+  // queued copies of ~5 us each stood in front of every decoder launch)
+  const bool pieces = on_dev && is_device_pointer_on(p, c->dev);
+  if (pieces) {
+    RecordPieces P{};
+    auto piece = [&](const void *src, void *to, size_t bytes) {
+      if (!bytes) return;
+      P.src[P.n] = (const uint8_t *)src;
+      P.dst[P.n] = (uint8_t *)to;
+      P.bytes[P.n] = bytes;
+      P.n++;
+    };
+    piece(p + L.huffmeta, c->bits.p, nchunk * 8);
+    piece(p + L.huffmeta + nchunk * 8, c->entry.p, nchunk * 8);
+    piece(p + L.decodebook, c->tables.p, dbsize);
+    piece(p + o_oidx, c->oidx.p, ocount * 8);
+    piece(p + o_oval, c->oval.p, ocount * 8);
+    size_t tot = 0;
+    for (int i = 0; i < P.n; i++) tot += P.bytes[i];
+    k_record_pieces<<<(unsigned)std::min<size_t>(std::max<size_t>(tot / (256 * 64), 1), 512), 256, 0, st>>>(P);
+    HL_HIP(hipGetLastError());
+  } else {
+    HL_HIP(hipMemcpyAsync(c->bits.p, meta_src + L.huffmeta, nchunk * 8, hipMemcpyDefault, st));
+    HL_HIP(hipMemcpyAsync(c->entry.p, meta_src + L.huffmeta + nchunk * 8, nchunk * 8, hipMemcpyDefault, st));
+    HL_HIP(hipMemcpyAsync(c->tables.p, meta_src + L.decodebook, dbsize, hipMemcpyDefault, st));
+  }
   static const bool serial_decode = env_get("MGH_HUFF_SERIAL_DECODE", 0) != 0;  // cross-check
   static const bool par_decode = env_get("MGH_HUFF_PAR_DECODE", 0) != 0;           // cross-check
   int book_max_len = 0;  // longest code of the decodebook (unused lengths carry first = 2^64-1)
@@ -892,7 +915,7 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
     if (units) HL_HIP(hipMemcpyAsync(c->units.p, p + L.ddata, units * 8, hipMemcpyDefault, st));
     HL_HIP(hipMemsetAsync((char *)c->units.p + units * 8, 0, 8, st));  // (the decoder peeks one unit ahead)
   }
-  if (ocount) {
+  if (ocount && !pieces) {
     HL_HIP(hipMemcpyAsync(c->oidx.p, p + o_oidx, ocount * 8, hipMemcpyDefault, st));
     HL_HIP(hipMemcpyAsync(c->oval.p, p + o_oval, ocount * 8, hipMemcpyDefault, st));
   }
