@@ -38,6 +38,7 @@ inline const EnvSwitch *env_switches(size_t *count) {
       {"MGH_IPK_SPEC_MAX", 0, 1 << 30},
       {"MGH_IPK_CHUNK", 0, 1},
       {"MGH_OUTLIER_AGG", 0, 2},
+      {"MGH_ND_IPK", 0, 1},
       {"MGH_HUFF_SYNC", 0, 1},
       {"MGH_HUFF_SYNC_DECODE", 0, 1},
       {"MGH_IPK_CHUNK_K", 0, 64},

@@ -346,14 +346,19 @@ def test_fused_dequantize_recompose_bit_exact(shape, s, dt):
     h.close()
 
 
+@pytest.mark.parametrize("nd_ipk", [None, "1"])
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 @pytest.mark.parametrize("shape", [(5, 5, 5, 5), (3, 3, 3, 3), (6, 9, 8, 12), (17, 5, 20, 33), (3, 4, 5, 6, 7),
-                                   (5, 5, 9, 6, 10)])
-def test_nd_decompose_recompose_bit_exact(shape, dt):
+                                   (5, 5, 9, 6, 10), (3, 3, 3, 5, 6000), (3, 2600, 3, 4, 5)])
+def test_nd_decompose_recompose_bit_exact(shape, dt, nd_ipk, monkeypatch):
     """D = 4, 5: generic N-D kernels against the oracle's N-D
     restatement, which itself reproduces the reference's 4-D golden vectors and equals the
-    3-D code on D <= 3."""
+    3-D code on D <= 3. The Thomas solves of the N-D path run on the 3-D kernels through a
+    (dims before, dim, dims behind) view of the compact box -- a long dimension in verified
+    chunks -- or (MGH_ND_IPK=1) on the path's own one-thread-per-pencil kernel."""
     torch, mg = _gpu()
+    if nd_ipk:
+        monkeypatch.setenv("MGH_ND_IPK", nd_ipk)
     u = smooth_field(shape, dt, noise=1e-2)
     h = mg.Hierarchy(shape, dt)
     o = oracle.Hierarchy(shape, dt)
