@@ -88,7 +88,7 @@ struct mgh_hierarchy {
   int fused_faces = 1;
   int fused_xcd = 1;  // MGH_FUSED_XCD: tiles of a level in contiguous ranges per XCD (default 1)
   int fused_fixed = 1; // MGH_FUSED_FIXED: the int64 + dictionary variant of the level kernel (default 1)
-  int fused_wide = 1; // MGH_FUSED_WIDE: 4 x 64 tiles for 0 = no level, 1 = long marches, 2 = all
+  int fused_wide = 1; // MGH_FUSED_WIDE: 4 x 64 tiles for 0 = no level, 1 = long marches, 2 = all (unset: 1 for floats, 0 for doubles)
   int fused4 = 1;     // MGH_FUSED4: D = 4 through the 3-D tile code, slice by slice (default 1)
   // MGH_BOX: levels up to this march class (0 = few tiles, 1 = mid-size, 2 = long marches) run
   // the box kernel (kernels_box.hpp: no march, every phase once over a 4 x 4 x 8 box) instead of
@@ -2316,7 +2316,7 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->fused_faces = (int)env_get("MGH_FUSED_FACES", h->fused_faces);
     h->fused_xcd = (int)env_get("MGH_FUSED_XCD", h->fused_xcd);
     h->fused_fixed = (int)env_get("MGH_FUSED_FIXED", h->fused_fixed);
-    h->fused_wide = (int)env_get("MGH_FUSED_WIDE", h->fused_wide);
+    h->fused_wide = (int)env_get("MGH_FUSED_WIDE", -1);  // (-1: by data type, below)
     h->fused4 = (int)env_get("MGH_FUSED4", h->fused4);
     h->box = (int)env_get("MGH_BOX", h->box);
     h->restore_v = (int)env_get("MGH_RESTORE_V", h->restore_v);
@@ -2344,6 +2344,10 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
   }
   h->dtype = dtype;
   h->device = device;
+  // tile shape of the long marches: 4 x 64 for floats, 8 x 32 for doubles -- fine rows of ~512 bytes
+  // either way (512^3 f64 non-uniform, three alternating runs on one box: top-level pass
+  // 612 -> 593 us, step 1.413 -> 1.384 ms)
+  if (h->fused_wide < 0) h->fused_wide = dtype == MGH_FLOAT ? 1 : 0;
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
