@@ -25,27 +25,7 @@ int main() {
   const long long cyc = 100000;  // 100 MHz wall clock: 1 ms
   auto now = [] { return std::chrono::steady_clock::now(); };
   for (int mode = 0; mode < 4; mode++) {
-    std::vector<double> lat;
-    for (int it = 0; it < 30; it++) {
-      *word = 0;
-      spin<<<1, 64, 0, st>>>(cyc, dbuf);
-      CK(hipMemcpyAsync(pin, dbuf, 32768, hipMemcpyDeviceToHost, st));
-      if (mode == 1) flag<<<1, 1, 0, st>>>(word, 1u);
-      if (mode == 2) { hipError_t e = hipStreamWriteValue32(st, (void *)word, 1u, 0); if (e != hipSuccess) { printf("hipStreamWriteValue32: %s\n", hipGetErrorString(e)); (void)hipGetLastError(); break; } }
-      CK(hipEventRecord(ev, st));
-      if (mode == 0) CK(hipStreamSynchronize(st));
-      else if (mode == 3) { while (hipEventQuery(ev) == hipErrorNotReady) {} }
-      else { while (*word == 0) { __builtin_ia32_pause(); } }
-      const auto t_host = now();
-      CK(hipStreamSynchronize(st));
-      // time of the event on the device is not comparable with the host clock: measure the total
-      // instead (launch to knowledge) against the same sequence's minimum over the modes
-      static std::chrono::steady_clock::time_point t_start;
-      (void)t_start;
-      lat.push_back(0);
-      (void)t_host;
-    }
-    // second loop: total wall time of the sequence
+    // total wall time of the sequence, launch to knowledge
     std::vector<double> tot;
     for (int it = 0; it < 50; it++) {
       *word = 0;
