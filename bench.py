@@ -383,7 +383,7 @@ def gpu_field(torch, shape, dtype, dev, seed=20260101):
 
 
 def config_leg(torch, mgard_amd, name, dev, local_rank, steps=5, end_to_end=False, dist=None, world=1,
-               rank=0):
+               rank=0, host_e2e=False):
     """One of the other BASELINE.json configurations as a step-only leg of the default run
     (`other_configs`): input generated on the device, `steps` timed steps after 2 warm-ups."""
     import numpy as np
@@ -535,7 +535,124 @@ def config_leg(torch, mgard_amd, name, dev, local_rank, steps=5, end_to_end=Fals
                              "within_tolerance": bool(err <= TOL * nrm_host)}
         del back, obuf, stream
         highlevel.release_cache()
+        if host_e2e:
+            try:
+                u_host = d_u.cpu().numpy()
+                del d_u
+                torch.cuda.empty_cache()
+                out["end_to_end_host"] = host_leg(torch, mgard_amd, u_host, TOL, S, nrm_host, reps=2, batches=2)
+                del u_host
+            except (mgard_amd.MgardHipError, RuntimeError, ValueError) as e:
+                out["end_to_end_host"] = {"error": str(e)[:300]}
     h.close()
+    return out
+
+
+def host_leg(torch, mgard_amd, u, tol, s, nrm_host, reps=4, batches=3):
+    """SURVEY.md section 8(d), the reference's own usage: mgh_compress / mgh_decompress with HOST
+    buffers in and out (H2D + every device stage + lossless + D2H inside the timed call). Three kinds
+    of caller memory -- pageable, registered by the caller (mgard_x::pin_memory) and
+    auto_pin_host_buffers = 1 (the reference's default: the library registers and unregisters inside
+    the call) -- next to the box's own pinned H2D / D2H rate for the same bytes, measured here.
+    Never `value`: the metric is defined on device-resident input."""
+    import ctypes as C
+    import numpy as np
+    from mgard_amd import highlevel
+    in_bytes = u.nbytes
+    out = {"what": "mgh_compress / mgh_decompress, host buffers in and out (pre-allocated, touched), "
+                   "MGARD-X container (Huffman); best of %d batches of %d calls" % (batches, reps),
+           "shape": list(u.shape), "dtype": str(u.dtype), "input_bytes": in_bytes}
+
+    def best(fn):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(batches):
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                r = fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / reps * 1e3)
+        return min(ts), r
+
+    # the link itself: one pinned copy of the same bytes each way (and of the container's bytes)
+    pin_t = torch.empty(in_bytes, dtype=torch.uint8, pin_memory=True)
+    dev_t = torch.empty(in_bytes, dtype=torch.uint8, device="cuda")
+    h2d_ms, _ = best(lambda: dev_t.copy_(pin_t, non_blocking=True))
+    d2h_ms, _ = best(lambda: pin_t.copy_(dev_t, non_blocking=True))
+    del pin_t, dev_t
+    out["link"] = {"pinned_h2d_GBps": round(in_bytes / h2d_ms / 1e6, 2), "pinned_d2h_GBps": round(in_bytes / d2h_ms / 1e6, 2),
+                   "pinned_h2d_ms": round(h2d_ms, 3), "pinned_d2h_ms": round(d2h_ms, 3)}
+    h2d, d2h = in_bytes / h2d_ms / 1e6, in_bytes / d2h_ms / 1e6
+
+    def rows(kind, cfg, x, cbuf, back):
+        c_ms, stream = best(lambda: highlevel.compress(x, tol, s, mgard_amd.REL, config=cfg, out=cbuf))
+        x_ms, v = best(lambda: highlevel.decompress(stream, config=cfg, out=back))
+        err = float(np.max(np.abs(v - u))) if s == float("inf") else float(np.sqrt(np.mean((v.astype(np.float64) - u) ** 2)))
+        cb = int(stream.size)
+        # what the call cannot go below with ONE subdomain under a REL bound: all of the input on the
+        # link, then (the norm needs every byte) the record back -- and the mirror image for decompression
+        floor_ms = in_bytes / h2d / 1e6 + cb / d2h / 1e6
+        floor_x_ms = cb / h2d / 1e6 + in_bytes / d2h / 1e6
+        out[kind] = {"compress_ms": round(c_ms, 3), "compress_GBps": round(in_bytes / c_ms / 1e6, 2),
+                     "compress_frac_of_h2d_rate": round(in_bytes / c_ms / 1e6 / h2d, 3),
+                     "compress_frac_of_link_floor": round(floor_ms / c_ms, 3),
+                     "decompress_ms": round(x_ms, 3), "decompress_GBps": round(in_bytes / x_ms / 1e6, 2),
+                     "decompress_frac_of_d2h_rate": round(in_bytes / x_ms / 1e6 / d2h, 3),
+                     "decompress_frac_of_link_floor": round(floor_x_ms / x_ms, 3),
+                     "container_bytes": cb, "within_tolerance": bool(err <= tol * nrm_host)}
+        return stream
+
+    cbuf = np.zeros(in_bytes + 1000000, dtype=np.uint8)   # (touched: no first-touch faults inside the calls)
+    back = np.zeros(u.shape, dtype=u.dtype)
+    stream = rows("pageable", highlevel.Config(), u, cbuf, back)
+    ref_stream = bytes(stream[:4096])
+    # auto_pin_host_buffers = 1 on the same pageable arrays
+    try:
+        rows("auto_pin", highlevel.Config(auto_pin_host_buffers=1), u, cbuf, back)
+    except mgard_amd.MgardHipError as e:
+        out["auto_pin"] = {"error": str(e)[:200]}
+    # registered by the caller: input, container and output
+    try:
+        t0 = time.perf_counter()
+        for a in (u, cbuf, back):
+            highlevel.pin(a)
+        out["caller_pinned_register_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+        try:
+            stream = rows("caller_pinned", highlevel.Config(), u, cbuf, back)
+            out["caller_pinned"]["same_container_head_as_pageable"] = bool(bytes(stream[:4096]) == ref_stream)
+        finally:
+            for a in (u, cbuf, back):
+                highlevel.unpin(a)
+    except mgard_amd.MgardHipError as e:
+        out["caller_pinned"] = {"error": str(e)[:200]}
+    # output allocated BY THE LIBRARY (output_pre_allocated = 0, the reference's plain call): fresh pages
+    try:
+        L = highlevel._hl()
+        cfg = highlevel.Config()
+        libc = C.CDLL(None)
+        libc.free.argtypes = [C.c_void_p]
+        sbuf = np.ascontiguousarray(stream)
+
+        ts, free_ms = [], []
+        for _ in range(batches + 1):   # (first batch = warm-up)
+            ptrs = []
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                optr = C.c_void_p()
+                mgard_amd._check(L.mgh_decompress(C.c_void_p(sbuf.ctypes.data), sbuf.size, C.byref(optr), C.byref(cfg), 0))
+                ptrs.append(optr)
+            ts.append((time.perf_counter() - t0) / reps * 1e3)
+            t0 = time.perf_counter()
+            for optr in ptrs:   # (the caller's free() is not part of the call: timed beside it)
+                libc.free(optr)
+            free_ms.append((time.perf_counter() - t0) / reps * 1e3)
+        x_ms = min(ts[1:])
+        out["library_allocated_output"] = {"decompress_ms": round(x_ms, 3), "decompress_GBps": round(in_bytes / x_ms / 1e6, 2),
+                                           "callers_free_ms": round(min(free_ms[1:]), 3)}
+    except (mgard_amd.MgardHipError, OSError) as e:
+        out["library_allocated_output"] = {"error": str(e)[:200]}
+    highlevel.release_cache()
     return out
 
 
@@ -738,6 +855,8 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="512f32",
                     help="BASELINE.json configuration: 512f32 = configs[1] (the metric's, default), "
                          "512f64nu = configs[2], 1024f32 = configs[4]")
+    ap.add_argument("--no-host-leg", action="store_true",
+                    help="skip the host-buffer end-to-end leg (end_to_end_host)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the step-only legs of configs[2], [3], [4] in the default run")
     ap.add_argument("--no-native-multi", action="store_true",
@@ -1060,6 +1179,12 @@ def main():
             highlevel.release_cache()
         except mgard_amd.MgardHipError as e:  # the headline metric does not depend on this path
             result["end_to_end"] = {"error": str(e)}
+        # ... and with HOST buffers on both sides, the way the reference is called
+        if rank == 0 and dist is None and not args.no_host_leg:
+            try:
+                result["end_to_end_host"] = host_leg(torch, mgard_amd, u, TOL, S, nrm_host)
+            except (mgard_amd.MgardHipError, RuntimeError, ValueError) as e:
+                result["end_to_end_host"] = {"error": str(e)[:300]}
     q_host = None
     # ---- the other BASELINE.json configurations, on the driver's line (step-only legs; `value`
     # stays configs[1]) ----
@@ -1072,7 +1197,8 @@ def main():
         if dist is None:
             for name, e2e in (("512f64nu", False), ("4d", False), ("1024f32", True)):
                 try:
-                    oc[name] = config_leg(torch, mgard_amd, name, dev, local_rank, end_to_end=e2e)
+                    oc[name] = config_leg(torch, mgard_amd, name, dev, local_rank, end_to_end=e2e,
+                                          host_e2e=e2e and not args.no_host_leg)
                 except (mgard_amd.MgardHipError, RuntimeError, AssertionError) as e:
                     oc[name] = {"error": str(e)[:300]}
                 torch.cuda.empty_cache()

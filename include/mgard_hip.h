@@ -164,6 +164,20 @@ int mgh_dequantize_recompose_sym16(mgh_hierarchy *h, const uint16_t *d_symbols, 
                                    uint64_t outlier_count, void *d_data_out, void *stream);
 int mgh_sym16_supported(const mgh_hierarchy *h);
 
+/* Norm of an input that is still ARRIVING (host -> device in slabs): _begin once, _add
+ * for every part that has landed (any partition of the array; `cold` != 0: the part is
+ * read with nontemporal loads, for parts the level pass will not find in the cache
+ * anyway), then ONE call of mgh_decompose_quantize / mgh_decompose_quantize_sym16 with
+ * a REL bound and norm = 0 on the same hierarchy, which takes the accumulated value
+ * instead of reducing the array again. max|x| is exact in any order; the L2 sum has
+ * the order dependence of its last bits that the one-pass reduction has too. All calls
+ * ASYNCHRONOUS, in stream order. Fused 3-D / 4-D path only
+ * (MGH_ERR_UNSUPPORTED_DIMENSION elsewhere). No reference counterpart: the reference
+ * computes the norm after the whole subdomain has arrived (Compressor.hpp:158-176). */
+int mgh_norm_stream_begin(mgh_hierarchy *h, void *stream);
+int mgh_norm_stream_add(mgh_hierarchy *h, const void *d_part, uint64_t count, double s, int cold,
+                        void *stream);
+
 /* Norm that stays on the device: writes one value of the hierarchy's dtype to
  * d_norm_out (max|x| for s = +inf, else the L2 norm of this array as
  * norm_calculator defines it). ASYNCHRONOUS. For a decomposed domain the caller

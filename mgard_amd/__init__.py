@@ -26,7 +26,7 @@ SYMBOLS = [
     "mgh_norm_device", "mgh_decompose_quantize_dn", "mgh_decompose_quantize_sym16",
     "mgh_dequantize_recompose_sym16", "mgh_sym16_supported",
     "mgh_profile_enable", "mgh_profile_filter", "mgh_profile_read", "mgh_stream_calibrate",
-    "mgh_level_linearize", "mgh_outlier_restore",
+    "mgh_level_linearize", "mgh_outlier_restore", "mgh_norm_stream_begin", "mgh_norm_stream_add",
 ]
 
 
@@ -74,6 +74,8 @@ def load_library():
                                          C.POINTER(C.c_double), u64, C.c_int, vp, vp, vp, vp, u64,
                                          vp, vp]
     L.mgh_norm_device.argtypes = [vp, vp, C.c_double, vp, vp]
+    L.mgh_norm_stream_begin.argtypes = [vp, vp]
+    L.mgh_norm_stream_add.argtypes = [vp, vp, u64, C.c_double, C.c_int, vp]
     L.mgh_dequantize_recompose_sym16.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, C.c_double, u64,
                                                  vp, vp, u64, vp, vp]
     L.mgh_sym16_supported.argtypes = [vp]
@@ -272,6 +274,20 @@ class Hierarchy:
         n = int(cnt.item())
         k = min(n, cap)
         return q, idx[:k], val[:k], n, nout.value
+
+    def norm_stream(self, data, s, parts):
+        """mgh_norm_stream_begin + one mgh_norm_stream_add per part of the (flattened) array: the next
+        fused decompose_quantize* call with a REL bound and norm = 0 takes the accumulated norm.
+        `parts`: element counts that add up to the array."""
+        flat = data.reshape(-1)
+        assert sum(parts) == flat.numel()
+        L = load_library()
+        _check(L.mgh_norm_stream_begin(self._h, _stream()))
+        off = 0
+        for k, cnt in enumerate(parts):
+            _check(L.mgh_norm_stream_add(self._h, C.c_void_p(flat.data_ptr() + off * flat.element_size()),
+                                         int(cnt), s, int(k + 1 < len(parts)), _stream()))
+            off += cnt
 
     def decompose_quantize_sym16(self, data, ebtype, tol, s, norm=0.0, dict_size=8192, outlier_cap=None):
         """mgh_decompose_quantize_sym16: (symbols uint16, outlier_idx, outlier_val, count, norm)."""

@@ -197,6 +197,9 @@ template <typename T> struct DeviceState {
   unsigned long long *fscal = nullptr;
   int scalar_slot = 0;
   bool fscal_dirty = false;
+  // mgh_norm_stream_begin/add: the slot of the NEXT fused call already holds the reduction of its
+  // input (accumulated slab by slab while the input was arriving from the host)
+  bool norm_streamed = false;
   T *normval = nullptr;                  // norm as T, written by k_make_qparams
   unsigned long long *oh_key = nullptr;  // outlier table of the 16-bit symbol path (grown on demand)
   long long *oh_val = nullptr;
@@ -2215,11 +2218,15 @@ int fused_q_entry_device(mgh_hierarchy *h, const T *data, int ebtype, double tol
                          uint64_t *oidx, int64_t *oval, uint64_t ocap, hipStream_t st,
                          uint16_t *q16 = nullptr) {
   auto *ds = DS<T>(h);
-  const bool need_norm = !d_norm && ebtype == MGH_REL;
+  // (mgh_norm_stream_*: the reduction is in the slot already; anything else the caller passes
+  // alongside -- a given norm, an ABS bound -- overrides it)
+  const bool streamed = ds->norm_streamed && !d_norm && ebtype == MGH_REL;
+  ds->norm_streamed = false;
+  const bool need_norm = !d_norm && ebtype == MGH_REL && !streamed;
   // The norm scalar has two slots used alternately: this call reduces into scalar[slot] (zero on
   // entry) and k_make_qparams zeroes the other one for the next call, together with the outlier
   // counter -- two memset launches less per step.
-  if (ds->fscal_dirty) HIP_TRY(hipMemsetAsync(ds->fscal, 0, 16, st));
+  if (ds->fscal_dirty && !streamed) HIP_TRY(hipMemsetAsync(ds->fscal, 0, 16, st));
   ds->fscal_dirty = true;
   unsigned long long *slot = ds->fscal + ds->scalar_slot;
   unsigned long long *other = ds->fscal + (1 - ds->scalar_slot);
@@ -2269,6 +2276,27 @@ int fused_q_entry_device(mgh_hierarchy *h, const T *data, int ebtype, double tol
     *h_norm_out = (double)nv;
   }
   return MGH_SUCCESS;
+}
+
+// Norm accumulated over parts of the input (mgh_norm_stream_begin / _add): the same reduction
+// kernels on a range, into the slot the next fused call reads.
+template <typename T> int norm_stream_begin(mgh_hierarchy *h, hipStream_t st) {
+  auto *ds = DS<T>(h);
+  if (ds->fscal_dirty) HIP_TRY(hipMemsetAsync(ds->fscal, 0, 16, st));
+  ds->fscal_dirty = true;  // (the slot is in use from here on)
+  ds->norm_streamed = true;
+  return MGH_SUCCESS;
+}
+template <typename T>
+int norm_stream_add(mgh_hierarchy *h, const T *part, size_t count, double s, int cold, hipStream_t st) {
+  auto *ds = DS<T>(h);
+  if (!ds->norm_streamed) return fail(MGH_ERR_INVALID_ARGUMENT, "mgh_norm_stream_add without mgh_norm_stream_begin");
+  if (count == 0) return MGH_SUCCESS;
+  unsigned long long *slot = ds->fscal + ds->scalar_slot;
+  const unsigned grid = (unsigned)std::min<size_t>((count + 1023) / 1024, 256 * 8);
+  if ((T)s == std::numeric_limits<T>::infinity())
+    return launch(h, "absmax", st, [&] { k_absmax<T><<<grid, 256, 0, st>>>(part, count, slot, cold ? count : 0); });
+  return launch(h, "sqsum", st, [&] { k_sqsum<T><<<grid, 256, 0, st>>>(part, count, (double *)slot, cold ? count : 0); });
 }
 
 #define DISPATCH(h, call_f, call_d)                                              \
@@ -2626,6 +2654,21 @@ int mgh_norm_device(mgh_hierarchy *h, const void *d_data, double s, void *d_norm
     HIP_TRY(hipMemcpyAsync(d_norm_out, DS<double>(h)->normval, sizeof(double), hipMemcpyDeviceToDevice, st));
   }
   return MGH_SUCCESS;
+}
+
+int mgh_norm_stream_begin(mgh_hierarchy *h, void *stream) {
+  if (!h) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
+  if (!fusedc_ok(h) || h->force_v1)
+    return fail(MGH_ERR_UNSUPPORTED_DIMENSION, "streamed norm: only in front of the fused 3-D / 4-D path");
+  HIP_TRY(hipSetDevice(h->device));
+  return DISPATCH(h, norm_stream_begin<float>(h, (hipStream_t)stream), norm_stream_begin<double>(h, (hipStream_t)stream));
+}
+
+int mgh_norm_stream_add(mgh_hierarchy *h, const void *d_part, uint64_t count, double s, int cold, void *stream) {
+  if (!h || (!d_part && count)) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  return DISPATCH(h, norm_stream_add<float>(h, (const float *)d_part, count, s, cold, (hipStream_t)stream),
+                  norm_stream_add<double>(h, (const double *)d_part, count, s, cold, (hipStream_t)stream));
 }
 
 int mgh_decompose_quantize_dn(mgh_hierarchy *h, const void *d_data, int error_bound_type,

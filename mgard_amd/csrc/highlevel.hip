@@ -9,6 +9,7 @@
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <atomic>
@@ -19,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <map>
 #include <stdexcept>
@@ -284,7 +286,8 @@ struct mgh_lossless_ctx {
 
 namespace {
 
-int copy_any(void *dst, const void *src, size_t bytes, hipStream_t st);  // (below)
+using ChunkFn = std::function<int(size_t, size_t, hipEvent_t)>;
+int copy_any(void *dst, const void *src, size_t bytes, hipStream_t st, const ChunkFn *on_chunk = nullptr);  // (below)
 
 // The single-pass encoder stages code table and symbols of a chunk in LDS.
 inline bool lossless_sym16_ok(uint64_t dict, uint64_t chunk) {
@@ -857,7 +860,6 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
   HL_TRY(c->bits.ensure(nchunk * 8));
   HL_TRY(c->entry.ensure(nchunk * 8));
   HL_TRY(c->tables.ensure(dbsize));
-  HL_TRY(c->units.ensure((units + 1) * 8));
   HL_TRY(c->oidx.ensure(std::max<size_t>(ocount, 1) * 8));
   HL_TRY(c->oval.ensure(std::max<size_t>(ocount, 1) * 8));
   // (a record in device memory: these go device-to-device from the record itself, not back up
@@ -912,7 +914,10 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
   if (units_in_place) {
     d_units = (const unsigned long long *)(p + L.ddata);
   } else {
-    if (units) HL_HIP(hipMemcpyAsync(c->units.p, p + L.ddata, units * 8, hipMemcpyDefault, st));
+    HL_TRY(c->units.ensure((units + 1) * 8));  // (not for units decoded in place: 8 N bytes a lane would hold for nothing)
+    d_units = (const unsigned long long *)c->units.p;
+    // (a record in pageable host memory travels through the pinned ring: copy_any)
+    if (units) HL_TRY(copy_any(c->units.p, p + L.ddata, units * 8, st));
     HL_HIP(hipMemsetAsync((char *)c->units.p + units * 8, 0, 8, st));  // (the decoder peeks one unit ahead)
   }
   if (ocount && !pieces) {
@@ -1146,6 +1151,21 @@ size_t estimate_footprint(const std::vector<uint64_t> &shape, size_t elem, const
   return (size_t)(b + comp);
 }
 
+// Device bytes THIS implementation keeps for a compression with `nlanes` pipeline lanes and
+// `nbufs` input buffers (upper bound): per lane the quantized array (8 N: int64 where the 16-bit
+// symbols do not apply), its level-linearised copy, the outlier lists (16 per estimated outlier),
+// the hierarchy's workspace (levels below the top, per-slice vectors; the generic N-D path keeps
+// three whole arrays) and the lossless stage's code units (a subdomain that does not compress
+// below its own size is stored raw); per input buffer one dense subdomain.
+size_t own_resident_bytes(int D, uint64_t max_elems, size_t elem, const mgh_config &cfg, uint64_t ocap,
+                          int nlanes, int nbufs) {
+  const double n = (double)max_elems;
+  const double hier = (D <= 3 ? 0.5 : D == 4 ? 1.5 : 4.0) * n * (double)elem;
+  const double lane = 8 * n + (cfg.reorder ? 8 * n : 0) + 16.0 * (double)ocap + hier + (n * (double)elem + 4096) +
+                      (double)(64 << 20);  // (tables, chunk states, synchronisation points, allocator granularity)
+  return (size_t)(lane * nlanes + (double)nbufs * n * (double)elem);
+}
+
 int make_decomposer(Decomposer &dd, int D, const uint64_t *shape, size_t elem, const mgh_config &cfg) {
   dd.D = D;
   dd.shape.assign(shape, shape + D);
@@ -1214,32 +1234,145 @@ int make_decomposer(Decomposer &dd, int D, const uint64_t *shape, size_t elem, c
   return MGH_SUCCESS;
 }
 
-// Large contiguous transfers between PAGEABLE host memory and the device go through two pinned
-// bounce buffers owned by the library, the host-side memcpy split over a few threads: the runtime
-// moves pageable memory at ~11 GB/s (one staging thread), this way the transfer runs near the
-// slower of PCIe and the host's copy bandwidth. (The reference registers the caller's buffers
-// instead -- auto_pin_host_buffers -- which this ROCm version does not survive, see
-// mgh_config_default.) Buffers are per thread, released with the cache.
-struct PinnedBounce {
-  static constexpr size_t kChunk = (size_t)32 << 20;
-  void *buf[2] = {nullptr, nullptr};
-  hipEvent_t ev[2] = {nullptr, nullptr};
+// ---- host side of the host <-> device transfers ----------------------------------------------
+// Numbers of the box the design follows (tools/micro/host_link.hip, 512 MB): pinned DMA 57.6 GB/s
+// either way in one piece, 56.7 in 64 MB pieces, 55.2 in 16 MB pieces; memcpy pageable <-> pinned
+// 32 GB/s on one thread, 85 on 4, 120 on 8; a ring of four pinned 16-32 MB slots filled by 4
+// persistent threads while the DMA drains them: 52-53 GB/s; first touch of 512 MB of fresh 4 KB
+// pages 72 ms on one thread (40 ms inside hipMemcpy), 3 ms with transparent huge pages and 8 threads;
+// hipHostRegister of 512 MB 16 ms.
+//
+// Copy pool: a few persistent threads of the calling thread (released with its cache). A job is
+// a function over part numbers; whoever waits for a job works on it too, so a job always
+// completes even when the workers are busy with an earlier one. (Round 5 spawned 7 std::threads
+// per 32 MB chunk.)
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#else
+  std::this_thread::yield();
+#endif
+}
+struct HostPool {
+  static constexpr int kWorkers = 4;
+  struct Job {
+    std::function<void(int)> fn;
+    int nparts = 0;
+    std::atomic<int> next{0}, done{0};
+  };
+  std::thread th[kWorkers];
+  bool started = false;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::atomic<uint64_t> gen{0};
+  std::shared_ptr<Job> cur;  // (guarded by mu)
+  bool stop = false;
+
+  static void work(Job &j) {
+    for (;;) {
+      const int p = j.next.fetch_add(1, std::memory_order_relaxed);
+      if (p >= j.nparts) break;
+      j.fn(p);
+      j.done.fetch_add(1, std::memory_order_release);
+    }
+  }
+  void worker() {
+    uint64_t seen = 0;
+    for (;;) {
+      std::shared_ptr<Job> j;
+      // a chunked transfer posts a job every few hundred microseconds: poll that long before sleeping
+      for (int spin = 0; spin < 4000 && gen.load(std::memory_order_acquire) == seen; spin++) cpu_relax();
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || gen.load(std::memory_order_acquire) != seen; });
+        if (stop) return;
+        seen = gen.load(std::memory_order_acquire);
+        j = cur;
+      }
+      if (j) work(*j);
+    }
+  }
+  std::shared_ptr<Job> post(std::function<void(int)> fn, int nparts) {
+    auto j = std::make_shared<Job>();
+    j->fn = std::move(fn);
+    j->nparts = nparts;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!started) {
+        for (auto &t : th) t = std::thread([this] { worker(); });
+        started = true;
+      }
+      cur = j;
+      gen.fetch_add(1, std::memory_order_release);
+    }
+    cv.notify_all();
+    return j;
+  }
+  static void wait(Job &j) {
+    work(j);
+    while (j.done.load(std::memory_order_acquire) < j.nparts) cpu_relax();
+  }
+  void run(std::function<void(int)> fn, int nparts) {
+    auto j = post(std::move(fn), nparts);
+    wait(*j);
+  }
+  // dst <- src on the pool (both host memory)
+  void copy(void *dst, const void *src, size_t bytes) {
+    if (bytes < ((size_t)1 << 20)) {
+      std::memcpy(dst, src, bytes);
+      return;
+    }
+    constexpr int kParts = kWorkers + 1;
+    const size_t part = (bytes / kParts + 4095) / 4096 * 4096;
+    run([=](int t) {
+      const size_t lo = std::min(bytes, (size_t)t * part), hi = std::min(bytes, (size_t)(t + 1) * part);
+      if (hi > lo) std::memcpy((char *)dst + lo, (const char *)src + lo, hi - lo);
+    }, kParts);
+  }
+  void shutdown() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!started) return;
+      stop = true;
+    }
+    cv.notify_all();
+    for (auto &t : th) t.join();
+    started = false;
+    stop = false;
+    cur.reset();
+  }
+};
+thread_local HostPool *g_pool_ptr = nullptr;  // (never destroyed automatically, like the cache)
+inline HostPool &host_pool() {
+  if (!g_pool_ptr) g_pool_ptr = new HostPool();
+  return *g_pool_ptr;
+}
+
+// Ring of pinned slots between PAGEABLE host memory and the device: the pool fills (drains) slot
+// c % kSlots while the DMA engine works on the slots before it. (The reference registers the
+// caller's buffers instead -- auto_pin_host_buffers -- at 16 ms per 512 MB on this box, and see
+// mgh_config_default.) One ring per direction and thread, released with the cache.
+struct PinnedRing {
+  static constexpr int kSlots = 4;
+  static constexpr size_t kChunk = (size_t)16 << 20;
+  void *buf[kSlots] = {};
+  hipEvent_t ev[kSlots] = {};
   int dev = -1;  // device the events belong to
-  int ensure() {
+  int ensure(bool buffers) {
     int cur = 0;
     HL_HIP(hipGetDevice(&cur));
     if (cur != dev) {  // events recorded into another device's stream fail: recreate them
       release();
       dev = cur;
     }
-    for (int i = 0; i < 2; i++) {
-      if (!buf[i]) HL_HIP(hipHostMalloc(&buf[i], kChunk, hipHostMallocDefault));
+    for (int i = 0; i < kSlots; i++) {
+      if (buffers && !buf[i]) HL_HIP(hipHostMalloc(&buf[i], kChunk, hipHostMallocDefault));
       if (!ev[i]) HL_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
     }
     return MGH_SUCCESS;
   }
   void release() {
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < kSlots; i++) {
       if (buf[i]) (void)hipHostFree(buf[i]);
       if (ev[i]) (void)hipEventDestroy(ev[i]);
       buf[i] = nullptr;
@@ -1247,43 +1380,46 @@ struct PinnedBounce {
     }
   }
 };
-// One set per direction: the host->device prefetch of subdomain id+1 and the device->host copy of
-// record id run on different streams of the same thread and must not share buffers.
-thread_local PinnedBounce *g_bounce_ptr[2] = {nullptr, nullptr};  // (never destroyed automatically, like the cache)
-inline PinnedBounce &bounce(int dir) {
-  if (!g_bounce_ptr[dir]) g_bounce_ptr[dir] = new PinnedBounce();
-  return *g_bounce_ptr[dir];
+// One ring per direction: the host->device prefetch of subdomain id+1 and the device->host copy of
+// record id run on different streams of the same thread and must not share slots.
+thread_local PinnedRing *g_ring_ptr[2] = {nullptr, nullptr};
+inline PinnedRing &ring(int dir) {
+  if (!g_ring_ptr[dir]) g_ring_ptr[dir] = new PinnedRing();
+  return *g_ring_ptr[dir];
+}
+void release_host_transfer_state() {
+  for (auto *&r : g_ring_ptr)
+    if (r) {
+      r->release();
+      delete r;
+      r = nullptr;
+    }
+  if (g_pool_ptr) {
+    g_pool_ptr->shutdown();
+    delete g_pool_ptr;
+    g_pool_ptr = nullptr;
+  }
 }
 
-inline void parallel_memcpy(void *dst, const void *src, size_t bytes) {
-  constexpr int kThreads = 8;
-  if (bytes < ((size_t)4 << 20)) {
-    std::memcpy(dst, src, bytes);
-    return;
-  }
-  const size_t part = (bytes / kThreads + 4095) / 4096 * 4096;
-  std::thread th[kThreads - 1];
-  for (int t = 1; t < kThreads; t++) {
-    const size_t lo = std::min(bytes, t * part), hi = std::min(bytes, (t + 1) * part);
-    th[t - 1] = std::thread([=] { if (hi > lo) std::memcpy((char *)dst + lo, (const char *)src + lo, hi - lo); });
-  }
-  std::memcpy(dst, src, std::min(bytes, part));
-  for (auto &x : th) x.join();
-}
+// Called for every piece of a host -> device transfer once its copy has been QUEUED on the
+// transfer's stream: [off, off + nb) of the destination is complete when `landed` fires (the event
+// is recorded again for a later piece: wait for it -- hipStreamWaitEvent -- before returning).
 
 // dst (device) <- src (pageable host). The source is consumed when the call returns; the device
 // side is complete in stream order.
-int staged_h2d(void *dst, const void *src, size_t bytes, hipStream_t st) {
-  PinnedBounce &b = bounce(0);
-  HL_TRY(b.ensure());
+int staged_h2d(void *dst, const void *src, size_t bytes, hipStream_t st, const ChunkFn *on_chunk) {
+  PinnedRing &b = ring(0);
+  HL_TRY(b.ensure(true));
+  HostPool &pool = host_pool();
   size_t off = 0;
   for (int c = 0; off < bytes; c++) {
-    const int i = c & 1;
-    const size_t nb = std::min(PinnedBounce::kChunk, bytes - off);
-    HL_HIP(hipEventSynchronize(b.ev[i]));  // the previous transfer out of this buffer is done
-    parallel_memcpy(b.buf[i], (const char *)src + off, nb);
+    const int i = c % PinnedRing::kSlots;
+    const size_t nb = std::min(PinnedRing::kChunk, bytes - off);
+    HL_HIP(hipEventSynchronize(b.ev[i]));  // the previous transfer out of this slot is done
+    pool.copy(b.buf[i], (const char *)src + off, nb);
     HL_HIP(hipMemcpyAsync((char *)dst + off, b.buf[i], nb, hipMemcpyHostToDevice, st));
     HL_HIP(hipEventRecord(b.ev[i], st));
+    if (on_chunk) HL_TRY((*on_chunk)(off, nb, b.ev[i]));
     off += nb;
   }
   return MGH_SUCCESS;
@@ -1291,45 +1427,94 @@ int staged_h2d(void *dst, const void *src, size_t bytes, hipStream_t st) {
 
 // dst (pageable host) <- src (device), after everything queued on st. Complete on return.
 int staged_d2h(void *dst, const void *src, size_t bytes, hipStream_t st) {
-  PinnedBounce &b = bounce(1);
-  HL_TRY(b.ensure());
+  PinnedRing &b = ring(1);
+  HL_TRY(b.ensure(true));
+  HostPool &pool = host_pool();
+  constexpr int K = PinnedRing::kSlots;
   size_t off = 0, done = 0;
-  size_t len[2] = {0, 0};
+  size_t len[K] = {};
   int c = 0;
   for (; off < bytes; c++) {
-    const int i = c & 1;
-    if (c >= 2) {  // drain the buffer we are about to reuse
-      HL_HIP(hipEventSynchronize(b.ev[i]));
-      parallel_memcpy((char *)dst + done, b.buf[i], len[i]);
+    const int i = c % K;
+    HL_HIP(hipEventSynchronize(b.ev[i]));  // (c < K: a transfer of an earlier call may still use the slot)
+    if (c >= K) {  // drain the slot we are about to reuse
+      pool.copy((char *)dst + done, b.buf[i], len[i]);
       done += len[i];
-    } else {
-      HL_HIP(hipEventSynchronize(b.ev[i]));  // a transfer of an earlier call may still use it
     }
-    len[i] = std::min(PinnedBounce::kChunk, bytes - off);
+    len[i] = std::min(PinnedRing::kChunk, bytes - off);
     HL_HIP(hipMemcpyAsync(b.buf[i], (const char *)src + off, len[i], hipMemcpyDeviceToHost, st));
     HL_HIP(hipEventRecord(b.ev[i], st));
     off += len[i];
   }
-  for (int k = std::max(0, c - 2); k < c; k++) {
-    const int i = k & 1;
+  for (int k = std::max(0, c - K); k < c; k++) {
+    const int i = k % K;
     HL_HIP(hipEventSynchronize(b.ev[i]));
-    parallel_memcpy((char *)dst + done, b.buf[i], len[i]);
+    pool.copy((char *)dst + done, b.buf[i], len[i]);
     done += len[i];
   }
   return MGH_SUCCESS;
 }
 
 // contiguous copy between any two of device / pinned host / pageable host memory
-int copy_any(void *dst, const void *src, size_t bytes, hipStream_t st) {
+int copy_any(void *dst, const void *src, size_t bytes, hipStream_t st, const ChunkFn *on_chunk) {
   constexpr size_t kStagedMin = (size_t)8 << 20;
+  const bool dd = is_device_pointer(dst), sd = is_device_pointer(src);
   if (bytes >= kStagedMin) {
-    const bool dd = is_device_pointer(dst), sd = is_device_pointer(src);
-    if (dd && !sd && !is_registered_host(src)) return staged_h2d(dst, src, bytes, st);
+    if (dd && !sd && !is_registered_host(src)) return staged_h2d(dst, src, bytes, st, on_chunk);
     if (sd && !dd && !is_registered_host(dst)) return staged_d2h(dst, src, bytes, st);
+  }
+  if (on_chunk && dd && !sd) {
+    // pinned source, a consumer per piece: 64 MB pieces (56.7 GB/s against 57.6 in one piece)
+    constexpr size_t kPiece = (size_t)64 << 20;
+    PinnedRing &b = ring(0);
+    HL_TRY(b.ensure(false));
+    size_t off = 0;
+    for (int c = 0; off < bytes; c++) {
+      const size_t nb = std::min(kPiece, bytes - off);
+      hipEvent_t ev = b.ev[c % PinnedRing::kSlots];
+      HL_HIP(hipMemcpyAsync((char *)dst + off, (const char *)src + off, nb, hipMemcpyHostToDevice, st));
+      HL_HIP(hipEventRecord(ev, st));
+      HL_TRY((*on_chunk)(off, nb, ev));
+      off += nb;
+    }
+    return MGH_SUCCESS;
   }
   HL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st));
   return MGH_SUCCESS;
 }
+
+// Host memory the library hands to the caller (released with free()): 2 MB aligned and advised for
+// transparent huge pages -- the first touch of 512 MB costs 3 ms that way instead of 40-70 ms of
+// 4 KB faults inside the device -> host copy. `touch`: fault the pages in now, on a few short-lived
+// threads the caller joins before it writes (mgh_decompress: while the device decodes).
+void *host_alloc_large(size_t bytes) {
+  constexpr size_t kHuge = (size_t)2 << 20;
+  if (bytes < 4 * kHuge) return std::malloc(bytes);
+  void *p = nullptr;
+  if (posix_memalign(&p, kHuge, bytes) != 0) return nullptr;
+  (void)madvise(p, bytes, MADV_HUGEPAGE);
+  return p;
+}
+struct Pretouch {
+  std::vector<std::thread> th;
+  void start(void *p, size_t bytes) {
+    constexpr int kThreads = 8;
+    if (bytes < ((size_t)64 << 20)) return;
+    const size_t part = (bytes / kThreads + 4095) / 4096 * 4096;
+    for (int t = 0; t < kThreads; t++) {
+      const size_t lo = std::min(bytes, (size_t)t * part), hi = std::min(bytes, (size_t)(t + 1) * part);
+      if (hi > lo)
+        th.emplace_back([=] {
+          for (size_t o = lo; o < hi; o += 4096) ((volatile char *)p)[o] = 0;
+        });
+    }
+  }
+  void join() {
+    for (auto &t : th) t.join();
+    th.clear();
+  }
+  ~Pretouch() { join(); }
+};
 
 // A box of an array <-> a dense buffer, both in memory of the current device: one launch whatever
 // the dimension (the reference copies subdomains with its own N-D kernels too:
@@ -1507,6 +1692,17 @@ struct HlCache {
   hipStream_t aux_st = nullptr;   // small device -> host reads that must not wait for the lanes
   PinBuf aux_pin;
   int dev = -1;
+  // device bytes the cache holds now (they are reused, so they count as available to the next call)
+  size_t held_bytes() const {
+    size_t b = 0;
+    for (auto &kv : hier) b += mgh_device_bytes(kv.second);
+    for (auto &x : in) b += x.cap;
+    for (auto &l : lane) {
+      b += l.q.cap + l.q2.cap + l.oidx.cap + l.oval.cap + l.sub.cap;
+      if (l.ll) b += l.ll->units.cap + l.ll->oidx.cap + l.ll->oval.cap;
+    }
+    return b;
+  }
   void release() {
     for (auto &kv : hier) mgh_hierarchy_destroy(kv.second);
     hier.clear();
@@ -1713,23 +1909,30 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
   if (!prealloc) {
     cap = total * elem + (size_t)1e6;
     if (in_dev) HL_HIP(hipMalloc(compressed, cap));
-    else if (!(*compressed = std::malloc(cap))) return hl_fail(MGH_ERR_OUT_OF_MEMORY, "malloc");
+    else if (!(*compressed = host_alloc_large(cap))) return hl_fail(MGH_ERR_OUT_OF_MEMORY, "malloc");
   } else {
     cap = *compressed_size;
   }
   const bool out_dev = is_device_pointer(*compressed);
-  // pin the host input for asynchronous prefetch (auto_pin_host_buffers)
-  bool pinned_here = false;
+  // pin the host buffers for asynchronous transfers (auto_pin_host_buffers,
+  // CompressionHighLevel.hpp:164-189: input and output)
+  bool pinned_here = false, out_pinned_here = false;
   if (!in_dev && cfg.auto_pin_host_buffers && !is_registered_host(original)) {
     if (hipHostRegister(const_cast<void *>(original), total * elem, hipHostRegisterDefault) == hipSuccess)
       pinned_here = true;
     else
       (void)hipGetLastError();
   }
+  if (!out_dev && cfg.auto_pin_host_buffers && !is_registered_host(*compressed)) {
+    if (hipHostRegister(*compressed, cap, hipHostRegisterDefault) == hipSuccess)
+      out_pinned_here = true;
+    else
+      (void)hipGetLastError();
+  }
   // MGH_HL_PIPELINE=0: every subdomain runs start to end before the next one is queued (cross-check;
   // same container byte for byte up to the order of the outlier lists)
   const bool pipelined = env_get("MGH_HL_PIPELINE", 1) != 0;
-  const int nlanes = dd.num > 1 && pipelined ? kLanes : 1;
+  int nlanes = dd.num > 1 && pipelined ? kLanes : 1;
   auto drain = [&] {  // nothing of this call may be in flight when it returns
     for (int l = 0; l < kLanes; l++) (void)hipStreamSynchronize(g_cache.lane[l].st);
     (void)hipStreamSynchronize(g_cache.copy_st);
@@ -1740,6 +1943,7 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
     for (mgh_hierarchy *h : owned_alive) mgh_hierarchy_destroy(h);
     owned_alive.clear();
     if (pinned_here) (void)hipHostUnregister(const_cast<void *>(original));
+    if (out_pinned_here) (void)hipHostUnregister(*compressed);
     if (rc != MGH_SUCCESS && !prealloc) {
       if (in_dev) (void)hipFree(*compressed); else std::free(*compressed);
       *compressed = nullptr;
@@ -1750,7 +1954,21 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
   const uint64_t ocap = std::max<uint64_t>(1, (uint64_t)(cfg.estimate_outlier_ratio * (double)max_elems));
   // device-resident input whose subdomains are contiguous slabs: compress them where they are
   const bool zero_copy = in_dev && dd.all_contiguous();
-  const int nbufs = zero_copy ? 0 : (int)std::min<uint64_t>(dd.num, nlanes > 1 ? kInBufs : 2);
+  int nbufs = zero_copy ? 0 : (int)std::min<uint64_t>(dd.num, nlanes > 1 ? kInBufs : 2);
+  // The subdomain sizes follow the REFERENCE's footprint estimate (make_decomposer). What this
+  // implementation keeps resident is different -- less per subdomain, but the two-lane pipeline
+  // holds up to three inputs and two sets of everything else: where that set does not fit what is
+  // free (plus what the cache already holds), the schedule falls back to one lane and two inputs
+  // instead of failing in an allocation half way through.
+  if (nlanes > 1) {
+    size_t free_b = 0, total_b = 0;
+    HL_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t avail = std::min<size_t>(free_b + g_cache.held_bytes(), cfg.max_memory_footprint);
+    if (own_resident_bytes(D, max_elems, elem, cfg, ocap, nlanes, nbufs) > avail) {
+      nlanes = 1;
+      nbufs = zero_copy ? 0 : (int)std::min<uint64_t>(dd.num, 2);
+    }
+  }
   auto sub_in = [&](uint64_t id) -> const void * {
     return zero_copy ? (const void *)((const char *)original + dd.linear_offset(id) * elem)
                      : (const void *)g_cache.in[id % nbufs].p;
@@ -1858,6 +2076,9 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
     double norm_out = 0;
     LosslessJob lj;
   };
+  // (pre_h: the hierarchy of a subdomain whose norm was reduced while it arrived, see below)
+  mgh_hierarchy *pre_h = nullptr;
+  bool pre_owned = false;
   auto issue = [&](SubJob &J, uint64_t id) -> int {
     J = SubJob();
     J.id = id;
@@ -1868,8 +2089,14 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
     J.n = 1;
     for (uint64_t e : sshape) J.n *= e;
     if (!zero_copy) HL_HIP(hipStreamWaitEvent(st, g_cache.in_ready[id % nbufs], 0));
-    HL_TRY(get_hierarchy(&J.h, &J.owned, dtype, sshape, cptr, dd.subdomain_offset(id), cfg, J.lane));
-    if (J.owned) owned_alive.push_back(J.h);
+    if (pre_h) {
+      J.h = pre_h;
+      J.owned = pre_owned;
+      pre_h = nullptr;
+    } else {
+      HL_TRY(get_hierarchy(&J.h, &J.owned, dtype, sshape, cptr, dd.subdomain_offset(id), cfg, J.lane));
+      if (J.owned) owned_alive.push_back(J.h);
+    }
     hl_debug("compress: subdomain ready");
     // (outlier counter of the lane + the lossless stage's bins and chunk states: one launch, here)
     if (cfg.reorder || cfg.lossless == MGH_LOSSLESS_HUFFMAN_ZSTD) {
@@ -1982,7 +2209,7 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
     if (raw) {
       // the dense subdomain itself (decompose_quantize does not modify its input, so the buffer
       // still holds it)
-      HL_HIP(hipMemcpyAsync(dst, sub_in(id), csize, hipMemcpyDefault, st));
+      HL_TRY(copy_any(dst, sub_in(id), csize, st));
     } else {
       const uint64_t cs64 = csize;
       HL_TRY(record_write(L.ll, dst, st, prefix_with_record ? &cs64 : nullptr));
@@ -2015,7 +2242,34 @@ int compress_impl(int D, int dtype, const uint64_t *shape, double tol_d, double 
   // At the start of iteration id the buffer of subdomain id + P is the one subdomain id - 1 used,
   // and finish(id - 1) ended with a synchronisation of its lane.
   const uint64_t P = nbufs > 0 ? (uint64_t)(nbufs - 1) : 0;
-  for (uint64_t id = 0; id < std::max<uint64_t>(P, 1) && id < dd.num; id++)
+  // One subdomain arriving from the host under a REL bound: its norm is reduced piece by piece on
+  // the lane's stream while the following pieces are still on the link (the norm pass is a pure
+  // reduction), so the decomposition starts when the last piece has landed instead of a whole norm
+  // pass later. MGH_HL_STREAM_NORM=0: norm after arrival (cross-check).
+  bool first_fetched = false;
+  if (dd.num == 1 && !in_dev && ebtype == MGH_REL && env_get("MGH_HL_STREAM_NORM", 1) != 0) {
+    if ((rc = get_hierarchy(&pre_h, &pre_owned, dtype, dd.subdomain_shape(0), cptr, dd.subdomain_offset(0), cfg, 0)) !=
+        MGH_SUCCESS)
+      return cleanup(rc);
+    if (pre_owned) owned_alive.push_back(pre_h);
+    if (mgh_sym16_supported(pre_h)) {  // (= the fused path will run, which takes the streamed norm)
+      hipStream_t lst = g_cache.lane[0].st;
+      if ((rc = mgh_norm_stream_begin(pre_h, lst)) != MGH_SUCCESS) return cleanup(rc);
+      const size_t bytes = total * elem, warm = (size_t)192 << 20;  // (what the level pass may still find cached)
+      mgh_hierarchy *const hh = pre_h;
+      const ChunkFn on_piece = [&, hh, lst](size_t off, size_t nb, hipEvent_t landed) -> int {
+        HL_HIP(hipStreamWaitEvent(lst, landed, 0));
+        return mgh_norm_stream_add(hh, (const char *)g_cache.in[0].p + off, nb / elem, s_d,
+                                   off + nb + warm < bytes ? 1 : 0, lst);
+      };
+      if ((rc = copy_any(g_cache.in[0].p, original, bytes, g_cache.copy_st, &on_piece)) != MGH_SUCCESS)
+        return cleanup(rc);
+      if (hipEventRecord(g_cache.in_ready[0], g_cache.copy_st) != hipSuccess)
+        return cleanup(hl_fail(MGH_ERR_DEVICE, "hipEventRecord"));
+      first_fetched = true;
+    }
+  }
+  for (uint64_t id = first_fetched ? 1 : 0; id < std::max<uint64_t>(P, 1) && id < dd.num; id++)
     if ((rc = fetch_sub(id)) != MGH_SUCCESS) return cleanup(rc);
   SubJob jobs[kLanes];
   if ((rc = issue(jobs[0], 0)) != MGH_SUCCESS) return cleanup(rc);
@@ -2110,9 +2364,25 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
   else return hl_fail(MGH_ERR_FORMAT, "this lossless compressor is not supported");
   if (hd.hierarchy != fmt::HIER_MULTIDIM) return hl_fail(MGH_ERR_FORMAT, "only the multi-dimensional decomposition is supported");
   const bool in_dev = is_device_pointer(compressed);
+  Pretouch pretouch;  // (joined before the first byte of the output is written, and on every way out)
   if (!prealloc) {
     if (in_dev) HL_HIP(hipMalloc(out, total * elem));
-    else if (!(*out = std::malloc(total * elem))) return hl_fail(MGH_ERR_OUT_OF_MEMORY, "malloc");
+    else if (!(*out = host_alloc_large(total * elem))) return hl_fail(MGH_ERR_OUT_OF_MEMORY, "malloc");
+    // fresh host pages: faulted in beside the decoder instead of inside the device -> host copy
+    if (!in_dev) pretouch.start(*out, total * elem);
+  }
+  // auto_pin_host_buffers (CompressionHighLevel.hpp:470-497): stream and output registered for the call
+  bool in_pinned_here = false, out_pinned_here = false;
+  if (cfg.auto_pin_host_buffers) {
+    if (!in_dev && !is_registered_host(compressed)) {
+      if (hipHostRegister(const_cast<void *>(compressed), csize_total, hipHostRegisterDefault) == hipSuccess) in_pinned_here = true;
+      else (void)hipGetLastError();
+    }
+    if (!is_device_pointer(*out) && !is_registered_host(*out)) {
+      pretouch.join();
+      if (hipHostRegister(*out, total * elem, hipHostRegisterDefault) == hipSuccess) out_pinned_here = true;
+      else (void)hipGetLastError();
+    }
   }
   const bool pipelined = env_get("MGH_HL_PIPELINE", 1) != 0;
   const int nlanes = dd.num > 1 && pipelined ? kLanes : 1;
@@ -2123,6 +2393,9 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
       if (owned_h[l]) mgh_hierarchy_destroy(owned_h[l]);
       owned_h[l] = nullptr;
     }
+    pretouch.join();
+    if (in_pinned_here) (void)hipHostUnregister(const_cast<void *>(compressed));
+    if (out_pinned_here) (void)hipHostUnregister(*out);
     if (rc != MGH_SUCCESS && !prealloc) {
       if (in_dev) (void)hipFree(*out); else std::free(*out);
       *out = nullptr;
@@ -2210,8 +2483,7 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
     byte_offset += csize;
     if (!((double)(n * elem) / (double)csize > 1.0)) {  // GPUPipelines.hpp:414-417
       if (csize != n * elem) return hl_fail(MGH_ERR_FORMAT, "raw subdomain record has the wrong size");
-      HL_HIP(hipMemcpyAsync(sub, rec, csize, hipMemcpyDefault, st));
-      return MGH_SUCCESS;
+      return copy_any(sub, rec, csize, st);
     }
     const uint8_t *payload = (const uint8_t *)rec;
     uint64_t ocount = 0;
@@ -2250,6 +2522,7 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
   };
   auto finish = [&](uint64_t id) -> int {
     if (zero_copy) return MGH_SUCCESS;
+    pretouch.join();
     Lane &L = g_cache.lane[id % nlanes];
     return copy_subdomain(dd, id, elem, L.sub.p, nullptr, *out, false, L.st);
   };
@@ -2760,10 +3033,6 @@ void worker_thread_teardown() {
   mgh_release_cache();
   delete g_cache_ptr;
   g_cache_ptr = nullptr;
-  for (auto *&b : g_bounce_ptr) {
-    delete b;
-    b = nullptr;
-  }
 }
 
 int check_devs(int num_dev, const int *dev_ids) {
@@ -2891,8 +3160,7 @@ void mgh_free_device(void *p) {
 
 void mgh_release_cache(void) {
   if (g_cache_ptr) g_cache_ptr->release();
-  for (auto *b : g_bounce_ptr)
-    if (b) b->release();
+  release_host_transfer_state();  // pinned rings, copy threads
 }
 
 int mgh_memcpy(void *dst, const void *src, size_t bytes) {
@@ -3012,7 +3280,8 @@ int mgh_lossless_create(mgh_lossless_ctx **out, int dev_id) {
 void mgh_lossless_destroy(mgh_lossless_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->dev);
-  for (DevBuf *b : {&c->freq, &c->code, &c->bits, &c->entry, &c->total, &c->units, &c->tables, &c->oidx, &c->oval, &c->state, &c->dtable})
+  for (DevBuf *b : {&c->freq, &c->code, &c->bits, &c->entry, &c->total, &c->units, &c->tables, &c->oidx, &c->oval, &c->state, &c->dtable,
+                    &c->sync})
     b->release();
   c->pin.release();
   c->dpin.release();

@@ -270,24 +270,67 @@ def infer(buf):
 
 def decompress(buf, config=None, out=None):
     """mgard_x::decompress. Returns a numpy array (host stream) or a cuda tensor (device stream).
-    `out`: optional pre-allocated cuda tensor of the right shape and type (device streams)."""
+    `out`: optional pre-allocated buffer -- a contiguous cuda tensor (device streams) or a
+    C-contiguous numpy array (host streams). Its element count and type are checked against the
+    header; for a device stream that check is skipped when MGARD_HIP_TRUST_OUT=1 (it costs two small
+    reads of device memory, ~60 us)."""
+    import os
     import torch
     L = _hl()
     cfg = config if config is not None else Config()
+
+    def check(out_numel, out_is_f32):
+        if isinstance(buf, torch.Tensor):
+            # ONE small read of device memory (the header of a uniform grid is a few hundred bytes)
+            try:
+                shape, dt = infer(buf[:4096].cpu().numpy())
+            except MgardHipError:
+                shape, dt = infer(buf)
+        else:
+            shape, dt = infer(buf)
+        if int(np.prod(shape)) != int(out_numel) or (dt == FLOAT) != bool(out_is_f32):
+            raise ValueError("`out` does not match the stream: %r elements of %s expected"
+                             % (int(np.prod(shape)), "float32" if dt == FLOAT else "float64"))
+        return shape, dt
+
     if isinstance(buf, torch.Tensor) and buf.is_cuda:
         if out is None:
-            # (two header reads from device memory, ~60 us: a caller who passes `out` vouches for its
-            # shape and type like the caller of mgard_x::decompress with a pre-allocated buffer does)
             shape, dt = infer(buf)
             out = torch.empty(shape, dtype=torch.float32 if dt == FLOAT else torch.float64, device=buf.device)
+        else:
+            if not (isinstance(out, torch.Tensor) and out.is_cuda and out.is_contiguous() and
+                    out.dtype in (torch.float32, torch.float64) and out.device == buf.device):
+                raise ValueError("`out` must be a contiguous float32/float64 cuda tensor on the stream's device")
+            if os.environ.get("MGARD_HIP_TRUST_OUT", "0") != "1":
+                check(out.numel(), out.dtype == torch.float32)
         p, n, optr = C.c_void_p(buf.data_ptr()), buf.numel(), C.c_void_p(out.data_ptr())
     else:
-        shape, dt = infer(buf)
         buf = np.ascontiguousarray(buf)
-        out = np.empty(shape, dtype=np.float32 if dt == FLOAT else np.float64)
+        if out is None:
+            shape, dt = infer(buf)
+            out = np.empty(shape, dtype=np.float32 if dt == FLOAT else np.float64)
+        else:
+            if not (isinstance(out, np.ndarray) and out.flags.c_contiguous and out.flags.writeable and
+                    out.dtype in (np.float32, np.float64)):
+                raise ValueError("`out` must be a writeable C-contiguous float32/float64 numpy array")
+            check(out.size, out.dtype == np.float32)
         p, n, optr = C.c_void_p(buf.ctypes.data), buf.size, C.c_void_p(out.ctypes.data)
     _check(L.mgh_decompress(p, n, C.byref(optr), C.byref(cfg), 1))
     return out
+
+
+def pin(a):
+    """mgard_x::pin_memory on a numpy array (hipHostRegister): transfers of it run asynchronously at
+    the link's rate. Undo with unpin() before the array is freed."""
+    _check(_hl().mgh_pin_memory(C.c_void_p(a.ctypes.data), a.nbytes))
+
+
+def is_pinned(a):
+    return bool(_hl().mgh_check_memory_pinned(C.c_void_p(a.ctypes.data)))
+
+
+def unpin(a):
+    _check(_hl().mgh_unpin_memory(C.c_void_p(a.ctypes.data)))
 
 
 def compress_multi(data, tol, s=INF, mode=REL, devices=(0,), coords=None, config=None):
@@ -412,12 +455,17 @@ class Lossless:
         import torch
         q = torch.empty(n, dtype=torch.int64, device="cuda")
         if isinstance(payload, torch.Tensor):
-            raw = C.c_void_p(payload.data_ptr())
+            if not (payload.is_cuda and payload.dtype == torch.uint8 and payload.dim() == 1 and
+                    payload.is_contiguous()):
+                raise ValueError("payload tensor must be a contiguous 1-D uint8 cuda tensor")
+            if payload.device != q.device:
+                raise ValueError("payload tensor is on %s, the context decodes on %s" % (payload.device, q.device))
+            raw, nbytes = C.c_void_p(payload.data_ptr()), int(payload.numel())
         else:
-            raw = (C.c_uint8 * len(payload)).from_buffer_copy(payload)
+            raw, nbytes = (C.c_uint8 * len(payload)).from_buffer_copy(payload), len(payload)
         oi, ov, cnt = C.c_void_p(), C.c_void_p(), C.c_uint64()
         _check(_hl().mgh_lossless_decompress(
-            self._c, raw, len(payload), lossless, C.c_void_p(q.data_ptr()), n, C.byref(oi), C.byref(ov),
+            self._c, raw, nbytes, lossless, C.c_void_p(q.data_ptr()), n, C.byref(oi), C.byref(ov),
             C.byref(cnt), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         k = cnt.value
         idx = torch.empty(k, dtype=torch.int64, device="cuda")
