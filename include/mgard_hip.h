@@ -164,6 +164,24 @@ int mgh_dequantize_recompose_sym16(mgh_hierarchy *h, const uint16_t *d_symbols, 
                                    uint64_t outlier_count, void *d_data_out, void *stream);
 int mgh_sym16_supported(const mgh_hierarchy *h);
 
+/* Leading dimensions of the caller's arrays of the hierarchy's data type (mgard_x::Array::ld,
+ * RuntimeX/DataStructures/Array.hpp:70-84: the reference's HIP backend allocates its arrays
+ * with hipMallocPitch by default, which pads the FASTEST dimension; SubArray.hpp:136-139
+ * carries one ld per dimension). `ld`: D entries, ld[d] >= shape[d] for d >= 1 (ld[0] is not
+ * used); element (i0, .., i_{D-1}) lies at ((i0 * ld[1] + i1) * ld[2] + ...) + i_{D-1}.
+ * NULL = dense again. which = MGH_LD_IN: every T array an entry point READS (data of
+ * mgh_norm*, mgh_decompose, mgh_decompose_quantize*; coefficients of mgh_recompose,
+ * mgh_quantize); MGH_LD_OUT: every T array it WRITES (coefficients of mgh_decompose,
+ * mgh_dequantize, d_coeff_opt; data of mgh_recompose, mgh_dequantize_recompose*). The
+ * quantized integers, symbols and outlier indices are always dense (Compressor.hpp:48-53
+ * allocates them unpitched: they are linearised for the lossless stage). The setting stays
+ * until it is changed. The fused 3-D kernels read / write the pitched array in place; the
+ * other paths (D != 3, thin shapes, stand-alone stages) go through a dense copy inside the
+ * hierarchy. mgh_norm_stream_add takes parts of a dense array only. */
+#define MGH_LD_IN 0
+#define MGH_LD_OUT 1
+int mgh_set_ld(mgh_hierarchy *h, int which, const uint64_t *ld);
+
 /* Norm of an input that is still ARRIVING (host -> device in slabs): _begin once, _add
  * for every part that has landed (any partition of the array; `cold` != 0: the part is
  * read with nontemporal loads, for parts the level pass will not find in the cache

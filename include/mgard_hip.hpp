@@ -100,6 +100,12 @@ public:
   }
   SIZE level_shape(SIZE level, DIM dim) const { return dim >= D ? 1 : level_shape(level)[dim]; }
   mgh_hierarchy *handle() const { return h_; }
+  // Leading dimensions of the arrays the stages read (which = MGH_LD_IN) / write (MGH_LD_OUT):
+  // Array::ld(d) of a pitched mgard_x::Array (Array.hpp:70-84); an empty vector = dense.
+  void set_ld(int which, const std::vector<SIZE> &ld) {
+    if (!ld.empty() && ld.size() != D) throw std::runtime_error("set_ld: one entry per dimension");
+    check(mgh_set_ld(h_, which, ld.empty() ? nullptr : ld.data()), "set_ld");
+  }
 
 private:
   void init(const std::vector<SIZE> &shape, const void *const *coords, const Config &config) {

@@ -13,6 +13,7 @@ import numpy as np
 from . import _build
 
 REL, ABS = 0, 1          # mgard_x::error_bound_type
+LD_IN, LD_OUT = 0, 1     # mgh_set_ld
 FLOAT, DOUBLE = 0, 1     # mgard_x::data_type
 INF = float("inf")
 
@@ -27,6 +28,7 @@ SYMBOLS = [
     "mgh_dequantize_recompose_sym16", "mgh_sym16_supported",
     "mgh_profile_enable", "mgh_profile_filter", "mgh_profile_read", "mgh_stream_calibrate",
     "mgh_level_linearize", "mgh_outlier_restore", "mgh_norm_stream_begin", "mgh_norm_stream_add",
+    "mgh_set_ld",
 ]
 
 
@@ -75,6 +77,7 @@ def load_library():
                                          vp, vp]
     L.mgh_norm_device.argtypes = [vp, vp, C.c_double, vp, vp]
     L.mgh_norm_stream_begin.argtypes = [vp, vp]
+    L.mgh_set_ld.argtypes = [vp, C.c_int, u64p]
     L.mgh_norm_stream_add.argtypes = [vp, vp, u64, C.c_double, C.c_int, vp]
     L.mgh_dequantize_recompose_sym16.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, C.c_double, u64,
                                                  vp, vp, u64, vp, vp]
@@ -138,6 +141,7 @@ class Hierarchy:
                                       2**64 - 1 if max_level is None else int(max_level),
                                       self.device))
         self._h = h
+        self._ld = {LD_IN: None, LD_OUT: None}
         self.l_target = L.mgh_l_target(h)
         self.total = int(L.mgh_total_num_elems(h))
 
@@ -171,7 +175,15 @@ class Hierarchy:
     # ---- stages ----
     def _chk(self, t, dtype=None):
         import torch
-        assert t.is_cuda and t.is_contiguous() and t.numel() == self.total, "bad tensor"
+        ok = {self.total}
+        if dtype is None:  # (a T array may be a pitched allocation: mgh_set_ld)
+            for ld in self._ld.values():
+                if ld is not None:
+                    n = self.shape[0]
+                    for x in ld[1:]:
+                        n *= x
+                    ok.add(n)
+        assert t.is_cuda and t.is_contiguous() and t.numel() in ok, "bad tensor"
         assert t.dtype == (dtype or self.torch_dtype), "bad dtype"
         assert t.device.index == self.device
         return C.c_void_p(t.data_ptr())
@@ -181,15 +193,20 @@ class Hierarchy:
         _check(load_library().mgh_norm(self._h, self._chk(data), s, C.byref(out), _stream()))
         return out.value
 
-    def decompose(self, data, out=None):
+    def _new_out(self, device):
+        """A T array for the calls to write: dense, or the pitched allocation LD_OUT describes."""
         import torch
-        out = torch.empty_like(data) if out is None else out
+        ld = self._ld[LD_OUT]
+        shape = self.shape if ld is None else (self.shape[0],) + tuple(ld[1:])
+        return torch.empty(shape, dtype=self.torch_dtype, device=device)
+
+    def decompose(self, data, out=None):
+        out = self._new_out(data.device) if out is None else out
         _check(load_library().mgh_decompose(self._h, self._chk(data), self._chk(out), _stream()))
         return out
 
     def recompose(self, coeff, out=None):
-        import torch
-        out = torch.empty_like(coeff) if out is None else out
+        out = self._new_out(coeff.device) if out is None else out
         _check(load_library().mgh_recompose(self._h, self._chk(coeff), self._chk(out), _stream()))
         return out
 
@@ -219,7 +236,7 @@ class Hierarchy:
     def dequantize(self, q, ebtype, tol, s, norm, dict_size=8192, prep_huffman=True,
                    outlier_idx=None, outlier_val=None, out=None):
         import torch
-        out = torch.empty(self.shape, dtype=self.torch_dtype, device=q.device) if out is None else out
+        out = self._new_out(q.device) if out is None else out
         n = 0 if outlier_idx is None else int(outlier_idx.numel())
         _check(load_library().mgh_dequantize(
             self._h, self._chk(q, torch.int64), ebtype, tol, s, norm, dict_size, int(prep_huffman),
@@ -275,6 +292,17 @@ class Hierarchy:
         k = min(n, cap)
         return q, idx[:k], val[:k], n, nout.value
 
+    def sym16_supported(self):
+        return bool(load_library().mgh_sym16_supported(self._h))
+
+    def set_ld(self, which, ld):
+        """mgh_set_ld: leading dimensions (len D, or None = dense) of the T arrays the calls read
+        (which = LD_IN) or write (LD_OUT). Arrays are then passed as tensors whose STORAGE is the
+        pitched allocation (any shape with enough elements)."""
+        arr = None if ld is None else (C.c_uint64 * len(ld))(*[int(x) for x in ld])
+        _check(load_library().mgh_set_ld(self._h, int(which), arr))
+        self._ld[which] = None if ld is None else tuple(int(x) for x in ld)
+
     def norm_stream(self, data, s, parts):
         """mgh_norm_stream_begin + one mgh_norm_stream_add per part of the (flattened) array: the next
         fused decompose_quantize* call with a REL bound and norm = 0 takes the accumulated norm.
@@ -307,7 +335,7 @@ class Hierarchy:
     def dequantize_recompose_sym16(self, sym, ebtype, tol, s, norm, dict_size=8192, outlier_idx=None,
                                    outlier_val=None, out=None):
         import torch
-        out = torch.empty(self.shape, dtype=self.torch_dtype, device=sym.device) if out is None else out
+        out = self._new_out(sym.device) if out is None else out
         n = 0 if outlier_idx is None else int(outlier_idx.numel())
         _check(load_library().mgh_dequantize_recompose_sym16(
             self._h, C.c_void_p(sym.data_ptr()), ebtype, tol, s, norm, dict_size,
@@ -318,7 +346,7 @@ class Hierarchy:
     def dequantize_recompose(self, q, ebtype, tol, s, norm, dict_size=8192, prep_huffman=True,
                              outlier_idx=None, outlier_val=None, out=None):
         import torch
-        out = torch.empty(self.shape, dtype=self.torch_dtype, device=q.device) if out is None else out
+        out = self._new_out(q.device) if out is None else out
         n = 0 if outlier_idx is None else int(outlier_idx.numel())
         _check(load_library().mgh_dequantize_recompose(
             self._h, self._chk(q, torch.int64), ebtype, tol, s, norm, dict_size, int(prep_huffman),

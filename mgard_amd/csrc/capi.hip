@@ -118,6 +118,11 @@ struct mgh_hierarchy {
   bool debug_sync = false;         // MGH_DEBUG_SYNC: name every launch on stderr and synchronise behind it
   std::map<std::string, ProfileEntry> prof;
   size_t device_bytes = 0;
+  uint64_t shape[MGH_MAX_DIM] = {};
+  // mgh_set_ld: leading dimensions of the caller's T arrays, [MGH_LD_IN / MGH_LD_OUT][dim]
+  uint64_t ld[2][MGH_MAX_DIM] = {};
+  bool has_ld[2] = {false, false};
+  bool ld_guard = false;  // inside an entry point that has already dealt with the leading dimensions
 };
 
 namespace {
@@ -215,6 +220,11 @@ template <typename T> struct DeviceState {
   unsigned long long *outliers_seen = nullptr;
   QuantMeta qmeta;
   size_t full_I = 0, full_J = 0;   // strides of the full array in the 3-D view
+  // Strides of a PITCHED caller array for the one call that set them (mgh_set_ld; 0 = full_I /
+  // full_J): the finest level's input of the fused decomposition, the finest level's output of the
+  // fused recomposition. Every other path sees dense copies (ld_pack / ld_unpack).
+  size_t src_I = 0, src_J = 0, dst_I = 0, dst_J = 0;
+  T *pack_in = nullptr, *pack_out = nullptr;  // dense copies of pitched arrays (lazily allocated)
 };
 
 template <typename T> HostHierarchy<T> *HH(const mgh_hierarchy *h) {
@@ -455,6 +465,8 @@ template <typename T> void destroy_state(mgh_hierarchy *h) {
     (void)hipFree(ds->t2);
     (void)hipFree(ds->t3);
     (void)hipFree(ds->scratch_full);
+    (void)hipFree(ds->pack_in);
+    (void)hipFree(ds->pack_out);
     (void)hipFree(ds->nd_w);
     (void)hipFree(ds->nd_a);
     (void)hipFree(ds->nd_b);
@@ -996,7 +1008,7 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
   const int L = h->L;
   const size_t fI = ds->full_I, fJ = ds->full_J;
   const T *src = data;
-  size_t sI = fI, sJ = fJ;
+  size_t sI = ds->src_I ? ds->src_I : fI, sJ = ds->src_J ? ds->src_J : fJ;  // (pitched input: mgh_set_ld)
 
   FusedArgs<T> A{};
   A.coef = coeff;
@@ -1773,8 +1785,8 @@ int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> 
     HA.in = A;
     const Box3 &bl = ds->lt[l_head].box;
     HA.out = (l_head == L) ? data : ds->nodal[l_head];
-    HA.oJ = (l_head == L) ? ds->full_J : bl.n[2];
-    HA.oI = (l_head == L) ? ds->full_I : (size_t)bl.n[1] * bl.n[2];
+    HA.oJ = (l_head == L) ? (ds->dst_J ? ds->dst_J : ds->full_J) : bl.n[2];
+    HA.oI = (l_head == L) ? (ds->dst_I ? ds->dst_I : ds->full_I) : (size_t)bl.n[1] * bl.n[2];
     HA.tab_base = ds->tables;
     HA.tab_count = (uint32_t)ds->lt_end[l_head];
     const size_t lds = (head_lds_elems(bl) + ds->lt_end[l_head]) * sizeof(T);
@@ -1809,8 +1821,8 @@ int recompose_levels(mgh_hierarchy *h, RecomposeArgs<T> A, const std::vector<T> 
     TRY(ipk_fc_launch<T>(h, b.m, ds->t3, t.thomas[2], t.thomas[1], st));
     TRY(ipk_launch<T>(h, 0, b.m, ds->t3, t.thomas[0], ds->nodal[l - 1], -1, st));
     B.fine = (l == L) ? data : ds->nodal[l];
-    B.fJ = (l == L) ? ds->full_J : b.n[2];
-    B.fI = (l == L) ? ds->full_I : (size_t)b.n[1] * b.n[2];
+    B.fJ = (l == L) ? (ds->dst_J ? ds->dst_J : ds->full_J) : b.n[2];
+    B.fI = (l == L) ? (ds->dst_I ? ds->dst_I : ds->full_I) : (size_t)b.n[1] * b.n[2];
     if (top) TRY((launch_restore<T, QTL, false>(h, B, b, "restore_q", st)));
     else TRY((launch_restore<T, QT, false>(h, B, b, "restore_q", st)));
   }
@@ -2092,15 +2104,113 @@ int dequantize_impl(mgh_hierarchy *h, int64_t *q, int ebtype, double tol, double
   return MGH_SUCCESS;
 }
 
+// ---- pitched caller arrays (mgh_set_ld; mgard_x::Array::ld, Array.hpp:70-84: hipMallocPitch pads the
+// fastest dimension; SubArray.hpp:136-139 carries one ld per dimension) ------------------------
+// Rows of the array (all dimensions but the fastest, right-aligned, leading 1s) and the element
+// strides of those dimensions in the pitched array.
+struct LdView {
+  uint32_t ext[MGH_MAX_DIM];
+  uint64_t stride[MGH_MAX_DIM];
+  uint64_t rows;
+};
+inline LdView ld_view(const mgh_hierarchy *h, int which) {
+  LdView V{};
+  uint64_t st = 1, str[MGH_MAX_DIM] = {};
+  for (int d = h->D - 1; d >= 0; d--) {
+    str[d] = st;
+    st *= h->has_ld[which] ? h->ld[which][d] : h->shape[d];
+  }
+  V.rows = 1;
+  for (int k = 0; k < MGH_MAX_DIM; k++) {
+    const int d = k - (MGH_MAX_DIM - h->D);
+    V.ext[k] = d >= 0 ? (uint32_t)h->shape[d] : 1u;
+    V.stride[k] = d >= 0 ? str[d] : 0;
+    if (k < MGH_MAX_DIM - 1) V.rows *= V.ext[k];
+  }
+  return V;
+}
+__device__ __forceinline__ uint64_t ld_row_offset(const LdView &V, uint64_t row) {
+  uint64_t r = row, off = 0;
+#pragma unroll
+  for (int d = MGH_MAX_DIM - 2; d >= 0; d--) {
+    const uint64_t q = r / V.ext[d];
+    off += (r - q * V.ext[d]) * V.stride[d];
+    r = q;
+  }
+  return off;
+}
+// dense <-> pitched, one wave per row
+template <typename T>
+__global__ void __launch_bounds__(256) k_ld_copy(T *__restrict__ dense, T *__restrict__ pitched, LdView V, int to_dense) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t nf = V.ext[MGH_MAX_DIM - 1];
+  for (uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < V.rows; row += (uint64_t)gridDim.x * 4) {
+    T *p = pitched + ld_row_offset(V, row);
+    T *d = dense + row * nf;
+    if (to_dense)
+      for (uint32_t k = lane; k < nf; k += 64) d[k] = p[k];
+    else
+      for (uint32_t k = lane; k < nf; k += 64) p[k] = d[k];
+  }
+}
+// the norm reductions over the rows of a pitched array (same accumulation into `out` as k_absmax / k_sqsum)
+template <typename T, bool SQ>
+__global__ void __launch_bounds__(256) k_norm_ld(const T *__restrict__ v, LdView V, unsigned long long *out) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t nf = V.ext[MGH_MAX_DIM - 1];
+  T acc = 0;
+  for (uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < V.rows; row += (uint64_t)gridDim.x * 4) {
+    const T *p = v + ld_row_offset(V, row);
+    for (uint32_t k = lane; k < nf; k += 64) {
+      const T x = p[k];
+      if (SQ) {
+        acc += x * x;
+      } else {
+        const T a = abs_t(x);
+        acc = a > acc ? a : acc;
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const T o = __shfl_down(acc, off, 64);
+    if (SQ) acc += o; else acc = o > acc ? o : acc;
+  }
+  if (lane == 0) {
+    if (SQ) {
+      atomicAdd(reinterpret_cast<double *>(out), (double)acc);
+    } else if (sizeof(T) == 4) {
+      atomicMax(out, (unsigned long long)__float_as_uint((float)acc));
+    } else {
+      atomicMax(out, (unsigned long long)__double_as_longlong((double)acc));
+    }
+  }
+}
+inline unsigned ld_grid(const LdView &V) { return (unsigned)std::min<uint64_t>((V.rows + 3) / 4, 256 * 32); }
+
+// The norm reduction of `data` (dense, or pitched with the strides of `view`) accumulated into `slot`.
+template <typename T>
+int norm_reduce(mgh_hierarchy *h, const T *data, double s, unsigned long long *slot, const LdView *view,
+                size_t n_cold, hipStream_t st) {
+  const bool inf = (T)s == std::numeric_limits<T>::infinity();
+  if (view) {
+    if (inf) return launch(h, "absmax", st, [&] { k_norm_ld<T, false><<<ld_grid(*view), 256, 0, st>>>(data, *view, slot); });
+    return launch(h, "sqsum", st, [&] { k_norm_ld<T, true><<<ld_grid(*view), 256, 0, st>>>(data, *view, slot); });
+  }
+  const size_t total = h->total;
+  const unsigned grid = (unsigned)std::min<size_t>((total + 1023) / 1024, 256 * 8);
+  if (inf) return launch(h, "absmax", st, [&] { k_absmax<T><<<grid, 256, 0, st>>>(data, total, slot, n_cold); });
+  return launch(h, "sqsum", st, [&] { k_sqsum<T><<<grid, 256, 0, st>>>(data, total, (double *)slot, n_cold); });
+}
+
 // Launch the norm reduction; the result stays in ds->scalar (absmax bits or double sum).
 template <typename T> int norm_launch(mgh_hierarchy *h, const T *data, double s, hipStream_t st) {
   auto *ds = DS<T>(h);
-  const size_t total = h->total;
-  const unsigned grid = (unsigned)std::min<size_t>((total + 1023) / 1024, 256 * 8);
   HIP_TRY(hipMemsetAsync(ds->scalar, 0, 8, st));
-  if ((T)s == std::numeric_limits<T>::infinity())
-    return launch(h, "absmax", st, [&] { k_absmax<T><<<grid, 256, 0, st>>>(data, total, ds->scalar); });
-  return launch(h, "sqsum", st, [&] { k_sqsum<T><<<grid, 256, 0, st>>>(data, total, (double *)ds->scalar); });
+  if (h->has_ld[0] && !h->ld_guard) {
+    const LdView V = ld_view(h, 0);
+    return norm_reduce<T>(h, data, s, ds->scalar, &V, 0, st);
+  }
+  return norm_reduce<T>(h, data, s, ds->scalar, nullptr, 0, st);
 }
 
 // Quantizer table on the device from a device-resident norm (no host round trip).
@@ -2142,11 +2252,9 @@ int norm_impl(mgh_hierarchy *h, const T *data, double s, double *out, hipStream_
   auto *ds = DS<T>(h);
   auto *hh = HH<T>(h);
   const size_t total = h->total;
-  const unsigned grid = (unsigned)std::min<size_t>((total + 1023) / 1024, 256 * 8);
-  HIP_TRY(hipMemsetAsync(ds->scalar, 0, 8, st));
+  TRY(norm_launch<T>(h, data, s, st));
   T norm;
   if ((T)s == std::numeric_limits<T>::infinity()) {
-    TRY(launch(h, "absmax", st, [&] { k_absmax<T><<<grid, 256, 0, st>>>(data, total, ds->scalar); }));
     unsigned long long bits = 0;
     HIP_TRY(hipMemcpyAsync(&bits, ds->scalar, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -2161,7 +2269,6 @@ int norm_impl(mgh_hierarchy *h, const T *data, double s, double *out, hipStream_
       norm = (T)d;
     }
   } else {
-    TRY(launch(h, "sqsum", st, [&] { k_sqsum<T><<<grid, 256, 0, st>>>(data, total, (double *)ds->scalar); }));
     double sum = 0;
     HIP_TRY(hipMemcpyAsync(&sum, ds->scalar, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -2231,22 +2338,17 @@ int fused_q_entry_device(mgh_hierarchy *h, const T *data, int ebtype, double tol
   unsigned long long *slot = ds->fscal + ds->scalar_slot;
   unsigned long long *other = ds->fscal + (1 - ds->scalar_slot);
   if (need_norm) {
-    const size_t total = h->total;
-    const unsigned grid = (unsigned)std::min<size_t>((total + 1023) / 1024, 256 * 8);
-    if ((T)s == std::numeric_limits<T>::infinity())
-      TRY(launch(h, "absmax", st, [&] {
-        // all but the last MGH_ABSMAX_WARM_MB of the input with nontemporal loads: the level pass
-        // re-reads the input from its end, and only what the norm pass read last can still be in
-        // the 256 MB memory-side cache (512^3 f32, same box, 60 steps each: absmax 109 -> 93 us,
-        // top-level pass 384 -> 397 us, step 0.894 -> 0.889 ms)
-        const size_t warm = ((size_t)h->absmax_warm_mb << 20) / sizeof(T);
-        k_absmax<T><<<grid, 256, 0, st>>>(data, total, slot, total > warm ? total - warm : 0);
-      }));
-    else
-      TRY(launch(h, "sqsum", st, [&] {
-        const size_t warm = ((size_t)h->absmax_warm_mb << 20) / sizeof(T);
-        k_sqsum<T><<<grid, 256, 0, st>>>(data, total, (double *)slot, total > warm ? total - warm : 0);
-      }));
+    // all but the last MGH_ABSMAX_WARM_MB of the input with nontemporal loads: the level pass
+    // re-reads the input from its end, and only what the norm pass read last can still be in
+    // the 256 MB memory-side cache (512^3 f32, same box, 60 steps each: absmax 109 -> 93 us,
+    // top-level pass 384 -> 397 us, step 0.894 -> 0.889 ms)
+    const size_t total = h->total, warm = ((size_t)h->absmax_warm_mb << 20) / sizeof(T);
+    if (ds->src_J) {  // (pitched input read in place: row by row)
+      const LdView V = ld_view(h, 0);
+      TRY(norm_reduce<T>(h, data, s, slot, &V, 0, st));
+    } else {
+      TRY(norm_reduce<T>(h, data, s, slot, nullptr, total > warm ? total - warm : 0, st));
+    }
   }
   auto qparams = [&] {
     QParamArgs<T> P;
@@ -2278,6 +2380,39 @@ int fused_q_entry_device(mgh_hierarchy *h, const T *data, int ebtype, double tol
   return MGH_SUCCESS;
 }
 
+// Dense view of the caller's pitched arrays for the paths that do not take strides. ld_pack: the
+// input copied into a dense buffer of the hierarchy (p then points there); LdOut: the kernels write
+// a dense buffer, finish() spreads it into the caller's pitched array. Dense callers pay nothing.
+template <typename T> int ld_pack(mgh_hierarchy *h, const T *&p, hipStream_t st) {
+  if (!h->has_ld[0] || !p) return MGH_SUCCESS;
+  auto *ds = DS<T>(h);
+  if (!ds->pack_in) TRY(dev_alloc(h, &ds->pack_in, (size_t)h->total));
+  const LdView V = ld_view(h, 0);
+  TRY(launch(h, "ld_pack", st, [&] { k_ld_copy<T><<<ld_grid(V), 256, 0, st>>>(ds->pack_in, const_cast<T *>(p), V, 1); }));
+  p = ds->pack_in;
+  return MGH_SUCCESS;
+}
+template <typename T> struct LdOut {
+  T *user = nullptr;
+  int begin(mgh_hierarchy *h, T *&p) {
+    if (!h->has_ld[1] || !p) return MGH_SUCCESS;
+    auto *ds = DS<T>(h);
+    if (!ds->pack_out) TRY(dev_alloc(h, &ds->pack_out, (size_t)h->total));
+    user = p;
+    p = ds->pack_out;
+    return MGH_SUCCESS;
+  }
+  int finish(mgh_hierarchy *h, hipStream_t st) {
+    if (!user) return MGH_SUCCESS;
+    auto *ds = DS<T>(h);
+    const LdView V = ld_view(h, 1);
+    return launch(h, "ld_unpack", st, [&] { k_ld_copy<T><<<ld_grid(V), 256, 0, st>>>(ds->pack_out, user, V, 0); });
+  }
+};
+// Strides of a pitched array in the 3-D view of the fused kernels, when they can read / write it in
+// place: D <= 3 on the fused path, planes addressable in 32 bits like the dense ones.
+inline bool ld_native3(const mgh_hierarchy *h, int which, size_t &sI, size_t &sJ);
+
 // Norm accumulated over parts of the input (mgh_norm_stream_begin / _add): the same reduction
 // kernels on a range, into the slot the next fused call reads.
 template <typename T> int norm_stream_begin(mgh_hierarchy *h, hipStream_t st) {
@@ -2301,6 +2436,48 @@ int norm_stream_add(mgh_hierarchy *h, const T *part, size_t count, double s, int
 
 #define DISPATCH(h, call_f, call_d)                                              \
   ((h)->dtype == MGH_FLOAT ? (call_f) : (call_d))
+
+inline bool ld_native3(const mgh_hierarchy *h, int which, size_t &sI, size_t &sJ) {
+  if (!h->has_ld[which] || !fused_ok(h) || h->force_v1) return false;
+  const uint64_t lf = h->ld[which][2], lc = h->ld[which][1];
+  if (lf * lc >= ((uint64_t)1 << 30)) return false;
+  sJ = (size_t)lf;
+  sI = (size_t)(lf * lc);
+  return true;
+}
+
+// An entry point with a pitched T input and / or output (mgh_set_ld): `call(in, out)` is the entry
+// point itself, run once more under the guard with pointers it can take as dense ones -- copies
+// (ld_pack / LdOut), or the caller's own arrays where the fused 3-D kernels take the strides
+// (native_ok: the call is one that runs them).
+template <typename T, typename F>
+int ld_entry_t(mgh_hierarchy *h, const void *in, void *out, bool native_ok, hipStream_t st, F &&call) {
+  auto *ds = DS<T>(h);
+  const T *pin = (const T *)in;
+  T *pout = (T *)out;
+  size_t sI = 0, sJ = 0, oI = 0, oJ = 0;
+  const bool nat_in = pin && native_ok && ld_native3(h, 0, sI, sJ);
+  const bool nat_out = pout && native_ok && ld_native3(h, 1, oI, oJ);
+  if (pin && h->has_ld[0] && !nat_in) TRY(ld_pack<T>(h, pin, st));
+  LdOut<T> o;
+  if (pout && h->has_ld[1] && !nat_out) TRY(o.begin(h, pout));
+  if (nat_in) ds->src_I = sI, ds->src_J = sJ;
+  if (nat_out) ds->dst_I = oI, ds->dst_J = oJ;
+  h->ld_guard = true;
+  const int rc = call((const void *)pin, (void *)pout);
+  h->ld_guard = false;
+  ds->src_I = ds->src_J = ds->dst_I = ds->dst_J = 0;
+  if (rc != MGH_SUCCESS) return rc;
+  return o.finish(h, st);
+}
+template <typename F>
+int ld_entry(mgh_hierarchy *h, const void *in, void *out, bool native_ok, void *stream, F &&call) {
+  if (h->dtype == MGH_FLOAT) return ld_entry_t<float>(h, in, out, native_ok, (hipStream_t)stream, call);
+  return ld_entry_t<double>(h, in, out, native_ok, (hipStream_t)stream, call);
+}
+inline bool ld_wanted(const mgh_hierarchy *h, const void *in, const void *out) {
+  return !h->ld_guard && ((in && h->has_ld[0]) || (out && h->has_ld[1]));
+}
 
 } // namespace
 
@@ -2406,6 +2583,7 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
                 "invalid shape: every dimension must have at least 3 nodes");
   }
   h->plane_elems = shape[D - 1] * (D >= 2 ? shape[D - 2] : 1);
+  for (int d = 0; d < D; d++) h->shape[d] = shape[d];
   // Thin arrays (a long slowest dimension over planes of a few nodes: 300000 x 17 x 17): the tiled
   // level kernels cover the coarse (c, f) plane with tiles of 4 x 64 nodes and march along r; where
   // the plane fills less than an eighth of its tiles the one-thread-per-element kernels are the
@@ -2462,6 +2640,22 @@ int64_t mgh_hierarchy_table(const mgh_hierarchy *h, int kind, int level, int dim
                   table_impl<double>(h, kind, level, dim, h_out, cap));
 }
 
+int mgh_set_ld(mgh_hierarchy *h, int which, const uint64_t *ld) {
+  if (!h || (which != MGH_LD_IN && which != MGH_LD_OUT)) return fail(MGH_ERR_INVALID_ARGUMENT, "mgh_set_ld: which");
+  if (!ld) {
+    h->has_ld[which] = false;
+    return MGH_SUCCESS;
+  }
+  bool dense = true;
+  for (int d = 1; d < h->D; d++) {
+    if (ld[d] < h->shape[d]) return fail(MGH_ERR_INVALID_ARGUMENT, "mgh_set_ld: a leading dimension is smaller than the extent");
+    dense &= ld[d] == h->shape[d];
+  }
+  for (int d = 0; d < h->D; d++) h->ld[which][d] = d == 0 ? h->shape[0] : ld[d];
+  h->has_ld[which] = !dense;
+  return MGH_SUCCESS;
+}
+
 int mgh_norm(mgh_hierarchy *h, const void *d_data, double s, double *h_norm_out, void *stream) {
   if (!h || !d_data || !h_norm_out) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
   HIP_TRY(hipSetDevice(h->device));
@@ -2472,6 +2666,8 @@ int mgh_norm(mgh_hierarchy *h, const void *d_data, double s, double *h_norm_out,
 int mgh_decompose(mgh_hierarchy *h, const void *d_data, void *d_coeff, void *stream) {
   if (!h || !d_data || !d_coeff) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
   HIP_TRY(hipSetDevice(h->device));
+  if (ld_wanted(h, d_data, d_coeff))
+    return ld_entry(h, d_data, d_coeff, false, stream, [&](const void *i, void *o) { return mgh_decompose(h, i, o, stream); });
   return DISPATCH(h, decompose_impl<float>(h, (const float *)d_data, (float *)d_coeff, (hipStream_t)stream),
                   decompose_impl<double>(h, (const double *)d_data, (double *)d_coeff, (hipStream_t)stream));
 }
@@ -2479,6 +2675,8 @@ int mgh_decompose(mgh_hierarchy *h, const void *d_data, void *d_coeff, void *str
 int mgh_recompose(mgh_hierarchy *h, const void *d_coeff, void *d_data, void *stream) {
   if (!h || !d_data || !d_coeff) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
   HIP_TRY(hipSetDevice(h->device));
+  if (ld_wanted(h, d_coeff, d_data))
+    return ld_entry(h, d_coeff, d_data, false, stream, [&](const void *i, void *o) { return mgh_recompose(h, i, o, stream); });
   return DISPATCH(h, recompose_impl<float>(h, (const float *)d_coeff, (float *)d_data, (hipStream_t)stream),
                   recompose_impl<double>(h, (const double *)d_coeff, (double *)d_data, (hipStream_t)stream));
 }
@@ -2491,6 +2689,11 @@ int mgh_quantize(mgh_hierarchy *h, const void *d_coeff, int ebtype, double tol, 
   if (prep_huffman && (!d_outlier_count || (outlier_capacity && (!d_outlier_idx || !d_outlier_val))))
     return fail(MGH_ERR_INVALID_ARGUMENT, "outlier buffers required with prep_huffman");
   HIP_TRY(hipSetDevice(h->device));
+  if (ld_wanted(h, d_coeff, nullptr))  // (pitched coefficients: quantized from a dense copy; the integers are always dense)
+    return ld_entry(h, d_coeff, nullptr, false, stream, [&](const void *i, void *) {
+      return mgh_quantize(h, i, ebtype, tol, s, norm, dict_size, prep_huffman, d_quantized, d_outlier_count,
+                          d_outlier_idx, d_outlier_val, outlier_capacity, stream);
+    });
   return DISPATCH(h,
                   quantize_impl<float>(h, (const float *)d_coeff, ebtype, tol, s, norm, dict_size,
                                        prep_huffman, d_quantized, d_outlier_count, d_outlier_idx,
@@ -2506,6 +2709,11 @@ int mgh_dequantize(mgh_hierarchy *h, int64_t *d_quantized, int ebtype, double to
                    uint64_t outlier_count, void *d_coeff, void *stream) {
   if (!h || !d_coeff || !d_quantized) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
   HIP_TRY(hipSetDevice(h->device));
+  if (ld_wanted(h, nullptr, d_coeff))  // (pitched coefficients out: dequantized densely, then spread)
+    return ld_entry(h, nullptr, d_coeff, false, stream, [&](const void *, void *o) {
+      return mgh_dequantize(h, d_quantized, ebtype, tol, s, norm, dict_size, prep_huffman, d_outlier_idx,
+                            d_outlier_val, outlier_count, o, stream);
+    });
   return DISPATCH(h,
                   dequantize_impl<float>(h, d_quantized, ebtype, tol, s, norm, dict_size,
                                          prep_huffman, d_outlier_idx, d_outlier_val, outlier_count,
@@ -2526,6 +2734,11 @@ int mgh_decompose_quantize_sym16(mgh_hierarchy *h, const void *d_data, int error
   HIP_TRY(hipSetDevice(h->device));
   if (!(fusedc_ok(h) && !h->force_v1))
     return fail(MGH_ERR_UNSUPPORTED_DIMENSION, "16-bit symbols: only on the fused 3-D / 4-D path");
+  if (ld_wanted(h, d_data, nullptr))
+    return ld_entry(h, d_data, nullptr, true, stream, [&](const void *i, void *) {
+      return mgh_decompose_quantize_sym16(h, i, error_bound_type, tol, s, norm, h_norm_out, dict_size, d_symbols,
+                                          d_outlier_count, d_outlier_idx, d_outlier_val, outlier_capacity, stream);
+    });
   // (the norm and the quantizers stay on the device; a given norm is uploaded first)
   const void *d_norm = nullptr;
   if (!(error_bound_type == MGH_REL && !(norm > 0)) && error_bound_type == MGH_REL) {
@@ -2572,6 +2785,11 @@ int mgh_dequantize_recompose_sym16(mgh_hierarchy *h, const uint16_t *d_symbols, 
   HIP_TRY(hipSetDevice(h->device));
   if (!mgh_sym16_supported(h))
     return fail(MGH_ERR_UNSUPPORTED_DIMENSION, "16-bit symbols: only on the fused 3-D / 4-D path");
+  if (ld_wanted(h, nullptr, d_data_out))
+    return ld_entry(h, nullptr, d_data_out, true, stream, [&](const void *, void *o) {
+      return mgh_dequantize_recompose_sym16(h, d_symbols, error_bound_type, tol, s, norm, dict_size, d_outlier_idx,
+                                            d_outlier_val, outlier_count, o, stream);
+    });
   return DISPATCH(h,
                   dequantize_recompose_fused16<float>(h, d_symbols, error_bound_type, tol, s, norm, dict_size,
                                                       d_outlier_idx, d_outlier_val, outlier_count,
@@ -2590,6 +2808,12 @@ int mgh_decompose_quantize(mgh_hierarchy *h, const void *d_data, int error_bound
   HIP_TRY(hipSetDevice(h->device));
   // (the fused level kernels test the dictionary range in 32 bits: larger dictionaries are staged)
   const bool fused = !d_coeff_opt && fusedc_ok(h) && !h->force_v1 && dict_size <= ((uint64_t)1 << 30);
+  if (ld_wanted(h, d_data, d_coeff_opt))
+    return ld_entry(h, d_data, d_coeff_opt, fused, stream, [&](const void *i, void *o) {
+      return mgh_decompose_quantize(h, i, error_bound_type, tol, s, norm, h_norm_out, dict_size, prep_huffman,
+                                    d_quantized, d_outlier_count, d_outlier_idx, d_outlier_val, outlier_capacity, o,
+                                    stream);
+    });
   if (fused && error_bound_type == MGH_REL && !(norm > 0)) {
     // the norm and the quantizers stay on the device: no host round trip inside the call
     if (prep_huffman && (!d_outlier_count || (outlier_capacity && (!d_outlier_idx || !d_outlier_val))))
@@ -2666,6 +2890,7 @@ int mgh_norm_stream_begin(mgh_hierarchy *h, void *stream) {
 
 int mgh_norm_stream_add(mgh_hierarchy *h, const void *d_part, uint64_t count, double s, int cold, void *stream) {
   if (!h || (!d_part && count)) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
+  if (h->has_ld[0]) return fail(MGH_ERR_INVALID_ARGUMENT, "mgh_norm_stream_add takes parts of a dense array (mgh_set_ld is set)");
   HIP_TRY(hipSetDevice(h->device));
   return DISPATCH(h, norm_stream_add<float>(h, (const float *)d_part, count, s, cold, (hipStream_t)stream),
                   norm_stream_add<double>(h, (const double *)d_part, count, s, cold, (hipStream_t)stream));
@@ -2682,6 +2907,12 @@ int mgh_decompose_quantize_dn(mgh_hierarchy *h, const void *d_data, int error_bo
   if (prep_huffman && (!d_outlier_count || (outlier_capacity && (!d_outlier_idx || !d_outlier_val))))
     return fail(MGH_ERR_INVALID_ARGUMENT, "outlier buffers required with prep_huffman");
   HIP_TRY(hipSetDevice(h->device));
+  if (ld_wanted(h, d_data, nullptr))
+    return ld_entry(h, d_data, nullptr, true, stream, [&](const void *i, void *) {
+      return mgh_decompose_quantize_dn(h, i, error_bound_type, tol, s, d_norm, num_subdomains, dict_size,
+                                       prep_huffman, d_quantized, d_outlier_count, d_outlier_idx, d_outlier_val,
+                                       outlier_capacity, stream);
+    });
   return DISPATCH(h,
                   fused_q_entry_device<float>(h, (const float *)d_data, error_bound_type, tol, s,
                                               (const float *)d_norm, 1, num_subdomains, nullptr,
@@ -2700,6 +2931,11 @@ int mgh_dequantize_recompose(mgh_hierarchy *h, int64_t *d_quantized, int ebtype,
                              const uint64_t *d_outlier_idx, const int64_t *d_outlier_val,
                              uint64_t outlier_count, void *d_data, void *stream) {
   if (!h || !d_data || !d_quantized) return fail(MGH_ERR_INVALID_ARGUMENT, "null argument");
+  if (ld_wanted(h, nullptr, d_data))
+    return ld_entry(h, nullptr, d_data, fusedc_ok(h) && !h->force_v1, stream, [&](const void *, void *o) {
+      return mgh_dequantize_recompose(h, d_quantized, ebtype, tol, s, norm, dict_size, prep_huffman, d_outlier_idx,
+                                      d_outlier_val, outlier_count, o, stream);
+    });
   if (fusedc_ok(h) && !h->force_v1) {
     HIP_TRY(hipSetDevice(h->device));
     return DISPATCH(h,
