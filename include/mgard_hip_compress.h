@@ -116,6 +116,36 @@ int mgh_decompress_multi(int num_dev, const int *dev_ids, const void *compressed
                          size_t compressed_size, void **decompressed_data,
                          const mgh_config *config, int output_pre_allocated);
 
+/* One RANK per GPU over RCCL (the reference's own multi-GPU pattern: one MPI rank per device, each
+ * compressing its block -- examples/mgard-x/CompressXgcData/TestXGCAbsoluteError.cpp:36-252). The
+ * ranks' slabs of the SLOWEST dimension, in rank order, form one domain: every rank passes the
+ * shape of ITS slab (dimensions 1.. equal on all ranks; all ranks hold the same number of planes,
+ * the last one may hold fewer, at least 3) resident on config->dev_id. nccl_comm: the caller's
+ * ncclComm_t of `nranks` ranks (passed as void *, so this header needs no rccl.h). Collectives, on
+ * a stream of the library: ncclAllGather of the slab shapes and of the record sizes, ncclAllReduce
+ * of ONE double for the norm a REL bound refers to (MAX for s = inf, SUM of squares otherwise:
+ * ErrorToleranceCalculator.hpp:69-131; every slab then runs with the ABS bound of :134-155),
+ * ncclSend / ncclRecv of the records to `root`, which writes the container mgh_compress would write
+ * for a MaxDim decomposition of dimension 0 (GPUPipelines.hpp:189-193) -- in DEVICE memory of the
+ * root (hipMalloc'ed unless pre-allocated; release with mgh_free_device). Other ranks get
+ * *compressed_size = 0 and may pass compressed_data = NULL. coords: NULL, or D host arrays with the
+ * rank's own slice of dimension 0 and the full arrays of the other dimensions.
+ * mgh_decompress_dist is the mirror: the root holds the container (device memory), every rank gets
+ * its slab back in d_local_out (device memory it allocated: mgh_infer_shape on the root tells the
+ * global shape). Every rank must make the call; a rank that fails its argument checks returns before
+ * the first collective, a failure later leaves the others inside RCCL until its time-out.
+ * RCCL is resolved at first use: symbols already in the process (an application that links RCCL),
+ * else librccl.so.1; mgh_dist_use_library(path) names the library the communicator was created with
+ * when that is another one (e.g. the copy a Python framework bundles). With nranks == 1 the calls
+ * run their first collective and then ARE mgh_compress / mgh_decompress (same bytes). */
+int mgh_dist_use_library(const char *librccl_path);
+int mgh_compress_dist(void *nccl_comm, int rank, int nranks, int root, int D, int dtype,
+                      const uint64_t *local_shape, double tol, double s, int error_bound_type,
+                      const void *d_local_data, void **compressed_data, size_t *compressed_size,
+                      const void *const *coords, const mgh_config *config, int output_pre_allocated);
+int mgh_decompress_dist(void *nccl_comm, int rank, int nranks, int root, const void *compressed_data,
+                        size_t compressed_size, void *d_local_out, const mgh_config *config);
+
 /* infer_shape / infer_data_type (Metadata.hpp:244-247). compressed_data: host or device. */
 int mgh_infer_shape(const void *compressed_data, size_t compressed_size, int *D_out,
                     uint64_t *shape_out /* [MGH_MAX_DIM] */);

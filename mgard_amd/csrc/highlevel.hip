@@ -3115,6 +3115,410 @@ int mgh_decompress_multi(int num_dev, const int *dev_ids, const void *compressed
 
 }  // extern "C"
 
+// ---- one rank per GPU: RCCL ---------------------------------------------------------------------
+// The reference's multi-GPU pattern is one MPI rank per GPU, every rank compressing its own block
+// (examples/mgard-x/CompressXgcData/TestXGCAbsoluteError.cpp:36-252). Here the ranks' slabs of the
+// slowest dimension form ONE domain: the norm a REL bound refers to is reduced over the ranks
+// (ncclAllReduce: MAX for s = inf, SUM of squares otherwise -- ErrorToleranceCalculator.hpp:69-131),
+// every rank compresses its slab with the ABS bound of calc_local_abs_tol (:134-155), the record
+// sizes travel by ncclAllGather and the records by ncclSend / ncclRecv to the root, which writes the
+// container mgh_compress would write for this decomposition (GPUPipelines.hpp:189-193). RCCL is
+// resolved at first use (dlsym of an RCCL the application already carries, else librccl.so.1), so
+// single-GPU users do not link it; the communicator is the caller's.
+namespace {
+struct RcclApi {
+  void *lib = nullptr;
+  bool ready = false;
+  // (ncclResult_t, ncclDataType_t, ncclRedOp_t are ints; ncclComm_t is a pointer: rccl.h:448-470)
+  int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  static constexpr int kUint8 = 1, kUint64 = 5, kFloat64 = 8, kSum = 0, kMax = 2;
+  bool bind(void *from) {
+    auto sym = [&](const char *n) { return dlsym(from, n); };
+    AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));
+    AllGather = reinterpret_cast<decltype(AllGather)>(sym("ncclAllGather"));
+    Broadcast = reinterpret_cast<decltype(Broadcast)>(sym("ncclBroadcast"));
+    Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+    Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+    GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+    GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+    ready = AllReduce && AllGather && Broadcast && Send && Recv && GroupStart && GroupEnd && GetErrorString;
+    return ready;
+  }
+  bool load(const char *path) {
+    static std::mutex m;
+    std::lock_guard<std::mutex> lk(m);
+    if (path) {  // the library the caller's communicator comes from
+      void *l = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+      if (!l) return false;
+      lib = l;
+      return bind(l);
+    }
+    if (ready) return true;
+    if (bind(RTLD_DEFAULT)) return true;  // the application links RCCL itself
+    for (const char *n : {"librccl.so.1", "librccl.so"}) {
+      lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (lib && bind(lib)) return true;
+    }
+    return false;
+  }
+};
+RcclApi g_rccl;
+
+#define HL_NCCL(expr)                                                                            \
+  do {                                                                                           \
+    const int _r = (expr);                                                                       \
+    if (_r != 0) return hl_fail(MGH_ERR_DEVICE, std::string(#expr) + ": " + g_rccl.GetErrorString(_r)); \
+  } while (0)
+
+// slabs of dimension 0 in rank order as a MaxDim decomposition: all of one size, the last one
+// may be shorter
+int dist_slab_size(const std::vector<uint64_t> &n0, uint64_t *size) {
+  *size = n0[0];
+  for (size_t r = 0; r + 1 < n0.size(); r++)
+    if (n0[r] != *size) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "mgh_*_dist: every rank but the last must hold the same number of planes");
+  if (n0.back() > *size || n0.back() < 3) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "mgh_*_dist: the last rank holds more planes than the others, or fewer than 3");
+  return MGH_SUCCESS;
+}
+
+template <typename T>
+int compress_dist_impl(void *comm, int rank, int nranks, int root, int D, int dtype, const uint64_t *lshape,
+                       double tol_d, double s_d, int ebtype, const void *d_local, void **compressed,
+                       size_t *compressed_size, const void *const *coords_in, const mgh_config &cfg, bool prealloc) {
+  HL_TRY(cache_prepare(cfg.dev_id));
+  hipStream_t st = g_cache.lane[0].st;
+  const size_t elem = sizeof(T);
+  const T tol = (T)tol_d, s = (T)s_d;
+  // ---- every rank learns every slab's shape (and that they agree on everything else) ----
+  constexpr int kMeta = 8;
+  DevBuf dmeta;
+  struct Rel { DevBuf &b; ~Rel() { b.release(); } } rel_meta{dmeta};
+  HL_TRY(dmeta.ensure((size_t)(nranks + 1) * kMeta * 8));
+  uint64_t mine[kMeta] = {(uint64_t)D, (uint64_t)dtype, 0, 0, 0, 0, 0, coords_in ? 1u : 0u};
+  for (int d = 0; d < D; d++) mine[2 + d] = lshape[d];
+  uint64_t *d_mine = (uint64_t *)dmeta.p, *d_all = d_mine + kMeta;
+  HL_HIP(hipMemcpyAsync(d_mine, mine, sizeof mine, hipMemcpyHostToDevice, st));
+  HL_NCCL(g_rccl.AllGather(d_mine, d_all, kMeta, RcclApi::kUint64, comm, st));
+  std::vector<uint64_t> all((size_t)nranks * kMeta);
+  HL_HIP(hipMemcpyAsync(all.data(), d_all, all.size() * 8, hipMemcpyDeviceToHost, st));
+  HL_HIP(hipStreamSynchronize(st));
+  std::vector<uint64_t> n0(nranks);
+  for (int r = 0; r < nranks; r++) {
+    const uint64_t *m = &all[(size_t)r * kMeta];
+    bool same = m[0] == mine[0] && m[1] == mine[1] && m[7] == mine[7];
+    for (int d = 1; d < D; d++) same = same && m[2 + d] == mine[2 + d];
+    if (!same) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "mgh_compress_dist: the ranks disagree on dimension, type or the extents of dimensions 1..");
+    n0[r] = m[2];
+  }
+  if (nranks == 1)  // (nothing to share out: the plain call, like mgh_compress_multi on one slab)
+    return mgh_compress(D, dtype, lshape, tol_d, s_d, ebtype, d_local, compressed, compressed_size, coords_in, &cfg,
+                        prealloc);
+  uint64_t slab = 0;
+  HL_TRY(dist_slab_size(n0, &slab));
+  Decomposer dd;
+  dd.D = D;
+  dd.shape.assign(lshape, lshape + D);
+  dd.shape[0] = 0;
+  for (uint64_t e : n0) dd.shape[0] += e;
+  dd.method = MGH_DD_MAXDIM;
+  dd.dim = 0;
+  dd.size = slab;
+  dd.num = (uint64_t)nranks;
+  dd.decomposed = true;
+  size_t total = 1, cnt = 1;
+  for (int d = 0; d < D; d++) {
+    total *= dd.shape[d];
+    cnt *= lshape[d];
+  }
+  // ---- the norm of the whole domain ----
+  T norm = 1;
+  DevBuf dscal;
+  Rel rel_scal{dscal};
+  HL_TRY(dscal.ensure(64));
+  if (ebtype == MGH_REL) {
+    mgh_hierarchy *h = nullptr;
+    bool owned = false;
+    std::vector<uint64_t> sshape(lshape, lshape + D), off(D, 0);
+    HL_TRY(get_hierarchy(&h, &owned, dtype, sshape, nullptr, off, cfg, 0));
+    double ln = 0;
+    const int rc = mgh_norm(h, d_local, s_d, &ln, st);
+    if (owned) mgh_hierarchy_destroy(h);
+    HL_TRY(rc);
+    const bool inf = s == std::numeric_limits<T>::infinity();
+    double acc = inf ? ln : ln * ln * (cfg.normalize_coordinates ? (double)cnt : 1.0);
+    HL_HIP(hipMemcpyAsync(dscal.p, &acc, 8, hipMemcpyHostToDevice, st));
+    HL_NCCL(g_rccl.AllReduce(dscal.p, (char *)dscal.p + 8, 1, RcclApi::kFloat64, inf ? RcclApi::kMax : RcclApi::kSum, comm, st));
+    HL_HIP(hipMemcpyAsync(&acc, (char *)dscal.p + 8, 8, hipMemcpyDeviceToHost, st));
+    HL_HIP(hipStreamSynchronize(st));
+    if (inf) norm = (T)acc;
+    else norm = (T)(cfg.normalize_coordinates ? std::sqrt(acc / (double)total) : std::sqrt(acc));
+  }
+  const T local_tol = local_abs_tol<T>(ebtype, norm, tol, s, (uint64_t)nranks);
+  // ---- this rank's slab as a stand-alone ABS compression; its body is the record ----
+  void *part = nullptr;
+  size_t part_size = 0;
+  mgh_config c = cfg;
+  c.domain_decomposition = MGH_DD_MAXDIM;
+  HL_TRY(mgh_compress(D, dtype, lshape, (double)local_tol, s_d, MGH_ABS, d_local, &part, &part_size, coords_in, &c, 0));
+  struct FreePart { void *p; ~FreePart() { if (p) (void)hipFree(p); } } free_part{part};
+  fmt::Header sh;
+  size_t ms = 0;
+  HL_TRY(read_header(part, part_size, sh, ms));
+  if (sh.dd_method != fmt::DD_NOOP) return hl_fail(MGH_ERR_OUT_OF_MEMORY, "mgh_compress_dist: the slab does not fit its device in one piece");
+  uint64_t body = part_size - ms;
+  HL_HIP(hipMemcpyAsync(d_mine, &body, 8, hipMemcpyHostToDevice, st));
+  HL_NCCL(g_rccl.AllGather(d_mine, d_all, 1, RcclApi::kUint64, comm, st));
+  std::vector<uint64_t> len(nranks);
+  HL_HIP(hipMemcpyAsync(len.data(), d_all, (size_t)nranks * 8, hipMemcpyDeviceToHost, st));
+  // coordinates of dimension 0: every rank's slab of them to the root (padded to the slab size)
+  std::vector<double> c0;
+  if (coords_in) {
+    DevBuf dc;
+    Rel rel_c{dc};
+    HL_TRY(dc.ensure((size_t)(nranks + 1) * slab * 8));
+    std::vector<double> my(slab, 0.0);
+    for (uint64_t i = 0; i < lshape[0]; i++) my[i] = (double)static_cast<const T *>(coords_in[0])[i];
+    HL_HIP(hipMemcpyAsync(dc.p, my.data(), slab * 8, hipMemcpyHostToDevice, st));
+    HL_NCCL(g_rccl.AllGather(dc.p, (char *)dc.p + slab * 8, slab, RcclApi::kFloat64, comm, st));
+    std::vector<double> allc((size_t)nranks * slab);
+    HL_HIP(hipMemcpyAsync(allc.data(), (char *)dc.p + slab * 8, allc.size() * 8, hipMemcpyDeviceToHost, st));
+    HL_HIP(hipStreamSynchronize(st));
+    for (int r = 0; r < nranks; r++) c0.insert(c0.end(), allc.begin() + (size_t)r * slab, allc.begin() + (size_t)r * slab + n0[r]);
+  }
+  HL_HIP(hipStreamSynchronize(st));
+  if (rank != root) {
+    HL_NCCL(g_rccl.Send((const char *)part + ms, body, RcclApi::kUint8, root, comm, st));
+    HL_HIP(hipStreamSynchronize(st));
+    *compressed_size = 0;
+    return MGH_SUCCESS;
+  }
+  // ---- root: header of the whole domain, then the records in rank order ----
+  std::vector<std::vector<double>> coords;
+  if (coords_in) {
+    coords.resize(D);
+    coords[0] = c0;
+    for (int d = 1; d < D; d++) {
+      const T *cd = static_cast<const T *>(coords_in[d]);
+      coords[d].assign(cd, cd + lshape[d]);
+    }
+  }
+  fmt::Header hdr;
+  header_from(dd, dtype, ebtype, tol_d, s_d, ebtype == MGH_REL ? (double)norm : 0.0, coords_in ? &coords : nullptr, cfg, hdr);
+  const std::vector<uint8_t> meta = fmt::serialize_metadata(hdr);
+  size_t need = meta.size();
+  for (uint64_t l : len) need += l;
+  if (!prealloc) HL_HIP(hipMalloc(compressed, need));
+  else if (*compressed_size < need) return hl_fail(MGH_ERR_OUTPUT_TOO_LARGE, "output buffer too small");
+  else if (!is_device_pointer(*compressed)) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "mgh_compress_dist: the container is assembled in device memory");
+  char *o = (char *)*compressed;
+  auto bail = [&](int rc) {
+    if (!prealloc) {
+      (void)hipFree(*compressed);
+      *compressed = nullptr;
+    }
+    return rc;
+  };
+  HL_TRY(g_cache.hpin.ensure(64 + meta.size()));
+  std::memcpy((char *)g_cache.hpin.p + 64, meta.data(), meta.size());
+  if (hipMemcpyAsync(o, (char *)g_cache.hpin.p + 64, meta.size(), hipMemcpyHostToDevice, st) != hipSuccess)
+    return bail(hl_fail(MGH_ERR_DEVICE, "header"));
+  size_t at = meta.size();
+  int nrc = g_rccl.GroupStart();
+  for (int r = 0; r < nranks && nrc == 0; r++) {
+    if (r != root) nrc = g_rccl.Recv(o + at, len[r], RcclApi::kUint8, r, comm, st);
+    at += len[r];
+  }
+  if (nrc == 0) nrc = g_rccl.GroupEnd(); else (void)g_rccl.GroupEnd();
+  if (nrc != 0) return bail(hl_fail(MGH_ERR_DEVICE, std::string("ncclRecv: ") + g_rccl.GetErrorString(nrc)));
+  size_t mine_at = meta.size();
+  for (int r = 0; r < root; r++) mine_at += len[r];
+  if (hipMemcpyAsync(o + mine_at, (const char *)part + ms, body, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return bail(hl_fail(MGH_ERR_DEVICE, "assembling the container"));
+  *compressed_size = at;
+  return MGH_SUCCESS;
+}
+
+template <typename T>
+int decompress_dist_impl(void *comm, int rank, int nranks, int root, fmt::Header &hd, const void *compressed,
+                         size_t compressed_size, size_t meta_size, void *d_local_out, const mgh_config &cfg) {
+  hipStream_t st = g_cache.lane[0].st;
+  Decomposer dd;
+  HL_TRY(decomposer_from_header(hd, cfg, dd));
+  if (!(hd.dd_method == fmt::DD_MAX_DIMENSION && hd.dd_dim == 0 && dd.num == (uint64_t)nranks))
+    return hl_fail(MGH_ERR_INVALID_ARGUMENT, "mgh_decompress_dist: the container is not one slab of dimension 0 per rank");
+  // record table from the root
+  DevBuf dtab;
+  struct Rel { DevBuf &b; ~Rel() { b.release(); } } rel_tab{dtab};
+  HL_TRY(dtab.ensure((size_t)nranks * 16));
+  std::vector<uint64_t> tab((size_t)nranks * 2, 0);  // offset (of the size prefix), length (prefix included)
+  if (rank == root) {
+    size_t at = meta_size;
+    for (int r = 0; r < nranks; r++) {
+      if (at + 8 > compressed_size) return hl_fail(MGH_ERR_FORMAT, "truncated stream");
+      uint64_t cs = 0;
+      HL_TRY(aux_read(&cs, (const char *)compressed + at, 8));
+      if (cs > compressed_size - at - 8) return hl_fail(MGH_ERR_FORMAT, "truncated record");
+      tab[2 * r] = at;
+      tab[2 * r + 1] = 8 + cs;
+      at += 8 + cs;
+    }
+    HL_HIP(hipMemcpyAsync(dtab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, st));
+  }
+  HL_NCCL(g_rccl.Broadcast(dtab.p, dtab.p, tab.size(), RcclApi::kUint64, root, comm, st));
+  HL_HIP(hipMemcpyAsync(tab.data(), dtab.p, tab.size() * 8, hipMemcpyDeviceToHost, st));
+  HL_HIP(hipStreamSynchronize(st));
+  // this rank's record behind the header of its slab: a container of its own (decompress_multi_impl)
+  const T norm = (T)hd.norm, tol = (T)hd.tol, s = (T)hd.s;
+  const T local_tol = local_abs_tol<T>(hd.rel ? MGH_REL : MGH_ABS, norm, tol, s, (uint64_t)nranks);
+  fmt::Header sh = hd;
+  sh.shape = dd.subdomain_shape((uint64_t)rank);
+  if (!hd.uniform) {
+    const uint64_t o0 = dd.subdomain_offset((uint64_t)rank)[0];
+    sh.coords[0].assign(hd.coords[0].begin() + o0, hd.coords[0].begin() + o0 + sh.shape[0]);
+  }
+  sh.rel = false;
+  sh.tol = (double)local_tol;
+  sh.norm = 0.0;
+  sh.dd_method = fmt::DD_NOOP;
+  sh.dd_dim = 0;
+  sh.dd_size = 0;
+  const std::vector<uint8_t> meta = fmt::serialize_metadata(sh);
+  const size_t mylen = tab[2 * rank + 1];
+  DevBuf mini;
+  Rel rel_mini{mini};
+  HL_TRY(mini.ensure(meta.size() + mylen));
+  HL_TRY(g_cache.hpin.ensure(64 + meta.size()));
+  std::memcpy((char *)g_cache.hpin.p + 64, meta.data(), meta.size());
+  HL_HIP(hipMemcpyAsync(mini.p, (char *)g_cache.hpin.p + 64, meta.size(), hipMemcpyHostToDevice, st));
+  if (rank == root) {
+    HL_NCCL(g_rccl.GroupStart());
+    int nrc = 0;
+    for (int r = 0; r < nranks && nrc == 0; r++)
+      if (r != root) nrc = g_rccl.Send((const char *)compressed + tab[2 * r], tab[2 * r + 1], RcclApi::kUint8, r, comm, st);
+    const int erc = g_rccl.GroupEnd();
+    if (nrc != 0 || erc != 0) return hl_fail(MGH_ERR_DEVICE, std::string("ncclSend: ") + g_rccl.GetErrorString(nrc ? nrc : erc));
+    HL_HIP(hipMemcpyAsync((char *)mini.p + meta.size(), (const char *)compressed + tab[2 * rank], mylen, hipMemcpyDeviceToDevice, st));
+  } else {
+    HL_NCCL(g_rccl.Recv((char *)mini.p + meta.size(), mylen, RcclApi::kUint8, root, comm, st));
+  }
+  HL_HIP(hipStreamSynchronize(st));
+  void *dst = d_local_out;
+  return mgh_decompress(mini.p, meta.size() + mylen, &dst, &cfg, 1);
+}
+}  // namespace
+
+extern "C" {
+
+int mgh_dist_use_library(const char *path) {
+  if (!path) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (!g_rccl.load(path)) return hl_fail(MGH_ERR_INVALID_ARGUMENT, std::string("mgh_dist_use_library: no RCCL in ") + path);
+  return MGH_SUCCESS;
+}
+
+int mgh_compress_dist(void *nccl_comm, int rank, int nranks, int root, int D, int dtype, const uint64_t *local_shape,
+                      double tol, double s, int ebtype, const void *d_local_data, void **compressed_data,
+                      size_t *compressed_size, const void *const *coords, const mgh_config *config,
+                      int output_pre_allocated) {
+  if (!nccl_comm || !local_shape || !d_local_data || !compressed_size) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (nranks < 1 || rank < 0 || rank >= nranks || root < 0 || root >= nranks) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "rank / nranks / root");
+  if (rank == root && (!compressed_data || (output_pre_allocated && !*compressed_data)))
+    return hl_fail(MGH_ERR_INVALID_ARGUMENT, "the root needs an output");
+  if (D < 1 || D > MGH_MAX_DIM) return hl_fail(MGH_ERR_UNSUPPORTED_DIMENSION, "D must be 1..5");
+  if (dtype != MGH_FLOAT && dtype != MGH_DOUBLE) return hl_fail(MGH_ERR_UNSUPPORTED_DTYPE, "dtype");
+  if (ebtype != MGH_REL && ebtype != MGH_ABS) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "error_bound_type");
+  HL_TRY(check_config(config));
+  if (hipSetDevice(config->dev_id) != hipSuccess) return hl_fail(MGH_ERR_DEVICE, "hipSetDevice");
+  if (!is_device_pointer_on(d_local_data, config->dev_id))
+    return hl_fail(MGH_ERR_INVALID_ARGUMENT, "mgh_compress_dist: the slab must be resident on config->dev_id");
+  if (!g_rccl.load(nullptr)) return hl_fail(MGH_ERR_NO_DEVICE, "mgh_compress_dist: no RCCL (librccl.so.1) found");
+  size_t dummy = 0;
+  void *none = nullptr;
+  try {
+    if (dtype == MGH_FLOAT)
+      return compress_dist_impl<float>(nccl_comm, rank, nranks, root, D, dtype, local_shape, tol, s, ebtype, d_local_data,
+                                       rank == root ? compressed_data : &none, rank == root ? compressed_size : &dummy,
+                                       coords, *config, rank == root && output_pre_allocated != 0);
+    return compress_dist_impl<double>(nccl_comm, rank, nranks, root, D, dtype, local_shape, tol, s, ebtype, d_local_data,
+                                      rank == root ? compressed_data : &none, rank == root ? compressed_size : &dummy,
+                                      coords, *config, rank == root && output_pre_allocated != 0);
+  } catch (const std::exception &e) {
+    return hl_fail(MGH_ERR_DEVICE, e.what());
+  }
+}
+
+int mgh_decompress_dist(void *nccl_comm, int rank, int nranks, int root, const void *compressed_data,
+                        size_t compressed_size, void *d_local_out, const mgh_config *config) {
+  if (!nccl_comm || !d_local_out) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (nranks < 1 || rank < 0 || rank >= nranks || root < 0 || root >= nranks) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "rank / nranks / root");
+  if (rank == root && !compressed_data) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "the root needs the container");
+  mgh_config def;
+  if (!config) {
+    mgh_config_default(&def);
+    config = &def;
+  }
+  if (hipSetDevice(config->dev_id) != hipSuccess) return hl_fail(MGH_ERR_DEVICE, "hipSetDevice");
+  if (!g_rccl.load(nullptr)) return hl_fail(MGH_ERR_NO_DEVICE, "mgh_decompress_dist: no RCCL (librccl.so.1) found");
+  HL_TRY(cache_prepare(config->dev_id));
+  hipStream_t st = g_cache.lane[0].st;
+  try {
+    // the header travels first: its length, then its bytes
+    if (nranks > 1 && rank == root && !is_device_pointer_on(compressed_data, config->dev_id))
+      return hl_fail(MGH_ERR_INVALID_ARGUMENT, "mgh_decompress_dist: the container must be resident on the root's device");
+    fmt::Header hd;
+    size_t meta_size = 0;
+    std::vector<uint8_t> hbytes;
+    if (rank == root) {
+      std::unique_ptr<HostPrefix> prefix;
+      if (is_device_pointer(compressed_data)) prefix.reset(new HostPrefix(compressed_data, compressed_size));
+      HL_TRY(read_header(compressed_data, compressed_size, hd, meta_size));
+      HL_TRY(fetch_host(compressed_data, compressed_size, meta_size, hbytes));
+    }
+    DevBuf dh;
+    struct Rel { DevBuf &b; ~Rel() { b.release(); } } rel{dh};
+    HL_TRY(dh.ensure(8));
+    uint64_t ms64 = meta_size;
+    HL_HIP(hipMemcpyAsync(dh.p, &ms64, 8, hipMemcpyHostToDevice, st));
+    HL_NCCL(g_rccl.Broadcast(dh.p, dh.p, 1, RcclApi::kUint64, root, nccl_comm, st));
+    HL_HIP(hipMemcpyAsync(&ms64, dh.p, 8, hipMemcpyDeviceToHost, st));
+    HL_HIP(hipStreamSynchronize(st));
+    if (ms64 == 0 || ms64 > ((uint64_t)1 << 32)) return hl_fail(MGH_ERR_FORMAT, "header size");
+    HL_TRY(dh.ensure(ms64));
+    hbytes.resize(ms64);
+    if (rank == root) HL_HIP(hipMemcpyAsync(dh.p, hbytes.data(), ms64, hipMemcpyHostToDevice, st));
+    HL_NCCL(g_rccl.Broadcast(dh.p, dh.p, ms64, RcclApi::kUint8, root, nccl_comm, st));
+    HL_HIP(hipMemcpyAsync(hbytes.data(), dh.p, ms64, hipMemcpyDeviceToHost, st));
+    HL_HIP(hipStreamSynchronize(st));
+    if (rank != root) {
+      try {
+        meta_size = fmt::parse_metadata(hbytes.data(), hbytes.size(), hd);
+      } catch (const std::exception &e) {
+        return hl_fail(MGH_ERR_FORMAT, e.what());
+      }
+    }
+    if (nranks == 1) {  // (nothing to hand out: the plain call)
+      void *dst = d_local_out;
+      return mgh_decompress(compressed_data, compressed_size, &dst, config, 1);
+    }
+    if (hd.is_double)
+      return decompress_dist_impl<double>(nccl_comm, rank, nranks, root, hd, compressed_data, compressed_size, meta_size,
+                                          d_local_out, *config);
+    return decompress_dist_impl<float>(nccl_comm, rank, nranks, root, hd, compressed_data, compressed_size, meta_size,
+                                       d_local_out, *config);
+  } catch (const std::exception &e) {
+    return hl_fail(MGH_ERR_DEVICE, e.what());
+  }
+}
+
+}  // extern "C"
+
 extern "C" {
 
 int mgh_infer_shape(const void *data, size_t size, int *D_out, uint64_t *shape_out) {

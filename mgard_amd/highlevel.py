@@ -22,7 +22,7 @@ HL_SYMBOLS = [
     "mgh_metadata_parse", "mgh_lossless_create", "mgh_lossless_destroy", "mgh_lossless_compress",
     "mgh_lossless_decompress", "mgh_lossless_compress_device", "mgh_memcpy", "mgh_huffman_codebook",
     "mgh_compress_multi", "mgh_decompress_multi", "mgh_pin_memory", "mgh_check_memory_pinned",
-    "mgh_unpin_memory",
+    "mgh_unpin_memory", "mgh_dist_use_library", "mgh_compress_dist", "mgh_decompress_dist",
 ]
 
 
@@ -101,6 +101,10 @@ def _hl():
                                C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp),
                                C.POINTER(Config), C.c_int]
     L.mgh_decompress.argtypes = [vp, C.c_size_t, C.POINTER(vp), C.POINTER(Config), C.c_int]
+    L.mgh_dist_use_library.argtypes = [C.c_char_p]
+    L.mgh_compress_dist.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(u64), C.c_double,
+                                    C.c_double, C.c_int, vp, C.POINTER(vp), C.POINTER(C.c_size_t), vp, vp, C.c_int]
+    L.mgh_decompress_dist.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp, vp]
     L.mgh_pin_memory.argtypes = [vp, C.c_size_t]
     L.mgh_check_memory_pinned.argtypes = [vp]
     L.mgh_unpin_memory.argtypes = [vp]
@@ -386,6 +390,46 @@ def decompress_multi(buf, devices=(0,), config=None):
     devs = (C.c_int * len(devices))(*devices)
     _check(L.mgh_decompress_multi(len(devices), devs, C.c_void_p(buf.ctypes.data), buf.size,
                                   C.byref(optr), C.byref(cfg), 1))
+    return out
+
+
+def compress_dist(comm, rank, nranks, local, tol, s=INF, mode=REL, root=0, config=None, rccl_path=None):
+    """mgh_compress_dist: `comm` = the ncclComm_t (int / c_void_p) of an RCCL communicator of `nranks`
+    ranks, `local` = this rank's slab (cuda tensor). Returns the container (cuda uint8 tensor) on the
+    root, None elsewhere. rccl_path: the librccl the communicator was created with (when it is not
+    the one already in the process / librccl.so.1)."""
+    import torch
+    L = _hl()
+    if rccl_path is not None:
+        _check(L.mgh_dist_use_library(str(rccl_path).encode()))
+    cfg = config if config is not None else Config()
+    local = local.contiguous()
+    dt = FLOAT if local.dtype == torch.float32 else DOUBLE
+    shp = (C.c_uint64 * local.dim())(*local.shape)
+    optr, size = C.c_void_p(), C.c_size_t(0)
+    _check(L.mgh_compress_dist(C.c_void_p(int(comm)), rank, nranks, root, local.dim(), dt, shp, float(tol), float(s),
+                               int(mode), C.c_void_p(local.data_ptr()), C.byref(optr), C.byref(size), None,
+                               C.byref(cfg), 0))
+    if rank != root:
+        return None
+    out = torch.empty(size.value, dtype=torch.uint8, device=local.device)
+    _check(L.mgh_memcpy(C.c_void_p(out.data_ptr()), optr, size.value))
+    L.mgh_free_device(optr)
+    return out
+
+
+def decompress_dist(comm, rank, nranks, container, local_shape, dtype, root=0, config=None, device=None):
+    """mgh_decompress_dist: the root passes the container (cuda uint8 tensor), the others None; every
+    rank gets its slab (cuda tensor of local_shape)."""
+    import torch
+    L = _hl()
+    cfg = config if config is not None else Config()
+    dev = container.device if container is not None else device
+    out = torch.empty(tuple(local_shape), dtype=dtype, device=dev)
+    p = C.c_void_p(container.data_ptr()) if container is not None else None
+    n = int(container.numel()) if container is not None else 0
+    _check(L.mgh_decompress_dist(C.c_void_p(int(comm)), rank, nranks, root, p, n, C.c_void_p(out.data_ptr()),
+                                 C.byref(cfg)))
     return out
 
 
