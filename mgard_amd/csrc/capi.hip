@@ -70,6 +70,7 @@ struct mgh_hierarchy {
   void *host = nullptr;  // HostHierarchy<T>*
   void *impl = nullptr;  // DeviceState<T>*
   bool profiling = false;
+  int nd_rows = 1;  // MGH_ND_ROWS: the generic N-D path runs its row-wise kernels (kernels_nd.hpp; 0 = one thread per element, cross-check)
   bool force_nd_ipk = false;  // MGH_ND_IPK=1: the generic N-D path solves with its own one-thread-per-pencil kernel (cross-check)
   bool force_v1 = false;  // MGH_FORCE_V1=1: run the one-thread-per-element kernels only (unset: also for thin shapes, see mgh_hierarchy_create; 0: never)
   int force_v1_env = -1;
@@ -1433,6 +1434,41 @@ inline unsigned nd_grid(uint64_t total) {
 }
 
 // correction of level l from the reordered coefficients in v; returns the compact result
+// the row-wise kernels' view of a level (dimensions right-aligned to kNd)
+inline NdRowBox nd_row_box(const NdBox &b) {
+  NdRowBox r{};
+  const int sh = kNd - b.D;
+  for (int k = 0; k < kNd; k++) {
+    r.n[k] = r.m[k] = 1;
+    r.fs[k] = r.ns[k] = 0;
+  }
+  uint64_t sacc = 1;
+  for (int d = b.D - 1; d >= 0; d--) {
+    r.n[d + sh] = b.n[d];
+    r.m[d + sh] = b.m[d];
+    r.fs[d + sh] = b.fs[d];
+    r.ns[d + sh] = sacc;
+    sacc *= b.n[d];
+  }
+  r.rows = 1;
+  for (int k = 0; k < kNd - 1; k++) r.rows *= r.n[k];
+  return r;
+}
+inline unsigned nd_row_grid(uint64_t rows) {
+  return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((rows + 4 * kNdRowsPerWave - 1) / (4 * kNdRowsPerWave), 1u << 20));
+}
+template <typename T>
+int nd_coeff_launch(mgh_hierarchy *h, const NdBox &b, const NdTables<T> &tb, T *w, T *v, uint64_t nn, int mode,
+                    hipStream_t st) {
+  if (h->nd_rows && b.fs[b.D - 1] == 1) {
+    const NdRowBox rb = nd_row_box(b);
+    NdTables<T> ta{};
+    for (int d = 0; d < b.D; d++) ta.ratio[d + kNd - b.D] = tb.ratio[d];
+    return launch(h, "nd_coeff", st, [&] { k_nd_coeff_rows<T><<<nd_row_grid(rb.rows), 256, 0, st>>>(rb, ta, w, v, mode); });
+  }
+  return launch(h, "nd_coeff", st, [&] { k_nd_coeff<T><<<nd_grid(nn), 256, 0, st>>>(b, tb, w, v, nn, mode); });
+}
+
 template <typename T>
 int nd_correction(mgh_hierarchy *h, int l, const T *v, const NdBox &b, T **out, hipStream_t st) {
   auto *ds = DS<T>(h);
@@ -1455,9 +1491,33 @@ int nd_correction(mgh_hierarchy *h, int l, const T *v, const NdBox &b, T **out, 
     uint64_t total = 1;
     for (int d = 0; d < D; d++) total *= (d == a ? s.m : s.e[d]);
     T *dst = bufs[which];
-    TRY(launch(h, "nd_lpk", st, [&] {
-      k_nd_lpk<T><<<nd_grid(total), 256, 0, st>>>(s, cur, dst, ds->nd[l].mass[a], total);
-    }));
+    if (h->nd_rows) {
+      NdRowSweep rs{};
+      const int sh = kNd - D;
+      for (int k = 0; k < kNd; k++) {
+        rs.eo[k] = 1;
+        rs.is[k] = 0;
+        rs.mc[k] = 1;
+      }
+      for (int d = 0; d < D; d++) {
+        rs.eo[d + sh] = d == a ? s.m : s.e[d];
+        rs.is[d + sh] = s.is[d];
+        rs.mc[d + sh] = s.mc[d];
+      }
+      rs.a = a + sh;
+      rs.n = s.n;
+      rs.m = s.m;
+      rs.zero_all_coarse = s.zero_all_coarse;
+      rs.rows = 1;
+      for (int k = 0; k < kNd - 1; k++) rs.rows *= rs.eo[k];
+      TRY(launch(h, "nd_lpk", st, [&] {
+        k_nd_lpk_rows<T><<<nd_row_grid(rs.rows), 256, 0, st>>>(rs, cur, dst, ds->nd[l].mass[a]);
+      }));
+    } else {
+      TRY(launch(h, "nd_lpk", st, [&] {
+        k_nd_lpk<T><<<nd_grid(total), 256, 0, st>>>(s, cur, dst, ds->nd[l].mass[a], total);
+      }));
+    }
     cur = dst;
     which ^= 1;
     s.e[a] = s.m;
@@ -1498,9 +1558,16 @@ int nd_correction(mgh_hierarchy *h, int l, const T *v, const NdBox &b, T **out, 
   return MGH_SUCCESS;
 }
 
-template <typename T> int decompose_nd(mgh_hierarchy *h, T *v, hipStream_t st) {
+// src_top: the input when it is another array than v (out of place): the top level, whose fine box
+// IS the array, reads it where it is -- neither the copy into v nor the one into the natural-order
+// work array happen (two passes over the data; every element of v is written by that level).
+template <typename T> int decompose_nd(mgh_hierarchy *h, T *v, hipStream_t st, const T *src_top = nullptr) {
   auto *ds = DS<T>(h);
   TRY(nd_ensure<T>(h));
+  if (src_top && !(h->L >= 1 && nd_box_is_whole_array(nd_box<T>(h, h->L)))) {
+    HIP_TRY(hipMemcpyAsync(v, src_top, h->total * sizeof(T), hipMemcpyDeviceToDevice, st));
+    src_top = nullptr;
+  }
   for (int l = h->L; l >= 1; l--) {
     const NdBox b = nd_box<T>(h, l);
     NdTables<T> tb{};
@@ -1510,7 +1577,10 @@ template <typename T> int decompose_nd(mgh_hierarchy *h, T *v, hipStream_t st) {
       nn *= b.n[d];
       mm *= b.m[d];
     }
-    if (nd_box_is_whole_array(b)) {  // the top level: the fine box IS the array -- a plain copy
+    T *w = ds->nd_w;
+    if (l == h->L && src_top) {
+      w = const_cast<T *>(src_top);  // (mode 0 only reads it)
+    } else if (nd_box_is_whole_array(b)) {  // the top level: the fine box IS the array -- a plain copy
       TRY(launch(h, "nd_gather", st, [&] {
         (void)hipMemcpyAsync(ds->nd_w, v, nn * sizeof(T), hipMemcpyDeviceToDevice, st);
       }));
@@ -1519,9 +1589,7 @@ template <typename T> int decompose_nd(mgh_hierarchy *h, T *v, hipStream_t st) {
         k_nd_gather<T><<<nd_grid(nn), 256, 0, st>>>(b, v, ds->nd_w, nn, 0);
       }));
     }
-    TRY(launch(h, "nd_coeff", st, [&] {
-      k_nd_coeff<T><<<nd_grid(nn), 256, 0, st>>>(b, tb, ds->nd_w, v, nn, 0);
-    }));
+    TRY(nd_coeff_launch<T>(h, b, tb, w, v, nn, 0, st));
     T *corr = nullptr;
     TRY(nd_correction<T>(h, l, v, b, &corr, st));
     TRY(launch(h, "nd_apply", st, [&] {
@@ -1548,12 +1616,8 @@ template <typename T> int recompose_nd(mgh_hierarchy *h, T *v, hipStream_t st) {
     TRY(launch(h, "nd_apply", st, [&] {
       k_nd_apply<T><<<nd_grid(mm), 256, 0, st>>>(b, corr, v, mm, -1);
     }));
-    TRY(launch(h, "nd_coeff", st, [&] {
-      k_nd_coeff<T><<<nd_grid(nn), 256, 0, st>>>(b, tb, ds->nd_w, v, nn, 1);
-    }));
-    TRY(launch(h, "nd_coeff", st, [&] {
-      k_nd_coeff<T><<<nd_grid(nn), 256, 0, st>>>(b, tb, ds->nd_w, v, nn, 2);
-    }));
+    TRY(nd_coeff_launch<T>(h, b, tb, ds->nd_w, v, nn, 1, st));
+    TRY(nd_coeff_launch<T>(h, b, tb, ds->nd_w, v, nn, 2, st));
     if (nd_box_is_whole_array(b)) {
       TRY(launch(h, "nd_gather", st, [&] {
         (void)hipMemcpyAsync(v, ds->nd_w, nn * sizeof(T), hipMemcpyDeviceToDevice, st);
@@ -1579,11 +1643,8 @@ int decompose_impl(mgh_hierarchy *h, const T *data, T *coeff, hipStream_t s) {
     }
     return decompose_fused<T, OUT_T>(h, src4, coeff, nullptr, s);
   }
-  if (h->D > 3 || h->force_nd) {
-    if ((const void *)data != (const void *)coeff)
-      HIP_TRY(hipMemcpyAsync(coeff, data, h->total * sizeof(T), hipMemcpyDeviceToDevice, s));
-    return decompose_nd<T>(h, coeff, s);
-  }
+  if (h->D > 3 || h->force_nd)
+    return decompose_nd<T>(h, coeff, s, (const void *)data != (const void *)coeff ? data : nullptr);
   const int L = h->L;
   const size_t fI = ds->full_I, fJ = ds->full_J;
   const T *src = data;
@@ -2533,6 +2594,7 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->outlier_agg = (int)env_get("MGH_OUTLIER_AGG", h->outlier_agg);
     h->ipk_chunk_k = (int)env_get("MGH_IPK_CHUNK_K", h->ipk_chunk_k);
     h->tail_solves = (int)env_get("MGH_TAIL_SOLVES", h->tail_solves);
+    h->nd_rows = (int)env_get("MGH_ND_ROWS", h->nd_rows);
     h->cls1 = (size_t)env_get("MGH_CLS1", (long)h->cls1);
     h->cls2 = (size_t)env_get("MGH_CLS2", (long)h->cls2);
     if (const char *e = std::getenv("MGH_RCH")) std::sscanf(e, "%d,%d,%d", &h->rch[0], &h->rch[1], &h->rch[2]);

@@ -396,6 +396,43 @@ def test_nd_kernels_equal_3d_kernels(shape, monkeypatch):
     h.close()
 
 
+@pytest.mark.parametrize("rows", ["1", "0"])
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(6, 9, 8, 12), (3, 4, 5, 6, 7), (5, 5, 9, 6, 10), (4, 3, 70, 5, 131),
+                                   (8, 8, 20, 20, 20), (17, 20), (9, 6, 8), (3, 3, 3, 3, 200)])
+def test_generic_nd_row_kernels_bit_exact(shape, dt, rows, monkeypatch):
+    """The generic N-D path on its row-wise kernels (round 6: a wave per group of rows, positions by
+    counting up instead of five divisions per element; MGH_ND_ROWS=0: one thread per element) --
+    forced for D <= 4 as well (MGH_FORCE_ND / MGH_FUSED4=0) -- against the oracle, out of place
+    (the top level reads the input where it is) and in place, plus the quantizer behind it
+    (slot requests by ballot) with a dictionary small enough to leave outliers."""
+    torch, mg = _gpu()
+    monkeypatch.setenv("MGH_ND_ROWS", rows)
+    monkeypatch.setenv("MGH_FUSED4", "0")
+    if len(shape) <= 3:
+        monkeypatch.setenv("MGH_FORCE_ND", "1")
+    u = smooth_field(shape, dt, noise=1e-2)
+    h = mg.Hierarchy(shape, dt)
+    o = oracle.Hierarchy(shape, dt)
+    ud = torch.from_numpy(u).cuda()
+    ref = o.decompose(u)
+    c = h.decompose(ud)
+    assert_bit_equal(c.cpu().numpy(), ref, "nd decompose %r" % (shape,))
+    assert torch.equal(ud.cpu(), torch.from_numpy(u)), "the input of an out-of-place call was modified"
+    w = ud.clone()
+    h.decompose(w, out=w)
+    assert_bit_equal(w.cpu().numpy(), ref, "nd decompose in place %r" % (shape,))
+    back = h.recompose(c)
+    assert_bit_equal(back.cpu().numpy(), o.recompose(ref), "nd recompose %r" % (shape,))
+    nrm = oracle.norm(u, dt(np.inf))
+    q, oi, ov, n, nrm2 = h.decompose_quantize(ud, mg.REL, 1e-3, np.inf, dict_size=16)
+    rq, roi, rov, rn = o.quantize(ref, oracle.REL, dt(1e-3), dt(np.inf), dt(nrm), dict_size=16)
+    assert n == rn and rn > 0
+    np.testing.assert_array_equal(q.cpu().numpy(), rq)
+    assert sorted(zip(oi.tolist(), ov.tolist())) == sorted(zip(roi.tolist(), rov.tolist()))
+    h.close()
+
+
 def test_reference_4d_goldens_through_gpu():
     torch, mg = _gpu()
     G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_goldens.json")))

@@ -15,7 +15,7 @@ for _ in range(2): f()
 torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(5): f()
 torch.cuda.synchronize(); ms = (time.perf_counter() - t) / 5 * 1e3
-print(shape, "%.3f ms  %.1f GB/s" % (ms, u.nbytes / ms / 1e6), "L =", h.l_target)
+print(shape, "%.3f ms  %.1f GB/s" % (ms, u.nbytes / ms / 1e6), "L =", h.l_target, "outliers", int(cnt.item()))
 h.profile(True)
 for _ in range(3): f()
 torch.cuda.synchronize()
