@@ -4,8 +4,9 @@
 // include/mgard-x/RuntimeX/DataTypes.h:106-134) uses lives here in `namespace mgard_x` with the
 // same spelling, argument order, defaults, ownership rules and status codes, implemented on the
 // C ABI of mgard_hip_compress.h. A program written against the reference switches by changing that
-// one include line and linking libmgard_hip.so (tests/cpp/highlevel_api_example.cpp is the
-// reference's examples/mgard-x/HighLevelAPIs/Example.cpp with exactly that change).
+// one include line and linking libmgard_hip.so (tests/cpp/highlevel_api_example.cpp is a consumer
+// written against this header with the call shapes of the reference's
+// examples/mgard-x/HighLevelAPIs/Example.cpp -- same calls, its own data, sizes and checks).
 //
 // What differs, because this library is one backend and one path:
 //   * dev_type AUTO, HIP and CUDA select the HIP device `dev_id`; SERIAL / OPENMP / SYCL return

@@ -44,6 +44,7 @@ inline const EnvSwitch *env_switches(size_t *count) {
       {"MGH_IPK_CHUNK_K", 0, 64},
       {"MGH_HL_STREAM_NORM", 0, 1},
       {"MGH_ND_ROWS", 0, 1},
+      {"MGH_HUFF_PAIR", 0, 2},
   };
   *count = sizeof(k) / sizeof(k[0]);
   return k;

@@ -269,6 +269,8 @@ struct mgh_lossless_ctx {
   // lay.ddata bytes][histogram][code table][counts] in ONE pinned allocation
   PinBuf pin;
   PinBuf dpin;                         // decompression: pinned copy of the decode table (source of its upload)
+  PinBuf tagpin;                       // decompression: word a kernel clears when a device-resident record's sync tag is wrong
+  bool tag_pending = false;            // ... to be looked at once the stream has been synchronised (lossless_tag_check)
   uint8_t *chead = nullptr;            // = pin.p + 8
   unsigned long long *pcounts = nullptr;  // [0..2] encoder state, [3] outlier count read back, [4] n_outliers to write
   PayloadLayout lay;
@@ -338,9 +340,19 @@ struct RecordPieces {
   uint8_t *dst[5];
   size_t bytes[5];
   int n;
+  // decompression of a device-resident record: the 8 bytes that must be the tag of the
+  // synchronisation-point section (any alignment); *tag_ok (pinned host memory) = 0 if they are not
+  const uint8_t *tag_src;
+  unsigned long long tag_want;
+  unsigned *tag_ok;
 };
 __global__ void __launch_bounds__(256) k_record_pieces(RecordPieces P) {
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+  if (P.tag_src && t == 0) {
+    unsigned long long tag;
+    __builtin_memcpy(&tag, P.tag_src, 8);
+    if (tag != P.tag_want) *P.tag_ok = 0;
+  }
   for (int i = 0; i < P.n; i++) {
     const uint8_t *sp = P.src[i];
     uint8_t *dp = P.dst[i];
@@ -759,6 +771,16 @@ int lossless_compress(mgh_lossless_ctx *c, const int64_t *d_q, uint64_t n, uint6
 // to the host, the code units and outlier lists go device-to-device (or host-to-device).
 // sym16: decode to uint16_t symbols at d_q (the ring decoder only; *sym16 is cleared when another
 // decoder had to be used and d_q holds int64 values).
+// After a synchronisation of the stream lossless_decompress() ran on: was the tag of the
+// synchronisation-point section of a device-resident record what it has to be?
+int lossless_tag_check(mgh_lossless_ctx *c) {
+  if (!c->tag_pending) return MGH_SUCCESS;
+  c->tag_pending = false;
+  if (*reinterpret_cast<volatile unsigned *>(c->tagpin.p) == 0)
+    return hl_fail(MGH_ERR_FORMAT, "Huffman record: outlier lists");
+  return MGH_SUCCESS;
+}
+
 int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t size, int lossless,
                         int64_t *d_q, uint64_t n, uint64_t *ocount_out, hipStream_t st,
                         bool *sym16 = nullptr, bool sync_end = true) {
@@ -882,6 +904,23 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
     piece(p + L.decodebook, c->tables.p, dbsize);
     piece(p + o_oidx, c->oidx.p, ocount * 8);
     piece(p + o_oval, c->oval.p, ocount * 8);
+    if (has_sync) {
+      // The section was recognised by the record's size alone (no host copy of its tag): the kernel
+      // looks at the tag and clears a pinned word if it is not one; whoever synchronises the stream
+      // next turns that into MGH_ERR_FORMAT (lossless_tag_check) -- a damaged record must not decode
+      // quietly with arbitrary synchronisation points.
+      HL_TRY(c->tagpin.ensure(64));
+      void *dev_word = nullptr;
+      if (hipHostGetDevicePointer(&dev_word, c->tagpin.p, 0) == hipSuccess && dev_word) {
+        *reinterpret_cast<volatile unsigned *>(c->tagpin.p) = 1;
+        P.tag_src = p + o_sync - 8;
+        P.tag_want = PayloadLayout::kSyncTag;
+        P.tag_ok = (unsigned *)dev_word;
+        c->tag_pending = true;
+      } else {
+        (void)hipGetLastError();
+      }
+    }
     size_t tot = 0;
     for (int i = 0; i < P.n; i++) tot += P.bytes[i];
     k_record_pieces<<<(unsigned)std::min<size_t>(std::max<size_t>(tot / (256 * 64), 1), 512), 256, 0, st>>>(P);
@@ -949,7 +988,18 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
     const size_t per_wave = huff::decode_ring_lds(0, 1);
     // (kept in the context: the upload below is asynchronous and must not outlive its source)
     std::vector<uint32_t> &dt = c->h_dtable;
-    dt = huff::build_decode_table(book, book + 64, book + 128, (int)dict, rtb, (lds_cap - 8 * per_wave) / 4);
+    // Records with synchronisation points and SHORT codes: the decoder that takes two codes per
+    // root-table slot where both fit its 12 bits (k_decode_sync). 512^3 f32, int64 output, same box:
+    // 5.7 bits per symbol 0.79 against 0.85 ms with k_decode_ring's single-symbol steps; 7.4 bits 0.98
+    // against 0.87, 9.1 bits (the benchmark's field at 1e-3) 0.97 against 0.79 -- pairs no longer fit
+    // and the wider entries only cost. MGH_HUFF_PAIR: 0 never, 1 up to 6.5 bits per symbol (default),
+    // 2 whenever the record has the points (cross-check).
+    const long pair_env = env_get("MGH_HUFF_PAIR", 1);
+    const bool pair_decode = has_sync && (size_t)chunk <= 65535 &&
+                             (pair_env == 2 || (pair_env == 1 && (double)units * 64.0 <= 6.5 * (double)n));
+    dt = huff::build_decode_table(book, book + 64, book + 128, (int)dict, rtb,
+                                  (lds_cap - 8 * per_wave) / 4 - (pair_decode ? ((size_t)1 << rtb) : 0));
+    if (pair_decode) dt = huff::make_pair_table(dt, rtb);
     const int waves = huff::decode_ring_lds(dt.size(), 16) <= lds_cap ? 16 : 8;
     HL_TRY(c->dtable.ensure(dt.size() * 4));
     // (out of pinned memory: a copy from pageable memory is staged synchronously, ~15 us)
@@ -971,12 +1021,38 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
       if (on_dev && is_device_pointer_on(p, c->dev)) {
         d_sync = (const unsigned *)(p + o_sync);
       } else {
+        if (on_dev) {  // (a record on another device: its tag has not been looked at yet)
+          uint64_t tag = 0;
+          HL_TRY(aux_read(&tag, p + o_sync - 8, 8));
+          if (tag != PayloadLayout::kSyncTag) return hl_fail(MGH_ERR_FORMAT, "Huffman record: outlier lists");
+        }
         HL_TRY(c->sync.ensure(sync_bytes - 8));
         HL_HIP(hipMemcpyAsync(c->sync.p, p + o_sync, sync_bytes - 8, hipMemcpyDefault, st));
         d_sync = (const unsigned *)c->sync.p;
       }
     }
-    if (sym16 && *sym16)
+    if (pair_decode && !d_sync) return hl_fail(MGH_ERR_DEVICE, "lossless_decompress: pair table without synchronisation points");
+    if (pair_decode) {
+      static std::atomic<uint64_t> once4{0};
+      if (hl_attr_pending(once4)) {
+        HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_decode_sync<int64_t>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_decode_sync<uint16_t>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        hl_attr_done(once4);
+      }
+      const unsigned grid = (unsigned)((nchunk + waves - 1) / waves);
+      const size_t lds_b = huff::decode_ring_lds(dt.size(), waves);
+      if (sym16 && *sym16)
+        huff::k_decode_sync<uint16_t><<<grid, 64 * waves, lds_b, st>>>(
+            d_units, (const unsigned long long *)c->bits.p, (const unsigned long long *)c->entry.p, nchunk, chunk, n,
+            dict, rtb, (const unsigned *)c->dtable.p, (unsigned)dt.size(), tab, tab + 64, tab + 128, (uint16_t *)d_q,
+            d_sync);
+      else
+        huff::k_decode_sync<int64_t><<<grid, 64 * waves, lds_b, st>>>(
+            d_units, (const unsigned long long *)c->bits.p, (const unsigned long long *)c->entry.p, nchunk, chunk, n,
+            dict, rtb, (const unsigned *)c->dtable.p, (unsigned)dt.size(), tab, tab + 64, tab + 128, d_q, d_sync);
+    } else if (sym16 && *sym16)
       huff::k_decode_ring<uint16_t><<<(unsigned)((nchunk + waves - 1) / waves), 64 * waves,
                                       huff::decode_ring_lds(dt.size(), waves), st>>>(
           d_units, (const unsigned long long *)c->bits.p,
@@ -1017,8 +1093,11 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
   hl_debug("lossless_decompress: decode launched");
   // the host payload may go away when we return (the subdomain pipeline keeps it, and the context's
   // host-side sources, alive until the lane has drained: sync_end = false)
-  if (sync_end) HL_HIP(hipStreamSynchronize(st));
   *ocount_out = ocount;
+  if (sync_end) {
+    HL_HIP(hipStreamSynchronize(st));
+    return lossless_tag_check(c);
+  }
   return MGH_SUCCESS;
 }
 
@@ -2448,6 +2527,7 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
     // what the lane's previous subdomain read from the host (decode tables, record head) and its
     // hierarchy are free again once the lane has drained
     HL_HIP(hipStreamSynchronize(st));
+    HL_TRY(lossless_tag_check(L.ll));
     if (owned_h[lane]) mgh_hierarchy_destroy(owned_h[lane]);
     owned_h[lane] = nullptr;
     if (csize_total - byte_offset < 8) return hl_fail(MGH_ERR_FORMAT, "subdomain record truncated");
@@ -2532,8 +2612,10 @@ int decompress_impl(const fmt::Header &hd, size_t meta_size, const void *compres
     if ((rc = finish(id)) != MGH_SUCCESS) return cleanup(rc);
     if (nlanes == 1 && id + 1 < dd.num && (rc = issue(id + 1)) != MGH_SUCCESS) return cleanup(rc);
   }
-  for (int l = 0; l < nlanes; l++)
+  for (int l = 0; l < nlanes; l++) {
     if (hipStreamSynchronize(g_cache.lane[l].st) != hipSuccess) return cleanup(hl_fail(MGH_ERR_DEVICE, "sync"));
+    if ((rc = lossless_tag_check(g_cache.lane[l].ll)) != MGH_SUCCESS) return cleanup(rc);
+  }
   return cleanup(MGH_SUCCESS);
 }
 
@@ -3689,6 +3771,7 @@ void mgh_lossless_destroy(mgh_lossless_ctx *c) {
     b->release();
   c->pin.release();
   c->dpin.release();
+  c->tagpin.release();
   delete c;
 }
 

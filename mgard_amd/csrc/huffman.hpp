@@ -1394,5 +1394,212 @@ k_decode_ring(const unsigned long long *__restrict__ units, const unsigned long 
   (void)pass(M2{}, s, &c2, off < cap ? cnt : 0, off, 0, 0, 0);
 }
 
+// ---------------------------------------------------------------------------------------
+// Decoder for records WITH synchronisation points (round 6). k_decode_ring at 512^3 is bound by
+// VALU issue: 137 instructions per symbol step, one symbol per step. With the encoder's entries
+// every lane knows its first code and the place of its symbols, so nothing of the speculative
+// machinery is needed, and -- codes of a quantized field are short (4-5 bits on average at 1e-3) --
+// most root-table slots hold TWO complete codes: the root entries are pairs,
+//     word 0: the entry of build_decode_table (code <= tb bits, pointer to a second level, or 0)
+//     word 1: (len1 + len2) << 16 | symbol2 when a second code of len2 <= tb - len1 bits follows
+//             the first inside the tb-bit window, else 0,
+// and a step that finds word 1 set (and has two symbols left to decode) emits both. The ring of
+// code units, the refill points and the write-out are k_decode_ring's.
+//   table layout (32-bit words): [2^tb pairs][second-level tables of build_decode_table]
+// ---------------------------------------------------------------------------------------
+inline std::vector<uint32_t> make_pair_table(const std::vector<uint32_t> &t, int tb) {
+  const size_t R = (size_t)1 << tb;
+  std::vector<uint32_t> out(2 * R + (t.size() - R), 0);
+  for (size_t i = 0; i < R; i++) {
+    const uint32_t e1 = t[i];
+    uint32_t w0 = e1, w1 = 0;
+    if (e1 & 0x80000000u) {
+      w0 = (e1 & 0xff000000u) | ((e1 & 0xffffffu) + (uint32_t)R);  // (the second levels moved up by R words)
+    } else if (e1) {
+      const uint32_t l1 = e1 >> 16;
+      if (l1 < (uint32_t)tb) {
+        const uint32_t e2 = t[(i << l1) & (R - 1)];  // the window behind the first code, unknown bits zero
+        if (e2 && !(e2 & 0x80000000u)) {
+          const uint32_t l2 = e2 >> 16;
+          if (l1 + l2 <= (uint32_t)tb) w1 = ((l1 + l2) << 16) | (e2 & 0xffffu);  // (all of its bits are real)
+        }
+      }
+    }
+    out[2 * i] = w0;
+    out[2 * i + 1] = w1;
+  }
+  for (size_t k = R; k < t.size(); k++) out[2 * R + (k - R)] = t[k];
+  return out;
+}
+
+constexpr int kSyncSteps = 8;  // decoding steps (one or two symbols each) between two refills / write-outs
+
+template <typename OUT>
+__global__ void __launch_bounds__(1024)
+k_decode_sync(const unsigned long long *__restrict__ units, const unsigned long long *__restrict__ bits,
+              const unsigned long long *__restrict__ entry_of_chunk, size_t nchunk, int chunk, size_t n,
+              int dict, int tb, const unsigned *__restrict__ g_table, unsigned table_words,
+              const unsigned long long *__restrict__ first,
+              const unsigned long long *__restrict__ entry, const unsigned long long *__restrict__ keys,
+              OUT *__restrict__ q, const unsigned *__restrict__ sync) {
+  __shared__ unsigned long long sfirst[64], sentry[64], slim[64];
+  __shared__ int smaxlen;
+  extern __shared__ unsigned dyn_lds[];
+  unsigned *table = dyn_lds;
+  const int nwaves = blockDim.x >> 6;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned long long *rings = reinterpret_cast<unsigned long long *>(dyn_lds + (table_words + 1) / 2 * 2);
+  unsigned long long *ring = rings + (size_t)wave * (kRingUnits * 64);
+  unsigned short *stage = reinterpret_cast<unsigned short *>(rings + (size_t)nwaves * (kRingUnits * 64)) +
+                          (size_t)wave * (64 * kRingBatch);
+  if (threadIdx.x < 64) {
+    sfirst[threadIdx.x] = first[threadIdx.x];
+    sentry[threadIdx.x] = entry[threadIdx.x];
+  }
+  for (unsigned i = threadIdx.x; i < table_words; i += blockDim.x) table[i] = g_table[i];
+  __syncthreads();
+  if (threadIdx.x == 0) {  // comparison path for prefixes the table leaves out (see k_decode_ring)
+    unsigned long long m = ~0ull;
+    int mx = 0;
+    for (int l = 1; l < 64; l++) {
+      const bool used = sfirst[l] != ~0ull && l <= kMaxCodeBits;
+      if (used) mx = l;
+      if (l > tb) {
+        if (used) m = min(m, sfirst[l] << (64 - l));
+        slim[l] = m;
+      } else {
+        slim[l] = ~0ull;
+      }
+    }
+    slim[0] = ~0ull;
+    smaxlen = mx;
+  }
+  __syncthreads();
+  const int maxlen = smaxlen;
+  const size_t c = (size_t)blockIdx.x * nwaves + wave;
+  if (c >= nchunk) return;  // (whole wave; no block-wide barrier follows)
+  const unsigned long long *src = units + entry_of_chunk[c];
+  const unsigned total = (unsigned)min(bits[c], (unsigned long long)chunk * kMaxCodeBits);
+  OUT *dst = q + c * (size_t)chunk;
+  const unsigned cap = (unsigned)min((size_t)chunk, n - c * (size_t)chunk);
+  const unsigned nun = (total + 63) / 64;  // src[nun] is readable (the window peeks ahead)
+  const unsigned B = (total + 63) / 64;    // bits per subsequence
+  const unsigned lim = min((unsigned)(lane + 1) * B, total);
+  // start and place of this lane's symbols (damaged entries decode garbage inside the chunk's own
+  // range of units and symbols at worst: every access below is bounded by total and cap)
+  const unsigned ent = load_u32(sync, c * kSyncLanes + lane);
+  const unsigned first_sym = lane ? min(ent & 0xffffu, cap) : 0u;
+  unsigned next_sym = __shfl_down(first_sym, 1, 64);
+  if (lane == 63) next_sym = cap;
+  const unsigned s0 = lane ? (unsigned)min((unsigned long long)lane * B + (ent >> 16), (unsigned long long)total) : 0u;
+  const unsigned want = next_sym > first_sym ? next_sym - first_sym : 0u;
+
+  unsigned pos = s0, cnt = 0;
+  bool live = pos < lim && want > 0;
+  const unsigned cw0 = pos >> 6;
+#pragma unroll
+  for (int r = 0; r < kRingUnits; r++)  // initial fill of the ring
+    ring[((cw0 + r) % kRingUnits) * 64 + lane] = load_unit(src, min(cw0 + r, nun));
+  unsigned hi = cw0 + kRingUnits;
+  unsigned long long win;
+  unsigned avail, wnext;
+  {
+    const unsigned long long u0 = ring[(cw0 % kRingUnits) * 64 + lane];
+    const unsigned long long u1 = ring[((cw0 + 1) % kRingUnits) * 64 + lane];
+    const int sh = (int)(pos & 63);
+    win = sh ? (u0 << sh) | (u1 >> (64 - sh)) : u0;  // 64 valid bits from pos on
+    avail = 64;
+    wnext = ((pos + 64) >> 5);
+    const unsigned part = (pos + 64) & 31;  // (keep whole words only: refills stay word-aligned)
+    avail -= part;
+    win = part ? (win >> part) << part : win;
+  }
+  unsigned long long pf[kRingFetch];
+  bool pending = false;
+  while (__any(live)) {
+    int got = 0;
+    if (live && !pending) {  // request the next units; they are committed kSyncSteps steps later
+#pragma unroll
+      for (int j = 0; j < kRingFetch; j++) pf[j] = load_unit(src, min(hi + j, nun));
+      pending = true;
+    }
+#pragma unroll
+    for (int k = 0; k < kSyncSteps; k++) {
+      if (live && avail <= 32 && (wnext >> 1) < hi) {  // top up (a lane out of units pauses)
+        const unsigned long long u = ring[((wnext >> 1) % kRingUnits) * 64 + lane];
+        const unsigned wd = (wnext & 1) ? (unsigned)u : (unsigned)(u >> 32);
+        win |= (unsigned long long)wd << (32 - avail);
+        avail += 32;
+        wnext++;
+      }
+      if (live && avail > 32) {
+        const uint2 pr = *reinterpret_cast<const uint2 *>(table + 2 * (unsigned)(win >> (64 - tb)));
+        const unsigned l2 = pr.y >> 16;
+        if (pr.y != 0 && cnt + 2 <= want && pos + l2 <= total) {  // two codes inside the window
+          stage[lane * kRingBatch + got] = (unsigned short)(pr.x & 0xffffu);
+          stage[lane * kRingBatch + got + 1] = (unsigned short)(pr.y & 0xffffu);
+          got += 2;
+          cnt += 2;
+          pos += l2;
+          win <<= l2;
+          avail -= l2;
+          live = pos < lim && cnt < want;
+        } else {
+          unsigned e = pr.x;
+          if (e & 0x80000000u) {  // second level: the next sub_bits bits
+            const int sb = (int)((e >> 24) & 0x7f);
+            e = table[(e & 0xffffff) + (unsigned)((win << tb) >> (64 - sb))];
+          }
+          int l = (int)(e >> 16);
+          unsigned sym = e & 0xffff;
+          bool hit = e != 0;
+          if (!hit) {  // not in the table
+            l = tb + 1;
+            for (int j = tb + 1; j <= maxlen; j++) l += win < slim[j] ? 1 : 0;
+            if (l <= maxlen) {
+              const unsigned long long v = win >> (64 - l);
+              const unsigned long long kk = sentry[l] + (v - sfirst[l]);
+              if (v >= sfirst[l] && kk < (unsigned long long)dict) {
+                sym = (unsigned)keys[kk] & 0xffff;
+                hit = true;
+              }
+            }
+          }
+          if (!hit || pos + l > total) {  // corrupt stream
+            pos = total;
+            live = false;
+          } else {
+            stage[lane * kRingBatch + got] = (unsigned short)sym;
+            got++;
+            cnt++;
+            pos += l;
+            win <<= l;
+            avail -= l;
+            live = pos < lim && cnt < want;
+          }
+        }
+      }
+    }
+    // refill point: commit the units requested before these steps if the ring has room
+    if (pending && hi + kRingFetch <= (wnext >> 1) + kRingUnits) {
+#pragma unroll
+      for (int j = 0; j < kRingFetch; j++) ring[((hi + j) % kRingUnits) * 64 + lane] = pf[j];
+      hi += kRingFetch;
+      pending = false;
+    }
+    {  // write-out: 64 / kRingBatch runs per instruction, the elements of a run side by side
+      constexpr int RPI = 64 / kRingBatch;  // runs per store instruction
+      const unsigned my_o = first_sym + cnt - got;
+#pragma unroll 4
+      for (int it = 0; it < 64 / RPI; it++) {
+        const int L = it * RPI + lane / kRingBatch, k = lane % kRingBatch;
+        const int n_L = __shfl(got, L, 64);
+        const unsigned o_L = __shfl(my_o, L, 64);
+        if (k < n_L && o_L + k < cap) dst[o_L + k] = (OUT)stage[L * kRingBatch + k];
+      }
+    }
+  }
+}
+
 } // namespace huff
 } // namespace mgh

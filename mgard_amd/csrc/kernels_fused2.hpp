@@ -512,9 +512,14 @@ __device__ __forceinline__ void level_tile2(FusedArgs<T> &A, const int F0, const
       *OS.base = atomicAdd(A.outlier_count, (unsigned long long)tot);
       __hip_atomic_store(OS.flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    if (lane == 0)
+    // (lane 0 reads the base behind ITS acquire and hands it to the other lanes: a plain load of
+    // theirs would have no happens-before edge to the leader's store)
+    unsigned long long o = 0;
+    if (lane == 0) {
       while (__hip_atomic_load(OS.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) __builtin_amdgcn_s_sleep(1);
-    unsigned long long o = *OS.base;  // (behind the leader's acquire: uniform in the wave)
+      o = *OS.base;
+    }
+    o = __shfl(o, 0, 64);
 #pragma unroll
     for (int k = 0; k < 8; k++)
       if (k < 2 * wave) o += c[k];

@@ -1098,11 +1098,41 @@ def test_synchronisation_points_behind_the_huffman_record(kind, n, chunk, monkey
     plain = ctx.compress(qd, *args)
     assert pl.parse_huffman_record(plain)["sync"] is None
     assert rec[:len(plain)] == plain
-    for sync_decode in ("1", "0"):
+    # (MGH_HUFF_PAIR: records with the section go through k_decode_sync -- two codes per table slot
+    # where they fit: 2 always, 1 for short codes only -- or, 0, through k_decode_ring's single-symbol steps)
+    for sync_decode, pair in (("1", "2"), ("1", "0"), ("1", "1"), ("0", "1")):
         monkeypatch.setenv("MGH_HUFF_SYNC_DECODE", sync_decode)
+        monkeypatch.setenv("MGH_HUFF_PAIR", pair)
         for payload in (rec, plain, torch.frombuffer(bytearray(rec), dtype=torch.uint8).cuda(),
                         torch.frombuffer(bytearray(b"xyz" + rec), dtype=torch.uint8).cuda()[3:]):
             back, bi, bv = ctx.decompress(payload, n, hl.HUFFMAN)
-            assert np.array_equal(back.cpu().numpy(), q), (kind, sync_decode)
+            assert np.array_equal(back.cpu().numpy(), q), (kind, sync_decode, pair)
             assert np.array_equal(bi.cpu().numpy(), oi) and np.array_equal(bv.cpu().numpy(), ov)
     ctx.close()
+
+
+@pytest.mark.parametrize("where", ["device", "host"])
+def test_damaged_sync_tag_is_an_error_not_a_quiet_decode(where):
+    """The synchronisation-point section behind a Huffman record is found by the record's size; its
+    tag "MGHSYNC1" decides whether it IS one. A record whose tag is damaged must not be decoded with
+    arbitrary synchronisation points: a host record falls back to decoding without them (the lists
+    then fail their own check or decode correctly), a device-resident record -- whose tag is looked
+    at by a kernel -- returns MGH_ERR_FORMAT."""
+    torch, mg, hl = _mods()
+    u = smooth_field((100, 128, 128), np.float32, noise=3e-3)   # (4+ bits per symbol: the encoder's rule for the section)
+    c = hl.compress(torch.from_numpy(u).cuda(), 1e-3, np.inf, mg.REL).cpu().numpy()
+    at = bytes(c).rfind(b"MGHSYNC1")
+    assert at > 0, "the record carries no synchronisation points (MGH_HUFF_SYNC=0?)"
+    bad = c.copy()
+    bad[at + 3] ^= 0x40
+    if where == "device":
+        with pytest.raises(mg.MgardHipError):
+            hl.decompress(torch.from_numpy(bad).cuda())
+        # ... and the context is fine afterwards
+        v = hl.decompress(torch.from_numpy(c).cuda()).cpu().numpy()
+    else:
+        try:
+            v = hl.decompress(bad)
+        except mg.MgardHipError:
+            v = hl.decompress(c)
+    assert float(np.max(np.abs(v - u))) <= 1e-3 * float(np.max(np.abs(u)))

@@ -7,9 +7,10 @@ import mgard_amd as mg
 from mgard_amd import highlevel as hl
 from tests.util import smooth_field
 shape = tuple(int(x) for x in sys.argv[1].split(","))
+tol = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-3
 u = torch.from_numpy(smooth_field(shape, np.float32)).cuda()
 h = mg.Hierarchy(shape, np.float32)
-q, oi, ov, n, nrm = h.decompose_quantize(u, mg.REL, 1e-3, np.inf)
+q, oi, ov, n, nrm = h.decompose_quantize(u, mg.REL, tol, np.inf)
 qq = q.flatten()
 cnt = torch.bincount(qq.clamp(0, 8191).to(torch.int64), minlength=8192).cpu().numpy().astype(np.float64)
 p = cnt / cnt.sum()
