@@ -45,6 +45,8 @@ inline const EnvSwitch *env_switches(size_t *count) {
       {"MGH_HL_STREAM_NORM", 0, 1},
       {"MGH_ND_ROWS", 0, 1},
       {"MGH_HUFF_PAIR", 0, 2},
+      {"MGH_HL_COPY_THREADS", 1, 32},
+      {"MGH_HL_RING_MB", 1, 256},
   };
   *count = sizeof(k) / sizeof(k[0]);
   return k;

@@ -1333,13 +1333,14 @@ inline void cpu_relax() {
 #endif
 }
 struct HostPool {
-  static constexpr int kWorkers = 4;
+  static constexpr int kMaxWorkers = 31;
+  int kWorkers = (int)env_get("MGH_HL_COPY_THREADS", 5) - 1;  // copy threads beside the calling one
   struct Job {
     std::function<void(int)> fn;
     int nparts = 0;
     std::atomic<int> next{0}, done{0};
   };
-  std::thread th[kWorkers];
+  std::thread th[kMaxWorkers];
   bool started = false;
   std::mutex mu;
   std::condition_variable cv;
@@ -1378,7 +1379,7 @@ struct HostPool {
     {
       std::lock_guard<std::mutex> lk(mu);
       if (!started) {
-        for (auto &t : th) t = std::thread([this] { worker(); });
+        for (int k = 0; k < kWorkers; k++) th[k] = std::thread([this] { worker(); });
         started = true;
       }
       cur = j;
@@ -1401,7 +1402,7 @@ struct HostPool {
       std::memcpy(dst, src, bytes);
       return;
     }
-    constexpr int kParts = kWorkers + 1;
+    const int kParts = kWorkers + 1;
     const size_t part = (bytes / kParts + 4095) / 4096 * 4096;
     run([=](int t) {
       const size_t lo = std::min(bytes, (size_t)t * part), hi = std::min(bytes, (size_t)(t + 1) * part);
@@ -1415,7 +1416,7 @@ struct HostPool {
       stop = true;
     }
     cv.notify_all();
-    for (auto &t : th) t.join();
+    for (int k = 0; k < kWorkers; k++) th[k].join();
     started = false;
     stop = false;
     cur.reset();
@@ -1433,7 +1434,7 @@ inline HostPool &host_pool() {
 // mgh_config_default.) One ring per direction and thread, released with the cache.
 struct PinnedRing {
   static constexpr int kSlots = 4;
-  static constexpr size_t kChunk = (size_t)16 << 20;
+  size_t kChunk = (size_t)env_get("MGH_HL_RING_MB", 16) << 20;
   void *buf[kSlots] = {};
   hipEvent_t ev[kSlots] = {};
   int dev = -1;  // device the events belong to
@@ -1493,7 +1494,7 @@ int staged_h2d(void *dst, const void *src, size_t bytes, hipStream_t st, const C
   size_t off = 0;
   for (int c = 0; off < bytes; c++) {
     const int i = c % PinnedRing::kSlots;
-    const size_t nb = std::min(PinnedRing::kChunk, bytes - off);
+    const size_t nb = std::min(b.kChunk, bytes - off);
     HL_HIP(hipEventSynchronize(b.ev[i]));  // the previous transfer out of this slot is done
     pool.copy(b.buf[i], (const char *)src + off, nb);
     HL_HIP(hipMemcpyAsync((char *)dst + off, b.buf[i], nb, hipMemcpyHostToDevice, st));
@@ -1520,7 +1521,7 @@ int staged_d2h(void *dst, const void *src, size_t bytes, hipStream_t st) {
       pool.copy((char *)dst + done, b.buf[i], len[i]);
       done += len[i];
     }
-    len[i] = std::min(PinnedRing::kChunk, bytes - off);
+    len[i] = std::min(b.kChunk, bytes - off);
     HL_HIP(hipMemcpyAsync(b.buf[i], (const char *)src + off, len[i], hipMemcpyDeviceToHost, st));
     HL_HIP(hipEventRecord(b.ev[i], st));
     off += len[i];
@@ -2657,7 +2658,9 @@ void mgh_config_default(mgh_config *c) {
   // caller memory (hipHostRegister / hipHostUnregister) was observed to leave the runtime
   // treating later allocations at the same addresses as pinned -- a copy into such a buffer
   // then dies with a GPU memory fault (1 in 3 runs of the test suite). Without registration
-  // host buffers go through the runtime's pageable-copy path, measured within 20 %.
+  // pageable buffers travel through the library's own ring of pinned slots (staged_h2d / _d2h):
+  // 512^3 f32 host to host 15.2 / 16.9 ms against 13.7 / 13.7 ms with registered buffers (round 6,
+  // bench.py end_to_end_host) -- and registering costs 16 ms per 512 MB the first time.
   c->auto_pin_host_buffers = 0;
 }
 

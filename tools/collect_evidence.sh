@@ -24,7 +24,7 @@ done
 cp $O/traffic_512cube_f32.json $O/traffic_1024cube_f32.json $O/traffic_512cube_f64nu.json $O/traffic_4d_slab_f32.json $P/
 cp $O/pmc_raw_f64nu.json $P/${TAG}_pmc_counters_512cube_f64nu.json
 cp $O/pmc_raw_4d.json $P/${TAG}_pmc_counters_4d_slab_f32.json
-for f in hl_pipeline_lanes hl_pipeline_sequential hl_pipeline_ab recompose_profile 5d_profile e2e_512 grid_barrier; do
+for f in hl_pipeline_lanes hl_pipeline_sequential hl_pipeline_ab recompose_profile 5d_profile 5d_trace e2e_512 grid_barrier host_link; do
   [ -f $O/$f.txt ] && grep -v "amdgpu.ids" $O/$f.txt > $P/${TAG}_$f.txt
 done
 python - <<PY

@@ -34,6 +34,8 @@ python3 tools/exp_recompose_profile.py > $O/recompose_profile.txt 2>&1
 python3 tools/exp_5d_profile.py > $O/5d_profile.txt 2>&1
 python3 tools/exp_e2e_out.py > $O/e2e_512.txt 2>&1
 [ -x tools/micro/grid_barrier ] && ./tools/micro/grid_barrier > $O/grid_barrier.txt 2>&1
+[ -x tools/micro/host_link ] && ./tools/micro/host_link 512 > $O/host_link.txt 2>&1
+bash tools/exp_5d_trace.sh ${TAG}_5d > $O/5d_trace.txt 2>&1
 rm -rf $O/lanes1 $O/lanes0
 python tools/make_traffic.py $(ls $O/fetch_f64nu/*/*.db | head -1) $(ls $O/write_f64nu/*/*.db | head -1) $O/pmc_raw_f64nu.json traffic_512cube_f64nu.json > $O/traffic_f64nu.txt 2>&1
 python tools/make_traffic.py $(ls $O/fetch_4d/*/*.db | head -1) $(ls $O/write_4d/*/*.db | head -1) $O/pmc_raw_4d.json traffic_4d_slab_f32.json > $O/traffic_4d.txt 2>&1
