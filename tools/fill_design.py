@@ -24,6 +24,33 @@ R = {
  "KVS": "%.2f" % d["roofline"].get("stream_calibration", {}).get("kernel_vs_stream_time", 0.0),
  "A1024": "%.0f" % (1000 * k1024["absmax"]),
 }
+# host-buffer legs (round 6)
+def host_fields(prefix, hb):
+    out = {}
+    if not hb or "pageable" not in hb:
+        return out
+    for tag, key in (("P", "pageable"), ("R", "caller_pinned"), ("A", "auto_pin")):
+        r = hb.get(key, {})
+        if "compress_ms" not in r:
+            continue
+        out[prefix + tag + "C"] = "%.1f" % r["compress_ms"]
+        out[prefix + tag + "D"] = "%.1f" % r["decompress_ms"]
+        out[prefix + tag + "CG"] = "%.1f" % r["compress_GBps"]
+        out[prefix + tag + "DG"] = "%.1f" % r["decompress_GBps"]
+        out[prefix + tag + "CF"] = "%.2f" % r["compress_frac_of_link_floor"]
+        out[prefix + tag + "DF"] = "%.2f" % r["decompress_frac_of_link_floor"]
+    return out
+hb = d.get("end_to_end_host", {})
+R.update(host_fields("H", hb))
+if "link" in hb:
+    R["H2D"] = "%.1f" % hb["link"]["pinned_h2d_GBps"]
+    R["D2H"] = "%.1f" % hb["link"]["pinned_d2h_GBps"]
+R["HLIB"] = "%.1f" % hb.get("library_allocated_output", {}).get("decompress_ms", 0.0)
+R.update(host_fields("K", oc["1024f32"].get("end_to_end_host", {})))
+try:
+    R["MS5D"] = "%.2f" % float(open(O + "/5d_profile.txt").read().split(")")[1].split("ms")[0])
+except Exception as e:  # noqa: BLE001
+    print("5d profile:", e)
 rf = oc["512f64nu"].get("roofline", {})
 R["F64FR"] = "%.1f" % (100 * rf.get("frac", 0))
 R["F64TR"] = "%.2f" % ((rf.get("traffic") or 0) / max(rf.get("algorithmic_bytes_per_step", 1), 1))
