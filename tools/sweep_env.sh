@@ -14,4 +14,6 @@ run MGH_CLS2=1024
 run MGH_CLS2=512 MGH_RCH=1,4,8
 run MGH_CLS1=512
 run MGH_BOX=2
+run MGH_FUSED_WIDE=2
+run MGH_FUSED_WIDE=0
 done
