@@ -47,6 +47,8 @@ inline const EnvSwitch *env_switches(size_t *count) {
       {"MGH_HUFF_PAIR", 0, 2},
       {"MGH_HL_COPY_THREADS", 1, 32},
       {"MGH_HL_RING_MB", 1, 256},
+      {"MGH_HL_DECODE_FOLLOWS", 0, 1},
+      {"MGH_HL_COPY_AFFINITY", 0, 1},
   };
   *count = sizeof(k) / sizeof(k[0]);
   return k;

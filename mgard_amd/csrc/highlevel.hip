@@ -9,10 +9,13 @@
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <sched.h>
 #include <sys/mman.h>
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <cmath>
 #include <memory>
 #include <mutex>
@@ -320,6 +323,7 @@ struct HostPrefix {
   ~HostPrefix() { host_prefix().base = nullptr; }
 };
 int aux_read(void *dst, const void *src, size_t bytes);  // (below, with the cache)
+hipStream_t cache_copy_stream();                          // (below: the calling thread's copy stream, or nullptr)
 // device -> host copy that is served from the prefix where it can be
 inline int dev_to_host(void *dst, const void *src, size_t bytes) {
   const HostPrefixState &s = host_prefix();
@@ -950,13 +954,18 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
   const bool units_in_place = on_dev && units && (ring_decode || ((uintptr_t)(p + L.ddata) & 7) == 0) &&
                               is_device_pointer_on(p, c->dev);
   const unsigned long long *d_units = (const unsigned long long *)c->units.p;
+  bool units_follow = false;
   if (units_in_place) {
     d_units = (const unsigned long long *)(p + L.ddata);
   } else {
     HL_TRY(c->units.ensure((units + 1) * 8));  // (not for units decoded in place: 8 N bytes a lane would hold for nothing)
     d_units = (const unsigned long long *)c->units.p;
-    // (a record in pageable host memory travels through the pinned ring: copy_any)
-    if (units) HL_TRY(copy_any(c->units.p, p + L.ddata, units * 8, st));
+    // A large record in HOST memory is decoded while it arrives (below: the ring decoder's launches
+    // follow the pieces of the copy, which runs on the cache's copy stream); everything else is
+    // copied here, in stream order. (A record in pageable memory travels through the pinned ring.)
+    units_follow = !on_dev && ring_decode && units * 8 >= ((size_t)32 << 20) && cache_copy_stream() &&
+                   env_get("MGH_HL_DECODE_FOLLOWS", 1) != 0;
+    if (units && !units_follow) HL_TRY(copy_any(c->units.p, p + L.ddata, units * 8, st));
     HL_HIP(hipMemsetAsync((char *)c->units.p + units * 8, 0, 8, st));  // (the decoder peeks one unit ahead)
   }
   if (ocount && !pieces) {
@@ -1041,29 +1050,70 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         hl_attr_done(once4);
       }
-      const unsigned grid = (unsigned)((nchunk + waves - 1) / waves);
-      const size_t lds_b = huff::decode_ring_lds(dt.size(), waves);
-      if (sym16 && *sym16)
-        huff::k_decode_sync<uint16_t><<<grid, 64 * waves, lds_b, st>>>(
-            d_units, (const unsigned long long *)c->bits.p, (const unsigned long long *)c->entry.p, nchunk, chunk, n,
-            dict, rtb, (const unsigned *)c->dtable.p, (unsigned)dt.size(), tab, tab + 64, tab + 128, (uint16_t *)d_q,
-            d_sync);
-      else
-        huff::k_decode_sync<int64_t><<<grid, 64 * waves, lds_b, st>>>(
-            d_units, (const unsigned long long *)c->bits.p, (const unsigned long long *)c->entry.p, nchunk, chunk, n,
-            dict, rtb, (const unsigned *)c->dtable.p, (unsigned)dt.size(), tab, tab + 64, tab + 128, d_q, d_sync);
-    } else if (sym16 && *sym16)
-      huff::k_decode_ring<uint16_t><<<(unsigned)((nchunk + waves - 1) / waves), 64 * waves,
-                                      huff::decode_ring_lds(dt.size(), waves), st>>>(
-          d_units, (const unsigned long long *)c->bits.p,
-          (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, rtb, (const unsigned *)c->dtable.p,
-          (unsigned)dt.size(), tab, tab + 64, tab + 128, (uint16_t *)d_q, d_sync);
-    else
-      huff::k_decode_ring<int64_t><<<(unsigned)((nchunk + waves - 1) / waves), 64 * waves,
-                                     huff::decode_ring_lds(dt.size(), waves), st>>>(
-          d_units, (const unsigned long long *)c->bits.p,
-          (const unsigned long long *)c->entry.p, nchunk, chunk, n, dict, rtb, (const unsigned *)c->dtable.p,
-          (unsigned)dt.size(), tab, tab + 64, tab + 128, d_q, d_sync);
+    }
+    const size_t lds_b = huff::decode_ring_lds(dt.size(), waves);
+    const bool out16 = sym16 && *sym16;
+    // chunks [c0, c1): the kernels index everything by chunk, so a range is the same launch with
+    // the per-chunk arrays, the output and the symbol count moved up by c0 chunks
+    auto launch_range = [&](size_t c0, size_t c1) -> int {
+      if (c1 <= c0) return MGH_SUCCESS;
+      const size_t cnt = c1 - c0, n_r = n - c0 * (size_t)chunk;
+      const unsigned grid = (unsigned)((cnt + waves - 1) / waves);
+      const unsigned long long *bits_r = (const unsigned long long *)c->bits.p + c0;
+      const unsigned long long *ent_r = (const unsigned long long *)c->entry.p + c0;
+      const unsigned *sync_r = d_sync ? reinterpret_cast<const unsigned *>(reinterpret_cast<const uint8_t *>(d_sync) + c0 * huff::kSyncLanes * 4) : nullptr;
+      int64_t *q64 = d_q + c0 * (size_t)chunk;
+      uint16_t *q16 = (uint16_t *)d_q + c0 * (size_t)chunk;
+      if (pair_decode) {
+        if (out16)
+          huff::k_decode_sync<uint16_t><<<grid, 64 * waves, lds_b, st>>>(d_units, bits_r, ent_r, cnt, chunk, n_r, dict, rtb,
+                                                                         (const unsigned *)c->dtable.p, (unsigned)dt.size(),
+                                                                         tab, tab + 64, tab + 128, q16, sync_r);
+        else
+          huff::k_decode_sync<int64_t><<<grid, 64 * waves, lds_b, st>>>(d_units, bits_r, ent_r, cnt, chunk, n_r, dict, rtb,
+                                                                        (const unsigned *)c->dtable.p, (unsigned)dt.size(),
+                                                                        tab, tab + 64, tab + 128, q64, sync_r);
+      } else if (out16) {
+        huff::k_decode_ring<uint16_t><<<grid, 64 * waves, lds_b, st>>>(d_units, bits_r, ent_r, cnt, chunk, n_r, dict, rtb,
+                                                                       (const unsigned *)c->dtable.p, (unsigned)dt.size(),
+                                                                       tab, tab + 64, tab + 128, q16, sync_r);
+      } else {
+        huff::k_decode_ring<int64_t><<<grid, 64 * waves, lds_b, st>>>(d_units, bits_r, ent_r, cnt, chunk, n_r, dict, rtb,
+                                                                      (const unsigned *)c->dtable.p, (unsigned)dt.size(),
+                                                                      tab, tab + 64, tab + 128, q64, sync_r);
+      }
+      HL_HIP(hipGetLastError());
+      return MGH_SUCCESS;
+    };
+    if (units_follow) {
+      // the record's code units on the copy stream, piece by piece; behind every piece the chunks
+      // whose units (and the one unit the decoder peeks at behind them) have landed are decoded on st
+      const uint64_t *h_bits = reinterpret_cast<const uint64_t *>(head.data() + L.huffmeta);
+      const uint64_t *h_ent = h_bits + nchunk;
+      size_t c_done = 0;
+      const size_t total_b = units * 8;
+      const ChunkFn on_piece = [&](size_t off, size_t nb, hipEvent_t landed) -> int {
+        const uint64_t have = (off + nb) / 8;  // units of the record on the device
+        size_t c_hi = c_done;
+        if (off + nb >= total_b) {
+          c_hi = nchunk;
+        } else {
+          while (c_hi < nchunk && h_ent[c_hi] + (h_bits[c_hi] + 63) / 64 + 1 <= have) c_hi++;
+        }
+        if (c_hi > c_done) {
+          HL_HIP(hipStreamWaitEvent(st, landed, 0));
+          HL_TRY(launch_range(c_done, c_hi));
+          c_done = c_hi;
+        }
+        return MGH_SUCCESS;
+      };
+      // (the copy stream must not run ahead of what st has queued in front: the small uploads above
+      // are independent of the units; the units buffer itself is free -- the caller drained st)
+      HL_TRY(copy_any(c->units.p, p + L.ddata, total_b, cache_copy_stream(), &on_piece));
+      if (c_done < nchunk) return hl_fail(MGH_ERR_DEVICE, "lossless_decompress: chunks left behind the last piece");
+    } else {
+      HL_TRY(launch_range(0, nchunk));
+    }
     HL_HIP(hipGetLastError());
   } else if (!serial_decode && (size_t)chunk >= 1024) {
     if (sym16) *sym16 = false;
@@ -1332,8 +1382,40 @@ inline void cpu_relax() {
   std::this_thread::yield();
 #endif
 }
+// CPUs next to the current device (local_cpulist of its PCI function), empty when sysfs does not say.
+// The boxes seen have two sockets and the GPU hangs on one of them: copy threads on the other
+// socket write the pinned slots across the socket link (512^3 f32 host to host, pageable, whole
+// process on the GPU's node 14.9 / 14.4 ms, on the other node 15.7 / 16.5 ms: tools/exp_numa.sh).
+inline std::vector<int> device_local_cpus() {
+  std::vector<int> cpus;
+  int dev = 0;
+  char bus[64] = {0};
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bus, sizeof bus, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return cpus;
+  }
+  for (char *q = bus; *q; q++) *q = (char)std::tolower((unsigned char)*q);
+  const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/local_cpulist";
+  std::FILE *f = std::fopen(path.c_str(), "r");
+  if (!f) return cpus;
+  char line[4096] = {0};
+  if (std::fgets(line, sizeof line, f)) {
+    for (char *tok = std::strtok(line, ",\n"); tok; tok = std::strtok(nullptr, ",\n")) {
+      int a = 0, b = 0;
+      if (std::sscanf(tok, "%d-%d", &a, &b) == 2) {
+        for (int c = a; c <= b && c < CPU_SETSIZE; c++) cpus.push_back(c);
+      } else if (std::sscanf(tok, "%d", &a) == 1 && a < CPU_SETSIZE) {
+        cpus.push_back(a);
+      }
+    }
+  }
+  std::fclose(f);
+  return cpus;
+}
+
 struct HostPool {
   static constexpr int kMaxWorkers = 31;
+  std::vector<int> near_cpus;  // where the workers run (MGH_HL_COPY_AFFINITY=0: wherever the scheduler puts them)
   int kWorkers = (int)env_get("MGH_HL_COPY_THREADS", 5) - 1;  // copy threads beside the calling one
   struct Job {
     std::function<void(int)> fn;
@@ -1357,6 +1439,12 @@ struct HostPool {
     }
   }
   void worker() {
+    if (!near_cpus.empty()) {
+      cpu_set_t set;
+      CPU_ZERO(&set);
+      for (int c : near_cpus) CPU_SET(c, &set);
+      (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);  // (refused by a cpuset: stay where we are)
+    }
     uint64_t seen = 0;
     for (;;) {
       std::shared_ptr<Job> j;
@@ -1379,6 +1467,7 @@ struct HostPool {
     {
       std::lock_guard<std::mutex> lk(mu);
       if (!started) {
+        if (env_get("MGH_HL_COPY_AFFINITY", 1) != 0) near_cpus = device_local_cpus();
         for (int k = 0; k < kWorkers; k++) th[k] = std::thread([this] { worker(); });
         started = true;
       }
@@ -1544,8 +1633,10 @@ int copy_any(void *dst, const void *src, size_t bytes, hipStream_t st, const Chu
     if (sd && !dd && !is_registered_host(dst)) return staged_d2h(dst, src, bytes, st);
   }
   if (on_chunk && dd && !sd) {
-    // pinned source, a consumer per piece: 64 MB pieces (56.7 GB/s against 57.6 in one piece)
-    constexpr size_t kPiece = (size_t)64 << 20;
+    // pinned source, a consumer per piece: 64 MB pieces (56.7 GB/s against 57.6 in one piece) for the
+    // big transfers, 16 MB (55.2 GB/s) where a consumer that is slower than the link follows the
+    // pieces (a record of a few hundred MB and its decoder)
+    const size_t kPiece = bytes >= ((size_t)256 << 20) ? (size_t)64 << 20 : (size_t)16 << 20;
     PinnedRing &b = ring(0);
     HL_TRY(b.ensure(false));
     size_t off = 0;
@@ -1812,6 +1903,8 @@ inline HlCache &hl_cache() {
   return *g_cache_ptr;
 }
 #define g_cache (hl_cache())
+
+hipStream_t cache_copy_stream() { return g_cache_ptr ? g_cache_ptr->copy_st : nullptr; }
 
 // Small synchronous device -> host read (record sizes, record heads). On the cache's own stream
 // and through its pinned buffer: hipMemcpy() would run on the NULL stream and with it wait for
@@ -3279,7 +3372,6 @@ int compress_dist_impl(void *comm, int rank, int nranks, int root, int D, int dt
                        size_t *compressed_size, const void *const *coords_in, const mgh_config &cfg, bool prealloc) {
   HL_TRY(cache_prepare(cfg.dev_id));
   hipStream_t st = g_cache.lane[0].st;
-  const size_t elem = sizeof(T);
   const T tol = (T)tol_d, s = (T)s_d;
   // ---- every rank learns every slab's shape (and that they agree on everything else) ----
   constexpr int kMeta = 8;

@@ -212,3 +212,33 @@ def test_decompress_out_is_validated():
     with pytest.raises(ValueError):
         ctx.decompress(torch.zeros((8, 8), dtype=torch.uint8, device="cuda"), 10)
     ctx.close()
+
+
+@pytest.mark.parametrize("lossless", ["HUFFMAN"])
+def test_decoder_follows_the_arriving_record(lossless, monkeypatch):
+    """A record of 32 MB and more in host memory is decoded piece by piece while it travels (the
+    decoder's launches follow the pieces of the copy on another stream; MGH_HL_DECODE_FOLLOWS=0: copy,
+    then decode): same reconstruction from pageable and from registered memory, with the symbol
+    widths both paths use."""
+    torch, mg, hl = _mods()
+    shape = (300, 400, 512)
+    u = smooth_field(shape, np.float32)
+    c = hl.compress(u, 1e-3, np.inf, mg.REL)
+    assert c.size > (40 << 20)
+    monkeypatch.setenv("MGH_HL_DECODE_FOLLOWS", "0")
+    ref = hl.decompress(c)
+    assert float(np.max(np.abs(ref - u))) <= 1e-3 * float(np.max(np.abs(u)))
+    monkeypatch.setenv("MGH_HL_DECODE_FOLLOWS", "1")
+    for sym16 in ("0", "1"):
+        monkeypatch.setenv("MGH_SYM16_DECODE", sym16)
+        assert np.array_equal(hl.decompress(c), ref)
+        cp = c.copy()
+        hl.pin(cp)
+        try:
+            assert np.array_equal(hl.decompress(cp), ref)
+        finally:
+            hl.unpin(cp)
+    monkeypatch.delenv("MGH_SYM16_DECODE")
+    # a record truncated in the middle of its code units: an error, not a hang or a fault
+    with pytest.raises(mg.MgardHipError):
+        hl.decompress(c[:c.size // 2])
