@@ -83,6 +83,7 @@ struct mgh_hierarchy {
   // (kernels_ipk_dma.hpp: LDS-DMA front end, everything requested up front; default), 0 = never
   int ipk_dma = 1;
   long ipk_dma_min_env = -1;
+  int ipk_dma_rounds = 4;  // MGH_IPK_DMA_ROUNDS: k_ipk_dma also for levels whose tiles need up to this many rounds of resident workgroups
   size_t ipk_dma_min = 512;  // MGH_IPK_DMA_MIN: fewest tiles of a level for k_ipk_dma (two per CU; set in mgh_hierarchy_create)
   int absmax_warm_mb = 192;  // MGH_ABSMAX_WARM_MB: the norm pass reads all but the last so many MB of the input with nontemporal loads
   // MGH_FUSED_FACES: 1 = face tiles for the remainder columns / rows of a level (default), 0 = off
@@ -649,7 +650,12 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
         // (a level with fewer than two tiles per CU is served better by the LDS-staged kernels, whose
         // four waves per tile stream it in and out: 129^3, 261 tiles, 18.8 vs 16.1 us)
         // (MGH_IPK_DMA_MIN: that threshold in tiles, 0 in the tests that run this kernel on small shapes)
-        if (tiles > per_cu * h->num_cu || tiles < h->ipk_dma_min) return kNotApplicable;
+        // (round 6: short pencils -- four or more tiles per CU -- also when the level needs up to
+        // MGH_IPK_DMA_ROUNDS rounds of resident workgroups: the 8 x 512^3 slab's 5168 tiles of
+        // 257-element pencils, ipk_c 242 -> 213 us, ipk_r 204 -> 190 us against k_ipk_stream; long
+        // pencils with ONE tile per CU lose badly that way -- 1024^3's 513-element pencils 430 -> 850 us)
+        const size_t rounds = per_cu >= 4 ? (size_t)h->ipk_dma_rounds : 1;
+        if (tiles > per_cu * h->num_cu * rounds || tiles < h->ipk_dma_min) return kNotApplicable;
         const unsigned blocks = (unsigned)((tiles + 7) / 8 * 8);
         uint32_t n_inner;
         size_t outer_stride, stride;
@@ -2594,6 +2600,7 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->outlier_agg = (int)env_get("MGH_OUTLIER_AGG", h->outlier_agg);
     h->ipk_chunk_k = (int)env_get("MGH_IPK_CHUNK_K", h->ipk_chunk_k);
     h->tail_solves = (int)env_get("MGH_TAIL_SOLVES", h->tail_solves);
+    h->ipk_dma_rounds = (int)env_get("MGH_IPK_DMA_ROUNDS", h->ipk_dma_rounds);
     h->nd_rows = (int)env_get("MGH_ND_ROWS", h->nd_rows);
     h->cls1 = (size_t)env_get("MGH_CLS1", (long)h->cls1);
     h->cls2 = (size_t)env_get("MGH_CLS2", (long)h->cls2);

@@ -1491,7 +1491,9 @@ struct HostPool {
       std::memcpy(dst, src, bytes);
       return;
     }
-    const int kParts = kWorkers + 1;
+    // (four parts per thread, taken as the threads get to them: a thread on the far socket, or one
+    // the scheduler holds up, takes fewer)
+    const int kParts = (int)std::max<size_t>(1, std::min<size_t>((size_t)4 * (kWorkers + 1), bytes >> 18));
     const size_t part = (bytes / kParts + 4095) / 4096 * 4096;
     run([=](int t) {
       const size_t lo = std::min(bytes, (size_t)t * part), hi = std::min(bytes, (size_t)(t + 1) * part);
