@@ -63,10 +63,17 @@ def test_one_rank_communicator_writes_what_mgh_compress_writes(comm, shape, dt, 
     tol = 1e-3
     got = hl.compress_dist(handle, 0, 1, d, tol, s, m, rccl_path=path)
     want = hl.compress(d, tol, s, m)
-    assert _same_container(hl, got.cpu().numpy(), want.cpu().numpy())
     back = hl.decompress_dist(handle, 0, 1, got, shape, d.dtype)
-    ref = hl.decompress(want)
-    assert torch.equal(back, ref)
+    if s == np.inf or mode == "ABS":
+        assert _same_container(hl, got.cpu().numpy(), want.cpu().numpy())
+        assert torch.equal(back, hl.decompress(want))
+    else:
+        # (an L2 norm is a sum whose last bits depend on the order of the atomics: two compressions of
+        # the same array may differ in the header's norm -- compare what the bound promises)
+        assert abs(hl.metadata_parse(bytes(got.cpu().numpy()))["norm"] - hl.metadata_parse(bytes(want.cpu().numpy()))["norm"]) \
+            <= 1e-12 * hl.metadata_parse(bytes(want.cpu().numpy()))["norm"]
+        l2 = float(np.sqrt(np.mean((back.cpu().numpy().astype(np.float64) - u) ** 2)))
+        assert l2 <= tol * float(np.sqrt(np.mean(u.astype(np.float64) ** 2)))
 
 
 def test_dist_argument_checks(comm):

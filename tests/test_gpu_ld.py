@@ -80,7 +80,8 @@ def test_every_stage_on_pitched_arrays_equals_the_dense_result(shape, dt, pad_mi
     cp = _pitched(torch, coef, ld)
     h.set_ld(mg.LD_IN, ld)
     assert h.norm(up, float("inf")) == nrm
-    assert abs(h.norm(up, 0.0) - nrm2) <= 8 * np.finfo(dt).eps * nrm2
+    # (a sum in another order: rows instead of 16-byte pieces, atomics in whatever order they arrive)
+    assert abs(h.norm(up, 0.0) - nrm2) <= 256 * np.finfo(dt).eps * nrm2
     out = torch.empty_like(u)
     h.decompose(up, out=out)
     assert torch.equal(out, coef)

@@ -6,7 +6,7 @@ TAG=${1:-rXX}
 R=$PWD
 O=$R/gpurun_out/$TAG
 mkdir -p $O
-python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/pytest_gpu.txt
+python -m pytest tests -q -m gpu -rf 2>&1 | grep -E "^FAILED|^ERROR|passed|failed" | tail -12 > $O/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 10 --warmup 3 --no-other-configs > $O/stats.log 2>&1
