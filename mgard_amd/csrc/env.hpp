@@ -50,6 +50,7 @@ inline const EnvSwitch *env_switches(size_t *count) {
       {"MGH_HL_DECODE_FOLLOWS", 0, 1},
       {"MGH_HL_COPY_AFFINITY", 0, 1},
       {"MGH_IPK_DMA_ROUNDS", 1, 64},
+      {"MGH_HL_COPY_PARTS", 1, 64},
   };
   *count = sizeof(k) / sizeof(k[0]);
   return k;

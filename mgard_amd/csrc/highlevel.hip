@@ -1491,9 +1491,12 @@ struct HostPool {
       std::memcpy(dst, src, bytes);
       return;
     }
-    // (four parts per thread, taken as the threads get to them: a thread on the far socket, or one
-    // the scheduler holds up, takes fewer)
-    const int kParts = (int)std::max<size_t>(1, std::min<size_t>((size_t)4 * (kWorkers + 1), bytes >> 18));
+    // (one part per thread. Several smaller parts per thread, taken as the threads get to them, were
+    // meant to balance a slow thread and LOSE: 512^3 f32 pageable, process on the far socket, 15.0 /
+    // 14.5 ms with 1 part per thread, 17-22 / 15-17 ms with 4, 17.6 / 16 ms with 8; near socket 15.0 /
+    // 14.4 against 15.4 / 14.7 and 15.0 / 14.6 -- MGH_HL_COPY_PARTS)
+    static const size_t per_thread = (size_t)env_get("MGH_HL_COPY_PARTS", 1);
+    const int kParts = (int)std::max<size_t>(1, std::min<size_t>(per_thread * (kWorkers + 1), bytes >> 18));
     const size_t part = (bytes / kParts + 4095) / 4096 * 4096;
     run([=](int t) {
       const size_t lo = std::min(bytes, (size_t)t * part), hi = std::min(bytes, (size_t)(t + 1) * part);
