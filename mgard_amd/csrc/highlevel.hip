@@ -1053,6 +1053,21 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
     }
     const size_t lds_b = huff::decode_ring_lds(dt.size(), waves);
     const bool out16 = sym16 && *sym16;
+    // MGH_HUFF_LEAN=1: the writing pass of records with synchronisation points without divergent
+    // control flow (k_decode_lean: half the instructions per step -- and the same 0.51 ms at 512^3 as
+    // k_decode_ring; it carries the ablation switches MGH_HUFF_DBG that say where the time goes,
+    // profiles/NOTES.md round 6). Off by default: no gain, one kernel less in the default path.
+    const bool lean_decode = d_sync && !pair_decode && env_get("MGH_HUFF_LEAN", 0) != 0;
+    if (lean_decode) {
+      static std::atomic<uint64_t> once5{0};
+      if (hl_attr_pending(once5)) {
+        HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_decode_lean<int64_t>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        HL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(huff::k_decode_lean<uint16_t>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        hl_attr_done(once5);
+      }
+    }
     // chunks [c0, c1): the kernels index everything by chunk, so a range is the same launch with
     // the per-chunk arrays, the output and the symbol count moved up by c0 chunks
     auto launch_range = [&](size_t c0, size_t c1) -> int {
@@ -1073,6 +1088,14 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
           huff::k_decode_sync<int64_t><<<grid, 64 * waves, lds_b, st>>>(d_units, bits_r, ent_r, cnt, chunk, n_r, dict, rtb,
                                                                         (const unsigned *)c->dtable.p, (unsigned)dt.size(),
                                                                         tab, tab + 64, tab + 128, q64, sync_r);
+      } else if (lean_decode && out16) {
+        huff::k_decode_lean<uint16_t><<<grid, 64 * waves, lds_b, st>>>(d_units, bits_r, ent_r, cnt, chunk, n_r, dict, rtb | ((int)env_get("MGH_HUFF_DBG", 0) << 8),
+                                                                       (const unsigned *)c->dtable.p, (unsigned)dt.size(),
+                                                                       tab, tab + 64, tab + 128, q16, sync_r);
+      } else if (lean_decode) {
+        huff::k_decode_lean<int64_t><<<grid, 64 * waves, lds_b, st>>>(d_units, bits_r, ent_r, cnt, chunk, n_r, dict, rtb | ((int)env_get("MGH_HUFF_DBG", 0) << 8),
+                                                                      (const unsigned *)c->dtable.p, (unsigned)dt.size(),
+                                                                      tab, tab + 64, tab + 128, q64, sync_r);
       } else if (out16) {
         huff::k_decode_ring<uint16_t><<<grid, 64 * waves, lds_b, st>>>(d_units, bits_r, ent_r, cnt, chunk, n_r, dict, rtb,
                                                                        (const unsigned *)c->dtable.p, (unsigned)dt.size(),

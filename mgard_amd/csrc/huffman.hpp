@@ -1142,10 +1142,16 @@ constexpr int kRingUnits = 8;   // units per lane in the ring
 constexpr int kRingFetch = 4;   // units per lane per refill
 constexpr int kRingStep = 8;    // symbols between two refills
 constexpr int kRingBatch = 16;  // symbols a lane stages between two write-outs (multiple of kRingStep)
+// Row length of a lane's staging slots: ONE MORE than the batch. With rows of 16 two-byte slots (32
+// bytes) the 64 lanes of the per-symbol store `stage[lane * 16 + got]` fall on four LDS banks, a
+// 16-way conflict on every symbol step. Rows of 17 slots spread the lanes over all banks, and the
+// write-out's reads stay contiguous. (Measured: no difference at 512^3 -- the decoder is bound by
+// neither this nor its instruction count alone, see k_decode_lean and profiles/NOTES.md round 6.)
+constexpr int kStageStride = kRingBatch + 1;
 constexpr int kRecStride = 8;   // every kRecStride-th code boundary of the first pass is remembered
 
 inline size_t decode_ring_lds(size_t table_entries, int waves) {
-  return (table_entries * 4 + 7) / 8 * 8 + (size_t)waves * (kRingUnits * 64 * 8 + 64 * kRingBatch * 2);
+  return (table_entries * 4 + 7) / 8 * 8 + (size_t)waves * (kRingUnits * 64 * 8 + 64 * kStageStride * 2);
 }
 
 template <typename OUT>  // int64_t (the reference's array of quantized values) or uint16_t symbols
@@ -1165,7 +1171,7 @@ k_decode_ring(const unsigned long long *__restrict__ units, const unsigned long 
   unsigned long long *rings = reinterpret_cast<unsigned long long *>(dyn_lds + (table_entries + 1) / 2 * 2);
   unsigned long long *ring = rings + (size_t)wave * (kRingUnits * 64);
   unsigned short *stage = reinterpret_cast<unsigned short *>(rings + (size_t)nwaves * (kRingUnits * 64)) +
-                          (size_t)wave * (64 * kRingBatch);
+                          (size_t)wave * (64 * kStageStride);
   if (threadIdx.x < 64) {
     sfirst[threadIdx.x] = first[threadIdx.x];
     sentry[threadIdx.x] = entry[threadIdx.x];
@@ -1204,7 +1210,7 @@ k_decode_ring(const unsigned long long *__restrict__ units, const unsigned long 
   const unsigned nun = (total + 63) / 64;  // src[nun] is readable (the window peeks ahead)
   const unsigned B = (total + 63) / 64;    // bits per subsequence
   const unsigned lim = min((unsigned)(lane + 1) * B, total);
-  unsigned short *rec = stage + lane * kRingBatch;  // this lane's slots of the staging area
+  unsigned short *rec = stage + lane * kStageStride;  // this lane's slots of the staging area
 
   // One pass over this lane's subsequence from bit `start`; all lanes of the wave call it
   // together. MODE 0: count the symbols up to position lim, remember where every kRecStride-th of the
@@ -1297,7 +1303,7 @@ k_decode_ring(const unsigned long long *__restrict__ units, const unsigned long 
               pos = total;
               live = false;
             } else {
-              if (MODE == 2) stage[lane * kRingBatch + got] = (unsigned short)sym;
+              if (MODE == 2) stage[lane * kStageStride + got] = (unsigned short)sym;
               got++;
               pos += l;
               win <<= l;
@@ -1342,7 +1348,7 @@ k_decode_ring(const unsigned long long *__restrict__ units, const unsigned long 
           const int L = it * RPI + lane / kRingBatch, k = lane % kRingBatch;
           const int n_L = __shfl(got, L, 64);
           const unsigned o_L = __shfl(my_o, L, 64);
-          if (k < n_L && o_L + k < cap) dst[o_L + k] = (OUT)stage[L * kRingBatch + k];
+          if (k < n_L && o_L + k < cap) dst[o_L + k] = (OUT)stage[L * kStageStride + k];
         }
       }
     }
@@ -1451,7 +1457,7 @@ k_decode_sync(const unsigned long long *__restrict__ units, const unsigned long 
   unsigned long long *rings = reinterpret_cast<unsigned long long *>(dyn_lds + (table_words + 1) / 2 * 2);
   unsigned long long *ring = rings + (size_t)wave * (kRingUnits * 64);
   unsigned short *stage = reinterpret_cast<unsigned short *>(rings + (size_t)nwaves * (kRingUnits * 64)) +
-                          (size_t)wave * (64 * kRingBatch);
+                          (size_t)wave * (64 * kStageStride);
   if (threadIdx.x < 64) {
     sfirst[threadIdx.x] = first[threadIdx.x];
     sentry[threadIdx.x] = entry[threadIdx.x];
@@ -1536,8 +1542,8 @@ k_decode_sync(const unsigned long long *__restrict__ units, const unsigned long 
         const uint2 pr = *reinterpret_cast<const uint2 *>(table + 2 * (unsigned)(win >> (64 - tb)));
         const unsigned l2 = pr.y >> 16;
         if (pr.y != 0 && cnt + 2 <= want && pos + l2 <= total) {  // two codes inside the window
-          stage[lane * kRingBatch + got] = (unsigned short)(pr.x & 0xffffu);
-          stage[lane * kRingBatch + got + 1] = (unsigned short)(pr.y & 0xffffu);
+          stage[lane * kStageStride + got] = (unsigned short)(pr.x & 0xffffu);
+          stage[lane * kStageStride + got + 1] = (unsigned short)(pr.y & 0xffffu);
           got += 2;
           cnt += 2;
           pos += l2;
@@ -1569,7 +1575,7 @@ k_decode_sync(const unsigned long long *__restrict__ units, const unsigned long 
             pos = total;
             live = false;
           } else {
-            stage[lane * kRingBatch + got] = (unsigned short)sym;
+            stage[lane * kStageStride + got] = (unsigned short)sym;
             got++;
             cnt++;
             pos += l;
@@ -1595,7 +1601,185 @@ k_decode_sync(const unsigned long long *__restrict__ units, const unsigned long 
         const int L = it * RPI + lane / kRingBatch, k = lane % kRingBatch;
         const int n_L = __shfl(got, L, 64);
         const unsigned o_L = __shfl(my_o, L, 64);
-        if (k < n_L && o_L + k < cap) dst[o_L + k] = (OUT)stage[L * kRingBatch + k];
+        if (k < n_L && o_L + k < cap) dst[o_L + k] = (OUT)stage[L * kStageStride + k];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_decode_ring's writing pass for records with synchronisation points, with the per-symbol step
+// rewritten WITHOUT divergent control flow (round 6). The ring decoder is bound by instruction issue:
+// 137 ISA instructions per symbol step at 512^3, about half of them the scalar bookkeeping of a dozen
+// `if`s per step (s_and_saveexec / s_cbranch_execz / s_or exec around a handful of vector
+// instructions each). Here a step is straight-line code under selects -- top-up word always read,
+// table always looked up, the staged symbol always written (into a slot that only counts when the
+// step was good) -- and everything rare (second table level, prefixes the table leaves out, a
+// damaged stream) sits behind WAVE-UNIFORM branches (`__any`), which cost one scalar branch when no
+// lane needs them. Same table, ring, refill points and write-out as k_decode_ring; same symbols.
+// RESULT: 75 instead of ~135 static instructions per step and the SAME kernel time (512^3 record,
+// 16-bit symbols out: 516 vs 511 us). Ablations (MGH_HUFF_DBG, tools/exp_decode_kernels.sh): without
+// the global stores 458 us, with a constant 9-bit code instead of the table's answer 416 us, without
+// the write-out loop 429 us, without both 309 us -- a 300 us skeleton (ring traffic, top-ups, the
+// step's bookkeeping on four waves per SIMD) that neither variant touches. Kept as the instrumented
+// kernel (MGH_HUFF_LEAN=1); k_decode_ring stays the default.
+// ---------------------------------------------------------------------------------------
+template <typename OUT>
+__global__ void __launch_bounds__(1024)
+k_decode_lean(const unsigned long long *__restrict__ units, const unsigned long long *__restrict__ bits,
+              const unsigned long long *__restrict__ entry_of_chunk, size_t nchunk, int chunk, size_t n,
+              int dict, int tb, const unsigned *__restrict__ g_table, unsigned table_entries,
+              const unsigned long long *__restrict__ first,
+              const unsigned long long *__restrict__ entry, const unsigned long long *__restrict__ keys,
+              OUT *__restrict__ q, const unsigned *__restrict__ sync) {
+  const int dbg = tb >> 8;  // (developer: 1 = no stores, 2 = constant code instead of the table's, 4 = no write-out)
+  tb &= 0xff;
+  __shared__ unsigned long long sfirst[64], sentry[64], slim[64];
+  __shared__ int smaxlen;
+  extern __shared__ unsigned dyn_lds[];
+  unsigned *table = dyn_lds;
+  const int nwaves = blockDim.x >> 6;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned long long *rings = reinterpret_cast<unsigned long long *>(dyn_lds + (table_entries + 1) / 2 * 2);
+  unsigned long long *ring = rings + (size_t)wave * (kRingUnits * 64);
+  const unsigned *ring32 = reinterpret_cast<const unsigned *>(ring);
+  unsigned short *stage = reinterpret_cast<unsigned short *>(rings + (size_t)nwaves * (kRingUnits * 64)) +
+                          (size_t)wave * (64 * kStageStride);
+  if (threadIdx.x < 64) {
+    sfirst[threadIdx.x] = first[threadIdx.x];
+    sentry[threadIdx.x] = entry[threadIdx.x];
+  }
+  for (unsigned i = threadIdx.x; i < table_entries; i += blockDim.x) table[i] = g_table[i];
+  __syncthreads();
+  if (threadIdx.x == 0) {  // comparison path for prefixes the table leaves out (see k_decode_ring)
+    unsigned long long m = ~0ull;
+    int mx = 0;
+    for (int l = 1; l < 64; l++) {
+      const bool used = sfirst[l] != ~0ull && l <= kMaxCodeBits;
+      if (used) mx = l;
+      if (l > tb) {
+        if (used) m = min(m, sfirst[l] << (64 - l));
+        slim[l] = m;
+      } else {
+        slim[l] = ~0ull;
+      }
+    }
+    slim[0] = ~0ull;
+    smaxlen = mx;
+  }
+  __syncthreads();
+  const int maxlen = smaxlen;
+  const size_t c = (size_t)blockIdx.x * nwaves + wave;
+  if (c >= nchunk) return;  // (whole wave; no block-wide barrier follows)
+  const unsigned long long *src = units + entry_of_chunk[c];
+  const unsigned total = (unsigned)min(bits[c], (unsigned long long)chunk * kMaxCodeBits);
+  OUT *dst = q + c * (size_t)chunk;
+  const unsigned cap = (unsigned)min((size_t)chunk, n - c * (size_t)chunk);
+  const unsigned nun = (total + 63) / 64;  // src[nun] is readable (the window peeks ahead)
+  const unsigned B = (total + 63) / 64;    // bits per subsequence
+  const unsigned lim = min((unsigned)(lane + 1) * B, total);
+  const unsigned ent = load_u32(sync, c * kSyncLanes + lane);
+  const unsigned first_sym = lane ? min(ent & 0xffffu, cap) : 0u;
+  unsigned next_sym = __shfl_down(first_sym, 1, 64);
+  if (lane == 63) next_sym = cap;
+  const unsigned s0 = lane ? (unsigned)min((unsigned long long)lane * B + (ent >> 16), (unsigned long long)total) : 0u;
+  const unsigned want = next_sym > first_sym ? next_sym - first_sym : 0u;
+
+  unsigned pos = s0, cnt = 0;
+  bool live = pos < lim && want > 0;
+  const unsigned cw0 = pos >> 6;
+#pragma unroll
+  for (int r = 0; r < kRingUnits; r++)  // initial fill of the ring
+    ring[((cw0 + r) % kRingUnits) * 64 + lane] = load_unit(src, min(cw0 + r, nun));
+  unsigned hi = cw0 + kRingUnits;
+  unsigned long long win;
+  unsigned avail, wnext;
+  {
+    const unsigned long long u0 = ring[(cw0 % kRingUnits) * 64 + lane];
+    const unsigned long long u1 = ring[((cw0 + 1) % kRingUnits) * 64 + lane];
+    const int sh = (int)(pos & 63);
+    win = sh ? (u0 << sh) | (u1 >> (64 - sh)) : u0;  // 64 valid bits from pos on
+    avail = 64;
+    wnext = ((pos + 64) >> 5);
+    const unsigned part = (pos + 64) & 31;  // (keep whole words only: refills stay word-aligned)
+    avail -= part;
+    win = part ? (win >> part) << part : win;
+  }
+  unsigned long long pf[kRingFetch];
+  bool pending = false;
+  const unsigned tsh = 32u - (unsigned)tb;
+  unsigned short *my_stage = stage + lane * kStageStride;
+  while (__any(live)) {
+    unsigned got = 0;
+    for (int rep = 0; rep < kRingBatch / kRingStep; rep++) {
+      if (live && !pending) {  // request the next units; they are committed kRingStep symbols later
+#pragma unroll
+        for (int j = 0; j < kRingFetch; j++) pf[j] = load_unit(src, min(hi + j, nun));
+        pending = true;
+      }
+#pragma unroll
+      for (int k = 0; k < kRingStep; k++) {
+        // top up 32 bits when 32 or fewer are left and the ring has the word (a lane out of units pauses)
+        const unsigned un = wnext >> 1;
+        const bool need = avail <= 32u && un < hi;
+        const unsigned wd = ring32[((un % kRingUnits) * 64 + lane) * 2 + ((wnext & 1u) ^ 1u)];
+        const unsigned long long add = (unsigned long long)wd << ((32u - avail) & 63u);
+        win |= need ? add : 0ull;
+        avail += need ? 32u : 0u;
+        wnext += need ? 1u : 0u;
+        const bool can = live && avail > 32u;
+        unsigned e = table[(unsigned)(win >> 32) >> tsh];
+        if (dbg & 2) e = (9u << 16) | 7u;  // (developer: every code 9 bits, no dependence on the table)
+        if (__any(can && (int)e < 0)) {  // second level for some lane: the next sub_bits bits
+          if (can && (int)e < 0) {
+            const int sb = (int)((e >> 24) & 0x7f);
+            e = table[(e & 0xffffff) + (unsigned)((win << tb) >> (64 - sb))];
+          }
+        }
+        unsigned l = e >> 16, sym = e & 0xffffu;
+        bool hit = e != 0;
+        if (__any(can && !hit)) {  // a prefix the table leaves out: count the lengths (see k_decode_ring)
+          if (can && !hit) {
+            int ll = tb + 1;
+            for (int j = tb + 1; j <= maxlen; j++) ll += win < slim[j] ? 1 : 0;
+            if (ll <= maxlen) {
+              const unsigned long long v = win >> (64 - ll);
+              const unsigned long long kk = sentry[ll] + (v - sfirst[ll]);
+              if (v >= sfirst[ll] && kk < (unsigned long long)dict) {
+                sym = (unsigned)keys[kk] & 0xffffu;
+                l = (unsigned)ll;
+                hit = true;
+              }
+            }
+          }
+        }
+        const bool good = can && hit && pos + l <= total;
+        my_stage[got] = (unsigned short)sym;  // (counts only when the step was good: `got` moves on then)
+        const unsigned lm = good ? l : 0u;
+        pos = (can && !good) ? total : pos + lm;  // (a damaged stream ends the lane)
+        win <<= lm;
+        avail -= lm;
+        got += good ? 1u : 0u;
+        cnt += good ? 1u : 0u;
+        live = live && (!can || (good && pos < lim && cnt < want));
+      }
+      // refill point: commit the units requested before these symbols if the ring has room
+      if (pending && hi + kRingFetch <= (wnext >> 1) + kRingUnits) {
+#pragma unroll
+        for (int j = 0; j < kRingFetch; j++) ring[((hi + j) % kRingUnits) * 64 + lane] = pf[j];
+        hi += kRingFetch;
+        pending = false;
+      }
+    }
+    if (!(dbg & 4)) {  // write-out: 64 / kRingBatch runs per instruction, the elements of a run side by side
+      constexpr int RPI = 64 / kRingBatch;  // runs per store instruction
+      const unsigned my_o = first_sym + cnt - got;
+#pragma unroll 4
+      for (int it = 0; it < 64 / RPI; it++) {
+        const int L = it * RPI + lane / kRingBatch, k = lane % kRingBatch;
+        const int n_L = __shfl((int)got, L, 64);
+        const unsigned o_L = __shfl(my_o, L, 64);
+        if (k < n_L && o_L + k < cap && !(dbg & 1)) dst[o_L + k] = (OUT)stage[L * kStageStride + k];
       }
     }
   }

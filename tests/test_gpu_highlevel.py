@@ -1100,13 +1100,15 @@ def test_synchronisation_points_behind_the_huffman_record(kind, n, chunk, monkey
     assert rec[:len(plain)] == plain
     # (MGH_HUFF_PAIR: records with the section go through k_decode_sync -- two codes per table slot
     # where they fit: 2 always, 1 for short codes only -- or, 0, through k_decode_ring's single-symbol steps)
-    for sync_decode, pair in (("1", "2"), ("1", "0"), ("1", "1"), ("0", "1")):
+    # MGH_HUFF_LEAN=1: the writing pass without divergent control flow (k_decode_lean) instead of k_decode_ring's
+    for sync_decode, pair, lean in (("1", "2", "0"), ("1", "0", "1"), ("1", "0", "0"), ("1", "1", "0"), ("0", "1", "0")):
         monkeypatch.setenv("MGH_HUFF_SYNC_DECODE", sync_decode)
         monkeypatch.setenv("MGH_HUFF_PAIR", pair)
+        monkeypatch.setenv("MGH_HUFF_LEAN", lean)
         for payload in (rec, plain, torch.frombuffer(bytearray(rec), dtype=torch.uint8).cuda(),
                         torch.frombuffer(bytearray(b"xyz" + rec), dtype=torch.uint8).cuda()[3:]):
             back, bi, bv = ctx.decompress(payload, n, hl.HUFFMAN)
-            assert np.array_equal(back.cpu().numpy(), q), (kind, sync_decode, pair)
+            assert np.array_equal(back.cpu().numpy(), q), (kind, sync_decode, pair, lean)
             assert np.array_equal(bi.cpu().numpy(), oi) and np.array_equal(bv.cpu().numpy(), ov)
     ctx.close()
 
