@@ -279,6 +279,16 @@ def launch_ranks(args, argv):
                 "error": "rc %d: %s" % (p2.returncode, p2.stderr[-300:])}
         except subprocess.TimeoutExpired:
             res["native_multi"] = {"error": "timeout"}
+        # ... and the C entry points for one rank per GPU (RCCL inside the library), one thread per rank
+        cmd3 = [sys.executable, os.path.abspath(__file__), "--capi-dist", "--gpus", str(args.gpus)]
+        try:
+            p3 = subprocess.run(cmd3, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                text=True, timeout=420)
+            r3 = _last_json_line(p3.stdout)
+            res["capi_dist"] = r3 if (p3.returncode == 0 and r3) else {
+                "error": "rc %d: %s" % (p3.returncode, p3.stderr[-300:])}
+        except subprocess.TimeoutExpired:
+            res["capi_dist"] = {"error": "timeout"}
     print(json.dumps(res), flush=True)
 
 
@@ -355,6 +365,95 @@ def native_multi(args):
     except (mgard_amd.MgardHipError, RuntimeError) as e:
         res["device_resident"] = {"error": str(e)[:300]}
     print(json.dumps(res), flush=True)
+
+
+def capi_dist(args):
+    """configs[3] through the C entry points for one rank per GPU (mgh_compress_dist /
+    mgh_decompress_dist, include/mgard_hip_compress.h): one host thread per device stands in for a rank
+    (its own RCCL communicator rank, its own 8 x 512^3 f32 slab resident on its device); the norm
+    all-reduce, the record gather to rank 0 and the hand-out on the way back run over RCCL inside the
+    library. Weak scaling: the domain is (8 N) x 512^3. Own child process with a time limit: a failure
+    here cannot touch the metric's line."""
+    import ctypes as C
+    import threading
+    import numpy as np
+    import torch
+    import mgard_amd
+    from mgard_amd import highlevel as hl
+    n = min(args.gpus, torch.cuda.device_count())
+    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    if not os.path.exists(path):
+        path = "librccl.so.1"
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    rccl = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    uid = UniqueId()
+    if rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+        raise SystemExit("ncclGetUniqueId failed")
+    slab = (8, 512, 512, 512)
+    slab_bytes = int(np.prod(slab)) * 4
+    bar = threading.Barrier(n)
+    out, errors, times = {}, [], {}
+
+    def rank_thread(r):
+        try:
+            torch.cuda.set_device(r)
+            dev = torch.device("cuda", r)
+            comm = C.c_void_p()
+            if rccl.ncclCommInitRank(C.byref(comm), n, uid, r) != 0:
+                raise RuntimeError("ncclCommInitRank failed")
+            base = gpu_field(torch, slab[1:], torch.float32, dev, seed=20260101 + r)
+            d = torch.stack([base * (1.0 + 0.002 * t) + 1e-4 * t for t in range(slab[0])])
+            del base
+            nrm = float(d.abs().max().item())
+            cfg = hl.Config(dev_id=r)
+            c = hl.compress_dist(comm.value, r, n, d, TOL, float("inf"), mgard_amd.REL, config=cfg, rccl_path=path)
+            torch.cuda.synchronize()
+            bar.wait()
+            t0 = time.perf_counter()
+            c = hl.compress_dist(comm.value, r, n, d, TOL, float("inf"), mgard_amd.REL, config=cfg)
+            torch.cuda.synchronize()
+            bar.wait()
+            t1 = time.perf_counter()
+            v = hl.decompress_dist(comm.value, r, n, c, d.shape, d.dtype, config=cfg, device=dev)
+            torch.cuda.synchronize()
+            bar.wait()
+            t2 = time.perf_counter()
+            v = hl.decompress_dist(comm.value, r, n, c, d.shape, d.dtype, config=cfg, device=dev)
+            torch.cuda.synchronize()
+            bar.wait()
+            t3 = time.perf_counter()
+            times[r] = (t1 - t0, t3 - t2)
+            out[r] = (float((v - d).abs().max().item()), nrm, None if c is None else int(c.numel()))
+            rccl.ncclCommDestroy(comm)
+            hl.release_cache()
+        except Exception as e:  # noqa: BLE001
+            errors.append("rank %d: %r" % (r, e))
+            bar.abort()
+
+    th = [threading.Thread(target=rank_thread, args=(r,)) for r in range(n)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errors:
+        print(json.dumps({"error": "; ".join(errors)[:500]}), flush=True)
+        return
+    gnorm = max(o[1] for o in out.values())
+    c_s, d_s = max(t[0] for t in times.values()), max(t[1] for t in times.values())
+    print(json.dumps({
+        "what": "mgh_compress_dist / mgh_decompress_dist: one host thread per device as a rank, RCCL inside the "
+                "library (norm all-reduce, record gather / hand-out); one 8x512^3 f32 slab per rank, device-resident",
+        "ranks": n, "domain": [8 * n, 512, 512, 512],
+        "compress_ms": round(c_s * 1e3, 3), "compress_GBps": round(n * slab_bytes / c_s / 1e9, 2),
+        "decompress_ms": round(d_s * 1e3, 3), "decompress_GBps": round(n * slab_bytes / d_s / 1e9, 2),
+        "container_bytes": out[0][2], "compression_ratio": round(n * slab_bytes / out[0][2], 3),
+        "roundtrip_linf_error": max(o[0] for o in out.values()), "tolerance_abs": TOL * gnorm,
+        "within_tolerance": bool(max(o[0] for o in out.values()) <= TOL * gnorm)}), flush=True)
 
 
 def gpu_field(torch, shape, dtype, dev, seed=20260101):
@@ -863,6 +962,8 @@ def main():
                     help="N > 1 launcher: skip the one-process / N-devices leg (mgh_compress_multi)")
     ap.add_argument("--native-multi", action="store_true",
                     help="run ONLY the one-process / N-devices leg (what the launcher starts as its second child)")
+    ap.add_argument("--capi-dist", action="store_true",
+                    help="(internal) run only the mgh_compress_dist leg: one thread per device as a rank")
     ap.add_argument("--dist-dry-run", action="store_true",
                     help="GPU-less check of the N > 1 launcher: gloo ranks, norm exchange only")
     ap.add_argument("--sg-slab", type=int, default=8,
@@ -876,6 +977,8 @@ def main():
     # BEFORE anything imports torch or touches a GPU ----
     if args.native_multi:
         return native_multi(args)
+    if args.capi_dist:
+        return capi_dist(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args, sys.argv[1:])
     if args.dist_dry_run:
