@@ -323,7 +323,7 @@ struct HostPrefix {
   ~HostPrefix() { host_prefix().base = nullptr; }
 };
 int aux_read(void *dst, const void *src, size_t bytes);  // (below, with the cache)
-hipStream_t cache_copy_stream();                          // (below: the calling thread's copy stream, or nullptr)
+hipStream_t cache_copy_stream(int dev);                   // (below: the calling thread's copy stream on that device, or nullptr)
 // device -> host copy that is served from the prefix where it can be
 inline int dev_to_host(void *dst, const void *src, size_t bytes) {
   const HostPrefixState &s = host_prefix();
@@ -963,7 +963,7 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
     // A large record in HOST memory is decoded while it arrives (below: the ring decoder's launches
     // follow the pieces of the copy, which runs on the cache's copy stream); everything else is
     // copied here, in stream order. (A record in pageable memory travels through the pinned ring.)
-    units_follow = !on_dev && ring_decode && units * 8 >= ((size_t)32 << 20) && cache_copy_stream() &&
+    units_follow = !on_dev && ring_decode && units * 8 >= ((size_t)32 << 20) && cache_copy_stream(c->dev) &&
                    env_get("MGH_HL_DECODE_FOLLOWS", 1) != 0;
     if (units && !units_follow) HL_TRY(copy_any(c->units.p, p + L.ddata, units * 8, st));
     HL_HIP(hipMemsetAsync((char *)c->units.p + units * 8, 0, 8, st));  // (the decoder peeks one unit ahead)
@@ -1132,7 +1132,7 @@ int lossless_decompress(mgh_lossless_ctx *c, const uint8_t *payload, uint64_t si
       };
       // (the copy stream must not run ahead of what st has queued in front: the small uploads above
       // are independent of the units; the units buffer itself is free -- the caller drained st)
-      HL_TRY(copy_any(c->units.p, p + L.ddata, total_b, cache_copy_stream(), &on_piece));
+      HL_TRY(copy_any(c->units.p, p + L.ddata, total_b, cache_copy_stream(c->dev), &on_piece));
       if (c_done < nchunk) return hl_fail(MGH_ERR_DEVICE, "lossless_decompress: chunks left behind the last piece");
     } else {
       HL_TRY(launch_range(0, nchunk));
@@ -1539,8 +1539,23 @@ struct HostPool {
     cur.reset();
   }
 };
-thread_local HostPool *g_pool_ptr = nullptr;  // (never destroyed automatically, like the cache)
+thread_local HostPool *g_pool_ptr = nullptr;
+// The pool's worker threads end with the thread that owns them (a thread_local destructor: joining
+// std::threads makes no HIP call, unlike the release of the cache and the pinned rings, which stays
+// with mgh_release_cache) -- a caller thread that exits without releasing leaves memory behind, not
+// threads.
+struct HostPoolGuard {
+  ~HostPoolGuard() {
+    if (g_pool_ptr) {
+      g_pool_ptr->shutdown();
+      delete g_pool_ptr;
+      g_pool_ptr = nullptr;
+    }
+  }
+};
 inline HostPool &host_pool() {
+  static thread_local HostPoolGuard guard;
+  (void)guard;
   if (!g_pool_ptr) g_pool_ptr = new HostPool();
   return *g_pool_ptr;
 }
@@ -1932,7 +1947,7 @@ inline HlCache &hl_cache() {
 }
 #define g_cache (hl_cache())
 
-hipStream_t cache_copy_stream() { return g_cache_ptr ? g_cache_ptr->copy_st : nullptr; }
+hipStream_t cache_copy_stream(int dev) { return g_cache_ptr && g_cache_ptr->dev == dev ? g_cache_ptr->copy_st : nullptr; }
 
 // Small synchronous device -> host read (record sizes, record heads). On the cache's own stream
 // and through its pinned buffer: hipMemcpy() would run on the NULL stream and with it wait for
