@@ -93,7 +93,7 @@ def test_dist_argument_checks(comm):
 
 @pytest.mark.parametrize("nranks", [2, 4])
 def test_ranks_on_several_gpus_of_one_node(nranks):
-    """N > 1 (only where the box has the GPUs; skipped on a one-GPU box): one thread per rank and
+    """N > 1 (opt-in, and only where the box has the GPUs): one thread per rank and
     device, ncclCommInitRank inside the threads, the container of mgh_compress_dist against
     mgh_compress with the same MaxDim decomposition on one device, slabs back through
     mgh_decompress_dist."""
@@ -102,6 +102,9 @@ def test_ranks_on_several_gpus_of_one_node(nranks):
     import mgard_amd as mg
     from mgard_amd import highlevel as hl
     from tests.test_gpu_host_path import _same_container
+    if os.environ.get("MGARD_HIP_TEST_MULTI_GPU", "0") != "1":
+        pytest.skip("opt-in (MGARD_HIP_TEST_MULTI_GPU=1): has never run -- no box with more than one GPU has been "
+                    "available to this repository; bench.py --gpus N runs the same calls in a child of its own")
     if torch.cuda.device_count() < nranks:
         pytest.skip("needs %d GPUs" % nranks)
     lib, path = _rccl()
