@@ -283,7 +283,7 @@ def launch_ranks(args, argv):
         cmd3 = [sys.executable, os.path.abspath(__file__), "--capi-dist", "--gpus", str(args.gpus)]
         try:
             p3 = subprocess.run(cmd3, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                                text=True, timeout=420)
+                                text=True, timeout=240)
             r3 = _last_json_line(p3.stdout)
             res["capi_dist"] = r3 if (p3.returncode == 0 and r3) else {
                 "error": "rc %d: %s" % (p3.returncode, p3.stderr[-300:])}
