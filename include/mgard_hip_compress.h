@@ -92,6 +92,14 @@ int mgh_decompress(const void *compressed_data, size_t compressed_size,
                    void **decompressed_data, const mgh_config *config,
                    int output_pre_allocated);
 
+/* mgh_decompress into a buffer of the caller whose size and type the library CHECKS (against the
+ * header it reads anyway, before anything is written): out_bytes must be exactly the bytes of the
+ * array in the stream, out_dtype its type (MGH_ERR_INVALID_ARGUMENT otherwise). The reference's
+ * pre-allocated form (compress_x.hpp:115-154) trusts the caller; this is the form for bindings that
+ * hand over buffers of known size (extension). Host or device memory like mgh_decompress. */
+int mgh_decompress_into(const void *compressed_data, size_t compressed_size, void *out, size_t out_bytes,
+                        int out_dtype, const mgh_config *config);
+
 /* One process, several devices (the reference's MGARD_ENABLE_MULTI_DEVICE switch is dead code,
  * include/mgard-x/RuntimeX/RuntimeX.h:53; its multi-GPU example runs one rank per GPU:
  * examples/mgard-x/CompressXgcData/TestXGCAbsoluteError.cpp:36-252). mgh_compress_multi takes a

@@ -2826,8 +2826,26 @@ int mgh_compress(int D, int dtype, const uint64_t *shape, double tol, double s, 
   }
 }
 
+static int decompress_entry(const void *compressed_data, size_t compressed_size, void **decompressed_data,
+                            const mgh_config *config, int output_pre_allocated, size_t expect_bytes, int expect_dtype);
+
 int mgh_decompress(const void *compressed_data, size_t compressed_size, void **decompressed_data,
                    const mgh_config *config, int output_pre_allocated) {
+  return decompress_entry(compressed_data, compressed_size, decompressed_data, config, output_pre_allocated, 0, -1);
+}
+
+int mgh_decompress_into(const void *compressed_data, size_t compressed_size, void *out, size_t out_bytes,
+                        int out_dtype, const mgh_config *config) {
+  if (!out) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (out_dtype != MGH_FLOAT && out_dtype != MGH_DOUBLE) return hl_fail(MGH_ERR_UNSUPPORTED_DTYPE, "dtype");
+  void *dst = out;
+  return decompress_entry(compressed_data, compressed_size, &dst, config, 1, out_bytes, out_dtype);
+}
+
+// expect_dtype >= 0: the caller's buffer holds expect_bytes bytes of that type -- checked against the
+// header the call reads anyway, before anything is written (mgh_decompress_into)
+static int decompress_entry(const void *compressed_data, size_t compressed_size, void **decompressed_data,
+                            const mgh_config *config, int output_pre_allocated, size_t expect_bytes, int expect_dtype) {
   if (!compressed_data || !decompressed_data) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "NULL argument");
   if (output_pre_allocated && !*decompressed_data) return hl_fail(MGH_ERR_INVALID_ARGUMENT, "pre-allocated output is NULL");
   {
@@ -2849,6 +2867,14 @@ int mgh_decompress(const void *compressed_data, size_t compressed_size, void **d
   HL_TRY(read_header(compressed_data, compressed_size, hd, meta_size));
   if (hd.shape.empty() || hd.shape.size() > MGH_MAX_DIM) return hl_fail(MGH_ERR_UNSUPPORTED_DIMENSION, "header: dimension");
   if (!hd.quantized) return hl_fail(MGH_ERR_FORMAT, "not a compressed (quantized) stream");
+  if (expect_dtype >= 0) {
+    size_t need = hd.is_double ? 8 : 4;
+    for (uint64_t e : hd.shape) need *= e;
+    if ((expect_dtype == MGH_DOUBLE) != hd.is_double)
+      return hl_fail(MGH_ERR_INVALID_ARGUMENT, "mgh_decompress_into: the stream holds the other data type");
+    if (expect_bytes != need)
+      return hl_fail(MGH_ERR_INVALID_ARGUMENT, "mgh_decompress_into: the buffer does not have the size of the array in the stream");
+  }
   try {
     if (hd.is_double)
       return decompress_impl<double>(hd, meta_size, compressed_data, compressed_size, decompressed_data,

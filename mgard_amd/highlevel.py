@@ -23,6 +23,7 @@ HL_SYMBOLS = [
     "mgh_lossless_decompress", "mgh_lossless_compress_device", "mgh_memcpy", "mgh_huffman_codebook",
     "mgh_compress_multi", "mgh_decompress_multi", "mgh_pin_memory", "mgh_check_memory_pinned",
     "mgh_unpin_memory", "mgh_dist_use_library", "mgh_compress_dist", "mgh_decompress_dist",
+    "mgh_decompress_into",
 ]
 
 
@@ -101,6 +102,7 @@ def _hl():
                                C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp),
                                C.POINTER(Config), C.c_int]
     L.mgh_decompress.argtypes = [vp, C.c_size_t, C.POINTER(vp), C.POINTER(Config), C.c_int]
+    L.mgh_decompress_into.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.c_int, vp]
     L.mgh_dist_use_library.argtypes = [C.c_char_p]
     L.mgh_compress_dist.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(u64), C.c_double,
                                     C.c_double, C.c_int, vp, C.POINTER(vp), C.POINTER(C.c_size_t), vp, vp, C.c_int]
@@ -275,51 +277,36 @@ def infer(buf):
 def decompress(buf, config=None, out=None):
     """mgard_x::decompress. Returns a numpy array (host stream) or a cuda tensor (device stream).
     `out`: optional pre-allocated buffer -- a contiguous cuda tensor (device streams) or a
-    C-contiguous numpy array (host streams). Its element count and type are checked against the
-    header; for a device stream that check is skipped when MGARD_HIP_TRUST_OUT=1 (it costs two small
-    reads of device memory, ~60 us)."""
-    import os
+    C-contiguous numpy array (host streams). Its size and type are checked by the library against the
+    header it reads anyway (mgh_decompress_into: ValueError on a mismatch, nothing written)."""
     import torch
     L = _hl()
     cfg = config if config is not None else Config()
-
-    def check(out_numel, out_is_f32):
-        if isinstance(buf, torch.Tensor):
-            # ONE small read of device memory (the header of a uniform grid is a few hundred bytes)
-            try:
-                shape, dt = infer(buf[:4096].cpu().numpy())
-            except MgardHipError:
-                shape, dt = infer(buf)
-        else:
-            shape, dt = infer(buf)
-        if int(np.prod(shape)) != int(out_numel) or (dt == FLOAT) != bool(out_is_f32):
-            raise ValueError("`out` does not match the stream: %r elements of %s expected"
-                             % (int(np.prod(shape)), "float32" if dt == FLOAT else "float64"))
-        return shape, dt
-
-    if isinstance(buf, torch.Tensor) and buf.is_cuda:
-        if out is None:
-            shape, dt = infer(buf)
+    on_dev = isinstance(buf, torch.Tensor) and buf.is_cuda
+    if not on_dev:
+        buf = np.ascontiguousarray(buf)
+    if out is None:
+        shape, dt = infer(buf)
+        if on_dev:
             out = torch.empty(shape, dtype=torch.float32 if dt == FLOAT else torch.float64, device=buf.device)
         else:
-            if not (isinstance(out, torch.Tensor) and out.is_cuda and out.is_contiguous() and
-                    out.dtype in (torch.float32, torch.float64) and out.device == buf.device):
-                raise ValueError("`out` must be a contiguous float32/float64 cuda tensor on the stream's device")
-            if os.environ.get("MGARD_HIP_TRUST_OUT", "0") != "1":
-                check(out.numel(), out.dtype == torch.float32)
-        p, n, optr = C.c_void_p(buf.data_ptr()), buf.numel(), C.c_void_p(out.data_ptr())
-    else:
-        buf = np.ascontiguousarray(buf)
-        if out is None:
-            shape, dt = infer(buf)
             out = np.empty(shape, dtype=np.float32 if dt == FLOAT else np.float64)
-        else:
-            if not (isinstance(out, np.ndarray) and out.flags.c_contiguous and out.flags.writeable and
-                    out.dtype in (np.float32, np.float64)):
-                raise ValueError("`out` must be a writeable C-contiguous float32/float64 numpy array")
-            check(out.size, out.dtype == np.float32)
+    if on_dev:
+        if not (isinstance(out, torch.Tensor) and out.is_cuda and out.is_contiguous() and
+                out.dtype in (torch.float32, torch.float64) and out.device == buf.device):
+            raise ValueError("`out` must be a contiguous float32/float64 cuda tensor on the stream's device")
+        p, n, optr = C.c_void_p(buf.data_ptr()), buf.numel(), C.c_void_p(out.data_ptr())
+        nbytes, odt = out.numel() * out.element_size(), FLOAT if out.dtype == torch.float32 else DOUBLE
+    else:
+        if not (isinstance(out, np.ndarray) and out.flags.c_contiguous and out.flags.writeable and
+                out.dtype in (np.float32, np.float64)):
+            raise ValueError("`out` must be a writeable C-contiguous float32/float64 numpy array")
         p, n, optr = C.c_void_p(buf.ctypes.data), buf.size, C.c_void_p(out.ctypes.data)
-    _check(L.mgh_decompress(p, n, C.byref(optr), C.byref(cfg), 1))
+        nbytes, odt = out.nbytes, FLOAT if out.dtype == np.float32 else DOUBLE
+    rc = L.mgh_decompress_into(p, n, optr, nbytes, odt, C.byref(cfg))
+    if rc == -1 and b"mgh_decompress_into" in L.mgh_last_error():
+        raise ValueError(L.mgh_last_error().decode())
+    _check(rc)
     return out
 
 
