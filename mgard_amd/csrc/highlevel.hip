@@ -311,18 +311,20 @@ inline HostPrefixState &host_prefix() {
   static thread_local HostPrefixState s;
   return s;
 }
+int aux_read(void *dst, const void *src, size_t bytes);  // (below, with the cache)
 struct HostPrefix {
   HostPrefix(const void *dev, size_t size) {
     HostPrefixState &s = host_prefix();
     s.base = nullptr;
     const size_t want = std::min<size_t>(size, 320 * 1024);
     s.bytes.resize(want);
-    if (hipMemcpy(s.bytes.data(), dev, want, hipMemcpyDeviceToHost) == hipSuccess)
+    // (through the cache's pinned buffer and its own stream once a cache exists: a hipMemcpy into
+    // pageable memory is staged by the runtime, ~20 us more per call)
+    if (aux_read(s.bytes.data(), dev, want) == MGH_SUCCESS)
       s.base = (const uint8_t *)dev;
   }
   ~HostPrefix() { host_prefix().base = nullptr; }
 };
-int aux_read(void *dst, const void *src, size_t bytes);  // (below, with the cache)
 hipStream_t cache_copy_stream(int dev);                   // (below: the calling thread's copy stream on that device, or nullptr)
 // device -> host copy that is served from the prefix where it can be
 inline int dev_to_host(void *dst, const void *src, size_t bytes) {
