@@ -83,6 +83,7 @@ struct mgh_hierarchy {
   // (kernels_ipk_dma.hpp: LDS-DMA front end, everything requested up front; default), 0 = never
   int ipk_dma = 1;
   long ipk_dma_min_env = -1;
+  int inline_qp = 0;   // MGH_INLINE_QP: the finest level's kernel computes its quantizer itself (no k_make_qparams launch in front of it)
   int ipk_dma_rounds = 4;  // MGH_IPK_DMA_ROUNDS: k_ipk_dma also for levels whose tiles need up to this many rounds of resident workgroups
   size_t ipk_dma_min = 512;  // MGH_IPK_DMA_MIN: fewest tiles of a level for k_ipk_dma (two per CU; set in mgh_hierarchy_create)
   int absmax_warm_mb = 192;  // MGH_ABSMAX_WARM_MB: the norm pass reads all but the last so many MB of the input with nontemporal loads
@@ -207,6 +208,10 @@ template <typename T> struct DeviceState {
   // mgh_norm_stream_begin/add: the slot of the NEXT fused call already holds the reduction of its
   // input (accumulated slab by slab while the input was arriving from the host)
   bool norm_streamed = false;
+  // MGH_INLINE_QP: quantizer constants of the last inline call, on the device and as uploaded
+  QParamArgs<T> *qinl_dev = nullptr;
+  QParamArgs<T> qinl_host;
+  bool qinl_valid = false;
   T *normval = nullptr;                  // norm as T, written by k_make_qparams
   unsigned long long *oh_key = nullptr;  // outlier table of the 16-bit symbol path (grown on demand)
   long long *oh_val = nullptr;
@@ -467,6 +472,7 @@ template <typename T> void destroy_state(mgh_hierarchy *h) {
     (void)hipFree(ds->t2);
     (void)hipFree(ds->t3);
     (void)hipFree(ds->scratch_full);
+    (void)hipFree(ds->qinl_dev);
     (void)hipFree(ds->pack_in);
     (void)hipFree(ds->pack_out);
     (void)hipFree(ds->nd_w);
@@ -891,6 +897,11 @@ template <typename T> struct QuantParams {
   int64_t *oval = nullptr;
   unsigned long long ocap = 0;
   const T *d_qp = nullptr;  // device table [2 * (L + 1)] (k_make_qparams) instead of qz / vol
+  // MGH_INLINE_QP: the call's quantizer constants in device memory + the reduction scalar; a finest
+  // level that runs k_level_fused2 computes its quantizer itself and `after_first` is not called
+  const QParamArgs<T> *d_qinl = nullptr;
+  const unsigned long long *d_qslot = nullptr;
+  std::function<int()> inline_done;  // host bookkeeping of the skipped launch
 };
 
 template <typename T>
@@ -1067,7 +1078,13 @@ int decompose_fused(mgh_hierarchy *h, const T *data, T *coeff, const QuantParams
     }
     const int cls = level_class(h, b);
     {
-      if (l == L) TRY(after_first());
+      const bool inl = OUT == OUT_Q && l == L && qp->d_qinl && !(cls < h->box);
+      A.qinl = inl ? qp->d_qinl : nullptr;
+      A.qslot = inl ? qp->d_qslot : nullptr;
+      if (l == L) {
+        if (inl) TRY(qp->inline_done());
+        else TRY(after_first());
+      }
       // (the level kernels test the dictionary range in 32 bits: the entry points send larger
       // dictionaries through decompose + quantize)
       if (OUT == OUT_Q && !(qp->dict_size >= 0 && qp->dict_size <= ((int64_t)1 << 30)))
@@ -2257,7 +2274,7 @@ inline unsigned ld_grid(const LdView &V) { return (unsigned)std::min<uint64_t>((
 // The norm reduction of `data` (dense, or pitched with the strides of `view`) accumulated into `slot`.
 template <typename T>
 int norm_reduce(mgh_hierarchy *h, const T *data, double s, unsigned long long *slot, const LdView *view,
-                size_t n_cold, hipStream_t st) {
+                size_t n_cold, hipStream_t st, unsigned long long *zero_a = nullptr, unsigned long long *zero_b = nullptr) {
   const bool inf = (T)s == std::numeric_limits<T>::infinity();
   if (view) {
     if (inf) return launch(h, "absmax", st, [&] { k_norm_ld<T, false><<<ld_grid(*view), 256, 0, st>>>(data, *view, slot); });
@@ -2265,8 +2282,8 @@ int norm_reduce(mgh_hierarchy *h, const T *data, double s, unsigned long long *s
   }
   const size_t total = h->total;
   const unsigned grid = (unsigned)std::min<size_t>((total + 1023) / 1024, 256 * 8);
-  if (inf) return launch(h, "absmax", st, [&] { k_absmax<T><<<grid, 256, 0, st>>>(data, total, slot, n_cold); });
-  return launch(h, "sqsum", st, [&] { k_sqsum<T><<<grid, 256, 0, st>>>(data, total, (double *)slot, n_cold); });
+  if (inf) return launch(h, "absmax", st, [&] { k_absmax<T><<<grid, 256, 0, st>>>(data, total, slot, n_cold, zero_a, zero_b); });
+  return launch(h, "sqsum", st, [&] { k_sqsum<T><<<grid, 256, 0, st>>>(data, total, (double *)slot, n_cold, zero_a, zero_b); });
 }
 
 // Launch the norm reduction; the result stays in ds->scalar (absmax bits or double sum).
@@ -2397,6 +2414,7 @@ int fused_q_entry_device(mgh_hierarchy *h, const T *data, int ebtype, double tol
   const bool streamed = ds->norm_streamed && !d_norm && ebtype == MGH_REL;
   ds->norm_streamed = false;
   const bool need_norm = !d_norm && ebtype == MGH_REL && !streamed;
+  bool inline_qp = false;
   // The norm scalar has two slots used alternately: this call reduces into scalar[slot] (zero on
   // entry) and k_make_qparams zeroes the other one for the next call, together with the outlier
   // counter -- two memset launches less per step.
@@ -2414,8 +2432,31 @@ int fused_q_entry_device(mgh_hierarchy *h, const T *data, int ebtype, double tol
       const LdView V = ld_view(h, 0);
       TRY(norm_reduce<T>(h, data, s, slot, &V, 0, st));
     } else {
-      TRY(norm_reduce<T>(h, data, s, slot, nullptr, total > warm ? total - warm : 0, st));
+      inline_qp = h->inline_qp && h->D == 3 && !decomposed;
+      TRY(norm_reduce<T>(h, data, s, slot, nullptr, total > warm ? total - warm : 0, st,
+                         inline_qp ? (unsigned long long *)ocount : nullptr, inline_qp ? other : nullptr));
     }
+  }
+  QuantParams<T> qp;
+  if (inline_qp) {
+    // the call's constants in device memory (uploaded when they change: per hierarchy they are a
+    // function of bound type, tolerance and s)
+    QParamArgs<T> P;
+    TRY(fill_qparam_args<T>(h, d_norm, ebtype, tol, s, decomposed, nsub, nullptr, P));
+    P.scalar = nullptr;  // (the slot alternates: it travels in FusedArgs::qslot)
+    if (!ds->qinl_dev) TRY(dev_alloc(h, &ds->qinl_dev, (size_t)1));
+    if (!ds->qinl_valid || std::memcmp(&ds->qinl_host, &P, sizeof(P)) != 0) {
+      std::memcpy(&ds->qinl_host, &P, sizeof(P));
+      HIP_TRY(hipMemcpyAsync(ds->qinl_dev, &ds->qinl_host, sizeof(P), hipMemcpyHostToDevice, st));
+      ds->qinl_valid = true;
+    }
+    qp.d_qinl = ds->qinl_dev;
+    qp.d_qslot = slot;
+    qp.inline_done = [ds] {
+      ds->scalar_slot = 1 - ds->scalar_slot;
+      ds->fscal_dirty = false;
+      return (int)MGH_SUCCESS;
+    };
   }
   auto qparams = [&] {
     QParamArgs<T> P;
@@ -2427,7 +2468,6 @@ int fused_q_entry_device(mgh_hierarchy *h, const T *data, int ebtype, double tol
     ds->fscal_dirty = false;
     return (int)MGH_SUCCESS;
   };
-  QuantParams<T> qp;
   qp.d_qp = ds->qz;
   qp.dict_size = (int64_t)dict_size;
   qp.prep_huffman = prep_huffman;
@@ -2601,6 +2641,7 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->ipk_chunk_k = (int)env_get("MGH_IPK_CHUNK_K", h->ipk_chunk_k);
     h->tail_solves = (int)env_get("MGH_TAIL_SOLVES", h->tail_solves);
     h->ipk_dma_rounds = (int)env_get("MGH_IPK_DMA_ROUNDS", h->ipk_dma_rounds);
+    h->inline_qp = (int)env_get("MGH_INLINE_QP", h->inline_qp);
     h->nd_rows = (int)env_get("MGH_ND_ROWS", h->nd_rows);
     h->cls1 = (size_t)env_get("MGH_CLS1", (long)h->cls1);
     h->cls2 = (size_t)env_get("MGH_CLS2", (long)h->cls2);

@@ -52,6 +52,7 @@ inline const EnvSwitch *env_switches(size_t *count) {
       {"MGH_IPK_DMA_ROUNDS", 1, 64},
       {"MGH_HL_COPY_PARTS", 1, 64},
       {"MGH_HUFF_LEAN", 0, 1},
+      {"MGH_INLINE_QP", 0, 1},
       {"MGH_HUFF_DBG", 0, 7},
   };
   *count = sizeof(k) / sizeof(k[0]);

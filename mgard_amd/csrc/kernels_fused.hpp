@@ -27,6 +27,8 @@
 
 namespace mgh {
 
+template <typename T> struct QParamArgs;  // (below)
+
 template <typename T> struct FusedArgs {
   // level geometry: fine sizes n, coarse sizes m (r, c, f)
   int n[3], m[3];
@@ -46,6 +48,12 @@ template <typename T> struct FusedArgs {
   // never left the device -- read from qp[level] / qp[nlev + level] (k_make_qparams)
   T quantizer, volume;
   const T *qp;
+  // ... or (round 6, MGH_INLINE_QP: the finest level of a REL call whose norm was just reduced)
+  // computed by every workgroup itself from the reduction scalar `qslot` and the call's constants
+  // `qinl` in device memory -- the k_make_qparams launch between the norm pass and this kernel
+  // is gone; workgroup 0 leaves the table for the levels below
+  const QParamArgs<T> *qinl;
+  const unsigned long long *qslot;
   int level, nlev;
   int64_t dict_size;
   int prep_huffman;
@@ -200,21 +208,24 @@ template <typename T> struct QParamArgs {
 };
 
 template <typename T>
-__device__ __forceinline__ void make_qparams_body(const QParamArgs<T> &P) {
+__device__ __forceinline__ T qparams_norm(const QParamArgs<T> &P, const unsigned long long *scalar) {
   T norm;
   if (P.d_norm) {
     norm = *P.d_norm;
   } else if (P.s_is_inf) {
-    const unsigned long long bits = *P.scalar;
+    const unsigned long long bits = *scalar;
     if (sizeof(T) == 4) norm = (T)__uint_as_float((unsigned)bits); else norm = (T)__longlong_as_double((long long)bits);
   } else {
-    const double sum = __longlong_as_double((long long)*P.scalar);
+    const double sum = __longlong_as_double((long long)*scalar);
     norm = (T)sum;
     if (sizeof(T) == 4) norm = P.normalize ? (T)sqrtf((float)(norm / (T)P.total)) : (T)sqrtf((float)norm);
     else norm = P.normalize ? (T)sqrt((double)(norm / (T)P.total)) : (T)sqrt((double)norm);
   }
   if (!P.d_norm && norm == 0) norm = sizeof(T) == 4 ? (T)1.1920928955078125e-7f : (T)2.220446049250313e-16;
-  *P.norm_out = norm;
+  return norm;
+}
+// 2 x the absolute tolerance of the call (the numerator of every level's quantizer)
+template <typename T> __device__ __forceinline__ double qparams_abs_tol2(const QParamArgs<T> &P, T norm) {
   double abs_tol;
   if (P.decomposed) {
     T lt;
@@ -230,14 +241,44 @@ __device__ __forceinline__ void make_qparams_body(const QParamArgs<T> &P) {
     if (P.rel) abs_tol *= norm;
   }
   abs_tol *= 2;
+  return abs_tol;
+}
+template <typename T> __device__ __forceinline__ T qparams_level(double abs_tol2, double den) {
+  T q = (T)(abs_tol2 / den);
+  q = 1.0f / q;
+  return q;
+}
+
+template <typename T>
+__device__ __forceinline__ void make_qparams_body(const QParamArgs<T> &P) {
+  const T norm = qparams_norm<T>(P, P.scalar);
+  *P.norm_out = norm;
+  const double abs_tol = qparams_abs_tol2<T>(P, norm);
   for (int l = 0; l < P.nlev; l++) {
-    T q = (T)(abs_tol / P.den[l]);
-    q = 1.0f / q;
-    P.qp[l] = q;
+    P.qp[l] = qparams_level<T>(abs_tol, P.den[l]);
     P.qp[P.nlev + l] = P.vol[l];
   }
   if (P.reset_count) *P.reset_count = 0;
   if (P.zero_next) *P.zero_next = 0;
+}
+
+// The finest level's own quantizer inside the level kernel (FusedArgs::qinl): every workgroup the
+// same single IEEE operations on the same inputs as make_qparams_body -- the same bits; the first
+// thread of the launch also leaves the table and the norm for the kernels behind it.
+template <typename T>
+__device__ __forceinline__ void inline_qparams(FusedArgs<T> &A, bool first_thread) {
+  const QParamArgs<T> &P = *A.qinl;
+  const T norm = qparams_norm<T>(P, A.qslot);
+  const double abs_tol = qparams_abs_tol2<T>(P, norm);
+  A.quantizer = qparams_level<T>(abs_tol, P.den[A.level]);
+  A.volume = P.vol[A.level];
+  if (first_thread) {
+    *P.norm_out = norm;
+    for (int l = 0; l < P.nlev; l++) {
+      P.qp[l] = qparams_level<T>(abs_tol, P.den[l]);
+      P.qp[P.nlev + l] = P.vol[l];
+    }
+  }
 }
 
 template <typename T> __global__ void k_make_qparams(QParamArgs<T> P) {

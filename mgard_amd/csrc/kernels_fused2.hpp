@@ -787,7 +787,9 @@ k_level_fused2(FusedArgs<T> A, Fused2Grid G, Fused4<T> Q) {
   __shared__ uint32_t ol_off[kLists ? 8 * kOutlierStashOf<T> : 1];
   if (kLists && threadIdx.x == 0) ol_flag = 0;  // (no pair has sequence number 0; visible behind the tile's first barrier)
   const OutlierShared<T> OS{ol_cnt, &ol_base, &ol_flag, ol_val, ol_off};
-  if ((OUT == OUT_Q || OUT == OUT_QH) && A.qp) {
+  if ((OUT == OUT_Q || OUT == OUT_QH) && A.qinl) {
+    inline_qparams<T>(A, threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
+  } else if ((OUT == OUT_Q || OUT == OUT_QH) && A.qp) {
     A.quantizer = A.qp[A.level];
     A.volume = A.qp[A.nlev + A.level];
   }

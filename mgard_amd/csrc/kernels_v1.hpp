@@ -583,7 +583,14 @@ template <> struct Vec16<double> { using type = double2; static constexpr int N 
 
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_absmax(const T *__restrict__ v, size_t n, unsigned long long *out_bits, size_t n_cold = 0) {
+k_absmax(const T *__restrict__ v, size_t n, unsigned long long *out_bits, size_t n_cold = 0,
+         unsigned long long *zero_a = nullptr, unsigned long long *zero_b = nullptr) {
+  // (MGH_INLINE_QP: the words k_make_qparams used to reset -- the call's outlier counter, the norm
+  // scalar of the NEXT call -- nothing touches them while the norm is reduced)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (zero_a) *zero_a = 0;
+    if (zero_b) *zero_b = 0;
+  }
   using V = typename Vec16<T>::type;
   constexpr int VN = Vec16<T>::N;
   T m = 0;
@@ -654,7 +661,12 @@ k_stream_mix(const T *__restrict__ in, int64_t *__restrict__ out, T *__restrict_
 
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_sqsum(const T *__restrict__ v, size_t n, double *out, size_t n_cold = 0) {
+k_sqsum(const T *__restrict__ v, size_t n, double *out, size_t n_cold = 0,
+        unsigned long long *zero_a = nullptr, unsigned long long *zero_b = nullptr) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // (see k_absmax)
+    if (zero_a) *zero_a = 0;
+    if (zero_b) *zero_b = 0;
+  }
   // 16-byte loads over the aligned body like k_absmax (the L2 norm is a sum: its last bits depend
   // on the order of the additions -- across lanes, waves and the atomicAdd below -- in any case);
   // the leading n_cold elements with nontemporal loads
