@@ -1480,14 +1480,41 @@ inline NdRowBox nd_row_box(const NdBox &b) {
 inline unsigned nd_row_grid(uint64_t rows) {
   return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((rows + 4 * kNdRowsPerWave - 1) / (4 * kNdRowsPerWave), 1u << 20));
 }
+// the coefficient kernel's view of a level; false: an offset does not fit 32 bits (k_nd_coeff then)
+inline bool nd_coeff_box(const NdBox &b, uint64_t nn, NdCoeffBox *out) {
+  const NdRowBox rb = nd_row_box(b);
+  uint64_t span = 0;
+  for (int k = 0; k < kNd; k++) span += (uint64_t)(rb.n[k] - 1) * rb.fs[k];
+  // rows of a group: eight where that still leaves every SIMD a wave (8 x 8 x 64^3: 13.5 us on the
+  // second level with eight, 16.9 us with two), fewer on the small levels (7.7 -> 4.5 us on the third)
+  const uint64_t lines = (uint64_t)rb.n[0] * rb.n[1] * rb.n[2];
+  uint32_t gsz = kNdRowsPerWave;
+  while (gsz > 2 && lines * ((rb.n[3] + gsz - 1) / gsz) < 4 * 1024) gsz /= 2;
+  const uint64_t gpl = (rb.n[3] + gsz - 1) / gsz;
+  const uint64_t groups = lines * gpl;
+  if (span >= ((uint64_t)1 << 31) || nn >= ((uint64_t)1 << 31) || groups >= ((uint64_t)1 << 31)) return false;
+  NdCoeffBox c{};
+  for (int k = 0; k < kNd; k++) {
+    c.n[k] = rb.n[k];
+    c.m[k] = rb.m[k];
+    c.fs[k] = (uint32_t)rb.fs[k];
+    c.ns[k] = (uint32_t)rb.ns[k];
+  }
+  c.gsz = gsz;
+  c.gpl = (uint32_t)gpl;
+  c.groups = (uint32_t)groups;
+  *out = c;
+  return true;
+}
 template <typename T>
 int nd_coeff_launch(mgh_hierarchy *h, const NdBox &b, const NdTables<T> &tb, T *w, T *v, uint64_t nn, int mode,
                     hipStream_t st) {
-  if (h->nd_rows && b.fs[b.D - 1] == 1) {
-    const NdRowBox rb = nd_row_box(b);
+  NdCoeffBox cb;
+  if (h->nd_rows && b.fs[b.D - 1] == 1 && nd_coeff_box(b, nn, &cb)) {
     NdTables<T> ta{};
     for (int d = 0; d < b.D; d++) ta.ratio[d + kNd - b.D] = tb.ratio[d];
-    return launch(h, "nd_coeff", st, [&] { k_nd_coeff_rows<T><<<nd_row_grid(rb.rows), 256, 0, st>>>(rb, ta, w, v, mode); });
+    const unsigned grid = (unsigned)std::max<uint32_t>(1, std::min<uint32_t>((cb.groups + 3) / 4, 1u << 20));
+    return launch(h, "nd_coeff", st, [&] { k_nd_coeff_rows<T><<<grid, 256, 0, st>>>(cb, ta, w, v, mode); });
   }
   return launch(h, "nd_coeff", st, [&] { k_nd_coeff<T><<<nd_grid(nn), 256, 0, st>>>(b, tb, w, v, nn, mode); });
 }

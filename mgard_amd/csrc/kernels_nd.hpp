@@ -89,6 +89,53 @@ template <typename T> struct NdLerp<T, 0> {
   }
 };
 
+// The row-wise kernel's form: the fastest dimension innermost as in NdLerp with it in front, but
+// every corner row of the slow dimensions is LOADED ONCE -- each lane one element -- and the odd
+// lanes take their two partners p - 1 and p + 1 from the neighbouring lanes' registers (one DPP
+// move each) instead of loading the corner row three times (p - 1 and p + 1 for the odd lanes, p
+// for the even ones).
+__device__ __forceinline__ int lane_below(int x) {  // lane i: the value of lane i - 1 (wave_shr:1)
+  return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int lane_above(int x) {  // lane i: the value of lane i + 1 (wave_shl:1)
+  return __builtin_amdgcn_update_dpp(x, x, 0x130, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float lane_below(float x) { return __int_as_float(lane_below(__float_as_int(x))); }
+__device__ __forceinline__ float lane_above(float x) { return __int_as_float(lane_above(__float_as_int(x))); }
+__device__ __forceinline__ double lane_below(double x) {
+  return __hiloint2double(lane_below(__double2hiint(x)), lane_below(__double2loint(x)));
+}
+__device__ __forceinline__ double lane_above(double x) {
+  return __hiloint2double(lane_above(__double2hiint(x)), lane_above(__double2loint(x)));
+}
+// (a wave-uniform pointer and the lane's BYTE offset in 32 bits: base[p] with a 32-bit p is p * 4 in
+// 64 bits to the compiler)
+template <typename T> __device__ __forceinline__ T *at32(T *base, uint32_t byte_off) {
+  return (T *)((char *)base + byte_off);
+}
+template <typename T> __device__ __forceinline__ const T *at32(const T *base, uint32_t byte_off) {
+  return (const T *)((const char *)base + byte_off);
+}
+// corner: the corner row (wave-uniform); lb: the byte offset of the element the lane loads of it.
+// The loads are unconditional -- a load behind a condition is a branch and a wait PER CORNER, the
+// rows' corners then come one round trip after the other -- so lb must be a valid element for
+// every lane (k_nd_coeff_rows chooses it).
+template <typename T, int K> struct NdLerpRow {
+  static __device__ __forceinline__ T run(const T *corner, uint32_t lb, bool odd_f, T tf, const uint32_t *st,
+                                          const T *t) {
+    return lerp_ref(NdLerpRow<T, K - 1>::run(corner - st[K - 1], lb, odd_f, tf, st, t),
+                    NdLerpRow<T, K - 1>::run(corner + st[K - 1], lb, odd_f, tf, st, t), t[K - 1]);
+  }
+};
+template <typename T> struct NdLerpRow<T, 0> {
+  static __device__ __forceinline__ T run(const T *corner, uint32_t lb, bool odd_f, T tf, const uint32_t *,
+                                          const T *) {
+    const T c = *at32(corner, lb);
+    const T lo = lane_below(c), hi = lane_above(c);
+    return odd_f ? lerp_ref(lo, hi, tf) : c;
+  }
+};
+
 // interpolant of the node at natural position pos (linear offset wl in the natural-order
 // compact box w with strides ns; odd dims marked): nested lerps, fastest dim innermost
 template <typename T>
@@ -280,85 +327,170 @@ __device__ __forceinline__ void nd_row_next(const uint32_t *e, uint32_t *pos) {
   }
 }
 
+// The coefficient kernel's view: 32-bit strides (the host sends larger arrays to k_nd_coeff) and the
+// rows in GROUPS -- gsz consecutive positions of dimension 3 at one position of dimensions 0..2 --
+// so that everything dimensions 0..2 decide (which of them interpolate, with what strides and
+// ratios) is worked out once for the group's rows.
+struct NdCoeffBox {
+  uint32_t n[kNd], m[kNd];   // fine / coarse extents, right-aligned
+  uint32_t fs[kNd];          // strides of the reordered (full) array
+  uint32_t ns[kNd];          // strides of the natural-order compact box
+  uint32_t gsz;              // rows of a group: 2, 4 or 8 (even: a group starts on a coarse position)
+  uint32_t gpl;              // groups per line of dimension 3
+  uint32_t groups;           // n[0] n[1] n[2] gpl
+};
+
+// The rows of one parity class of dimension 3 in a group (odd3: the rows that interpolate along it):
+// K slow dimensions interpolate, strides st / ratios tt fastest first (for the odd class entry 0 is
+// dimension 3's, its ratio the row's). Everything along the row itself -- the lane's byte offsets,
+// the ratio tf -- is the caller's: the same for all rows.
+template <typename T, int K> struct NdCoeffClass {
+  const NdCoeffBox &b;
+  const T *__restrict__ ratio3;
+  T *__restrict__ w, *__restrict__ v;
+  int mode;
+  bool odd3;
+  uint32_t off012, wl012;
+  const uint32_t *st;
+  T tt[K ? K : 1];
+  uint32_t pb, fb;   // the lane's BYTE offsets along the row: natural order / reordered
+  uint32_t lb;       // ... and of the element it loads of every corner row
+  bool act, any, odd_f;
+  T tf;
+
+  // the value row q stores (mode 0: into v, else into w; *vr / *wr: the row there, wave-uniform)
+  __device__ __forceinline__ T value(uint32_t q, T **vr, T **wr) {
+    const uint32_t n3 = b.n[3], m3 = b.m[3];
+    const uint32_t idx3 = odd3 ? m3 + (q - 1) / 2 : (q == n3 - 1 ? m3 - 1 : q / 2);
+    *vr = v + (off012 + idx3 * b.fs[3]);
+    *wr = w + (wl012 + q * b.ns[3]);
+    if (odd3) tt[0] = ratio3[q - 1];
+    const T mine = act ? (mode == 0 ? *at32(*wr, pb) : *at32(*vr, fb)) : (T)0;  // (in flight with the partners)
+    const T interp = NdLerpRow<T, K>::run(*wr, lb, odd_f, tf, st, tt);
+    return mode == 0 ? (any ? mine - interp : mine) : mine + interp;
+  }
+  __device__ __forceinline__ void store(T x, T *vr, T *wr) {
+    if (act) {
+      if (mode == 0) *at32(vr, fb) = x;
+      else *at32(wr, pb) = x;
+    }
+  }
+  // the class's rows of q0 <= q < q1, two at a time: the second row's loads leave before the first
+  // row's arithmetic (a row is one round trip to memory; the wave has nothing else to do meanwhile)
+  __device__ __forceinline__ void run(uint32_t q0, uint32_t q1) {
+    const uint32_t n3 = b.n[3];
+    const bool tail = n3 % 2 == 0 && q1 == n3;          // the last position of an even extent: coarse
+    const uint32_t qa = odd3 ? q0 + 1 : q0;              // (q0 is a multiple of the group size: even)
+    const uint32_t qe = odd3 && tail ? q1 - 1 : q1;
+    uint32_t q = qa;
+    for (; q + 2 < qe; q += 4) {
+      T *o0, *w0, *o1, *w1;
+      const T x0 = value(q, &o0, &w0), x1 = value(q + 2, &o1, &w1);
+      store(x0, o0, w0);
+      store(x1, o1, w1);
+    }
+    if (q < qe) {
+      T *o0, *w0;
+      const T x0 = value(q, &o0, &w0);
+      store(x0, o0, w0);
+    }
+    if (!odd3 && tail) {
+      T *o0, *w0;
+      const T x0 = value(n3 - 1, &o0, &w0);
+      store(x0, o0, w0);
+    }
+  }
+};
+
+template <typename T, int K>
+__device__ __forceinline__ void nd_coeff_class(const NdCoeffBox &b, const T *__restrict__ ratio3, T *__restrict__ w,
+                                               T *__restrict__ v, int mode, uint32_t q0, uint32_t q1, bool odd3,
+                                               uint32_t off012, uint32_t wl012, const uint32_t *st, const T *t,
+                                               uint32_t p, uint32_t off_f, uint32_t pl, bool own, bool odd_f, T tf) {
+  const bool any = odd_f || K > 0;
+  NdCoeffClass<T, K> c{b, ratio3, w, v, mode, odd3, off012, wl012, st, {}, p * (uint32_t)sizeof(T),
+                       off_f * (uint32_t)sizeof(T), pl * (uint32_t)sizeof(T), own && (mode == 0 || any), any, odd_f, tf};
+#pragma unroll
+  for (int k = 0; k < K; k++) c.tt[k] = t[k];
+  c.run(q0, q1);
+}
+
 // modes as in k_nd_coeff
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_nd_coeff_rows(NdRowBox b, NdTables<T> tb, T *__restrict__ w, T *__restrict__ v, int mode) {
+k_nd_coeff_rows(NdCoeffBox b, NdTables<T> tb, T *__restrict__ w, T *__restrict__ v, int mode) {
   const int lane = threadIdx.x & 63;
-  const uint64_t wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (uint64_t)blockIdx.x * 4;
-  const uint64_t nwave = (uint64_t)gridDim.x * 4;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + blockIdx.x * 4;
+  const uint32_t nwave = gridDim.x * 4;
   const uint32_t nf = b.n[kNd - 1], mf = b.m[kNd - 1];
   const T *__restrict__ rf = tb.ratio[kNd - 1];
-  for (uint64_t r0 = wave * kNdRowsPerWave; r0 < b.rows; r0 += nwave * kNdRowsPerWave) {
-    uint32_t pos[kNd - 1];
-    nd_row_start(b.n, r0, pos);
-    const uint64_t r1 = min(b.rows, r0 + kNdRowsPerWave);
-    for (uint64_t row = r0; row < r1; row++) {
-      // the row's slow dimensions: parity, reordered offset, natural offset, interpolation partners
-      uint64_t off_slow = 0, wl_row = 0;
-      uint64_t s1 = 0, s2 = 0, s3 = 0, s4 = 0;  // natural strides of the odd slow dims, fastest first
-      T t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-      int nod = 0;
+  for (uint32_t g = wave; g < b.groups; g += nwave) {
+    // the group: rows q0..q1 of the line at (pos[0], pos[1], pos[2])
+    uint32_t line = g / b.gpl;
+    const uint32_t q0 = (g - line * b.gpl) * b.gsz, q1 = min(b.n[3], q0 + b.gsz);
+    uint32_t pos[3];
 #pragma unroll
-      for (int d = kNd - 2; d >= 0; d--) {
-        const uint32_t p = pos[d], n = b.n[d], m = b.m[d];
-        const bool odd = (p & 1) && !(n % 2 == 0 && p == n - 1);
-        const uint32_t idx = odd ? m + (p - 1) / 2 : (p == n - 1 ? m - 1 : p / 2);
-        off_slow += idx * b.fs[d];
-        wl_row += p * b.ns[d];
-        if (odd) {
-          const uint64_t st = b.ns[d];
-          const T t = tb.ratio[d][p - 1];
-          if (nod == 0) s1 = st, t1 = t;
-          else if (nod == 1) s2 = st, t2 = t;
-          else if (nod == 2) s3 = st, t3 = t;
-          else s4 = st, t4 = t;
-          nod++;
-        }
+    for (int d = 2; d >= 0; d--) {
+      const uint32_t qq = line / b.n[d];
+      pos[d] = line - qq * b.n[d];
+      line = qq;
+    }
+    // dimensions 0..2: reordered offset, natural offset, and of the odd ones stride and ratio, fastest first
+    uint32_t off012 = 0, wl012 = 0;
+    uint32_t sx[3] = {0, 0, 0};
+    T tx[3] = {0, 0, 0};
+    int nod = 0;
+#pragma unroll
+    for (int d = 2; d >= 0; d--) {
+      const uint32_t pp = pos[d], n = b.n[d], m = b.m[d];
+      const bool odd = (pp & 1) && !(n % 2 == 0 && pp == n - 1);
+      const uint32_t idx = odd ? m + (pp - 1) / 2 : (pp == n - 1 ? m - 1 : pp / 2);
+      off012 += idx * b.fs[d];
+      wl012 += pp * b.ns[d];
+      if (odd) {
+        const T t = tb.ratio[d][pp - 1];
+        if (nod == 0) sx[0] = b.ns[d], tx[0] = t;
+        else if (nod == 1) sx[1] = b.ns[d], tx[1] = t;
+        else sx[2] = b.ns[d], tx[2] = t;
+        nod++;
       }
-      const uint64_t sa[kNd] = {1, s1, s2, s3, s4};  // with the fastest dimension in front ...
-      const uint64_t sb[kNd] = {s1, s2, s3, s4, 0};  // ... and without it
-      for (uint32_t p = lane; p < nf; p += 64) {
-        const bool odd_f = (p & 1) && !(nf % 2 == 0 && p == nf - 1);
-        const uint32_t idx_f = odd_f ? mf + (p - 1) / 2 : (p == nf - 1 ? mf - 1 : p / 2);
-        const uint64_t off = off_slow + idx_f * b.fs[kNd - 1], wl = wl_row + p;
-        const bool any = odd_f || nod > 0;
-        if (mode == 1) {
-          if (!any) w[wl] = v[off];
-          continue;
-        }
-        if (mode == 2 && !any) continue;
-        T interp = 0;
-        if (any) {
-          if (odd_f) {
-            const T ta[kNd] = {rf[p - 1], t1, t2, t3, t4};
-            switch (nod) {
-            case 0: interp = NdLerp<T, 1>::run(w, wl, sa, ta); break;
-            case 1: interp = NdLerp<T, 2>::run(w, wl, sa, ta); break;
-            case 2: interp = NdLerp<T, 3>::run(w, wl, sa, ta); break;
-            case 3: interp = NdLerp<T, 4>::run(w, wl, sa, ta); break;
-            default: interp = NdLerp<T, 5>::run(w, wl, sa, ta); break;
-            }
-          } else {
-            const T tb2[kNd] = {t1, t2, t3, t4, 0};
-            switch (nod) {
-            case 1: interp = NdLerp<T, 1>::run(w, wl, sb, tb2); break;
-            case 2: interp = NdLerp<T, 2>::run(w, wl, sb, tb2); break;
-            case 3: interp = NdLerp<T, 3>::run(w, wl, sb, tb2); break;
-            default: interp = NdLerp<T, 4>::run(w, wl, sb, tb2); break;
-            }
+    }
+    const uint32_t so[4] = {b.ns[3], sx[0], sx[1], sx[2]};  // the rows odd in dimension 3: it comes first
+    const T to[4] = {0, tx[0], tx[1], tx[2]};
+    // (the whole wave goes round, lanes trade values; of a row longer than the wave 62 elements a
+    // round, lanes 62 and 63 there only as partners: the odd lane 63 would want element p + 1)
+    for (uint32_t p0 = 0, step; p0 < nf; p0 += step) {
+      step = nf - p0 <= 64 ? 64 : 62;
+      const uint32_t p = p0 + lane;
+      const bool in = p < nf, own = in && lane < step;
+      const bool odd_f = in && (p & 1) && !(nf % 2 == 0 && p == nf - 1);
+      const uint32_t idx_f = odd_f ? mf + (p - 1) / 2 : (p == nf - 1 ? mf - 1 : p / 2);
+      const uint32_t off_f = idx_f * b.fs[kNd - 1];
+      // every lane loads, of every corner row, an element that is there and coarse along the row:
+      // its own, the odd lanes (who only want their neighbours' values) the one before, the lanes
+      // beyond the row its last
+      const uint32_t pl = !in ? nf - 1 : odd_f ? p - 1 : p;
+      if (mode == 1) {  // the all-coarse nodes: even rows of a group with no odd dimension, even lanes
+        if (nod == 0 && own && !odd_f)
+          for (uint32_t q = q0; q < q1; q++) {
+            const bool o = (q & 1) && !(b.n[3] % 2 == 0 && q == b.n[3] - 1);
+            if (o) continue;
+            const uint32_t idx3 = q == b.n[3] - 1 ? b.m[3] - 1 : q / 2;
+            w[wl012 + q * b.ns[3] + p] = v[off012 + idx3 * b.fs[3] + off_f];
           }
-        }
-        if (mode == 0) {
-          const T centre = w[wl];
-          v[off] = any ? centre - interp : centre;
-        } else {
-          T res = v[off];
-          res += interp;
-          w[wl] = res;
-        }
+        continue;
       }
-      nd_row_next(b.n, pos);
+      const T tf = odd_f ? rf[p - 1] : (T)0;
+#define MGH_ND_CLASSES(K)                                                                                              \
+  nd_coeff_class<T, K>(b, tb.ratio[3], w, v, mode, q0, q1, false, off012, wl012, sx, tx, p, off_f, pl, own, odd_f, tf); \
+  nd_coeff_class<T, K + 1>(b, tb.ratio[3], w, v, mode, q0, q1, true, off012, wl012, so, to, p, off_f, pl, own, odd_f, tf);
+      switch (nod) {  // (the group's)
+      case 0: MGH_ND_CLASSES(0) break;
+      case 1: MGH_ND_CLASSES(1) break;
+      case 2: MGH_ND_CLASSES(2) break;
+      default: MGH_ND_CLASSES(3) break;
+      }
+#undef MGH_ND_CLASSES
     }
   }
 }
