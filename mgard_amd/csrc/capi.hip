@@ -1541,7 +1541,16 @@ int nd_correction(mgh_hierarchy *h, int l, const T *v, const NdBox &b, T **out, 
     uint64_t total = 1;
     for (int d = 0; d < D; d++) total *= (d == a ? s.m : s.e[d]);
     T *dst = bufs[which];
-    if (h->nd_rows) {
+    uint64_t outer = 1, inner = 1;
+    for (int d = 0; d < a; d++) outer *= s.e[d];
+    for (int d = a + 1; d < D; d++) inner *= s.e[d];
+    const uint64_t plane = (uint64_t)s.m * inner, tiles = (plane + 1023) / 1024;
+    if (h->nd_rows && a < D - 1 && (uint64_t)s.n * inner < ((uint64_t)1 << 31) && outer * tiles < ((uint64_t)1 << 31)) {
+      // (the compact result of the sweep before: a 3-D view is all there is to it)
+      const NdMidSweep ms{(uint32_t)outer, s.n, s.m, (uint32_t)inner, (uint32_t)plane, (uint32_t)tiles};
+      const unsigned grid = (unsigned)std::min<uint64_t>(outer * tiles, 1u << 20);
+      TRY(launch(h, "nd_lpk", st, [&] { k_nd_lpk_mid<T><<<grid, 256, 0, st>>>(ms, cur, dst, ds->nd[l].mass[a]); }));
+    } else if (h->nd_rows) {
       NdRowSweep rs{};
       const int sh = kNd - D;
       for (int k = 0; k < kNd; k++) {

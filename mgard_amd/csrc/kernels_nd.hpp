@@ -574,6 +574,63 @@ k_nd_lpk_rows(NdRowSweep s, const T *__restrict__ in, T *__restrict__ out, const
   }
 }
 
+// k_nd_lpk along a dimension that is NOT the fastest: every sweep but the first reads the compact
+// result of the one before -- (outer, n along a, inner) with the inner elements contiguous, no zero
+// rule -- and that is all the kernel needs to know: no positions in five dimensions, no rows of 33
+// elements in 64 lanes. One element a thread, four a thread along the (q, i) plane of one outer
+// index; every load unconditional, of a row clamped into the pencil, the value then chosen or not
+// (a load behind a per-lane condition is a branch and a wait of its own).
+struct NdMidSweep {
+  uint32_t outer, n, m, inner;
+  uint32_t plane;   // m * inner: outputs per outer index
+  uint32_t tiles;   // ceil(plane / 1024)
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_nd_lpk_mid(NdMidSweep s, const T *__restrict__ in, T *__restrict__ out, const T *__restrict__ mt) {
+  const uint32_t m = s.m, nodd = s.n - s.m, I = s.inner;
+  const uint32_t olast = nodd ? nodd - 1 : 0;
+  const uint32_t nblk = s.outer * s.tiles;
+  for (uint32_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const uint32_t o = blk / s.tiles, tile = blk - o * s.tiles;
+    const T *pe = in + (uint64_t)o * s.n * I;        // the coarse rows of the pencil's plane ...
+    const T *po = nodd ? pe + (uint64_t)m * I : pe;  // ... and the odd ones behind them
+    T *po_out = out + (uint64_t)o * s.plane;
+    uint32_t r = tile * 1024 + threadIdx.x;
+    uint32_t q = r / I, i = r - q * I;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (r < s.plane) {
+        const uint32_t qm = q >= 1 ? q - 1 : 0;
+        const T la = pe[qm * I + i], lb = po[min(qm, olast) * I + i], lc = pe[q * I + i],
+                ld = po[min(q, olast) * I + i], le = pe[min(q + 1, m - 1) * I + i];
+        const T a = q >= 1 ? la : (T)0;
+        const T bq = (q >= 1 && q - 1 < nodd) ? lb : (T)0;
+        const T c = lc;
+        const T d = q < nodd ? ld : (T)0;
+        const T e = q + 1 < m ? le : (T)0;
+        const T w0 = mt[0 * m + q], w1 = mt[1 * m + q], w2 = mt[2 * m + q], w3 = mt[3 * m + q],
+                w4 = mt[4 * m + q], w5 = mt[5 * m + q], w6 = mt[6 * m + q], r1w = mt[7 * m + q],
+                r4w = mt[8 * m + q];
+        const T tb = a * w0 + bq * w1 + c * w2;
+        T tc = bq * w2 + c * w3 + d * w4;
+        const T td = c * w4 + d * w5 + e * w6;
+        tc += tb * r1w + td * r4w;
+        po_out[r] = tc;
+      }
+      r += 256;
+      if (I >= 256) {
+        i += 256;
+        if (i >= I) i -= I, q++;
+      } else {
+        q = r / I;
+        i = r - q * I;
+      }
+    }
+  }
+}
+
 // v[coarse box, full strides] +/-= corr[compact]
 template <typename T>
 __global__ void __launch_bounds__(256)
