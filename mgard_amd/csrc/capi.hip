@@ -1519,6 +1519,36 @@ int nd_coeff_launch(mgh_hierarchy *h, const NdBox &b, const NdTables<T> &tb, T *
   return launch(h, "nd_coeff", st, [&] { k_nd_coeff<T><<<nd_grid(nn), 256, 0, st>>>(b, tb, w, v, nn, mode); });
 }
 
+// the first sweep's view (along the fastest dimension, s.a = D - 1); false: too many rows for 32 bits
+inline bool nd_fast_sweep(const NdSweep &s, NdFastSweep *out) {
+  NdFastSweep f{};
+  const int sh = kNd - s.D;
+  for (int k = 0; k < kNd - 1; k++) {
+    f.e[k] = 1;
+    f.is[k] = 0;
+    f.mc[k] = 1;
+  }
+  for (int d = 0; d < s.D - 1; d++) {
+    f.e[d + sh] = s.e[d];
+    f.is[d + sh] = s.is[d];
+    f.mc[d + sh] = s.mc[d];
+  }
+  f.sf = s.is[s.D - 1];
+  f.n = s.n;
+  f.m = s.m;
+  f.zero_all_coarse = s.zero_all_coarse;
+  const uint64_t lines = (uint64_t)f.e[0] * f.e[1] * f.e[2];
+  uint32_t gsz = kNdRowsPerWave;
+  while (gsz > 2 && lines * ((f.e[3] + gsz - 1) / gsz) < 4 * 1024) gsz /= 2;  // (as nd_coeff_box)
+  const uint64_t gpl = (f.e[3] + gsz - 1) / gsz;
+  if (lines * gpl >= ((uint64_t)1 << 31)) return false;
+  f.gsz = gsz;
+  f.gpl = (uint32_t)gpl;
+  f.groups = (uint32_t)(lines * gpl);
+  *out = f;
+  return true;
+}
+
 template <typename T>
 int nd_correction(mgh_hierarchy *h, int l, const T *v, const NdBox &b, T **out, hipStream_t st) {
   auto *ds = DS<T>(h);
@@ -1541,6 +1571,7 @@ int nd_correction(mgh_hierarchy *h, int l, const T *v, const NdBox &b, T **out, 
     uint64_t total = 1;
     for (int d = 0; d < D; d++) total *= (d == a ? s.m : s.e[d]);
     T *dst = bufs[which];
+    NdFastSweep fs;
     uint64_t outer = 1, inner = 1;
     for (int d = 0; d < a; d++) outer *= s.e[d];
     for (int d = a + 1; d < D; d++) inner *= s.e[d];
@@ -1550,6 +1581,9 @@ int nd_correction(mgh_hierarchy *h, int l, const T *v, const NdBox &b, T **out, 
       const NdMidSweep ms{(uint32_t)outer, s.n, s.m, (uint32_t)inner, (uint32_t)plane, (uint32_t)tiles};
       const unsigned grid = (unsigned)std::min<uint64_t>(outer * tiles, 1u << 20);
       TRY(launch(h, "nd_lpk", st, [&] { k_nd_lpk_mid<T><<<grid, 256, 0, st>>>(ms, cur, dst, ds->nd[l].mass[a]); }));
+    } else if (h->nd_rows && a == D - 1 && nd_fast_sweep(s, &fs)) {
+      const unsigned grid = (unsigned)std::max<uint32_t>(1, std::min<uint32_t>((fs.groups + 3) / 4, 1u << 20));
+      TRY(launch(h, "nd_lpk", st, [&] { k_nd_lpk_fast<T><<<grid, 256, 0, st>>>(fs, cur, dst, ds->nd[l].mass[a]); }));
     } else if (h->nd_rows) {
       NdRowSweep rs{};
       const int sh = kNd - D;

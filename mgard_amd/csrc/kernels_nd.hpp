@@ -631,6 +631,87 @@ k_nd_lpk_mid(NdMidSweep s, const T *__restrict__ in, T *__restrict__ out, const 
   }
 }
 
+// k_nd_lpk along the FASTEST dimension (the first sweep: strided input with the zero rule), lane =
+// output index q. Rows in groups as in k_nd_coeff_rows (dimensions 0..2 once per group), the nine
+// weights of a lane once per group (they depend on q alone), and of the five inputs of an output
+// two loaded -- the coarse node q and the odd node behind it -- the other three the neighbouring
+// lanes' (q - 1 of both, q + 1 of the coarse ones), zeros already in place of what the rules leave
+// out. Two rows in flight.
+struct NdFastSweep {
+  uint32_t e[kNd - 1];    // extents of the slow dimensions, right-aligned
+  uint64_t is[kNd - 1];   // their input strides
+  uint32_t mc[kNd - 1];   // coarse extents (zero rule)
+  uint64_t sf;            // input stride along the fastest dimension
+  uint32_t n, m;          // fine / coarse size of the fastest dimension
+  int zero_all_coarse;
+  uint32_t gsz, gpl, groups;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_nd_lpk_fast(NdFastSweep s, const T *__restrict__ in, T *__restrict__ out, const T *__restrict__ mt) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + blockIdx.x * 4;
+  const uint32_t nwave = gridDim.x * 4;
+  const uint32_t m = s.m, nodd = s.n - s.m;
+  const uint32_t olast = nodd ? nodd - 1 : 0;
+  const int sh = m > 64 ? 1 : 0;  // longer than the wave: 62 outputs a round, lanes 0 and 63 partners only
+  for (uint32_t g = wave; g < s.groups; g += nwave) {
+    uint32_t line = g / s.gpl;
+    const uint32_t q0 = (g - line * s.gpl) * s.gsz, q1 = min(s.e[3], q0 + s.gsz);
+    const uint64_t row0 = (uint64_t)line * s.e[3];  // output row of dimension-3 position 0
+    uint64_t base012 = 0;
+    bool ez012 = s.zero_all_coarse;
+#pragma unroll
+    for (int d = 2; d >= 0; d--) {
+      const uint32_t qq = line / s.e[d];
+      const uint32_t pos = line - qq * s.e[d];
+      line = qq;
+      base012 += pos * s.is[d];
+      if (pos >= s.mc[d]) ez012 = false;
+    }
+    for (uint32_t c0 = 0; c0 < m; c0 += sh ? 62 : 64) {
+      const int qi = (int)c0 + lane - sh;
+      const bool valid = qi >= 0 && (uint32_t)qi < m;
+      const bool own = valid && (!sh || (lane >= 1 && lane <= 62));
+      const uint32_t q = valid ? (uint32_t)qi : 0;
+      T wk[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) wk[k] = mt[k * m + q];
+      const uint64_t oc = (uint64_t)q * s.sf;                                   // the coarse node q ...
+      const uint64_t oo = (nodd ? (uint64_t)(m + min(q, olast)) : (uint64_t)q) * s.sf;  // ... the odd one behind it
+      const bool has_d = valid && q < nodd;
+      auto row = [&](uint32_t q3) -> T {
+        const T *pr = in + base012 + q3 * s.is[3];
+        const bool ez = ez012 && q3 < s.mc[3];
+        const T lc = pr[oc], ld = pr[oo];
+        const T c = (valid && !ez) ? lc : (T)0;
+        const T d = has_d ? ld : (T)0;
+        const T a = lane_below(c), bq = lane_below(d), e = lane_above(c);  // (lane 0 / 63: own value back, unused or zero by construction below)
+        const T a0 = (lane >= 1 && q >= 1) ? a : (T)0;
+        const T b0 = (lane >= 1 && q >= 1) ? bq : (T)0;
+        const T e0 = (lane <= 62 && q + 1 < m) ? e : (T)0;
+        const T tb = a0 * wk[0] + b0 * wk[1] + c * wk[2];
+        T tc = b0 * wk[2] + c * wk[3] + d * wk[4];
+        const T td = c * wk[4] + d * wk[5] + e0 * wk[6];
+        tc += tb * wk[7] + td * wk[8];
+        return tc;
+      };
+      uint32_t q3 = q0;
+      for (; q3 + 1 < q1; q3 += 2) {
+        T *o0 = out + (row0 + q3) * m, *o1 = o0 + m;
+        const T x0 = row(q3), x1 = row(q3 + 1);
+        if (own) o0[q] = x0, o1[q] = x1;
+      }
+      if (q3 < q1) {
+        T *o0 = out + (row0 + q3) * m;
+        const T x0 = row(q3);
+        if (own) o0[q] = x0;
+      }
+    }
+  }
+}
+
 // v[coarse box, full strides] +/-= corr[compact]
 template <typename T>
 __global__ void __launch_bounds__(256)
