@@ -2219,22 +2219,28 @@ int upload_quantizers(mgh_hierarchy *h, int ebtype, double tol, double s, double
   return MGH_SUCCESS;
 }
 
+// the stand-alone quantizer with the table already in ds->qz (uploaded, or made on the device)
 template <typename T>
-int quantize_impl(mgh_hierarchy *h, const T *coeff, int ebtype, double tol, double s, double norm,
-                  uint64_t dict_size, int prep_huffman, int64_t *q, uint64_t *ocount,
-                  uint64_t *oidx, int64_t *oval, uint64_t ocap, hipStream_t st) {
+int quantize_launch(mgh_hierarchy *h, const T *coeff, uint64_t dict_size, int prep_huffman, int64_t *q,
+                    uint64_t *ocount, uint64_t *oidx, int64_t *oval, uint64_t ocap, hipStream_t st) {
   auto *ds = DS<T>(h);
-  TRY(upload_quantizers<T>(h, ebtype, tol, s, norm, true, st));
   if (ocount) HIP_TRY(hipMemsetAsync(ocount, 0, sizeof(uint64_t), st));
   const size_t total = h->total;
   const unsigned grid = (unsigned)std::min<size_t>((total + kQuantPerRound - 1) / kQuantPerRound, 256 * 32);
-  TRY(launch(h, "quantize", st, [&] {
+  return launch(h, "quantize", st, [&] {
     k_quantize<T><<<grid, 256, 0, st>>>(ds->qmeta, total, coeff, ds->marks, ds->qz,
                                         ds->qz + (h->L + 1), (int64_t)dict_size, prep_huffman, q,
                                         (unsigned long long *)ocount, oidx, oval,
                                         (unsigned long long)ocap);
-  }));
-  return MGH_SUCCESS;
+  });
+}
+
+template <typename T>
+int quantize_impl(mgh_hierarchy *h, const T *coeff, int ebtype, double tol, double s, double norm,
+                  uint64_t dict_size, int prep_huffman, int64_t *q, uint64_t *ocount,
+                  uint64_t *oidx, int64_t *oval, uint64_t ocap, hipStream_t st) {
+  TRY(upload_quantizers<T>(h, ebtype, tol, s, norm, true, st));
+  return quantize_launch<T>(h, coeff, dict_size, prep_huffman, q, ocount, oidx, oval, ocap, st);
 }
 
 template <typename T>
@@ -2658,6 +2664,29 @@ inline bool ld_wanted(const mgh_hierarchy *h, const void *in, const void *out) {
 
 } // namespace
 
+// REL bound without a norm on the shapes the fused level kernels do not take (D = 5, thin boxes ...):
+// norm, quantizer table, decomposition and quantizer queued one behind the other -- the norm and the
+// table stay on the device as in fused_q_entry_device (mgh_norm + mgh_quantize were two host round
+// trips, 35 us each on the 5-D step). h_norm_out != NULL: one synchronisation at the END.
+template <typename T>
+int staged_q_entry_device(mgh_hierarchy *h, const T *data, int ebtype, double tol, double s, double *h_norm_out,
+                          uint64_t dict_size, int prep_huffman, int64_t *q, uint64_t *ocount, uint64_t *oidx,
+                          int64_t *oval, uint64_t ocap, T *coeff, hipStream_t st) {
+  auto *ds = DS<T>(h);
+  TRY(norm_launch<T>(h, data, s, st));
+  TRY(make_qparams_launch<T>(h, nullptr, ebtype, tol, s, 0, 1, nullptr, st));
+  ds->qmeta.calc_vol = ((T)s == std::numeric_limits<T>::infinity()) ? 0 : 1;
+  TRY(mgh_decompose(h, data, coeff, (void *)st));
+  TRY(quantize_launch<T>(h, coeff, dict_size, prep_huffman, q, ocount, oidx, oval, ocap, st));
+  if (h_norm_out) {
+    T nv;
+    HIP_TRY(hipMemcpyAsync(&nv, ds->normval, sizeof(T), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *h_norm_out = (double)nv;
+  }
+  return MGH_SUCCESS;
+}
+
 extern "C" {
 
 const char *mgh_last_error(void) { return g_last_error.c_str(); }
@@ -3007,6 +3036,22 @@ int mgh_decompose_quantize(mgh_hierarchy *h, const void *d_data, int error_bound
                                                  nullptr, 0, 1, h_norm_out, dict_size, prep_huffman,
                                                  d_quantized, d_outlier_count, d_outlier_idx,
                                                  d_outlier_val, outlier_capacity, (hipStream_t)stream));
+  }
+  if (!fused && error_bound_type == MGH_REL && !(norm > 0)) {
+    void *coeff = d_coeff_opt;
+    if (!coeff) {
+      int rc = DISPATCH(h, ensure_scratch<float>(h), ensure_scratch<double>(h));
+      if (rc != MGH_SUCCESS) return rc;
+      coeff = h->dtype == MGH_FLOAT ? (void *)DS<float>(h)->scratch_full : (void *)DS<double>(h)->scratch_full;
+      if (coeff == d_data) return fail(MGH_ERR_INVALID_ARGUMENT, "aliasing");
+    }
+    return DISPATCH(h,
+                    staged_q_entry_device<float>(h, (const float *)d_data, error_bound_type, tol, s, h_norm_out,
+                                                 dict_size, prep_huffman, d_quantized, d_outlier_count, d_outlier_idx,
+                                                 d_outlier_val, outlier_capacity, (float *)coeff, (hipStream_t)stream),
+                    staged_q_entry_device<double>(h, (const double *)d_data, error_bound_type, tol, s, h_norm_out,
+                                                  dict_size, prep_huffman, d_quantized, d_outlier_count, d_outlier_idx,
+                                                  d_outlier_val, outlier_capacity, (double *)coeff, (hipStream_t)stream));
   }
   if (error_bound_type == MGH_REL && !(norm > 0)) {
     int rc = mgh_norm(h, d_data, s, &norm, stream);
