@@ -35,3 +35,20 @@ torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(5): f()
 torch.cuda.synchronize(); ms = (time.perf_counter() - t) / 5 * 1e3
 print("field inside the dictionary:", shape, "%.3f ms  %.1f GB/s" % (ms, u.nbytes / ms / 1e6), "outliers", int(cnt.item()))
+
+# the way back on that field: dequantize + recompose (int64 values in, as the reference's interface)
+n = int(cnt.item())
+qq = q.clone(); out = torch.empty_like(d)
+nrm = h.norm(d, float("inf"))
+fb = lambda: h.dequantize_recompose(qq, mgard_amd.REL, 1e-3, float("inf"), nrm, outlier_idx=oi[:n], outlier_val=ov[:n], out=out)
+for _ in range(2): fb()
+torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(5): fb()
+torch.cuda.synchronize(); ms = (time.perf_counter() - t) / 5 * 1e3
+print("dequantize + recompose: %.3f ms  %.1f GB/s, max error %.3g of the tolerance" %
+      (ms, u.nbytes / ms / 1e6, float((out - d).abs().max()) / (1e-3 * nrm)))
+h.profile(True)
+for _ in range(3): fb()
+torch.cuda.synchronize()
+for k, v in sorted(h.profile_read(reset=True).items(), key=lambda kv: -kv[1][0]):
+    print("  back: %-16s %8.1f us/step  %4d launches/step" % (k, v[0] / 3 * 1e3, v[1] // 3))

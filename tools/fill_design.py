@@ -48,7 +48,12 @@ if "link" in hb:
 R["HLIB"] = "%.1f" % hb.get("library_allocated_output", {}).get("decompress_ms", 0.0)
 R.update(host_fields("K", oc["1024f32"].get("end_to_end_host", {})))
 try:
-    R["MS5D"] = "%.2f" % float(open(O + "/5d_profile.txt").read().split(")")[1].split("ms")[0])
+    t5 = open(O + "/5d_profile.txt").read()
+    R["MS5D"] = "%.2f" % float(t5.split(")")[1].split("ms")[0])
+    inside = t5.split("field inside the dictionary:")[1]
+    R["MS5DIN"] = "%.2f" % float(inside.split(")")[1].split("ms")[0])
+    R["GB5DIN"] = "%.0f" % float(inside.split("ms")[1].split("GB/s")[0])
+    R["MS5DBACK"] = "%.2f" % float(t5.split("dequantize + recompose:")[1].split("ms")[0])
 except Exception as e:  # noqa: BLE001
     print("5d profile:", e)
 rf = oc["512f64nu"].get("roofline", {})
