@@ -89,6 +89,7 @@ struct mgh_hierarchy {
   int absmax_warm_mb = 192;  // MGH_ABSMAX_WARM_MB: the norm pass reads all but the last so many MB of the input with nontemporal loads
   // MGH_FUSED_FACES: 1 = face tiles for the remainder columns / rows of a level (default), 0 = off
   int fused_faces = 1;
+  int slice_batch = 1;  // MGH_SLICE_BATCH: D = 4 decompression, all t-slices of a kind in one launch (default 1)
   int fused_xcd = 1;  // MGH_FUSED_XCD: tiles of a level in contiguous ranges per XCD (default 1)
   int fused_fixed = 1; // MGH_FUSED_FIXED: the int64 + dictionary variant of the level kernel (default 1)
   int fused_wide = 1; // MGH_FUSED_WIDE: 4 x 64 tiles for 0 = no level, 1 = long marches, 2 = all (unset: 1 for floats, 0 for doubles)
@@ -932,6 +933,7 @@ inline int fused_rch(const mgh_hierarchy *h, int cls) { return h->rch[cls]; }
 
 // r-chunks of a level on the fused kernel: chunks of rch coarse planes, the last one takes what is
 // left (one plane more for sizes 2^k + 1)
+constexpr unsigned kXcdRangeMinTiles = 32;
 inline int fused_nchunk(int m_r, int rch) { return std::max(1, (m_r - 1 + rch - 1) / rch); }
 
 // Level loop on the fused kernels (3 active dims): per level one fused
@@ -962,8 +964,11 @@ int launch_fused2_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int 
   G.n_cf = face_c ? ((face_f ? G.ff_F0 : mfi) + 63) / 64 : 0;
   G.nchunk = fused_nchunk(mri, RCHv);
   G.chunk_hi = G.nchunk;
-  G.xcd_ranges = h->fused_xcd;
   const unsigned ntile = (unsigned)(G.n_main + G.n_ff + G.n_cf);
+  // (contiguous tile ranges per XCD only where there are tiles to hand out: a cross-section of three
+  // tiles padded to eight put every workgroup that had work on XCDs 0..2 -- 16395 x 39 x 39 f64: top
+  // level 778 us; without the ranges the r-chunks rotate the tiles over the XCDs)
+  G.xcd_ranges = h->fused_xcd && ntile >= kXcdRangeMinTiles;
   const dim3 grid(G.xcd_ranges ? (ntile + 7) / 8 * 8 : ntile, (unsigned)G.nchunk, 1);
   const bool faces = G.n_ff || G.n_cf;
 #define MGH_F2(RCH)                                                                           \
@@ -1223,8 +1228,8 @@ int launch_fused4_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Fused4<T> &Q,
     G.n_cf = face_c ? ((face_f ? G.ff_F0 : mfi) + 63) / 64 : 0;
     G.nchunk = fused_nchunk(mri, RCHv);
     G.chunk_hi = G.nchunk;
-    G.xcd_ranges = h->fused_xcd;
     const unsigned ntile = (unsigned)(G.n_main + G.n_ff + G.n_cf);
+    G.xcd_ranges = h->fused_xcd && ntile >= kXcdRangeMinTiles;  // (see launch_fused2_t)
     const unsigned gx = G.xcd_ranges ? (ntile + 7) / 8 * 8 : ntile;
     const bool faces = G.n_ff || G.n_cf;
     const unsigned n_even = (unsigned)m_t, n_odd = (unsigned)(n_t - m_t);
@@ -1869,10 +1874,11 @@ int launch_restore(mgh_hierarchy *h, const RecomposeArgs<T> &A, const Box3 &b, c
     G.ntile = G.gxm * (((int)b.m[1] + TC - 1) / TC);
     // chunk length: long marches where there are plenty of tiles, short ones (more workgroups)
     // on the small levels -- a chunk costs one extra coarse plane of interpolants only
+    const int nslice = A.zb_mode ? (A.zb_mode == 2 ? A.zb_mt : A.zb_nt - A.zb_mt) : 1;
     const int want = 2048;
-    G.rch = std::max(1, std::min(16, (int)((int64_t)b.m[0] * G.ntile / want)));
+    G.rch = std::max(1, std::min(16, (int)((int64_t)b.m[0] * G.ntile * nslice / want)));
     G.nchunk = ((int)b.m[0] + G.rch - 1) / G.rch;
-    const dim3 grid((unsigned)G.ntile, (unsigned)G.nchunk, 1);
+    const dim3 grid((unsigned)G.ntile, (unsigned)G.nchunk, (unsigned)nslice);
     return launch(h, nm, st, [&] { k_level_restore3_q<T, QT, TODD, TC, TF><<<grid, TC * TF, 0, st>>>(A, G); });
   }
   const dim3 blk(64, 4, 1);
@@ -1890,16 +1896,25 @@ template <typename T, typename QT>
 int launch_loadvec(mgh_hierarchy *h, const RecomposeArgs<T> &A, const Box3 &b, hipStream_t st) {
   constexpr int TC = 8, TF = 32;
   const unsigned gx = (b.m[2] + TF - 1) / TF, gy = (b.m[1] + TC - 1) / TC;
-  if ((size_t)gx * gy * ((b.m[0] + 15) / 16) >= 2048)
+  // (A.zb_mode == 1: all the padded t positions of a 4-D level in this launch, the r-chunks of one
+  // behind those of the other in grid.z)
+  const unsigned ns = A.zb_mode == 1 ? (unsigned)(2 * A.zb_mt - 1) : 1u;
+  RecomposeArgs<T> B = A;
+  if ((size_t)gx * gy * ((b.m[0] + 15) / 16) * ns >= 2048) {
+    B.zb_nz = (int)((b.m[0] + 15) / 16);
     return launch(h, "loadvec_q", st, [&] {
-      k_level_loadvec_q<T, QT, TC, TF, 16><<<dim3(gx, gy, (b.m[0] + 15) / 16), 256, 0, st>>>(A);
+      k_level_loadvec_q<T, QT, TC, TF, 16><<<dim3(gx, gy, B.zb_nz * ns), 256, 0, st>>>(B);
     });
-  if ((size_t)gx * gy * ((b.m[0] + 3) / 4) >= 256)
+  }
+  if ((size_t)gx * gy * ((b.m[0] + 3) / 4) * ns >= 256) {
+    B.zb_nz = (int)((b.m[0] + 3) / 4);
     return launch(h, "loadvec_q_small", st, [&] {
-      k_level_loadvec_q<T, QT, TC, TF, 4><<<dim3(gx, gy, (b.m[0] + 3) / 4), 256, 0, st>>>(A);
+      k_level_loadvec_q<T, QT, TC, TF, 4><<<dim3(gx, gy, B.zb_nz * ns), 256, 0, st>>>(B);
     });
+  }
+  B.zb_nz = (int)b.m[0];
   return launch(h, "loadvec_q_small", st, [&] {
-    k_level_loadvec_q<T, QT, TC, TF, 1><<<dim3(gx, gy, b.m[0]), 256, 0, st>>>(A);
+    k_level_loadvec_q<T, QT, TC, TF, 1><<<dim3(gx, gy, B.zb_nz * ns), 256, 0, st>>>(B);
   });
 }
 
@@ -2035,17 +2050,31 @@ int recompose_levels4(mgh_hierarchy *h, RecomposeArgs<T> A0, const std::vector<T
     A.ratio_t = ds->nd[l].ratio[0];
     const size_t M = (size_t)Mc[1] * Mc[2] * Mc[3];
     const int n_t = (int)N[0], m_t = (int)Mc[0];
-    // ---- load vectors of the padded t positions
-    for (int P = 0; P <= 2 * m_t - 2; P++) {
-      if (n_t % 2 == 0 && P == n_t - 1) {  // ghost slice
-        HIP_TRY(hipMemsetAsync(ds->load4 + (size_t)P * M, 0, M * sizeof(T), st));
-        continue;
-      }
-      A.allcoef = P & 1;
-      A.lin_base = (size_t)((P & 1) ? m_t + (P - 1) / 2 : P / 2) * sT;
-      A.load = ds->load4 + (size_t)P * M;
+    // ---- load vectors of the padded t positions: one launch for all of them (grid.z limit
+    // permitting; MGH_SLICE_BATCH=0: a launch per slice)
+    const bool batch = h->slice_batch && h->restore_v == 3 && !h->restore_rows &&
+                       (size_t)(2 * m_t - 1) * Mc[1] < 65536;
+    if (n_t % 2 == 0)  // ghost slice
+      HIP_TRY(hipMemsetAsync(ds->load4 + (size_t)(n_t - 1) * M, 0, M * sizeof(T), st));
+    if (batch) {
+      A.zb_mode = 1;
+      A.zb_mt = m_t;
+      A.zb_nt = n_t;
+      A.zb_sT = sT;
+      A.zb_M = M;
+      A.load = ds->load4;
       if (top) TRY((launch_loadvec<T, QTL>(h, A, b, st)));
       else TRY((launch_loadvec<T, QT>(h, A, b, st)));
+      A.zb_mode = 0;
+    } else {
+      for (int P = 0; P <= 2 * m_t - 2; P++) {
+        if (n_t % 2 == 0 && P == n_t - 1) continue;
+        A.allcoef = P & 1;
+        A.lin_base = (size_t)((P & 1) ? m_t + (P - 1) / 2 : P / 2) * sT;
+        A.load = ds->load4 + (size_t)P * M;
+        if (top) TRY((launch_loadvec<T, QTL>(h, A, b, st)));
+        else TRY((launch_loadvec<T, QT>(h, A, b, st)));
+      }
     }
     A.allcoef = 0;
     // ---- t-sweep, Thomas solves f, c, r, t; the last one subtracts from the coarse nodes
@@ -2062,6 +2091,24 @@ int recompose_levels4(mgh_hierarchy *h, RecomposeArgs<T> A0, const std::vector<T
     const size_t fT = (l == L) ? full[0] : (size_t)N[1] * N[2] * N[3];
     A.fI = (l == L) ? full[1] : (size_t)N[2] * N[3];
     A.fJ = (l == L) ? full[2] : (size_t)N[3];
+    if (batch) {
+      A.zb_mt = m_t;
+      A.zb_nt = n_t;
+      A.zb_sT = sT;
+      A.zb_M = M;
+      A.zb_fT = fT;
+      A.fine = fine;
+      A.coarse = ds->nodal4[l - 1];
+      A.zb_mode = 2;
+      if (top) TRY((launch_restore<T, QTL, false>(h, A, b, "restore_q", st)));
+      else TRY((launch_restore<T, QT, false>(h, A, b, "restore_q", st)));
+      if (n_t - m_t > 0) {
+        A.zb_mode = 3;
+        if (top) TRY((launch_restore<T, QTL, true>(h, A, b, "restore_q_odd", st)));
+        else TRY((launch_restore<T, QT, true>(h, A, b, "restore_q_odd", st)));
+      }
+      continue;
+    }
     for (int tp = 0; tp < n_t; tp++) {
       const bool last_even = n_t % 2 == 0 && tp == n_t - 1;  // the real last node: coarse m_t - 1
       A.fine = fine + (size_t)tp * fT;
@@ -2726,6 +2773,7 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->absmax_warm_mb = (int)env_get("MGH_ABSMAX_WARM_MB", h->absmax_warm_mb);
     h->fused_faces = (int)env_get("MGH_FUSED_FACES", h->fused_faces);
     h->fused_xcd = (int)env_get("MGH_FUSED_XCD", h->fused_xcd);
+    h->slice_batch = (int)env_get("MGH_SLICE_BATCH", h->slice_batch);
     h->fused_fixed = (int)env_get("MGH_FUSED_FIXED", h->fused_fixed);
     h->fused_wide = (int)env_get("MGH_FUSED_WIDE", -1);  // (-1: by data type, below)
     h->fused4 = (int)env_get("MGH_FUSED4", h->fused4);

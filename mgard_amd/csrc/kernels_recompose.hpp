@@ -43,7 +43,46 @@ template <typename T> struct RecomposeArgs {
   const T *coarse_b; // odd t-slice: corrected coarse nodes of the slice above (coarse: below)
   const T *ratio_t;  // ... interpolation ratios along t of the level,
   int tpos;          // ... and the slice's (odd) position: ratio_t[tpos - 1] applies
+  // ... or, with zb_mode != 0, on ALL slices of a kind in one launch (64^4: 131 + 131 launches of
+  // 5-9 us each a level loop otherwise): the slice is the workgroup's, the fields above are set
+  // from it by slice_batch() at the head of the kernel. 1: load vectors, slice = padded t position
+  // P (blockIdx.z = P * zb_nz + r-chunk); 2 / 3: node restore of the even / odd slices (blockIdx.z).
+  int zb_mode, zb_mt, zb_nt, zb_nz;
+  size_t zb_sT;      // elements between t-slices of the coefficient source
+  size_t zb_M;       // ... of the compact coarse / load arrays
+  size_t zb_fT;      // ... of the fine array
 };
+
+// false: the workgroup's slice has no work (the ghost slice of an even extent: zeroed by the host)
+template <typename T> __device__ __forceinline__ bool slice_batch(RecomposeArgs<T> &A, int *zchunk) {
+  *zchunk = (int)blockIdx.z;
+  if (A.zb_mode == 0) return true;
+  if (A.zb_mode == 1) {
+    const int P = (int)blockIdx.z / A.zb_nz;
+    *zchunk = (int)blockIdx.z - P * A.zb_nz;
+    if (A.zb_nt % 2 == 0 && P == A.zb_nt - 1) return false;
+    A.allcoef = P & 1;
+    A.lin_base = (size_t)((P & 1) ? A.zb_mt + (P - 1) / 2 : P / 2) * A.zb_sT;
+    A.load += (size_t)P * A.zb_M;
+    return true;
+  }
+  const int zi = (int)blockIdx.z;
+  *zchunk = 0;
+  if (A.zb_mode == 2) {
+    const int tp = (A.zb_nt % 2 == 0 && zi == A.zb_mt - 1) ? A.zb_nt - 1 : 2 * zi;
+    A.fine += (size_t)tp * A.zb_fT;
+    A.coarse += (size_t)zi * A.zb_M;
+    A.lin_base = (size_t)zi * A.zb_sT;
+  } else {
+    const int tp = 2 * zi + 1;
+    A.fine += (size_t)tp * A.zb_fT;
+    A.coarse += (size_t)zi * A.zb_M;
+    A.coarse_b = A.coarse + A.zb_M;
+    A.tpos = tp;
+    A.lin_base = (size_t)(A.zb_mt + zi) * A.zb_sT;
+  }
+  return true;
+}
 
 template <typename T> __device__ __forceinline__ T dequant_one(int64_t qd, int64_t half, T qv) {
   const int64_t d = qd - half;
@@ -117,7 +156,9 @@ k_level_loadvec_q(RecomposeArgs<T> A) {
   __shared__ T wrs[RCH][9];
 #define LI(lc, lf) ((lc) * ROW + ((lf) & 1) * HF + ((lf) >> 1))
   const int tid = threadIdx.x;
-  const int F0 = blockIdx.x * TF, C0 = blockIdx.y * TC, R0 = blockIdx.z * RCH;
+  int zchunk;
+  if (!slice_batch(A, &zchunk)) return;
+  const int F0 = blockIdx.x * TF, C0 = blockIdx.y * TC, R0 = zchunk * RCH;
   const int nr = A.n[0], nc = A.n[1], nf = A.n[2];
   const int mr = A.m[0], mc = A.m[1], mf = A.m[2];
   const int c_lo = 2 * C0 - 2, f_lo = 2 * F0 - 2, r_lo = 2 * R0 - 2;

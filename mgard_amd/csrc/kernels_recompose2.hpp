@@ -38,6 +38,8 @@ struct Restore3Grid {
 template <typename T, typename QT, bool TODD, int TC, int TF>
 __global__ void __launch_bounds__(TC * TF)
 k_level_restore3_q(RecomposeArgs<T> A, Restore3Grid G) {
+  int zunused;
+  slice_batch(A, &zunused);
   const int nr = A.n[0], nc = A.n[1], nf = A.n[2];
   const int mr = A.m[0], mc = A.m[1], mf = A.m[2];
   const int b = blockIdx.x;
