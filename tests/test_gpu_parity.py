@@ -627,6 +627,14 @@ def test_fused_4d_path_equals_generic_nd(shape, dt, monkeypatch):
     assert_bit_equal(h.recompose(c_in, out=c_in).cpu().numpy(), ref_back, "fused 4-D recompose in place")
     back = h.dequantize_recompose(q.clone(), mg.REL, 1e-3, np.inf, nrm, outlier_idx=oi[:cnt], outlier_val=ov[:cnt])
     h.close()
+    # (round 6: all t-slices of a kind in one launch; MGH_SLICE_BATCH=0: the launch per slice it replaced)
+    monkeypatch.setenv("MGH_SLICE_BATCH", "0")
+    p = mg.Hierarchy(shape, dt)
+    assert_bit_equal(p.recompose(c).cpu().numpy(), ref_back, "fused 4-D recompose, a launch per slice %r" % (shape,))
+    assert torch.equal(back, p.dequantize_recompose(q.clone(), mg.REL, 1e-3, np.inf, nrm, outlier_idx=oi[:cnt],
+                                                    outlier_val=ov[:cnt]))
+    p.close()
+    monkeypatch.delenv("MGH_SLICE_BATCH")
     monkeypatch.setenv("MGH_FUSED4", "0")
     g = mg.Hierarchy(shape, dt)
     q2, oi2, ov2, cnt2, nrm2 = g.decompose_quantize(ud, mg.REL, 1e-3, np.inf, outlier_cap=u.size)
