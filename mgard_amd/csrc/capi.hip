@@ -90,7 +90,7 @@ struct mgh_hierarchy {
   // MGH_FUSED_FACES: 1 = face tiles for the remainder columns / rows of a level (default), 0 = off
   int fused_faces = 1;
   int slice_batch = 1;  // MGH_SLICE_BATCH: D = 4 decompression, all t-slices of a kind in one launch (default 1)
-  int fused_xcd = 1;  // MGH_FUSED_XCD: tiles of a level in contiguous ranges per XCD (default 1)
+  int fused_xcd = 1;  // MGH_FUSED_XCD: tiles of a level in contiguous ranges per XCD (default 1; 2: the equal ranges of rounds 2-5 from 32 tiles on)
   int fused_fixed = 1; // MGH_FUSED_FIXED: the int64 + dictionary variant of the level kernel (default 1)
   int fused_wide = 1; // MGH_FUSED_WIDE: 4 x 64 tiles for 0 = no level, 1 = long marches, 2 = all (unset: 1 for floats, 0 for doubles)
   int fused4 = 1;     // MGH_FUSED4: D = 4 through the 3-D tile code, slice by slice (default 1)
@@ -933,7 +933,7 @@ inline int fused_rch(const mgh_hierarchy *h, int cls) { return h->rch[cls]; }
 
 // r-chunks of a level on the fused kernel: chunks of rch coarse planes, the last one takes what is
 // left (one plane more for sizes 2^k + 1)
-constexpr unsigned kXcdRangeMinTiles = 32;
+constexpr unsigned kXcdRangeMinTiles = 64;  // (below: at most 8 tiles an XCD, one more or less is 12 % and more)
 inline int fused_nchunk(int m_r, int rch) { return std::max(1, (m_r - 1 + rch - 1) / rch); }
 
 // Level loop on the fused kernels (3 active dims): per level one fused
@@ -965,10 +965,10 @@ int launch_fused2_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int 
   G.nchunk = fused_nchunk(mri, RCHv);
   G.chunk_hi = G.nchunk;
   const unsigned ntile = (unsigned)(G.n_main + G.n_ff + G.n_cf);
-  // (contiguous tile ranges per XCD only where there are tiles to hand out: a cross-section of three
+  // (contiguous tile ranges per XCD only where there are tiles to hand out -- a cross-section of three
   // tiles padded to eight put every workgroup that had work on XCDs 0..2 -- 16395 x 39 x 39 f64: top
   // level 778 us; without the ranges the r-chunks rotate the tiles over the XCDs)
-  G.xcd_ranges = h->fused_xcd && ntile >= kXcdRangeMinTiles;
+  G.xcd_ranges = ntile >= (h->fused_xcd == 2 ? 32u : kXcdRangeMinTiles) ? h->fused_xcd : 0;
   const dim3 grid(G.xcd_ranges ? (ntile + 7) / 8 * 8 : ntile, (unsigned)G.nchunk, 1);
   const bool faces = G.n_ff || G.n_cf;
 #define MGH_F2(RCH)                                                                           \
@@ -1229,7 +1229,7 @@ int launch_fused4_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Fused4<T> &Q,
     G.nchunk = fused_nchunk(mri, RCHv);
     G.chunk_hi = G.nchunk;
     const unsigned ntile = (unsigned)(G.n_main + G.n_ff + G.n_cf);
-    G.xcd_ranges = h->fused_xcd && ntile >= kXcdRangeMinTiles;  // (see launch_fused2_t)
+    G.xcd_ranges = ntile >= (h->fused_xcd == 2 ? 32u : kXcdRangeMinTiles) ? h->fused_xcd : 0;  // (see launch_fused2_t)
     const unsigned gx = G.xcd_ranges ? (ntile + 7) / 8 * 8 : ntile;
     const bool faces = G.n_ff || G.n_cf;
     const unsigned n_even = (unsigned)m_t, n_odd = (unsigned)(n_t - m_t);

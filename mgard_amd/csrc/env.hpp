@@ -22,7 +22,7 @@ struct EnvSwitch {
 inline const EnvSwitch *env_switches(size_t *count) {
   static const EnvSwitch k[] = {
       {"MGH_FORCE_V1", 0, 1},       {"MGH_FORCE_ND", 0, 1},        {"MGH_IPK_STREAM", 0, 1},      {"MGH_IPK_DMA", 0, 1},  {"MGH_IPK_DMA_MIN", 0, 1 << 30},  {"MGH_MULTI_FORCE_PEER", 0, 1},  {"MGH_ABSMAX_WARM_MB", 0, 1 << 20},      {"MGH_FUSED_FACES", 0, 1},
-      {"MGH_FUSED_XCD", 0, 1},      {"MGH_FUSED_FIXED", 0, 1},     {"MGH_FUSED_WIDE", 0, 2},
+      {"MGH_FUSED_XCD", 0, 2},      {"MGH_FUSED_FIXED", 0, 1},     {"MGH_FUSED_WIDE", 0, 2},
       {"MGH_SLICE_BATCH", 0, 1},
       {"MGH_FUSED4", 0, 1},         {"MGH_CLS1", 0, 1 << 30},     {"MGH_CLS2", 0, 1 << 30},      {"MGH_RCH", 1, 16},
       {"MGH_IPK_W", 16, 64},        {"MGH_IPK_PD", 1, 4},          {"MGH_NO_RECOMPOSE_HEAD", 0, 1}, {"MGH_RESTORE_ROWS", 0, 1}, {"MGH_DEBUG_SYNC", 0, 1},

@@ -820,11 +820,19 @@ k_level_fused2(FusedArgs<T> A, Fused2Grid G, Fused4<T> Q) {
   // workgroups go round-robin to the 8 XCDs (own L2 each): every XCD gets a contiguous range of
   // the launch's tiles, so that the partial cache lines neighbouring tiles write (the output rows
   // start at odd multiples of 8 bytes) meet in one L2. The grid is padded to a multiple of 8.
+  // XCD k's range is [k n / 8, (k + 1) n / 8): the ranges differ by one tile at most (equal ranges of
+  // ceil(n / 8) left the last XCD with what remained -- 33 tiles: 5, 5, 5, 5, 5, 5, 3, 0).
   int b = blockIdx.x;
   if (G.xcd_ranges) {
-    const int per = gridDim.x / 8;
-    b = (b % 8) * per + b / 8;
-    if (b >= G.n_main + G.n_ff + G.n_cf) return;
+    const int n = G.n_main + G.n_ff + G.n_cf, k = b % 8, j = b / 8;
+    if (G.xcd_ranges == 2) {  // (MGH_FUSED_XCD=2: the equal ranges of rounds 2-5, for A/B runs)
+      b = k * (int)(gridDim.x / 8) + j;
+      if (b >= n) return;
+    } else {
+      const int lo = k * n / 8, hi = (k + 1) * n / 8;
+      if (j >= hi - lo) return;
+      b = lo + j;
+    }
   }
   const int f_main_end = G.n_ff ? G.ff_F0 : A.m[2], c_main_end = G.n_cf ? G.cf_C0 : A.m[1];
   if (!FACES || b < G.n_main) {
