@@ -288,13 +288,17 @@ k_nd_ipk(int D, int a, NdSweep s, T *__restrict__ x, const T *__restrict__ tt, u
 
 // ---- row-wise variants (round 6) ---------------------------------------------------------------
 // The one-thread-per-element kernels above pay five integer divisions per element for its position
-// (no hardware division: ~25 instructions each) and decide every branch per lane. Here a wave owns
-// kNdRowsPerWave consecutive ROWS (a row = all dimensions but the fastest fixed): the position of the
-// first row is unravelled once, the following ones by counting up; parity, reordered offset and
-// interpolation partners of the slow dimensions are the same for the whole row (wave-uniform
-// branches), the lanes run along the fastest dimension. Same element arithmetic in the same order
-// (nested lerps slowest dimension outermost; mass_apply of k_nd_lpk): bit-identical results.
-// Dimensions are right-aligned to kNd = 5 (leading extents 1).
+// (no hardware division: ~25 instructions each) and decide every branch per lane. Here the lanes run
+// along the fastest dimension and a wave owns ROWS (a row = all dimensions but the fastest fixed):
+// parity, reordered offset and interpolation partners of the slow dimensions are the same for the
+// whole row (wave-uniform branches). Same element arithmetic in the same order (nested lerps
+// slowest dimension outermost; mass_apply of k_nd_lpk): bit-identical results. Dimensions are
+// right-aligned to kNd = 5 (leading extents 1). Which kernel runs what (capi.hip):
+//   coefficients            k_nd_coeff_rows  groups of up to kNdRowsPerWave rows of one dimension-3 line
+//   first correction sweep  k_nd_lpk_fast    the same groups, lane = output index
+//   the other sweeps        k_nd_lpk_mid     a 3-D view of the compact array, one element a thread
+//   (k_nd_lpk_rows: the sweeps of round 6's first version -- kNdRowsPerWave consecutive rows by
+//   odometer steps -- left for arrays whose group / tile counts do not fit 32 bits)
 constexpr int kNdRowsPerWave = 8;
 
 struct NdRowBox {
