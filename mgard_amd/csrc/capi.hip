@@ -920,11 +920,13 @@ QuantParams<T> make_quant_params(mgh_hierarchy *h, int ebtype, double tol, doubl
 
 // Size class of a level for the fused kernels: 2 = plenty of tiles (long marches, RCH = 16),
 // 1 = mid-size (RCH = 4), 0 = few tiles (one coarse plane per workgroup).
-inline int level_class(const mgh_hierarchy *h, const Box3 &b) {
+// nz: t-slices a launch of the D = 4 path covers (their workgroups count like tiles: 8 x 16395 x 39 x 39
+// f64 has 3 tiles a slice and ran its 16395 planes in marches of 4 -- 5.6 ms, 4.6 with marches of 16).
+inline int level_class(const mgh_hierarchy *h, const Box3 &b, size_t nz = 1) {
   constexpr int TC = 8, TF = 32;
   const size_t gx = (b.m[2] + TF - 1) / TF, gy = (b.m[1] + TC - 1) / TC;
-  if (gx * gy * ((b.m[0] + 15) / 16) >= h->cls2) return 2;
-  if (gx * gy * ((b.m[0] + 3) / 4) >= h->cls1) return 1;
+  if (gx * gy * nz * ((b.m[0] + 15) / 16) >= h->cls2) return 2;
+  if (gx * gy * nz * ((b.m[0] + 3) / 4) >= h->cls1) return 1;
   return 0;
 }
 
@@ -985,10 +987,22 @@ int launch_fused2_t(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int 
 // writes is 512 contiguous bytes instead of 256, which the memory system rewards more than the
 // larger halo (1.41 x instead of 1.24 x re-read) costs: top level of 512^3 f32 435 -> 383 us, same
 // box, alternating runs. The short marches of the lower levels are a few us faster on 8 x 32.
+// (... where the rows are long enough to fill them: 33 coarse nodes along f are one 8 x 32 tile and a
+// face tile, or half a 4 x 64 tile)
+inline bool fused_wide_tiles(const mgh_hierarchy *h, int cls, uint32_t mf) {
+  if (h->fused_wide >= 2) return true;
+  if (h->fused_wide != 1 || cls != 2) return false;
+  auto filled = [&](uint32_t tf) {  // share of a main tile's columns that hold nodes
+    const uint32_t nfull = (mf - 1) / tf, rem = mf - nfull * tf;
+    if (h->fused_faces && nfull >= 1 && rem <= 4) return 1.0;  // (the remainder goes to a face tile)
+    return (double)mf / (double)((mf + tf - 1) / tf * tf);
+  };
+  return filled(64) + 0.1 >= filled(32);
+}
 template <typename T, int OUTK, bool AGG = false>
 int launch_fused2(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int cls, const char *nm,
                   hipStream_t s) {
-  if (h->fused_wide >= 2 || (h->fused_wide == 1 && cls == 2))
+  if (fused_wide_tiles(h, cls, b.m[2]))
     return launch_fused2_t<T, OUTK, 4, 64, AGG>(h, A, b, cls, nm, s);
   return launch_fused2_t<T, OUTK, 8, 32, AGG>(h, A, b, cls, nm, s);
 }
@@ -1373,8 +1387,8 @@ int decompose_fused4(mgh_hierarchy *h, const T *data, T *coeff, const QuantParam
     // an even n_t has a ghost slice (padded position n_t - 1): its load vector is zero
     if (n_t % 2 == 0)
       HIP_TRY(hipMemsetAsync(ds->load4 + (size_t)(n_t - 1) * M, 0, M * sizeof(T), s));
-    const int cls = level_class(h, b);
-    const bool wide = h->fused_wide >= 2 || (h->fused_wide == 1 && cls == 2);
+    const int cls = level_class(h, b, (size_t)std::max(1, n_t - m_t));
+    const bool wide = fused_wide_tiles(h, cls, b.m[2]);
     if (OUT == OUT_Q && agg) {
       if (wide) TRY((launch_fused4_t<T, OUT, 4, 64, OUT == OUT_Q>(h, A, Q, b, cls, n_t, m_t, s)));
       else TRY((launch_fused4_t<T, OUT, 8, 32, OUT == OUT_Q>(h, A, Q, b, cls, n_t, m_t, s)));
