@@ -183,12 +183,15 @@ def test_device_input_still_being_produced_on_the_default_stream():
         assert float(w) <= 1e-3 * float(d.abs().max()) * (1 + 1e-6)
 
 
+@pytest.mark.parametrize("shape", [(40, 33, 70), (3, 4, 5, 6, 7), (300, 5, 7), (40, 50)],
+                         ids=["fused 3-D", "5-D", "thin 3-D", "2-D"])
 @pytest.mark.parametrize("mode", ["REL", "ABS"])
-def test_all_zero_input(mode):
+def test_all_zero_input(mode, shape):
     """norm == 0: the reference replaces it by epsilon (NormCalculator.hpp:61-66); the header
-    must keep the size it was reserved with and the round trip must give zeros back."""
+    must keep the size it was reserved with and the round trip must give zeros back -- on the fused
+    path and on the staged one (norm and quantizer table resident on the device there too)."""
     torch, mg, hl = _mods()
-    u = np.zeros((40, 33, 70), np.float32)
+    u = np.zeros(shape, np.float32)
     for src in (u, torch.from_numpy(u).cuda()):
         buf = hl.compress(src, 1e-3, np.inf, mg.REL if mode == "REL" else mg.ABS)
         v = hl.decompress(buf)
