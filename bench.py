@@ -647,6 +647,81 @@ def config_leg(torch, mgard_amd, name, dev, local_rank, steps=5, end_to_end=Fals
     return out
 
 
+def inside_field(torch, shape, dtype, dev, seed=20260102):
+    """A field whose quantized coefficients stay inside an 8192-entry dictionary at 1e-3 whatever the
+    dimensionality (the quantizer's bins shrink with 1 + 3^D: `gpu_field`'s recipe leaves the
+    dictionary in 4-D / 5-D and the step then measures outlier lists): one period of a sine across
+    every extent of 32 and more points, 1 % of that across the short ones, 1e-3 uniform noise."""
+    import numpy as np
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    u = (torch.rand(shape, dtype=dtype, device=dev, generator=g) * 2 - 1) * 1e-3
+    for k, n in enumerate(shape):
+        x = torch.arange(n, dtype=torch.float64, device=dev) / max(n - 1, 1)
+        view = [1] * len(shape)
+        view[k] = n
+        u += ((1.0 if n >= 32 else 0.01) * torch.sin(2 * np.pi * x + 0.3 * k)).to(dtype).view(view)
+    return u
+
+
+def beyond_leg(torch, mgard_amd, dev, local_rank, steps=5):
+    """Informational, never `value`: the step (norm + decompose + quantize, REL 1e-3, s = inf) and the
+    way back on two shapes outside BASELINE.json's list that the reference is used with -- D = 5 (the
+    generic N-D kernels) and the shape of its own flagship data set, XGC's 8 x 16395 x 39 x 39 float64
+    (examples/mgard-x/CompressXgcData) -- on `inside_field`."""
+    import numpy as np
+    out = {}
+    for name, shape, dt in (("5d_8x8x64x64x64_f32", (8, 8, 64, 64, 64), torch.float32),
+                            ("xgc_8x16395x39x39_f64", (8, 16395, 39, 39), torch.float64)):
+        np_dt = np.float32 if dt == torch.float32 else np.float64
+        u = inside_field(torch, shape, dt, dev)
+        h = mgard_amd.Hierarchy(shape, np_dt, device=local_rank)
+        N = u.numel()
+        q = torch.empty(shape, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        oi = torch.empty(N // 8, dtype=torch.int64, device=dev)
+        ov = torch.empty(N // 8, dtype=torch.int64, device=dev)
+        # the metric's step: [norm +] decompose + quantize, int64 out into the caller's buffers, no host sync
+        fwd = lambda: h.decompose_quantize(u, mgard_amd.REL, 1e-3, float("inf"), 0.0, outlier_cap=N // 8,
+                                           bufs=(q, cnt, oi, ov), want_norm=False)
+        for _ in range(2):
+            fwd()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fwd()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        nb = N * u.element_size()
+        n_out = int(cnt.item())
+        assert n_out <= N // 8, "outlier buffer too small"
+        nrm = h.norm(u, float("inf"))
+        back = torch.empty_like(u)
+        qq = q.clone()
+        bwd = lambda: h.dequantize_recompose(qq, mgard_amd.REL, 1e-3, float("inf"), nrm, outlier_idx=oi[:n_out],
+                                             outlier_val=ov[:n_out], out=back)
+        for _ in range(2):
+            bwd()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            bwd()
+        torch.cuda.synchronize()
+        msb = (time.perf_counter() - t0) / steps * 1e3
+        err = float((back - u).abs().max())
+        out[name] = {"shape": list(shape), "what": "[norm +] decompose + quantize, int64 out; back: dequantize + "
+                                                     "recompose, int64 in; REL 1e-3, s = inf",
+                     "ms_per_step": round(ms, 4), "GBps": round(nb / ms / 1e6, 1),
+                     "back_ms": round(msb, 4), "back_GBps": round(nb / msb / 1e6, 1),
+                     "outliers": n_out, "l_target": h.l_target,
+                     "roundtrip_linf_error": err, "tolerance_abs": 1e-3 * nrm,
+                     "within_tolerance": bool(err <= 1e-3 * nrm)}
+        h.close()
+        del u, back, q, qq, oi, ov
+        torch.cuda.empty_cache()
+    return out
+
+
 def host_leg(torch, mgard_amd, u, tol, s, nrm_host, reps=4, batches=3):
     """SURVEY.md section 8(d), the reference's own usage: mgh_compress / mgh_decompress with HOST
     buffers in and out (H2D + every device stage + lossless + D2H inside the timed call). Three kinds
@@ -944,8 +1019,9 @@ def scatter_gather_leg(torch, mgard_amd, dist, dev, local_rank, rank, world, sla
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # (defaults: a timed window of ~90 ms -- a fresh box was seen to run its first 25 ms at 2/3 speed once)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--only-step", action="store_true",
                     help="time the step only: no decompression / 16-bit / end-to-end legs, no CPU "
@@ -1309,6 +1385,11 @@ def main():
                 oc["4d_volume"] = volume_leg(torch, mgard_amd, dev)
             except (mgard_amd.MgardHipError, RuntimeError, AssertionError) as e:
                 oc["4d_volume"] = {"error": str(e)[:300]}
+            torch.cuda.empty_cache()
+            try:
+                oc["beyond_configs"] = beyond_leg(torch, mgard_amd, dev, local_rank)
+            except Exception as e:  # noqa: BLE001 -- informational leg: whatever happens, the line goes out
+                oc["beyond_configs"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             torch.cuda.empty_cache()
         else:
             # N > 1: configs[3] as it is meant -- the 64 x 512^3 volume split on dim 0, one

@@ -56,6 +56,10 @@ try:
     R["MS5DBACK"] = "%.2f" % float(t5.split("dequantize + recompose:")[1].split("ms")[0])
 except Exception as e:  # noqa: BLE001
     print("5d profile:", e)
+bc = oc.get("beyond_configs", {})
+b5, bx = bc.get("5d_8x8x64x64x64_f32", {}), bc.get("xgc_8x16395x39x39_f64", {})
+R["B5MS"], R["B5GB"], R["B5BK"] = "%.2f" % b5.get("ms_per_step", 0), "%.0f" % b5.get("GBps", 0), "%.2f" % b5.get("back_ms", 0)
+R["BXMS"], R["BXGB"], R["BXBK"] = "%.2f" % bx.get("ms_per_step", 0), "%.0f" % bx.get("GBps", 0), "%.2f" % bx.get("back_ms", 0)
 rf = oc["512f64nu"].get("roofline", {})
 R["F64FR"] = "%.1f" % (100 * rf.get("frac", 0))
 R["F64TR"] = "%.2f" % ((rf.get("traffic") or 0) / max(rf.get("algorithmic_bytes_per_step", 1), 1))
