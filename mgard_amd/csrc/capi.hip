@@ -103,6 +103,7 @@ struct mgh_hierarchy {
   int ipk_chunk = 1;    // MGH_IPK_CHUNK: the LDS-staged solve of contiguous pencils shares a tile's sweeps between the four waves (thomas_chunked: chunks verified against the sequential sweep)
   int ipk_chunk_k = 0;  // MGH_IPK_CHUNK_K: warm-up length of a chunk (0 = from the tables, chunk_warmup_need; small values make the verification fail and exercise the fall-back)
   int ipk_chunk_need = 0;  // warm-up length that the Thomas tables of this hierarchy need (set with the tables)
+  int ipk_spec_long = 1024;  // MGH_IPK_SPEC_LONG: strided pencils of this length and more, one round of tiles at most, run in verified chunks too (0: never)
   uint32_t ipk_spec_max = 16384;  // MGH_IPK_SPEC_MAX: most pencils of a solve whose pencils do not fit LDS that still run in verified chunks
   int ipk_spec_k = 0;   // MGH_IPK_SPEC_K: warm-up length of a chunk (0 = 64 floats / 128 doubles; tiny values make the verification fail and exercise the repair)
   int sym16_mixed = 1;  // MGH_SYM16_MIXED: 16-bit symbols for the finest level only, int64 below it (default), 0 = 16-bit symbols on every level
@@ -608,6 +609,14 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
       best_w = w;
     }
   }
+  // Long strided pencils, few enough of them to be one round of tiles with most of the chip idle
+  // (16395 x 64 x 64: the r-solve of the 2051 x 9 x 9 level is 6 tiles and a chain of 2051 steps down
+  // and 2051 back at ~40 ns each in LDS -- 161 us for 0.7 MB; the levels above it 91 and 53 us): the
+  // verified chunks put a wave on every piece of every pencil. MGH_IPK_SPEC_LONG: the pencil length
+  // from which on (default 1024; 0: never).
+  if (axis != 2 && nbatch == 1 && h->ipk_spec && h->ipk_spec_long && n >= (uint32_t)h->ipk_spec_long &&
+      npencil <= 64u * (uint32_t)h->num_cu && npencil <= h->ipk_spec_max)
+    return spec_solve();
   // Contiguous pencils, LDS-staged tiles whose sweeps are shared by the four waves (thomas_chunked;
   // warm-up length from the tables, ipk_chunk_need), ahead of the streaming kernels: 512^3 f32 top
   // level 53 -> 44 us, f64 120 -> 109 us, 1024^3 554 -> 543 us. (The same for strided pencils and
@@ -2796,6 +2805,7 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->sym16_mixed = (int)env_get("MGH_SYM16_MIXED", h->sym16_mixed);
     h->ipk_spec = (int)env_get("MGH_IPK_SPEC", h->ipk_spec);
     h->ipk_spec_k = (int)env_get("MGH_IPK_SPEC_K", h->ipk_spec_k);
+    h->ipk_spec_long = (int)env_get("MGH_IPK_SPEC_LONG", h->ipk_spec_long);
     h->ipk_spec_max = (uint32_t)env_get("MGH_IPK_SPEC_MAX", (long)h->ipk_spec_max);
     h->ipk_chunk = (int)env_get("MGH_IPK_CHUNK", h->ipk_chunk);
     h->outlier_agg = (int)env_get("MGH_OUTLIER_AGG", h->outlier_agg);

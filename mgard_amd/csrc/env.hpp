@@ -36,6 +36,7 @@ inline const EnvSwitch *env_switches(size_t *count) {
       {"MGH_SYM16_MIXED", 0, 1},
       {"MGH_IPK_SPEC", 0, 1},
       {"MGH_IPK_SPEC_K", 0, 4096},
+      {"MGH_IPK_SPEC_LONG", 0, 1 << 30},
       {"MGH_IPK_SPEC_MAX", 0, 1 << 30},
       {"MGH_IPK_CHUNK", 0, 1},
       {"MGH_OUTLIER_AGG", 0, 2},

@@ -1000,11 +1000,16 @@ def test_decompose_equals_the_operator_built_decomposition_on_nonuniform_grids(d
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{}, {"MGH_IPK_SPEC_K": "2"}, {"MGH_IPK_SPEC_K": "9"}, {"MGH_IPK_SPEC": "0"}])
+@pytest.mark.parametrize("env", [{}, {"MGH_IPK_SPEC_K": "2"}, {"MGH_IPK_SPEC_K": "9"}, {"MGH_IPK_SPEC": "0"},
+                                 {"MGH_IPK_SPEC_LONG": "0"}])
 @pytest.mark.parametrize("shape,dt,nonuniform", [((1 << 20,), np.float32, False), ((300001,), np.float64, True),
                                                  ((3, 40000), np.float32, False), ((70001,), np.float32, True),
                                                  ((40000, 3), np.float32, False), ((20001, 4, 5), np.float64, True),
-                                                 ((6, 9000, 7), np.float32, False), ((70, 9, 5000), np.float32, True)])
+                                                 ((6, 9000, 7), np.float32, False), ((70, 9, 5000), np.float32, True),
+                                                 # (round 6: strided pencils of 1024 and more that WOULD fit LDS, one
+                                                 # round of tiles: chunked too -- MGH_IPK_SPEC_LONG)
+                                                 ((2500, 6, 7), np.float32, False), ((5, 2300, 9), np.float64, True),
+                                                 ((2100, 33, 40), np.float32, True)])
 def test_long_contiguous_pencils_are_solved_in_verified_chunks(shape, dt, nonuniform, env, monkeypatch):
     """Few long pencils (a 1-D array is one pencil per level; 40000 x 3 has three strided ones; pencils too
     long for LDS in general) are solved in chunks that start
