@@ -553,7 +553,7 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
     G.npencil = npencil;
     if (axis == 2) { G.n_inner = npencil; G.outer_stride = 0; G.inner_stride = n; G.stride = 1; G.along_p = 0; }
     else if (axis == 1) { G.n_inner = m[2]; G.outer_stride = (size_t)m[1] * m[2]; G.inner_stride = 1; G.stride = m[2]; G.along_p = 1; }
-    else { G.n_inner = m[1] * m[2]; G.outer_stride = 0; G.inner_stride = 1; G.stride = (size_t)m[1] * m[2]; G.along_p = 1; }
+    else { G.n_inner = m[1] * m[2]; G.outer_stride = batch_stride; G.inner_stride = 1; G.stride = (size_t)m[1] * m[2]; G.along_p = 1; }  // (batches: boxes back to back, spec_ok)
     const uint32_t nchunk = G.nchunk;
     const size_t total = (size_t)npencil * n, edges = (size_t)npencil * nchunk;
     if (total > ds->spec_y_elems) {
@@ -595,6 +595,8 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
     }));
     return MGH_SUCCESS;
   };
+  // (the batches of a 4-D level: only back to back -- the chunk buffers and the add-to pass see one array)
+  const bool spec_ok = h->ipk_spec && (nbatch == 1 || batch_stride == (size_t)m[0] * m[1] * m[2]);
   if (axis == 2 && nbatch == 1 && h->ipk_spec && npencil <= 64 && n >= 2048) return spec_solve();
   int best_w = 0;
   size_t best_rounds = ~(size_t)0;
@@ -614,7 +616,7 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
   // and 2051 back at ~40 ns each in LDS -- 161 us for 0.7 MB; the levels above it 91 and 53 us): the
   // verified chunks put a wave on every piece of every pencil. MGH_IPK_SPEC_LONG: the pencil length
   // from which on (default 1024; 0: never).
-  if (axis != 2 && nbatch == 1 && h->ipk_spec && h->ipk_spec_long && n >= (uint32_t)h->ipk_spec_long &&
+  if (axis != 2 && spec_ok && h->ipk_spec_long && n >= (uint32_t)h->ipk_spec_long &&
       npencil <= 64u * (uint32_t)h->num_cu && npencil <= h->ipk_spec_max)
     return spec_solve();
   // Contiguous pencils, LDS-staged tiles whose sweeps are shared by the four waves (thomas_chunked;
@@ -804,7 +806,7 @@ int ipk_launch(mgh_hierarchy *h, int axis, const uint32_t *m, T *x, const T *tt,
   }
   // pencils too long for LDS. Not too many of them (a 4194304 x 9 array: 9 strided pencils of
   // 2^21 elements per level; 100 x 100 x 6000: 2601 contiguous ones of 3001): in verified chunks
-  if (nbatch == 1 && h->ipk_spec && n >= 2048 && npencil <= h->ipk_spec_max) return spec_solve();
+  if (spec_ok && n >= 2048 && npencil <= h->ipk_spec_max) return spec_solve();
   // ... else one thread per pencil straight from global memory
   if (nbatch > 1) {
     for (uint32_t bi = 0; bi < nbatch; bi++)

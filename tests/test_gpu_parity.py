@@ -603,7 +603,9 @@ def _slab4d(shape, dt=np.float32):
 
 
 @pytest.mark.parametrize("shape,dt", [((8, 66, 70, 129), np.float32), ((7, 33, 130, 65), np.float64),
-                                      ((5, 40, 36, 72), np.float32), ((16, 65, 65, 65), np.float32)])
+                                      ((5, 40, 36, 72), np.float32), ((16, 65, 65, 65), np.float32),
+                                      # (long r-pencils: the batched solve of the slices in verified chunks)
+                                      ((3, 2100, 9, 10), np.float32), ((4, 4200, 6, 7), np.float64)])
 def test_fused_4d_path_equals_generic_nd(shape, dt, monkeypatch):
     """D = 4 runs slice by slice on the 3-D tile code (decompose_fused4: even slices of the
     slowest dim as 3-D passes, odd slices interpolating across t as well, then the t-sweep and
