@@ -89,6 +89,7 @@ struct mgh_hierarchy {
   int absmax_warm_mb = 192;  // MGH_ABSMAX_WARM_MB: the norm pass reads all but the last so many MB of the input with nontemporal loads
   // MGH_FUSED_FACES: 1 = face tiles for the remainder columns / rows of a level (default), 0 = off
   int fused_faces = 1;
+  int fused_tall = 1;  // MGH_FUSED_TALL: 64 x 4 tiles for levels with a short fastest extent (default 1)
   int slice_batch = 1;  // MGH_SLICE_BATCH: D = 4 decompression, all t-slices of a kind in one launch (default 1)
   int fused_xcd = 1;  // MGH_FUSED_XCD: tiles of a level in contiguous ranges per XCD (default 1; 2: the equal ranges of rounds 2-5 from 32 tiles on)
   int fused_fixed = 1; // MGH_FUSED_FIXED: the int64 + dictionary variant of the level kernel (default 1)
@@ -1010,9 +1011,17 @@ inline bool fused_wide_tiles(const mgh_hierarchy *h, int cls, uint32_t mf) {
   };
   return filled(64) + 0.1 >= filled(32);
 }
+// A short FASTEST extent (AoS-like data: 2048 x 2048 x 17, 512^3 x 5): nine coarse nodes along f fill a
+// quarter of an 8 x 32 tile's lanes, three of them a tenth. Tiles of 64 x 4 coarse nodes there -- the face
+// tiles' shape as the main one (the (c, f) plane of such a level is nearly contiguous in memory, the short
+// rows cost little). MGH_FUSED_TALL=0: never.
+inline bool fused_tall_tiles(const mgh_hierarchy *h, const Box3 &b) {
+  return h->fused_tall && b.m[2] <= 16 && b.m[1] >= 48;
+}
 template <typename T, int OUTK, bool AGG = false>
 int launch_fused2(mgh_hierarchy *h, const FusedArgs<T> &A, const Box3 &b, int cls, const char *nm,
                   hipStream_t s) {
+  if (fused_tall_tiles(h, b)) return launch_fused2_t<T, OUTK, 64, 4, AGG>(h, A, b, cls, nm, s);
   if (fused_wide_tiles(h, cls, b.m[2]))
     return launch_fused2_t<T, OUTK, 4, 64, AGG>(h, A, b, cls, nm, s);
   return launch_fused2_t<T, OUTK, 8, 32, AGG>(h, A, b, cls, nm, s);
@@ -1399,11 +1408,14 @@ int decompose_fused4(mgh_hierarchy *h, const T *data, T *coeff, const QuantParam
     if (n_t % 2 == 0)
       HIP_TRY(hipMemsetAsync(ds->load4 + (size_t)(n_t - 1) * M, 0, M * sizeof(T), s));
     const int cls = level_class(h, b, (size_t)std::max(1, n_t - m_t));
-    const bool wide = fused_wide_tiles(h, cls, b.m[2]);
+    const bool wide = fused_wide_tiles(h, cls, b.m[2]), tall = fused_tall_tiles(h, b);
     if (OUT == OUT_Q && agg) {
-      if (wide) TRY((launch_fused4_t<T, OUT, 4, 64, OUT == OUT_Q>(h, A, Q, b, cls, n_t, m_t, s)));
+      if (tall) TRY((launch_fused4_t<T, OUT, 64, 4, OUT == OUT_Q>(h, A, Q, b, cls, n_t, m_t, s)));
+      else if (wide) TRY((launch_fused4_t<T, OUT, 4, 64, OUT == OUT_Q>(h, A, Q, b, cls, n_t, m_t, s)));
       else TRY((launch_fused4_t<T, OUT, 8, 32, OUT == OUT_Q>(h, A, Q, b, cls, n_t, m_t, s)));
-    } else if (wide)
+    } else if (tall)
+      TRY((launch_fused4_t<T, OUT, 64, 4>(h, A, Q, b, cls, n_t, m_t, s)));
+    else if (wide)
       TRY((launch_fused4_t<T, OUT, 4, 64>(h, A, Q, b, cls, n_t, m_t, s)));
     else
       TRY((launch_fused4_t<T, OUT, 8, 32>(h, A, Q, b, cls, n_t, m_t, s)));
@@ -1890,10 +1902,9 @@ int recompose_impl(mgh_hierarchy *h, const T *coeff, T *data, hipStream_t s) {
 // Node restore of one level (or one t-slice of a 4-D level): the marching kernel
 // (kernels_recompose2.hpp), or the row-pair / row kernels of kernels_recompose.hpp
 // (MGH_RESTORE_V=2, MGH_RESTORE_ROWS=1: cross-checks).
-template <typename T, typename QT, bool TODD>
-int launch_restore(mgh_hierarchy *h, const RecomposeArgs<T> &A, const Box3 &b, const char *nm, hipStream_t st) {
-  if (h->restore_v == 3 && !h->restore_rows) {
-    constexpr int TC = 4, TF = 64;
+// (TC x TF coarse nodes per workgroup: 4 x 64, or 64 x 4 where the fastest extent is short -- fused_tall_tiles)
+template <typename T, typename QT, bool TODD, int TC, int TF>
+int launch_restore3(mgh_hierarchy *h, const RecomposeArgs<T> &A, const Box3 &b, const char *nm, hipStream_t st) {
     Restore3Grid G{};
     G.gxm = ((int)b.m[2] + TF - 1) / TF;
     G.ntile = G.gxm * (((int)b.m[1] + TC - 1) / TC);
@@ -1905,7 +1916,13 @@ int launch_restore(mgh_hierarchy *h, const RecomposeArgs<T> &A, const Box3 &b, c
     G.nchunk = ((int)b.m[0] + G.rch - 1) / G.rch;
     const dim3 grid((unsigned)G.ntile, (unsigned)G.nchunk, (unsigned)nslice);
     return launch(h, nm, st, [&] { k_level_restore3_q<T, QT, TODD, TC, TF><<<grid, TC * TF, 0, st>>>(A, G); });
-  }
+}
+
+template <typename T, typename QT, bool TODD>
+int launch_restore(mgh_hierarchy *h, const RecomposeArgs<T> &A, const Box3 &b, const char *nm, hipStream_t st) {
+  if (h->restore_v == 3 && !h->restore_rows && fused_tall_tiles(h, b))
+    return launch_restore3<T, QT, TODD, 64, 4>(h, A, b, nm, st);
+  if (h->restore_v == 3 && !h->restore_rows) return launch_restore3<T, QT, TODD, 4, 64>(h, A, b, nm, st);
   const dim3 blk(64, 4, 1);
   if (h->restore_rows && !TODD)
     return launch(h, nm, st, [&] {
@@ -1914,33 +1931,40 @@ int launch_restore(mgh_hierarchy *h, const RecomposeArgs<T> &A, const Box3 &b, c
   const dim3 grid(1, ((b.n[1] + 1) / 2 + 3) / 4, b.n[0]);
   return launch(h, nm, st, [&] { k_level_restore2_q<T, QT, TODD><<<grid, blk, 0, st>>>(A); });
 }
-
 // Load-vector pass of the decompression side (one level, or one t-slice of a 4-D level):
 // one plane per step, march length by the number of tiles.
-template <typename T, typename QT>
-int launch_loadvec(mgh_hierarchy *h, const RecomposeArgs<T> &A, const Box3 &b, hipStream_t st) {
-  constexpr int TC = 8, TF = 32;
+template <typename T, typename QT, int TC, int TF>
+int launch_loadvec_t(mgh_hierarchy *h, const RecomposeArgs<T> &A, const Box3 &b, hipStream_t st) {
   const unsigned gx = (b.m[2] + TF - 1) / TF, gy = (b.m[1] + TC - 1) / TC;
   // (A.zb_mode == 1: all the padded t positions of a 4-D level in this launch, the r-chunks of one
-  // behind those of the other in grid.z)
+  // behind those of the other in grid.z -- which holds 65535 at most: shorter marches only where
+  // they fit)
   const unsigned ns = A.zb_mode == 1 ? (unsigned)(2 * A.zb_mt - 1) : 1u;
+  const unsigned z16 = (b.m[0] + 15) / 16, z4 = (b.m[0] + 3) / 4, z1 = b.m[0];
   RecomposeArgs<T> B = A;
-  if ((size_t)gx * gy * ((b.m[0] + 15) / 16) * ns >= 2048) {
-    B.zb_nz = (int)((b.m[0] + 15) / 16);
+  if ((size_t)gx * gy * z16 * ns >= 2048 || (size_t)z4 * ns > 65535) {
+    B.zb_nz = (int)z16;
     return launch(h, "loadvec_q", st, [&] {
-      k_level_loadvec_q<T, QT, TC, TF, 16><<<dim3(gx, gy, B.zb_nz * ns), 256, 0, st>>>(B);
+      k_level_loadvec_q<T, QT, TC, TF, 16><<<dim3(gx, gy, z16 * ns), 256, 0, st>>>(B);
     });
   }
-  if ((size_t)gx * gy * ((b.m[0] + 3) / 4) * ns >= 256) {
-    B.zb_nz = (int)((b.m[0] + 3) / 4);
+  if ((size_t)gx * gy * z4 * ns >= 256 || (size_t)z1 * ns > 65535) {
+    B.zb_nz = (int)z4;
     return launch(h, "loadvec_q_small", st, [&] {
-      k_level_loadvec_q<T, QT, TC, TF, 4><<<dim3(gx, gy, B.zb_nz * ns), 256, 0, st>>>(B);
+      k_level_loadvec_q<T, QT, TC, TF, 4><<<dim3(gx, gy, z4 * ns), 256, 0, st>>>(B);
     });
   }
-  B.zb_nz = (int)b.m[0];
+  B.zb_nz = (int)z1;
   return launch(h, "loadvec_q_small", st, [&] {
-    k_level_loadvec_q<T, QT, TC, TF, 1><<<dim3(gx, gy, B.zb_nz * ns), 256, 0, st>>>(B);
+    k_level_loadvec_q<T, QT, TC, TF, 1><<<dim3(gx, gy, z1 * ns), 256, 0, st>>>(B);
   });
+}
+
+// (8 x 32 coarse nodes per workgroup, or 64 x 4 where the fastest extent is short -- fused_tall_tiles)
+template <typename T, typename QT>
+int launch_loadvec(mgh_hierarchy *h, const RecomposeArgs<T> &A, const Box3 &b, hipStream_t st) {
+  if (fused_tall_tiles(h, b)) return launch_loadvec_t<T, QT, 64, 4>(h, A, b, st);
+  return launch_loadvec_t<T, QT, 8, 32>(h, A, b, st);
 }
 
 // QTL / AL: coefficient source of the `ntop` FINEST levels when it differs from that of the levels
@@ -2078,7 +2102,7 @@ int recompose_levels4(mgh_hierarchy *h, RecomposeArgs<T> A0, const std::vector<T
     // ---- load vectors of the padded t positions: one launch for all of them (grid.z limit
     // permitting; MGH_SLICE_BATCH=0: a launch per slice)
     const bool batch = h->slice_batch && h->restore_v == 3 && !h->restore_rows &&
-                       (size_t)(2 * m_t - 1) * Mc[1] < 65536;
+                       (size_t)(2 * m_t - 1) * ((Mc[1] + 15) / 16) < 65536;  // (grid.z of the load-vector launch)
     if (n_t % 2 == 0)  // ghost slice
       HIP_TRY(hipMemsetAsync(ds->load4 + (size_t)(n_t - 1) * M, 0, M * sizeof(T), st));
     if (batch) {
@@ -2799,6 +2823,7 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
     h->fused_faces = (int)env_get("MGH_FUSED_FACES", h->fused_faces);
     h->fused_xcd = (int)env_get("MGH_FUSED_XCD", h->fused_xcd);
     h->slice_batch = (int)env_get("MGH_SLICE_BATCH", h->slice_batch);
+    h->fused_tall = (int)env_get("MGH_FUSED_TALL", h->fused_tall);
     h->fused_fixed = (int)env_get("MGH_FUSED_FIXED", h->fused_fixed);
     h->fused_wide = (int)env_get("MGH_FUSED_WIDE", -1);  // (-1: by data type, below)
     h->fused4 = (int)env_get("MGH_FUSED4", h->fused4);
@@ -2874,7 +2899,9 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
   // 2048 x 2048 x 17 at 14 %: 5.5 vs 5.3 ms).
   if (h->force_v1_env < 0 && D == 3) {
     const uint64_t m1 = shape[1] / 2 + 1, m2 = shape[2] / 2 + 1;
-    const double tiles = (double)((m1 + 3) / 4) * (double)((m2 + 63) / 64);
+    double tiles = (double)((m1 + 3) / 4) * (double)((m2 + 63) / 64);
+    // (a short fastest extent under a long middle one: the 64 x 4 tiles -- fused_tall_tiles)
+    if (h->fused_tall && m2 <= 16 && m1 >= 48) tiles = (double)((m1 + 63) / 64) * (double)((m2 + 3) / 4);
     if ((double)(m1 * m2) < 0.125 * tiles * 256.0) h->force_v1 = true;
   }
   int rc = DISPATCH(h, build_device_state<float>(h), build_device_state<double>(h));

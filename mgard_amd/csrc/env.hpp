@@ -23,7 +23,7 @@ inline const EnvSwitch *env_switches(size_t *count) {
   static const EnvSwitch k[] = {
       {"MGH_FORCE_V1", 0, 1},       {"MGH_FORCE_ND", 0, 1},        {"MGH_IPK_STREAM", 0, 1},      {"MGH_IPK_DMA", 0, 1},  {"MGH_IPK_DMA_MIN", 0, 1 << 30},  {"MGH_MULTI_FORCE_PEER", 0, 1},  {"MGH_ABSMAX_WARM_MB", 0, 1 << 20},      {"MGH_FUSED_FACES", 0, 1},
       {"MGH_FUSED_XCD", 0, 2},      {"MGH_FUSED_FIXED", 0, 1},     {"MGH_FUSED_WIDE", 0, 2},
-      {"MGH_SLICE_BATCH", 0, 1},
+      {"MGH_SLICE_BATCH", 0, 1},      {"MGH_FUSED_TALL", 0, 1},
       {"MGH_FUSED4", 0, 1},         {"MGH_CLS1", 0, 1 << 30},     {"MGH_CLS2", 0, 1 << 30},      {"MGH_RCH", 1, 16},
       {"MGH_IPK_W", 16, 64},        {"MGH_IPK_PD", 1, 4},          {"MGH_NO_RECOMPOSE_HEAD", 0, 1}, {"MGH_RESTORE_ROWS", 0, 1}, {"MGH_DEBUG_SYNC", 0, 1},
       {"MGH_HL_TIMING", 0, 1},      {"MGH_HUFF_TB", 8, 15},        {"MGH_HUFF_SERIAL_DECODE", 0, 1},

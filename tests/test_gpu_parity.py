@@ -16,7 +16,9 @@ pytestmark = pytest.mark.gpu
 
 SHAPES = [(5,), (33,), (6,), (100,), (1025,), (5, 5), (17, 20), (6, 9), (64, 48), (129, 33),
           (5, 5, 5), (9, 6, 8), (17, 20, 33), (33, 33, 33), (34, 33, 32), (65, 70, 129),
-          (3, 3, 3), (4, 4, 4), (3, 4, 200)]
+          (3, 3, 3), (4, 4, 4), (3, 4, 200),
+          # (short fastest extent under a long middle one: the 64 x 4 tiles of round 6)
+          (40, 130, 9), (33, 100, 17), (36, 128, 12), (20, 200, 30), (70, 300, 5)]
 
 
 def _gpu():
@@ -605,7 +607,9 @@ def _slab4d(shape, dt=np.float32):
 @pytest.mark.parametrize("shape,dt", [((8, 66, 70, 129), np.float32), ((7, 33, 130, 65), np.float64),
                                       ((5, 40, 36, 72), np.float32), ((16, 65, 65, 65), np.float32),
                                       # (long r-pencils: the batched solve of the slices in verified chunks)
-                                      ((3, 2100, 9, 10), np.float32), ((4, 4200, 6, 7), np.float64)])
+                                      ((3, 2100, 9, 10), np.float32), ((4, 4200, 6, 7), np.float64),
+                                      # (64 x 4 tiles: a short fastest extent)
+                                      ((6, 20, 130, 9), np.float32), ((5, 33, 100, 5), np.float64)])
 def test_fused_4d_path_equals_generic_nd(shape, dt, monkeypatch):
     """D = 4 runs slice by slice on the 3-D tile code (decompose_fused4: even slices of the
     slowest dim as 3-D passes, odd slices interpolating across t as well, then the t-sweep and
