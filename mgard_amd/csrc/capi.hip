@@ -2892,14 +2892,15 @@ int mgh_hierarchy_create(mgh_hierarchy **out, int D, const uint64_t *shape, int 
   }
   h->plane_elems = shape[D - 1] * (D >= 2 ? shape[D - 2] : 1);
   for (int d = 0; d < D; d++) h->shape[d] = shape[d];
-  // Thin arrays (a long slowest dimension over planes of a few nodes: 300000 x 17 x 17): the tiled
-  // level kernels cover the coarse (c, f) plane with tiles of 4 x 64 nodes and march along r; where
+  // Thin arrays (a long slowest dimension over planes of a few nodes: 1000000 x 5 x 5): the tiled
+  // level kernels cover the coarse (c, f) plane with tiles of 8 x 32 nodes and march along r; where
   // the plane fills less than an eighth of its tiles the one-thread-per-element kernels are the
-  // faster ones (4194304 x 3 x 3: 82 -> 12.5 ms per mgh_compress, 300000 x 17 x 17: 16 -> 6.8 ms,
-  // 2048 x 2048 x 17 at 14 %: 5.5 vs 5.3 ms).
+  // faster ones (4194304 x 3 x 3: 82 -> 12.5 ms per mgh_compress; step of 1000000 x 5 x 5 5.0 vs 6.2 ms,
+  // of 100000 x 9 x 9 1.15 vs 1.30 ms -- and 300000 x 17 x 17, 16 % of its tiles, 5.6 vs 3.9 ms the
+  // other way round since the tiles of a small cross-section reach all XCDs: round 6).
   if (h->force_v1_env < 0 && D == 3) {
     const uint64_t m1 = shape[1] / 2 + 1, m2 = shape[2] / 2 + 1;
-    double tiles = (double)((m1 + 3) / 4) * (double)((m2 + 63) / 64);
+    double tiles = (double)((m1 + 7) / 8) * (double)((m2 + 31) / 32);
     // (a short fastest extent under a long middle one: the 64 x 4 tiles -- fused_tall_tiles)
     if (h->fused_tall && m2 <= 16 && m1 >= 48) tiles = (double)((m1 + 63) / 64) * (double)((m2 + 3) / 4);
     if ((double)(m1 * m2) < 0.125 * tiles * 256.0) h->force_v1 = true;
