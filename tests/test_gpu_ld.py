@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 SHAPES = [
     ((33, 40, 65), "fused 3-D"),
     ((129, 66, 130), "fused 3-D, several levels"),
+    ((40, 130, 9), "fused 3-D, 64 x 4 tiles (short fastest extent)"),
     ((300, 5, 7), "thin 3-D: one-thread-per-element kernels"),
     ((100, 129), "2-D"),
     ((5, 9, 10, 17), "fused 4-D"),
