@@ -30,3 +30,15 @@ def nonuniform_coords(shape, dtype=np.float64, seed=7):
         z = rng.uniform(-1, 1, size=n)
         out.append(((np.arange(n) + 0.3 * z) / (n - 1)).astype(dtype))
     return out
+
+
+def inside_field(shape, dtype=np.float32, seed=1):
+    """A field whose quantized coefficients stay inside an 8192-entry dictionary at 1e-3 in 4-D / 5-D and on
+    short extents too (the quantizer's bins shrink with 1 + 3^D; smooth_field puts whole periods across
+    extents of a few nodes): one period of a sine across every extent of 32 and more points, 1 % of that
+    across the short ones, 1e-3 uniform noise."""
+    ax = np.meshgrid(*[np.arange(n, dtype=np.float64) / max(n - 1, 1) for n in shape], indexing="ij", sparse=True)
+    g = sum((1.0 if shape[k] >= 32 else 0.01) * np.sin(2 * np.pi * a + 0.3 * k) for k, a in enumerate(ax))
+    g = g + 1e-3 * np.random.default_rng(seed).uniform(-1, 1, size=shape)
+    return np.ascontiguousarray(g.astype(dtype))
+
