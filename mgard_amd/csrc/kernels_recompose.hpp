@@ -278,7 +278,7 @@ k_level_restore_q(RecomposeArgs<T> A) {
   const size_t mJ = mf, mI = (size_t)mc * mf;
   const int r0 = ro ? (rp - 1) / 2 : i, c0 = co ? (cp - 1) / 2 : j;
   const T rr = ro ? A.ratio[0][rp - 1] : (T)0, rc = co ? A.ratio[1][cp - 1] : (T)0;
-  const size_t qlin = (size_t)i * A.dI + (size_t)j * A.dJ;
+  const size_t qlin = A.lin_base + (size_t)i * A.dI + (size_t)j * A.dJ;  // (lin_base: the t-slice of a 4-D level)
   const QT *qrow = qsrc<T>(A, QT()) + qlin;
   T *out = A.fine + (size_t)rp * A.fI + (size_t)cp * A.fJ;
   const bool pure_coarse = !ro && !co;

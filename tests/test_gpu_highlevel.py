@@ -457,6 +457,9 @@ def test_alternative_kernels_give_the_same_result():
     # level above it, other residency plans of the streaming Thomas solves
     assert run({"MGH_BOX": "0", "MGH_TAIL_SOLVES": "0", "MGH_RESTORE_V": "2", "MGH_IPK_CONTIG": "2"}) == ref
     assert run({"MGH_BOX": "3", "MGH_IPK_WPC": "16"}) == ref
+    # round 6: tile placement and shapes, slice batching, chunked strided solves, the N-D row kernels
+    assert run({"MGH_FUSED_XCD": "2", "MGH_FUSED_TALL": "0", "MGH_SLICE_BATCH": "0"}) == ref
+    assert run({"MGH_IPK_SPEC_LONG": "0", "MGH_ND_ROWS": "0", "MGH_FUSED_XCD": "0"}) == ref
 
 
 def test_incompressible_subdomain_is_stored_raw():
